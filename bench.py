@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): CSR SpMV GFLOP/s + achieved HBM GB/s on
+the 1M-row 5-pt Poisson matrix (configs[1], SURVEY.md 8(d) "P2"), plus CG
+iterations/s to 1e-10 on the same matrix, with the reference's omp/ path
+(restated in oracle/, kind "port") timed on the host cores in the same run.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path = one `Csr::apply` (y = A x) over the
+rank's matrix.  Inputs are resident in HBM before the timed region.  The
+headline `value` is measured COLD: steps rotate over enough independent
+copies of (A, x, y) that the 256 MiB Infinity Cache cannot hold them between
+two uses (the 80 MB problem would otherwise be served on-die); the warm
+(same-matrix, reference benchmark/spmv methodology) figure is reported next
+to it under "warm".
+
+N > 1 (one process per GPU under torch.distributed / RCCL): weak scaling of
+the row-partitioned distributed SpMV -- every rank owns a 1000 x 1000 slab of
+a (1000 N) x 1000 grid, exchanges its two boundary grid rows with its
+neighbours over RCCL and applies local + non-local parts
+(core/distributed/matrix.cpp:307-335).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "repo-8852-ginkgo_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, MI355X_MICROARCH.md "HBM3E peak BW"
+GRID = 1000            # P2: 1000 x 1000 grid per GPU
+
+
+def algorithmic_bytes(nrows, ncols, nnz):
+    """CSR SpMV fp64/i32, 1 rhs."""
+    return 12 * nnz + 4 * (nrows + 1) + 8 * ncols + 8 * nrows
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--strategy", type=int, default=0, help="C-ABI strategy word (0 = automatic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cg", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def time_loop(fn, steps, barrier):
+    """Exactly `steps` calls bracketed by barrier + synchronize; returns
+    (wall seconds, HIP-event seconds on the launch stream)."""
+    barrier()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(steps):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    return t1 - t0, e0.elapsed_time(e1) * 1e-3
+
+
+def cpu_baseline(n, rp, ci, v, x, seconds):
+    """Reference omp/ CSR SpMV (oracle port, omp/matrix/csr_kernels.cpp:76-99)
+    on this host's cores, bounded to ~`seconds` of work."""
+    import oracle_lib
+    orc = oracle_lib.load()
+    y = np.empty((n, 1))
+    orc.omp_csr_spmv(n, 1, rp, ci, v, x, 1, y, 1)  # warm-up, first touch
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        orc.omp_csr_spmv(n, 1, rp, ci, v, x, 1, y, 1)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or reps >= 2000:
+            break
+    nnz = int(rp[-1])
+    return {
+        "value": round(2.0 * nnz * reps / el / 1e9, 3), "unit": "GFLOP/s",
+        "cores": int(orc.oracle_num_threads()), "kind": "port",
+        "sample": f"{reps} x omp csr::spmv on the same 1M-row 5-pt Poisson matrix ({el:.1f} s)",
+        "gbs": round(algorithmic_bytes(n, n, nnz) * reps / el / 1e9, 2),
+    }, y
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+        barrier = lambda: dist.barrier(device_ids=[local_rank])
+    else:
+        barrier = lambda: None
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import gkomi
+    import matgen
+    gk = gkomi.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    n, rp, ci, v = matgen.poisson_2d_5pt(GRID)
+    nnz = int(rp[-1])
+    x_host = np.sin(0.01 * (np.arange(n) + rank * n)).reshape(n, 1)
+    bytes_per_launch = algorithmic_bytes(n, n, nnz)
+    flops_per_launch = 2.0 * nnz
+
+    if distributed:
+        import gkomi.distributed as gd
+        dmat = gd.poisson_slab_matrix(gk, GRID, rank, world, device)
+        flops_per_launch = 2.0 * dmat.global_nnz_local_rows
+        copies = [dmat]
+        xs = [dev(x_host, device)]
+        ys = [torch.empty((n, 1), dtype=torch.float64, device=device)]
+
+        def step_cold(i):
+            dmat.apply(xs[0], ys[0])
+        step_warm = step_cold
+        ncopies = 1
+    else:
+        # enough copies that a copy's lines are evicted from the 256 MiB
+        # Infinity Cache before it is used again
+        ncopies = 8
+        copies = []
+        for _ in range(ncopies):
+            copies.append((dev(rp, device), dev(ci, device), dev(v, device),
+                           dev(x_host, device), torch.empty((n, 1), dtype=torch.float64, device=device)))
+
+        def launch(c):
+            gk.csr_spmv_f64_i32(stream, n, n, 1, c[0], c[1], c[2], c[3], 1, c[4], 1, None, None,
+                                args.strategy, 5)
+
+        def step_cold(i):
+            launch(copies[i % ncopies])
+
+        def step_warm(i):
+            launch(copies[0])
+
+    for i in range(args.warmup):
+        step_cold(i)
+    wall, ev = time_loop(step_cold, args.steps, barrier)
+    if distributed:
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    ms_per_step = wall / args.steps * 1e3
+    gflops = flops_per_launch * world * args.steps / wall / 1e9
+
+    out = {
+        "metric": "CSR SpMV GFLOP/s (fp64, 1M-row 5-pt Poisson per GPU)",
+        "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "benchmark/spmv: CSR fp64/int32 y=Ax on 1000x1000 5-pt Poisson "
+                               "(n=1e6, nnz=4996000) per GPU, x=sin(0.01 i)",
+                   "cache_state": f"cold: rotating over {ncopies} copies (> 256 MiB Infinity Cache)"
+                   if not distributed else "warm (single resident copy per rank)",
+                   "partition": "one GPU" if not distributed else f"{world} row slabs, RCCL halo exchange",
+                   "strategy": args.strategy},
+    }
+
+    if rank == 0:
+        # dominant kernel's launch duration from HIP events on the launch
+        # stream over the timed region (back-to-back launches: includes the
+        # ~1.5 us dependent-launch boundary, so it is an upper bound of the
+        # rocprofv3 kernel duration in profiles/)
+        kern_s = ev / args.steps
+        achieved = bytes_per_launch / kern_s / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                           "traffic": None,
+                           "kernel": "csr_stream_kernel" if not distributed else "distributed apply",
+                           "bytes_per_launch": bytes_per_launch,
+                           "us_per_launch": round(kern_s * 1e6, 3)}
+    if not distributed:
+        for i in range(args.warmup):
+            step_warm(i)
+        wwall, wev = time_loop(step_warm, args.steps, barrier)
+        out["warm"] = {"gflops": round(flops_per_launch * args.steps / wwall / 1e9, 2),
+                       "gbs": round(bytes_per_launch * args.steps / wev / 1e9, 1),
+                       "us_per_launch": round(wev / args.steps * 1e6, 3),
+                       "note": "same matrix every step (benchmark/spmv methodology); 80 MB working "
+                               "set is Infinity-Cache resident"}
+
+    if not distributed and not args.no_cg and hasattr(gk, "cg_solve_f64_i32"):
+        import gkomi.solvers as solvers
+        c = copies[0]
+        s = np.sin(np.arange(n, dtype=np.float64))
+        s /= np.linalg.norm(s)
+        sb = dev(s.reshape(n, 1), device)
+        b = torch.empty((n, 1), dtype=torch.float64, device=device)
+        gk.csr_spmv_f64_i32(stream, n, n, 1, c[0], c[1], c[2], sb, 1, b, 1, None, None, 0, 5)
+        res = solvers.cg_solve(gk, n, c[0], c[1], c[2], b, max_iters=20000, reduction=1e-10)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = solvers.cg_solve(gk, n, c[0], c[1], c[2], b, max_iters=20000, reduction=1e-10)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        xerr = float(torch.linalg.norm(res["x"] - sb) / torch.linalg.norm(sb))
+        out["cg"] = {"metric": "CG iters/sec to 1e-10 (Identity preconditioner, sinus rhs)",
+                     "iterations": res["iterations"], "seconds": round(el, 5),
+                     "iters_per_sec": round(res["iterations"] / el, 1),
+                     "final_residual_norm_rel": res["rel_residual"], "solution_rel_err": xerr,
+                     "converged": bool(res["converged"])}
+
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        base, y_cpu = cpu_baseline(n, rp, ci, v, x_host, args.cpu_seconds)
+        out["cpu_baseline"] = base
+        # the baseline doubles as an end-of-run parity check of what was timed
+        got = copies[0][4].cpu().numpy()
+        out["parity_vs_oracle"] = "bit-exact" if np.array_equal(got, y_cpu) else \
+            f"rel err {matgen.rel_err(got, y_cpu):.3e}"
+
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

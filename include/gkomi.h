@@ -1,0 +1,196 @@
+/*
+ * gkomi.h -- C ABI of the MI355X (gfx950) kernel backend for the Ginkgo
+ * SpMV + Krylov-solver hot path.
+ *
+ * This is the drop-in boundary: every entry point below replaces one free
+ * function `gko::kernels::hip::<component>::<fn>(std::shared_ptr<const
+ * HipExecutor>, ...)` of the reference (declared once for all backends in
+ * core/<area>/<x>_kernels.hpp, enumerated in
+ * core/device_hooks/common_kernels.inc.cpp:182-845).  The C++ shims that
+ * re-create the reference signatures on top of these symbols are in
+ * repo-8852-ginkgo_amd/include/ginkgo/ and shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all data pointers are DEVICE pointers
+ *    unless a parameter is named host_*;
+ *  - values are fp64 (`_f64`), indices int32 (`_i32`); dense matrices are
+ *    row-major with an explicit stride (gko::matrix::Dense layout);
+ *  - scalars alpha/beta/rho... live in device memory (1x1 or 1xnrhs Dense in
+ *    the reference);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream, the
+ *    reference's choice, common/cuda_hip/base/kernel_launch.hpp.inc:66);
+ *  - every function returns 0 on success, a positive hipError_t value when
+ *    the HIP runtime failed, or a negative GKOMI_E* code;
+ *  - nothing here allocates or synchronizes unless documented;
+ *    workspace is caller-provided (reference: array<char>& tmp).
+ */
+#ifndef GKOMI_H_
+#define GKOMI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gkomi_stream_t;
+
+enum {
+    GKOMI_SUCCESS = 0,
+    GKOMI_EINVAL = -1,       /* bad argument (gko::BadDimension / ValueMismatch) */
+    GKOMI_ENOTSUPPORTED = -2, /* gko::NotSupported */
+    GKOMI_ENOTIMPL = -3,      /* gko::NotImplemented */
+    GKOMI_EWORKSPACE = -4     /* workspace too small */
+};
+
+/* stopping_status bit layout (include/ginkgo/core/stop/stopping_status.hpp:144-147) */
+#define GKOMI_STATUS_CONVERGED 0x80u
+#define GKOMI_STATUS_FINALIZED 0x40u
+#define GKOMI_STATUS_ID_MASK 0x3fu
+
+/* ---- library / device ------------------------------------------------- */
+
+/* version_info::get_hip_version analogue (core/device_hooks/hip_hooks.cpp:45) */
+const char* gkomi_version(void);
+/* HipExecutor::get_num_devices (hip/base/executor.hip.cpp) */
+int gkomi_get_num_devices(int* count);
+/* HipExecutor::set_gpu_property: CUs, wave size, LDS bytes, XCDs.
+ * out[0]=num CUs, out[1]=wavefront size, out[2]=LDS bytes/CU, out[3]=L2 bytes */
+int gkomi_device_properties(int device, int64_t out[4]);
+/* HipExecutor::synchronize */
+int gkomi_synchronize(gkomi_stream_t stream);
+/* readable name of the last HIP error code returned (Hip*Error::get_error) */
+const char* gkomi_error_string(int code);
+
+/* ---- CSR SpMV (core/matrix/csr_kernels.hpp:58-75) ----------------------- */
+
+/* Kernel selection, the role of Csr::strategy_type / srow
+ * (include/ginkgo/core/matrix/csr.hpp:170-705). */
+enum {
+    GKOMI_CSR_AUTO = 0,    /* "automatical": pick from row statistics        */
+    GKOMI_CSR_STREAM = 1,  /* row-block streaming through LDS, bit-exact      */
+    GKOMI_CSR_VECTOR = 2,  /* "classical": one sub-wave per row               */
+    GKOMI_CSR_BALANCED = 3 /* "load_balance": nnz-split + segmented reduction */
+};
+
+/* csr::spmv  c = A b   and   csr::advanced_spmv  c = alpha A b + beta c.
+ * alpha == NULL && beta == NULL selects the simple form (c is never read).
+ * reference/matrix/csr_kernels.cpp:75-128. */
+int gkomi_csr_spmv_f64_i32(gkomi_stream_t stream, int64_t nrows, int64_t ncols,
+                           int64_t nrhs, const int32_t* row_ptrs,
+                           const int32_t* col_idxs, const double* vals,
+                           const double* b, int64_t b_stride, double* c,
+                           int64_t c_stride, const double* alpha,
+                           const double* beta, int strategy,
+                           int64_t max_row_nnz_hint);
+
+/* ell::compute_max_row_nnz analogue on a CSR row_ptrs array
+ * (reference/matrix/ell_kernels.cpp:159-170 / csr strategy statistics).
+ * result: device int32[1]. */
+int gkomi_csr_max_row_nnz_i32(gkomi_stream_t stream, int64_t nrows,
+                              const int32_t* row_ptrs, int32_t* result);
+
+/* ---- dense BLAS-1 (core/matrix/dense_kernels.hpp) ----------------------- */
+/* x is nrows x ncols row-major with stride; alpha is 1 x alpha_ncols on the
+ * device with alpha_ncols in {1, ncols} (reference/matrix/dense_kernels.cpp:157-246). */
+int gkomi_dense_fill_f64(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                         double* x, int64_t stride, double value);
+int gkomi_dense_copy_f64(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                         const double* in, int64_t in_stride, double* out,
+                         int64_t out_stride);
+int gkomi_dense_scale_f64(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                          const double* alpha, int64_t alpha_ncols, double* x,
+                          int64_t stride);
+int gkomi_dense_inv_scale_f64(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                              const double* alpha, int64_t alpha_ncols,
+                              double* x, int64_t stride);
+int gkomi_dense_add_scaled_f64(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                               const double* alpha, int64_t alpha_ncols,
+                               const double* x, int64_t x_stride, double* y,
+                               int64_t y_stride);
+int gkomi_dense_sub_scaled_f64(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                               const double* alpha, int64_t alpha_ncols,
+                               const double* x, int64_t x_stride, double* y,
+                               int64_t y_stride);
+/* bytes of scratch the reductions below need for an nrows x ncols operand
+ * (the reference's caller-cached array<char>& tmp). */
+size_t gkomi_dense_reduction_workspace_bytes(int64_t nrows, int64_t ncols);
+/* compute_dot / compute_conj_dot (identical for real values): result[j] = sum_i x[i,j] y[i,j] */
+int gkomi_dense_compute_dot_f64(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                                const double* x, int64_t x_stride,
+                                const double* y, int64_t y_stride,
+                                double* result, void* workspace,
+                                size_t workspace_bytes);
+/* compute_norm2: result[j] = sqrt(sum_i x[i,j]^2) */
+int gkomi_dense_compute_norm2_f64(gkomi_stream_t s, int64_t nrows,
+                                  int64_t ncols, const double* x,
+                                  int64_t x_stride, double* result,
+                                  void* workspace, size_t workspace_bytes);
+/* compute_squared_norm2 */
+int gkomi_dense_compute_squared_norm2_f64(gkomi_stream_t s, int64_t nrows,
+                                          int64_t ncols, const double* x,
+                                          int64_t x_stride, double* result,
+                                          void* workspace,
+                                          size_t workspace_bytes);
+/* compute_norm1: result[j] = sum_i |x[i,j]| */
+int gkomi_dense_compute_norm1_f64(gkomi_stream_t s, int64_t nrows,
+                                  int64_t ncols, const double* x,
+                                  int64_t x_stride, double* result,
+                                  void* workspace, size_t workspace_bytes);
+/* compute_sqrt in place on an nrows x ncols matrix */
+int gkomi_dense_compute_sqrt_f64(gkomi_stream_t s, int64_t nrows,
+                                 int64_t ncols, double* x, int64_t stride);
+/* row_gather: out[i,:] = in[rows[i],:]  (dense::row_gather, used to pack halos) */
+int gkomi_dense_row_gather_f64_i32(gkomi_stream_t s, int64_t nout,
+                                   int64_t ncols, const int32_t* rows,
+                                   const double* in, int64_t in_stride,
+                                   double* out, int64_t out_stride);
+
+/* ---- CG step kernels (core/solver/cg_kernels.hpp:54-80) ----------------- */
+/* stop_status: device uint8[nrhs] (array<stopping_status>) */
+int gkomi_cg_initialize_f64(gkomi_stream_t s, int64_t nrows, int64_t nrhs,
+                            const double* b, int64_t b_stride, double* r,
+                            int64_t r_stride, double* z, int64_t z_stride,
+                            double* p, int64_t p_stride, double* q,
+                            int64_t q_stride, double* prev_rho, double* rho,
+                            uint8_t* stop_status);
+int gkomi_cg_step_1_f64(gkomi_stream_t s, int64_t nrows, int64_t nrhs,
+                        double* p, int64_t p_stride, const double* z,
+                        int64_t z_stride, const double* rho,
+                        const double* prev_rho, const uint8_t* stop_status);
+int gkomi_cg_step_2_f64(gkomi_stream_t s, int64_t nrows, int64_t nrhs,
+                        double* x, int64_t x_stride, double* r,
+                        int64_t r_stride, const double* p, int64_t p_stride,
+                        const double* q, int64_t q_stride, const double* beta,
+                        const double* rho, const uint8_t* stop_status);
+
+/* ---- stopping criteria (core/stop/residual_norm_kernels.hpp,
+ *      core/stop/criterion_kernels.hpp) ------------------------------------ */
+/* residual_norm: for each rhs i: tau[i] < goal*orig_tau[i] -> converge(id, finalized).
+ * device_flags: device uint8[2] = {all_converged, one_changed} (the reference's
+ * array<bool> device_storage); the two values are also copied to the two host
+ * bytes when host_flags != NULL (blocking, like
+ * hip/stop/residual_norm_kernels.hip.cpp:119-120). */
+int gkomi_residual_norm_f64(gkomi_stream_t s, int64_t nrhs, const double* tau,
+                            const double* orig_tau, double rel_residual_goal,
+                            uint8_t stopping_id, int set_finalized,
+                            uint8_t* stop_status, uint8_t* device_flags,
+                            uint8_t* host_flags);
+/* implicit_residual_norm: sqrt(|tau|) < goal*orig_tau */
+int gkomi_implicit_residual_norm_f64(gkomi_stream_t s, int64_t nrhs,
+                                     const double* tau, const double* orig_tau,
+                                     double rel_residual_goal,
+                                     uint8_t stopping_id, int set_finalized,
+                                     uint8_t* stop_status,
+                                     uint8_t* device_flags,
+                                     uint8_t* host_flags);
+/* set_all_statuses: stop(id, finalized) on every entry */
+int gkomi_set_all_statuses(gkomi_stream_t s, int64_t nrhs, uint8_t stopping_id,
+                           int set_finalized, uint8_t* stop_status);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* GKOMI_H_ */

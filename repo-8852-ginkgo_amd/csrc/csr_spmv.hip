@@ -1,0 +1,342 @@
+// CSR SpMV for gfx950.  Replaces gko::kernels::hip::csr::{spmv,
+// advanced_spmv} (core/matrix/csr_kernels.hpp:58-75); numerical contract =
+// reference/matrix/csr_kernels.cpp:75-128.
+//
+// Two kernels:
+//
+//  * stream  -- a workgroup owns a contiguous block of rows, streams that
+//    block's (vals, col_idxs) range with 16-B/8-B per-lane coalesced loads,
+//    gathers b[col], writes the per-nonzero products into an LDS tile and
+//    then lets one thread per row add its row's products LEFT TO RIGHT.  No
+//    atomics, no tree: the summation order is the reference's
+//    (`c += val*b` in storage order, unfused), so the result is bit-identical
+//    to the reference executor for any row-length distribution.  Rows longer
+//    than the tile are carried across tiles in a register.
+//
+//  * vector  -- Ginkgo's "classical" idea re-cut for 64-wide waves: a
+//    sub-wave of 2..64 lanes per row, strided over the row, xor-shuffle tree.
+//    Used for long rows, where one thread adding a whole row serialises.
+//
+// HBM traffic per row of the 5-pt stencil: 5*(8+4) + 4 + 8 (b, once, the rest
+// from L2) + 8 = 80 B.
+#include "common.hpp"
+
+namespace gkomi {
+namespace {
+
+constexpr int num_xcd = 8;
+
+// Blocks are dealt round-robin to the 8 XCDs (MI355X_MICROARCH.md §Workgroup
+// dispatch).  Give each XCD one contiguous chunk of row blocks so that the
+// b entries shared by neighbouring row blocks hit in that XCD's L2.  The
+// launch grid is 8*per, surplus ids exit; pure speed, never correctness.
+__device__ __forceinline__ int xcd_chunked_block(int bid, int per)
+{
+    return (bid % num_xcd) * per + bid / num_xcd;
+}
+
+template <int Block, int RowsPerThread, int Tile, bool Advanced, bool Swizzle>
+__global__ __launch_bounds__(Block) void csr_stream_kernel(
+    int nrows, const int32_t* __restrict__ row_ptrs,
+    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
+    int64_t c_stride, const double* __restrict__ alpha_p,
+    const double* __restrict__ beta_p, int nblocks, int per_xcd)
+{
+    constexpr int rows_per_block = Block * RowsPerThread;
+    constexpr int pairs = Tile / (2 * Block);
+    static_assert(Tile % (2 * Block) == 0, "tile must be a whole number of pair sweeps");
+    __shared__ __attribute__((aligned(16))) double prod[Tile];
+
+    const int logical =
+        Swizzle ? xcd_chunked_block(blockIdx.x, per_xcd) : blockIdx.x;
+    if (logical >= nblocks) return;
+    // rhs column handled by this grid row
+    b += blockIdx.y;
+    c += blockIdx.y;
+
+    const int tid = threadIdx.x;
+    const int r0 = logical * rows_per_block;
+    const int r1 = min(r0 + rows_per_block, nrows);
+    const int p0 = row_ptrs[r0];
+    const int p1 = row_ptrs[r1];
+    const int nnz_total = row_ptrs[nrows];
+
+    double alpha = 1.0, beta = 0.0;
+    if (Advanced) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+
+    int ra[RowsPerThread], rb[RowsPerThread];
+    double sum[RowsPerThread];
+#pragma unroll
+    for (int i = 0; i < RowsPerThread; ++i) {
+        const int row = r0 + tid + i * Block;
+        if (row < r1) {
+            ra[i] = row_ptrs[row];
+            rb[i] = row_ptrs[row + 1];
+            // advanced: c = beta*c first, then accumulate (reference :119-126)
+            sum[i] = Advanced ? c[row * c_stride] * beta : 0.0;
+        } else {
+            ra[i] = rb[i] = p1;
+            sum[i] = 0.0;
+        }
+    }
+
+    for (int t0 = p0 & ~1; t0 < p1; t0 += Tile) {
+        double2 v[pairs];
+        int2 ci[pairs];
+        // 1) issue every streaming load of this tile
+#pragma unroll
+        for (int u = 0; u < pairs; ++u) {
+            const int k = t0 + 2 * (tid + u * Block);
+            v[u] = make_double2(0.0, 0.0);
+            ci[u] = make_int2(0, 0);
+            if (k < p1) {
+                if (k + 1 < nnz_total) {
+                    v[u] = *reinterpret_cast<const double2*>(vals + k);
+                    ci[u] = *reinterpret_cast<const int2*>(col_idxs + k);
+                } else {
+                    v[u].x = vals[k];
+                    ci[u].x = col_idxs[k];
+                }
+            }
+        }
+        // 2) gather b, branch-free so that all gathers are in flight
+        //    together: every ci is either a loaded (valid) column -- possibly
+        //    of a neighbouring block's row -- or 0, so the load is always in
+        //    bounds; products outside [p0, p1) land in LDS slots nobody reads.
+        double2 xv[pairs];
+#pragma unroll
+        for (int u = 0; u < pairs; ++u) {
+            xv[u].x = b[ci[u].x * b_stride];
+            xv[u].y = b[ci[u].y * b_stride];
+        }
+#pragma unroll
+        for (int u = 0; u < pairs; ++u) {
+            double2 pr;
+            if (Advanced) {
+                // reference order: (valpha * val) * b
+                pr.x = (alpha * v[u].x) * xv[u].x;
+                pr.y = (alpha * v[u].y) * xv[u].y;
+            } else {
+                pr.x = v[u].x * xv[u].x;
+                pr.y = v[u].y * xv[u].y;
+            }
+            *reinterpret_cast<double2*>(prod + 2 * (tid + u * Block)) = pr;
+        }
+        __syncthreads();
+        // 3) one thread per row: add this tile's part of the row in order
+        const int t1 = t0 + Tile;
+#pragma unroll
+        for (int i = 0; i < RowsPerThread; ++i) {
+            const int lo = max(ra[i], t0);
+            const int hi = min(rb[i], t1);
+            for (int k = lo; k < hi; ++k) {
+                sum[i] += prod[k - t0];
+            }
+        }
+        if (t1 < p1) __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < RowsPerThread; ++i) {
+        const int row = r0 + tid + i * Block;
+        if (row < r1) c[row * c_stride] = sum[i];
+    }
+}
+
+// Variant of the stream kernel's staging for arrays whose base pointers are
+// not 16-/8-byte aligned is not needed: misaligned inputs take the vector
+// kernel, which only uses natural-width loads.
+
+template <int SubWave, bool Advanced>
+__global__ __launch_bounds__(256) void csr_vector_kernel(
+    int nrows, const int32_t* __restrict__ row_ptrs,
+    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
+    int64_t c_stride, const double* __restrict__ alpha_p,
+    const double* __restrict__ beta_p)
+{
+    b += blockIdx.y;
+    c += blockIdx.y;
+    const int sub_lane = threadIdx.x % SubWave;
+    const int64_t subs_per_block = 256 / SubWave;
+    const int64_t first = blockIdx.x * subs_per_block + threadIdx.x / SubWave;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * subs_per_block;
+    double alpha = 1.0, beta = 0.0;
+    if (Advanced) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    // all lanes of a wave run the same number of iterations (shuffles need
+    // the partner lanes active)
+    const int64_t rounds = (nrows + step - 1) / step;
+    for (int64_t it = 0; it < rounds; ++it) {
+        const int64_t row = first + it * step;
+        double acc = 0.0;
+        if (row < nrows) {
+            const int end = row_ptrs[row + 1];
+            for (int k = row_ptrs[row] + sub_lane; k < end; k += SubWave) {
+                const double val = Advanced ? alpha * vals[k] : vals[k];
+                acc += val * b[col_idxs[k] * b_stride];
+            }
+        }
+        acc = subwave_reduce_sum<SubWave>(acc);
+        if (row < nrows && sub_lane == 0) {
+            c[row * c_stride] =
+                Advanced ? c[row * c_stride] * beta + acc : acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void csr_max_row_nnz_kernel(
+    int64_t nrows, const int32_t* __restrict__ row_ptrs,
+    int32_t* __restrict__ result)
+{
+    __shared__ int smax[4];
+    int m = 0;
+    for (int64_t row = blockIdx.x * 256 + threadIdx.x; row < nrows;
+         row += static_cast<int64_t>(gridDim.x) * 256) {
+        m = max(m, row_ptrs[row + 1] - row_ptrs[row]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+        atomicMax(result, m);  // integer max: order-independent, exact
+    }
+}
+
+template <int Block, int RowsPerThread, int Tile>
+int launch_stream(hipStream_t stream, bool swizzle, int nrows, int nrhs,
+                  const int32_t* row_ptrs, const int32_t* col_idxs,
+                  const double* vals, const double* b, int64_t b_stride,
+                  double* c, int64_t c_stride, const double* alpha,
+                  const double* beta)
+{
+    constexpr int rows_per_block = Block * RowsPerThread;
+    const int nblocks = static_cast<int>(ceildiv(nrows, rows_per_block));
+    const int per = static_cast<int>(ceildiv(nblocks, num_xcd));
+    const bool advanced = alpha != nullptr;
+    const bool swz = swizzle && nblocks >= 2 * num_xcd;
+    dim3 grid(swz ? per * num_xcd : nblocks, nrhs);
+#define GKOMI_LAUNCH(ADV, SWZ)                                                 \
+    hipLaunchKernelGGL(                                                        \
+        (csr_stream_kernel<Block, RowsPerThread, Tile, ADV, SWZ>), grid,       \
+        dim3(Block), 0, stream, nrows, row_ptrs, col_idxs, vals, b, b_stride,  \
+        c, c_stride, alpha, beta, nblocks, per)
+    if (advanced) {
+        if (swz) GKOMI_LAUNCH(true, true); else GKOMI_LAUNCH(true, false);
+    } else {
+        if (swz) GKOMI_LAUNCH(false, true); else GKOMI_LAUNCH(false, false);
+    }
+#undef GKOMI_LAUNCH
+    return check_launch();
+}
+
+template <int SubWave>
+int launch_vector(hipStream_t stream, int nrows, int nrhs,
+                  const int32_t* row_ptrs, const int32_t* col_idxs,
+                  const double* vals, const double* b, int64_t b_stride,
+                  double* c, int64_t c_stride, const double* alpha,
+                  const double* beta)
+{
+    const int64_t subs_per_block = 256 / SubWave;
+    dim3 grid(grid_for(nrows, static_cast<int>(subs_per_block), 8192), nrhs);
+    if (alpha != nullptr) {
+        hipLaunchKernelGGL((csr_vector_kernel<SubWave, true>), grid, dim3(256),
+                           0, stream, nrows, row_ptrs, col_idxs, vals, b,
+                           b_stride, c, c_stride, alpha, beta);
+    } else {
+        hipLaunchKernelGGL((csr_vector_kernel<SubWave, false>), grid,
+                           dim3(256), 0, stream, nrows, row_ptrs, col_idxs,
+                           vals, b, b_stride, c, c_stride, alpha, beta);
+    }
+    return check_launch();
+}
+
+}  // namespace
+}  // namespace gkomi
+
+
+extern "C" int gkomi_csr_spmv_f64_i32(
+    gkomi_stream_t stream_, int64_t nrows, int64_t ncols, int64_t nrhs,
+    const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
+    const double* b, int64_t b_stride, double* c, int64_t c_stride,
+    const double* alpha, const double* beta, int strategy,
+    int64_t max_row_nnz_hint)
+{
+    using namespace gkomi;
+    if (nrows < 0 || ncols < 0 || nrhs < 0) return GKOMI_EINVAL;
+    if ((alpha == nullptr) != (beta == nullptr)) return GKOMI_EINVAL;
+    if (nrows > INT32_MAX - 1024 || nrhs > 65535) return GKOMI_ENOTSUPPORTED;
+    // empty output: no-op (hip/matrix/csr_kernels.hip.cpp:291-292)
+    if (nrows == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    if (b_stride < nrhs || c_stride < nrhs) return GKOMI_EINVAL;
+    hipStream_t stream = to_stream(stream_);
+    const int n = static_cast<int>(nrows);
+    const int r = static_cast<int>(nrhs);
+
+    int kind = strategy & 0xff;
+    const int variant = (strategy >> 8) & 0xff;
+    const bool no_swizzle = (strategy >> 16) & 1;
+    const bool aligned = (reinterpret_cast<uintptr_t>(vals) % 16 == 0) &&
+                         (reinterpret_cast<uintptr_t>(col_idxs) % 8 == 0);
+    if (kind == GKOMI_CSR_AUTO) {
+        // the role of Csr::automatical (csr.hpp:526-705): short rows stream,
+        // long rows go one sub-wave per row
+        kind = (max_row_nnz_hint < 0 || max_row_nnz_hint <= 256)
+                   ? GKOMI_CSR_STREAM
+                   : GKOMI_CSR_VECTOR;
+    }
+    if (kind == GKOMI_CSR_BALANCED) kind = GKOMI_CSR_VECTOR;
+    if (kind == GKOMI_CSR_STREAM && !aligned) kind = GKOMI_CSR_VECTOR;
+
+#define GKOMI_ARGS                                                            \
+    n, r, row_ptrs, col_idxs, vals, b, b_stride, c, c_stride, alpha, beta
+    if (kind == GKOMI_CSR_STREAM) {
+        switch (variant) {
+        case 1: return launch_stream<256, 2, 4096>(stream, !no_swizzle, GKOMI_ARGS);
+        case 2: return launch_stream<512, 1, 4096>(stream, !no_swizzle, GKOMI_ARGS);
+        case 3: return launch_stream<256, 4, 8192>(stream, !no_swizzle, GKOMI_ARGS);
+        case 4: return launch_stream<128, 1, 1024>(stream, !no_swizzle, GKOMI_ARGS);
+        case 5: return launch_stream<256, 1, 1536>(stream, !no_swizzle, GKOMI_ARGS);
+        case 6: return launch_stream<512, 1, 3072>(stream, !no_swizzle, GKOMI_ARGS);
+        case 7: return launch_stream<1024, 1, 6144>(stream, !no_swizzle, GKOMI_ARGS);
+        default: return launch_stream<256, 1, 2048>(stream, !no_swizzle, GKOMI_ARGS);
+        }
+    }
+    if (kind == GKOMI_CSR_VECTOR) {
+        int64_t len = max_row_nnz_hint;
+        if (variant != 0) len = variant;  // explicit sub-wave width for tests
+        if (len < 0) len = 8;
+        if (len <= 2) return launch_vector<2>(stream, GKOMI_ARGS);
+        if (len <= 4) return launch_vector<4>(stream, GKOMI_ARGS);
+        if (len <= 8) return launch_vector<8>(stream, GKOMI_ARGS);
+        if (len <= 16) return launch_vector<16>(stream, GKOMI_ARGS);
+        if (len <= 32) return launch_vector<32>(stream, GKOMI_ARGS);
+        return launch_vector<64>(stream, GKOMI_ARGS);
+    }
+#undef GKOMI_ARGS
+    return GKOMI_EINVAL;
+}
+
+
+extern "C" int gkomi_csr_max_row_nnz_i32(gkomi_stream_t stream_,
+                                          int64_t nrows,
+                                          const int32_t* row_ptrs,
+                                          int32_t* result)
+{
+    using namespace gkomi;
+    hipStream_t stream = to_stream(stream_);
+    int err = static_cast<int>(hipMemsetAsync(result, 0, sizeof(int32_t), stream));
+    if (err) return err;
+    if (nrows <= 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(csr_max_row_nnz_kernel, dim3(grid_for(nrows, 256)),
+                       dim3(256), 0, stream, nrows, row_ptrs, result);
+    return check_launch();
+}

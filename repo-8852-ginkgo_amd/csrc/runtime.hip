@@ -1,0 +1,50 @@
+// Executor-level entry points: the parts of gko::HipExecutor that sit on the
+// boundary (core/device_hooks/hip_hooks.cpp:45-140: get_num_devices,
+// set_gpu_property / populate_exec_info, synchronize, error strings).
+#include "common.hpp"
+
+extern "C" const char* gkomi_version(void) { return "gkomi 0.1.0 (gfx950)"; }
+
+extern "C" int gkomi_get_num_devices(int* count)
+{
+    if (count == nullptr) return GKOMI_EINVAL;
+    *count = 0;
+    hipError_t err = hipGetDeviceCount(count);
+    if (err == hipErrorNoDevice) {
+        *count = 0;
+        return GKOMI_SUCCESS;
+    }
+    return static_cast<int>(err);
+}
+
+extern "C" int gkomi_device_properties(int device, int64_t out[4])
+{
+    if (out == nullptr) return GKOMI_EINVAL;
+    hipDeviceProp_t prop;
+    hipError_t err = hipGetDeviceProperties(&prop, device);
+    if (err != hipSuccess) return static_cast<int>(err);
+    out[0] = prop.multiProcessorCount;
+    out[1] = prop.warpSize;
+    out[2] = static_cast<int64_t>(prop.maxSharedMemoryPerMultiProcessor);
+    out[3] = prop.l2CacheSize;
+    return GKOMI_SUCCESS;
+}
+
+extern "C" int gkomi_synchronize(gkomi_stream_t stream)
+{
+    return static_cast<int>(hipStreamSynchronize(gkomi::to_stream(stream)));
+}
+
+extern "C" const char* gkomi_error_string(int code)
+{
+    switch (code) {
+    case GKOMI_SUCCESS: return "success";
+    case GKOMI_EINVAL: return "gkomi: invalid argument";
+    case GKOMI_ENOTSUPPORTED: return "gkomi: not supported";
+    case GKOMI_ENOTIMPL: return "gkomi: not implemented";
+    case GKOMI_EWORKSPACE: return "gkomi: workspace too small";
+    default: break;
+    }
+    if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+    return "gkomi: unknown error";
+}

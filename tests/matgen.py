@@ -1,0 +1,126 @@
+"""Synthetic inputs (test + bench infrastructure, numpy only).
+
+Generators emit CSR in (row, col) order, which Csr::read expects from its
+caller (core/matrix/csr.cpp:453-470).
+"""
+import numpy as np
+
+
+def poisson_2d_5pt(nx, ny=None):
+    """5-point stencil (-1 N, -1 W, 4 C, -1 E, -1 S) on an nx x ny grid,
+    row = i*ny + j, ascending columns.  SURVEY.md 8(d) config P2 at 1000x1000."""
+    ny = nx if ny is None else ny
+    n = nx * ny
+    i, j = np.divmod(np.arange(n, dtype=np.int64), ny)
+    cols = np.stack([np.arange(n) - ny, np.arange(n) - 1, np.arange(n),
+                     np.arange(n) + 1, np.arange(n) + ny], axis=1)
+    valid = np.stack([i > 0, j > 0, np.ones(n, bool), j < ny - 1, i < nx - 1], axis=1)
+    vals = np.broadcast_to(np.array([-1.0, -1.0, 4.0, -1.0, -1.0]), (n, 5))
+    row_ptrs = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(valid.sum(axis=1), out=row_ptrs[1:])
+    return (n, row_ptrs, cols[valid].astype(np.int32),
+            np.ascontiguousarray(vals[valid], dtype=np.float64))
+
+
+def poisson_3d_7pt(nx, ny=None, nz=None):
+    """7-point stencil on nx x ny x nz, row = (i*ny + j)*nz + k (config P3)."""
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    n = nx * ny * nz
+    idx = np.arange(n, dtype=np.int64)
+    k = idx % nz
+    j = (idx // nz) % ny
+    i = idx // (nz * ny)
+    offs = [-ny * nz, -nz, -1, 0, 1, nz, ny * nz]
+    valid = np.stack([i > 0, j > 0, k > 0, np.ones(n, bool), k < nz - 1,
+                      j < ny - 1, i < nx - 1], axis=1)
+    cols = np.stack([idx + o for o in offs], axis=1)
+    vals = np.broadcast_to(np.array([-1.0, -1, -1, 6.0, -1, -1, -1]), (n, 7))
+    row_ptrs = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(valid.sum(axis=1), out=row_ptrs[1:])
+    return (n, row_ptrs, cols[valid].astype(np.int32),
+            np.ascontiguousarray(vals[valid], dtype=np.float64))
+
+
+def random_csr(nrows, ncols, min_nnz, max_nnz, seed, sort=True, dist="uniform"):
+    """Random CSR like gko::test::generate_random_matrix
+    (core/test/utils/matrix_generator.hpp): per-row nnz count from a
+    distribution, distinct columns, normal(0,1)-like values."""
+    rng = np.random.default_rng(seed)
+    if dist == "uniform":
+        counts = rng.integers(min_nnz, max_nnz + 1, size=nrows)
+    else:  # heavy tail: most rows short, a few very long
+        counts = np.minimum(max_nnz, min_nnz + rng.geometric(0.15, size=nrows) - 1)
+        long_rows = rng.choice(nrows, size=max(1, nrows // 100), replace=False)
+        counts[long_rows] = max_nnz
+    counts = np.minimum(counts, ncols)
+    row_ptrs = np.zeros(nrows + 1, dtype=np.int32)
+    np.cumsum(counts, out=row_ptrs[1:])
+    nnz = int(row_ptrs[-1])
+    cols = np.empty(nnz, dtype=np.int32)
+    for r in range(nrows):
+        c = rng.choice(ncols, size=counts[r], replace=False)
+        if sort:
+            c.sort()
+        cols[row_ptrs[r]:row_ptrs[r + 1]] = c
+    vals = rng.standard_normal(nnz)
+    return row_ptrs, cols, vals
+
+
+def read_mtx(path):
+    """Minimal MatrixMarket reader (coordinate real/integer general|symmetric,
+    array real general).  Returns ('coo', nrows, ncols, rows, cols, vals)
+    sorted row-major like gko::read (include/ginkgo/core/base/mtx_io.hpp:89-90),
+    or ('array', nrows, ncols, values[nrows, ncols])."""
+    with open(path) as f:
+        header = f.readline().lower().split()
+        assert header[0] == "%%matrixmarket"
+        layout, field, sym = header[2], header[3], header[4]
+        line = f.readline()
+        while line.startswith("%"):
+            line = f.readline()
+        dims = [int(t) for t in line.split()]
+        body = f.read().split()
+    if layout == "array":
+        nrows, ncols = dims
+        vals = np.array(body, dtype=np.float64).reshape(ncols, nrows).T.copy()
+        return ("array", nrows, ncols, vals)
+    nrows, ncols, nnz = dims
+    per = 2 if field == "pattern" else 3
+    data = np.array(body, dtype=np.float64).reshape(nnz, per)
+    rows = data[:, 0].astype(np.int64) - 1
+    cols = data[:, 1].astype(np.int64) - 1
+    vals = data[:, 2] if per == 3 else np.ones(nnz)
+    if sym == "symmetric":
+        off = rows != cols
+        rows, cols, vals = (np.concatenate([rows, cols[off]]),
+                            np.concatenate([cols, rows[off]]),
+                            np.concatenate([vals, vals[off]]))
+    order = np.lexsort((cols, rows))
+    return ("coo", nrows, ncols, rows[order].astype(np.int32),
+            cols[order].astype(np.int32), vals[order].copy())
+
+
+def coo_to_csr(nrows, rows, cols, vals):
+    row_ptrs = np.zeros(nrows + 1, dtype=np.int32)
+    np.add.at(row_ptrs, rows.astype(np.int64) + 1, 1)
+    np.cumsum(row_ptrs, out=row_ptrs)
+    return row_ptrs, cols.astype(np.int32), vals.astype(np.float64)
+
+
+def dense_to_csr(a):
+    a = np.asarray(a, dtype=np.float64)
+    rows, cols = np.nonzero(a)
+    return coo_to_csr(a.shape[0], rows.astype(np.int32), cols.astype(np.int32), a[rows, cols])
+
+
+def rel_err(a, b):
+    """GKO_ASSERT_MTX_NEAR metric: sqrt(sum|a-b|^2 / max(sum|a|^2, sum|b|^2))
+    (core/test/utils/assertions.hpp:205-233)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = max(float(np.sum(a * a)), float(np.sum(b * b)))
+    num = float(np.sum((a - b) ** 2))
+    if den == 0.0:
+        return 0.0 if num == 0.0 else float("inf")
+    return (num / den) ** 0.5

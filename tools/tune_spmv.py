@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of CSR SpMV kernel variants in ONE process
+(cdna_hip_programming.md §5.4 rule 24).  Prints median/min us per launch, cold
+(rotating copies) and warm, and the algorithmic GB/s."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "repo-8852-ginkgo_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import gkomi
+import matgen
+
+gk = gkomi.lib()
+grid = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+n, rp, ci, v = matgen.poisson_2d_5pt(grid)
+nnz = int(rp[-1])
+bytes_ = 12 * nnz + 4 * (n + 1) + 16 * n
+d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+x = np.sin(0.01 * np.arange(n)).reshape(n, 1)
+ncopies = max(2, int(700e6 // bytes_))
+copies = [(d(rp), d(ci), d(v), d(x), torch.empty((n, 1), dtype=torch.float64, device="cuda")) for _ in range(ncopies)]
+s = torch.cuda.current_stream().cuda_stream
+STREAM, VECTOR = 1, 2
+variants = {"stream_v0(256,1,2048)": STREAM, "v1(256,2,4096)": STREAM | (1 << 8), "v2(512,1,4096)": STREAM | (2 << 8),
+            "v3(256,4,8192)": STREAM | (3 << 8), "v4(128,1,1024)": STREAM | (4 << 8), "v5(256,1,1536)": STREAM | (5 << 8),
+            "v6(512,1,3072)": STREAM | (6 << 8), "v7(1024,1,6144)": STREAM | (7 << 8),
+            "v0_noswz": STREAM | (1 << 16), "v5_noswz": STREAM | (5 << 8) | (1 << 16),
+            "vector4": VECTOR | (4 << 8), "vector8": VECTOR | (8 << 8)}
+extra = [a for a in sys.argv[2:]]
+for e in extra:
+    variants[f"custom_{e}"] = int(e, 0)
+
+
+def run(strategy, cold, reps=200):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(reps):
+        c = copies[i % ncopies] if cold else copies[0]
+        gk.csr_spmv_f64_i32(s, n, n, 1, c[0], c[1], c[2], c[3], 1, c[4], 1, None, None, strategy, 5)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+res = {k: {"cold": [], "warm": []} for k in variants}
+for rnd in range(7):
+    for k, st in variants.items():
+        for mode in ("cold", "warm"):
+            t = run(st, mode == "cold")
+            if rnd > 0:
+                res[k][mode].append(t)
+print(f"grid {grid}: n={n} nnz={nnz} algorithmic bytes={bytes_} copies={ncopies}")
+print(f"{'variant':26s} {'cold med us':>11s} {'min':>7s} {'GB/s':>8s} | {'warm med us':>11s} {'min':>7s} {'GB/s':>8s}")
+for k in variants:
+    c, w = np.array(res[k]["cold"]), np.array(res[k]["warm"])
+    print(f"{k:26s} {np.median(c):11.2f} {c.min():7.2f} {bytes_/np.median(c)/1e3:8.0f} | "
+          f"{np.median(w):11.2f} {w.min():7.2f} {bytes_/np.median(w)/1e3:8.0f}")
