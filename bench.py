@@ -149,7 +149,7 @@ def main():
                            dev(x_host, device), torch.empty((n, 1), dtype=torch.float64, device=device)))
 
         def launch(c):
-            gk.csr_spmv_f64_i32(stream, n, n, 1, c[0], c[1], c[2], c[3], 1, c[4], 1, None, None,
+            gk.csr_spmv_f64_i32(stream, n, n, 1, nnz, c[0], c[1], c[2], c[3], 1, c[4], 1, None, None,
                                 args.strategy, 5)
 
         def step_cold(i):
@@ -212,7 +212,7 @@ def main():
         s /= np.linalg.norm(s)
         sb = dev(s.reshape(n, 1), device)
         b = torch.empty((n, 1), dtype=torch.float64, device=device)
-        gk.csr_spmv_f64_i32(stream, n, n, 1, c[0], c[1], c[2], sb, 1, b, 1, None, None, 0, 5)
+        gk.csr_spmv_f64_i32(stream, n, n, 1, nnz, c[0], c[1], c[2], sb, 1, b, 1, None, None, 0, 5)
         res = solvers.cg_solve(gk, n, c[0], c[1], c[2], b, max_iters=20000, reduction=1e-10)  # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()

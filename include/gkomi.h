@@ -76,9 +76,11 @@ enum {
 
 /* csr::spmv  c = A b   and   csr::advanced_spmv  c = alpha A b + beta c.
  * alpha == NULL && beta == NULL selects the simple form (c is never read).
+ * nnz = Csr::get_num_stored_elements() (known on the host in the reference;
+ * pass -1 if unknown: the kernels that need it are then not selected).
  * reference/matrix/csr_kernels.cpp:75-128. */
 int gkomi_csr_spmv_f64_i32(gkomi_stream_t stream, int64_t nrows, int64_t ncols,
-                           int64_t nrhs, const int32_t* row_ptrs,
+                           int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
                            const int32_t* col_idxs, const double* vals,
                            const double* b, int64_t b_stride, double* c,
                            int64_t c_stride, const double* alpha,
@@ -188,6 +190,41 @@ int gkomi_implicit_residual_norm_f64(gkomi_stream_t s, int64_t nrhs,
 /* set_all_statuses: stop(id, finalized) on every entry */
 int gkomi_set_all_statuses(gkomi_stream_t s, int64_t nrhs, uint8_t stopping_id,
                            int set_finalized, uint8_t* stop_status);
+
+/* ---- CG solver driver (core/solver/cg.cpp:107-193) ----------------------- */
+/* Cg::apply_dense_impl for a CSR system matrix, an optional preconditioner
+ * and the criteria Combined(Iteration(max_iters) [id 1], ResidualNorm(
+ * reduction_factor, baseline) [id 2]) (core/stop/combined.cpp:40,
+ * core/stop/residual_norm.cpp:119-228).  b, x: n x nrhs row-major, stride nrhs.
+ *
+ * precond: z = M r callback (NULL = Identity, which copies r to z like
+ * matrix::Identity::apply); it must enqueue on `s` and not synchronize.
+ * baseline: 0 rhs_norm, 1 initial_resnorm, 2 absolute
+ *           (include/ginkgo/core/stop/residual_norm.hpp mode).
+ * mode 0: the reference's kernel sequence, criterion checked on the host
+ *         every iteration (one blocking 2-byte copy per iteration, like
+ *         hip/stop/residual_norm_kernels.hip.cpp:119-120); any nrhs.
+ * mode 1: fused single-rhs path -- 3 launches per iteration, scalars stay on
+ *         the device, the device stops updating at the iteration the
+ *         criterion fires (same iteration count and iterates as mode 0 up to
+ *         reduction order) and the host polls the status every `check_every`
+ *         iterations.
+ * host_info (may be NULL): [0] iterations, [1] converged (1) / iteration
+ * limit (0), then per rhs j: [2+2j] final ||r||_2 (recurrence residual),
+ * [3+2j] baseline norm.  Needs 2 + 2 nrhs doubles.
+ * Blocks until the solve is complete. */
+typedef int (*gkomi_apply_fn)(void* ctx, gkomi_stream_t s, const double* in,
+                              double* out);
+size_t gkomi_cg_workspace_bytes(int64_t n, int64_t nrhs);
+int gkomi_cg_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                           int64_t nnz, const int32_t* row_ptrs,
+                           const int32_t* col_idxs, const double* vals,
+                           int spmv_strategy, int64_t max_row_nnz_hint,
+                           gkomi_apply_fn precond, void* precond_ctx,
+                           const double* b, double* x, int64_t max_iters,
+                           double reduction_factor, int baseline, int mode,
+                           int check_every, void* workspace,
+                           size_t workspace_bytes, double* host_info);
 
 #ifdef __cplusplus
 }

@@ -35,13 +35,19 @@ __device__ __forceinline__ int xcd_chunked_block(int bid, int per)
     return (bid % num_xcd) * per + bid / num_xcd;
 }
 
-template <int Block, int RowsPerThread, int Tile, bool Advanced, bool Swizzle>
+// Dot = true adds the CG epilogue: partial[logical block] = sum over the
+// block's rows of b[row] * c[row] (fixed-order tree, no atomics), and the whole
+// launch is skipped when stop_status[0] says the solver has stopped.
+template <int Block, int RowsPerThread, int Tile, bool Advanced, bool Swizzle,
+          bool Dot = false>
 __global__ __launch_bounds__(Block) void csr_stream_kernel(
     int nrows, const int32_t* __restrict__ row_ptrs,
     const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
     const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
     int64_t c_stride, const double* __restrict__ alpha_p,
-    const double* __restrict__ beta_p, int nblocks, int per_xcd)
+    const double* __restrict__ beta_p, int nblocks, int per_xcd,
+    double* __restrict__ dot_partial = nullptr,
+    const uint8_t* __restrict__ stop_status = nullptr)
 {
     constexpr int rows_per_block = Block * RowsPerThread;
     constexpr int pairs = Tile / (2 * Block);
@@ -51,6 +57,7 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
     const int logical =
         Swizzle ? xcd_chunked_block(blockIdx.x, per_xcd) : blockIdx.x;
     if (logical >= nblocks) return;
+    if (Dot && status_has_stopped(stop_status[0])) return;
     // rhs column handled by this grid row
     b += blockIdx.y;
     c += blockIdx.y;
@@ -140,12 +147,23 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
         if (t1 < p1) __syncthreads();
     }
 
+    double pq = 0.0;
 #pragma unroll
     for (int i = 0; i < RowsPerThread; ++i) {
         const int row = r0 + tid + i * Block;
-        if (row < r1) c[row * c_stride] = sum[i];
+        if (row < r1) {
+            c[row * c_stride] = sum[i];
+            if (Dot) pq += b[row * b_stride] * sum[i];
+        }
+    }
+    if (Dot) {
+        __shared__ double red[Block / wave_size];
+        __syncthreads();
+        const double total = block_reduce_sum<Block>(pq, red);
+        if (tid == 0) dot_partial[logical] = total;
     }
 }
+
 
 // Variant of the stream kernel's staging for arrays whose base pointers are
 // not 16-/8-byte aligned is not needed: misaligned inputs take the vector
@@ -263,9 +281,57 @@ int launch_vector(hipStream_t stream, int nrows, int nrhs,
 }  // namespace gkomi
 
 
+namespace gkomi {
+
+// q = A p with the dot(p, q) partials epilogue, for the fused CG path
+// (cg_solver.hip).  One partial per row block; returns their count.
+int csr_spmv_dot_launch(hipStream_t stream, int nrows, int64_t nnz,
+                        const int32_t* row_ptrs, const int32_t* col_idxs,
+                        const double* vals, const double* p, double* q,
+                        double* partial, const uint8_t* stop_status,
+                        bool swizzle)
+{
+    constexpr int Block = 256, Tile = 1536;
+    const int nblocks = static_cast<int>(ceildiv(nrows, Block));
+    const int per = static_cast<int>(ceildiv(nblocks, num_xcd));
+    const bool swz = swizzle && nblocks >= 2 * num_xcd;
+    dim3 grid(swz ? per * num_xcd : nblocks, 1);
+    if (swz) {
+        hipLaunchKernelGGL((csr_stream_kernel<Block, 1, Tile, false, true, true>),
+                           grid, dim3(Block), 0, stream, nrows, row_ptrs,
+                           col_idxs, vals, p, int64_t{1}, q, int64_t{1},
+                           nullptr, nullptr, nblocks, per, partial, stop_status);
+    } else {
+        hipLaunchKernelGGL((csr_stream_kernel<Block, 1, Tile, false, false, true>),
+                           grid, dim3(Block), 0, stream, nrows, row_ptrs,
+                           col_idxs, vals, p, int64_t{1}, q, int64_t{1},
+                           nullptr, nullptr, nblocks, per, partial, stop_status);
+    }
+    return check_launch();
+}
+
+int csr_spmv_dot_num_partials(int nrows)
+{
+    return static_cast<int>(ceildiv(nrows, 256));
+}
+
+// swizzle heuristic shared by the automatic strategy: XCD-chunked row blocks
+// pay while the matrix is Infinity-Cache resident (measured 13.7 vs 15.1 us
+// warm at 1M rows) and cost ~4 % once it streams from HBM (57.3 vs 59.6 us at
+// 4M rows) -- profiles/README.md.
+bool csr_auto_swizzle(int64_t nrows, int64_t nnz)
+{
+    if (nnz < 0) return true;
+    return 12 * nnz + 20 * nrows < (int64_t{192} << 20);
+}
+
+}  // namespace gkomi
+
+
 extern "C" int gkomi_csr_spmv_f64_i32(
     gkomi_stream_t stream_, int64_t nrows, int64_t ncols, int64_t nrhs,
-    const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
+    int64_t nnz, const int32_t* row_ptrs, const int32_t* col_idxs,
+    const double* vals,
     const double* b, int64_t b_stride, double* c, int64_t c_stride,
     const double* alpha, const double* beta, int strategy,
     int64_t max_row_nnz_hint)
@@ -273,7 +339,7 @@ extern "C" int gkomi_csr_spmv_f64_i32(
     using namespace gkomi;
     if (nrows < 0 || ncols < 0 || nrhs < 0) return GKOMI_EINVAL;
     if ((alpha == nullptr) != (beta == nullptr)) return GKOMI_EINVAL;
-    if (nrows > INT32_MAX - 1024 || nrhs > 65535) return GKOMI_ENOTSUPPORTED;
+    if (nrows > INT32_MAX - 1024 || nrhs > 65535 || nnz > INT32_MAX) return GKOMI_ENOTSUPPORTED;
     // empty output: no-op (hip/matrix/csr_kernels.hip.cpp:291-292)
     if (nrows == 0 || nrhs == 0) return GKOMI_SUCCESS;
     if (b_stride < nrhs || c_stride < nrhs) return GKOMI_EINVAL;
@@ -282,8 +348,9 @@ extern "C" int gkomi_csr_spmv_f64_i32(
     const int r = static_cast<int>(nrhs);
 
     int kind = strategy & 0xff;
-    const int variant = (strategy >> 8) & 0xff;
-    const bool no_swizzle = (strategy >> 16) & 1;
+    int variant = (strategy >> 8) & 0xff;
+    bool no_swizzle = (strategy >> 16) & 1;
+    const bool automatic = kind == GKOMI_CSR_AUTO;
     const bool aligned = (reinterpret_cast<uintptr_t>(vals) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(col_idxs) % 8 == 0);
     if (kind == GKOMI_CSR_AUTO) {
@@ -295,6 +362,11 @@ extern "C" int gkomi_csr_spmv_f64_i32(
     }
     if (kind == GKOMI_CSR_BALANCED) kind = GKOMI_CSR_VECTOR;
     if (kind == GKOMI_CSR_STREAM && !aligned) kind = GKOMI_CSR_VECTOR;
+    if (automatic) {
+        // 256 threads, 256 rows, 1536-nonzero tile: fastest measured
+        variant = kind == GKOMI_CSR_STREAM ? 5 : 0;
+        no_swizzle = !csr_auto_swizzle(nrows, nnz);
+    }
 
 #define GKOMI_ARGS                                                            \
     n, r, row_ptrs, col_idxs, vals, b, b_stride, c, c_stride, alpha, beta
@@ -307,6 +379,12 @@ extern "C" int gkomi_csr_spmv_f64_i32(
         case 5: return launch_stream<256, 1, 1536>(stream, !no_swizzle, GKOMI_ARGS);
         case 6: return launch_stream<512, 1, 3072>(stream, !no_swizzle, GKOMI_ARGS);
         case 7: return launch_stream<1024, 1, 6144>(stream, !no_swizzle, GKOMI_ARGS);
+        case 8: return launch_stream<64, 1, 384>(stream, !no_swizzle, GKOMI_ARGS);
+        case 9: return launch_stream<192, 1, 1152>(stream, !no_swizzle, GKOMI_ARGS);
+        case 10: return launch_stream<320, 1, 1920>(stream, !no_swizzle, GKOMI_ARGS);
+        case 11: return launch_stream<128, 1, 768>(stream, !no_swizzle, GKOMI_ARGS);
+        case 12: return launch_stream<256, 1, 1024>(stream, !no_swizzle, GKOMI_ARGS);
+        case 13: return launch_stream<384, 1, 2304>(stream, !no_swizzle, GKOMI_ARGS);
         default: return launch_stream<256, 1, 2048>(stream, !no_swizzle, GKOMI_ARGS);
         }
     }

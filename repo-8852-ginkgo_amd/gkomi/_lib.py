@@ -35,6 +35,7 @@ _SCALARS = {
     "double": ctypes.c_double,
     "float": ctypes.c_float,
     "gkomi_stream_t": ctypes.c_void_p,
+    "gkomi_apply_fn": ctypes.c_void_p,
 }
 
 

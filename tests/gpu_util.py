@@ -25,6 +25,7 @@ class DevCsr:
         self.row_ptrs = dev(np.asarray(row_ptrs, np.int32))
         self.col_idxs = dev(np.asarray(col_idxs, np.int32))
         self.vals = dev(np.asarray(vals, np.float64))
+        self.nnz = int(np.asarray(row_ptrs)[-1]) if nrows > 0 else 0
         self.max_row_nnz = int(np.max(np.diff(row_ptrs))) if nrows > 0 else 0
 
 
@@ -35,7 +36,7 @@ def csr_apply(gk, A, b, c=None, alpha=None, beta=None, strategy=0, hint=None):
         c = torch.full((A.nrows, nrhs), float("nan"), dtype=torch.float64, device=b.device)
     al = dev(np.array([alpha], np.float64)) if alpha is not None else None
     be = dev(np.array([beta], np.float64)) if beta is not None else None
-    gk.csr_spmv_f64_i32(stream_ptr(), A.nrows, A.ncols, nrhs, A.row_ptrs, A.col_idxs, A.vals,
+    gk.csr_spmv_f64_i32(stream_ptr(), A.nrows, A.ncols, nrhs, A.nnz, A.row_ptrs, A.col_idxs, A.vals,
                         b, b.stride(0), c, c.stride(0), al, be, strategy,
                         A.max_row_nnz if hint is None else hint)
     return c

@@ -31,7 +31,7 @@ def test_no_torch_types_in_abi():
     for name, (ret, params) in gkomi.parse_header().items():
         for ctype, _, _ in params:
             assert ctype in ("int", "int32_t", "int64_t", "uint8_t", "size_t", "double",
-                             "float", "void", "gkomi_stream_t", "char"), (name, ctype)
+                             "float", "void", "gkomi_stream_t", "gkomi_apply_fn", "char"), (name, ctype)
 
 
 def test_version_and_error_strings(gk):
@@ -45,12 +45,12 @@ def test_version_and_error_strings(gk):
 def test_invalid_arguments_are_rejected_before_launch(gk):
     # negative sizes / alpha without beta: GKOMI_EINVAL, no HIP call involved
     with pytest.raises(gkomi.GkomiError) as e:
-        gk.csr_spmv_f64_i32(None, -1, 1, 1, None, None, None, None, 1, None, 1, None, None, 0, -1)
+        gk.csr_spmv_f64_i32(None, -1, 1, 1, -1, None, None, None, None, 1, None, 1, None, None, 0, -1)
     assert e.value.code == -1
     with pytest.raises(gkomi.GkomiError):
-        gk.csr_spmv_f64_i32(None, 1, 1, 1, 8, 8, 8, 8, 1, 8, 1, 8, None, 0, -1)
+        gk.csr_spmv_f64_i32(None, 1, 1, 1, -1, 8, 8, 8, 8, 1, 8, 1, 8, None, 0, -1)
     # empty output is a no-op (hip/matrix/csr_kernels.hip.cpp:291-292)
-    assert gk.csr_spmv_f64_i32(None, 0, 5, 1, None, None, None, None, 1, None, 1, None, None, 0, -1) == 0
+    assert gk.csr_spmv_f64_i32(None, 0, 5, 1, 0, None, None, None, None, 1, None, 1, None, None, 0, -1) == 0
     assert gk.dense_scale_f64(None, 0, 3, None, 1, None, 3) == 0
     with pytest.raises(gkomi.GkomiError):
         gk.dense_scale_f64(None, 2, 3, 8, 2, 8, 3)  # alpha must be 1 or ncols wide

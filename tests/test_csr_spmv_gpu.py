@@ -19,6 +19,8 @@ STREAM, VECTOR = 1, 2
 STRATEGIES = {"auto": 0, "stream": STREAM, "stream_v1": STREAM | (1 << 8),
               "stream_v2": STREAM | (2 << 8), "stream_v3": STREAM | (3 << 8),
               "stream_v4": STREAM | (4 << 8), "stream_noswz": STREAM | (1 << 16),
+              "stream_v5": STREAM | (5 << 8), "stream_v8": STREAM | (8 << 8), "stream_v9": STREAM | (9 << 8),
+              "stream_v13": STREAM | (13 << 8), "stream_v11_noswz": STREAM | (11 << 8) | (1 << 16),
               "vector": VECTOR, "vector64": VECTOR | (64 << 8), "vector2": VECTOR | (2 << 8)}
 BITEXACT = {k for k in STRATEGIES if k.startswith("stream") or k == "auto"}
 
@@ -73,7 +75,7 @@ def test_random_532x231(gk, oracle, strategy, advanced, nrhs, sort):
         assert matgen.rel_err(got, expect) <= 1e-14
 
 
-@pytest.mark.parametrize("strategy", ["stream", "stream_v1", "stream_v3", "vector", "auto"])
+@pytest.mark.parametrize("strategy", ["stream", "stream_v1", "stream_v3", "stream_v5", "stream_v8", "stream_v11_noswz", "vector", "auto"])
 def test_ragged_and_empty_rows(gk, oracle, strategy):
     # empty rows, rows longer than one LDS tile (8192), an empty last row
     rng = np.random.default_rng(7)
@@ -114,7 +116,7 @@ def test_strided_rhs_and_output(gk, oracle):
     A = DevCsr(n, n, rp, ci, v)
     bd, cd = dev(bfull), dev(cfull)
     # 2 rhs living in a 5-wide / 4-wide buffer
-    gk.csr_spmv_f64_i32(torch.cuda.current_stream().cuda_stream, n, n, 2, A.row_ptrs, A.col_idxs,
+    gk.csr_spmv_f64_i32(torch.cuda.current_stream().cuda_stream, n, n, 2, A.nnz, A.row_ptrs, A.col_idxs,
                         A.vals, bd, 5, cd, 4, None, None, STREAM, 5)
     expect = np.full((n, 2), np.nan)
     oracle.ref_csr_spmv(n, 2, rp, ci, v, bfull, 5, expect, 2)
@@ -131,7 +133,7 @@ def test_misaligned_arrays_fall_back(gk, oracle):
     cols_buf = dev(np.concatenate([[0], ci]).astype(np.int32))
     rpd = dev(rp)
     c = torch.empty((n, 1), dtype=torch.float64, device="cuda:0")
-    gk.csr_spmv_f64_i32(torch.cuda.current_stream().cuda_stream, n, n, 1, rpd, cols_buf[1:],
+    gk.csr_spmv_f64_i32(torch.cuda.current_stream().cuda_stream, n, n, 1, int(rp[-1]), rpd, cols_buf[1:],
                         vals_buf[1:], dev(b), 1, c, 1, None, None, 0, 5)
     assert matgen.rel_err(host(c), _oracle_apply(oracle, n, rp, ci, v, b)) <= 1e-14
 
@@ -153,7 +155,7 @@ def test_full_size_poisson_p2_bitexact_and_linear(gk, oracle):
     A = DevCsr(n, n, rp, ci, v)
     xd = dev(x)
     expect = _oracle_apply(oracle, n, rp, ci, v, x)
-    for s in ("stream", "stream_v1", "stream_v2", "stream_noswz"):
+    for s in ("stream", "stream_v1", "stream_v2", "stream_noswz", "stream_v5", "stream_v8", "stream_v9", "stream_v13"):
         got = host(csr_apply(gk, A, xd, strategy=STRATEGIES[s]))
         assert np.array_equal(got, expect), s
     got2 = host(csr_apply(gk, A, xd, strategy=STRATEGIES["stream"]))

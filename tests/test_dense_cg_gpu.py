@@ -126,7 +126,7 @@ def test_dense_reductions_vs_oracle(gk, oracle, shape):
     e = np.zeros((1, nc))
     # tolerance: sequential vs tree sums differ by O(eps*sqrt(n)) relative to sum|x y|
     def close(got, exp, scale):
-        return np.all(np.abs(got - exp) <= 1e-14 * np.maximum(scale, 1e-300) * max(1.0, np.log2(nr + 1)))
+        return np.all(np.abs(got - exp) <= 4 * np.finfo(np.float64).eps * max(1.0, np.sqrt(nr)) * np.maximum(scale, 1e-300))
     gk.dense_compute_dot_f64(s, nr, nc, xd, nc, yd, nc, res, ws, nb)
     oracle.ref_dense_compute_dot(nr, nc, x, nc, y, nc, e)
     assert close(host(res), e, np.sum(np.abs(x * y), axis=0))
@@ -135,13 +135,14 @@ def test_dense_reductions_vs_oracle(gk, oracle, shape):
     assert np.array_equal(first, host(res))  # no atomics: reproducible
     gk.dense_compute_norm2_f64(s, nr, nc, xd, nc, res, ws, nb)
     oracle.ref_dense_compute_norm2(nr, nc, x, nc, e)
-    assert np.all(np.abs(host(res) - e) <= 1e-14 * e)
+    tol = 4 * np.finfo(np.float64).eps * max(1.0, np.sqrt(nr))  # sequential-vs-tree sum
+    assert np.all(np.abs(host(res) - e) <= tol * e)
     gk.dense_compute_squared_norm2_f64(s, nr, nc, xd, nc, res, ws, nb)
     oracle.ref_dense_compute_squared_norm2(nr, nc, x, nc, e)
-    assert np.all(np.abs(host(res) - e) <= 1e-14 * e)
+    assert np.all(np.abs(host(res) - e) <= tol * e)
     gk.dense_compute_norm1_f64(s, nr, nc, xd, nc, res, ws, nb)
     oracle.ref_dense_compute_norm1(nr, nc, x, nc, e)
-    assert np.all(np.abs(host(res) - e) <= 1e-14 * e)
+    assert np.all(np.abs(host(res) - e) <= tol * e)
 
 
 def test_reduction_workspace_too_small_is_an_error(gk):

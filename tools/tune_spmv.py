@@ -29,7 +29,10 @@ variants = {"stream_v0(256,1,2048)": STREAM, "v1(256,2,4096)": STREAM | (1 << 8)
             "v3(256,4,8192)": STREAM | (3 << 8), "v4(128,1,1024)": STREAM | (4 << 8), "v5(256,1,1536)": STREAM | (5 << 8),
             "v6(512,1,3072)": STREAM | (6 << 8), "v7(1024,1,6144)": STREAM | (7 << 8),
             "v0_noswz": STREAM | (1 << 16), "v5_noswz": STREAM | (5 << 8) | (1 << 16),
-            "vector4": VECTOR | (4 << 8), "vector8": VECTOR | (8 << 8)}
+            "vector4": VECTOR | (4 << 8),
+            "v8(64,1,384)": STREAM | (8 << 8), "v9(192,1,1152)": STREAM | (9 << 8), "v10(320,1,1920)": STREAM | (10 << 8),
+            "v11(128,1,768)": STREAM | (11 << 8), "v12(256,1,1024)": STREAM | (12 << 8), "v13(384,1,2304)": STREAM | (13 << 8),
+            "v9_noswz": STREAM | (9 << 8) | (1 << 16), "v11_noswz": STREAM | (11 << 8) | (1 << 16)}
 extra = [a for a in sys.argv[2:]]
 for e in extra:
     variants[f"custom_{e}"] = int(e, 0)
@@ -40,7 +43,7 @@ def run(strategy, cold, reps=200):
     e0.record()
     for i in range(reps):
         c = copies[i % ncopies] if cold else copies[0]
-        gk.csr_spmv_f64_i32(s, n, n, 1, c[0], c[1], c[2], c[3], 1, c[4], 1, None, None, strategy, 5)
+        gk.csr_spmv_f64_i32(s, n, n, 1, nnz, c[0], c[1], c[2], c[3], 1, c[4], 1, None, None, strategy, 5)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
