@@ -43,6 +43,19 @@ def algorithmic_bytes(nrows, ncols, nnz):
     return 12 * nnz + 4 * (nrows + 1) + 8 * ncols + 8 * nrows
 
 
+def traffic_from_profiles():
+    """Per-launch HBM bytes of the dominant kernel from the committed PMC
+    passes (profiles/r*_traffic.json, newest round); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        return int(json.load(open(files[-1]))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,7 +204,7 @@ def main():
         achieved = bytes_per_launch / kern_s / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                           "traffic": None,
+                           "traffic": traffic_from_profiles() if not distributed else None,
                            "kernel": "csr_stream_kernel" if not distributed else "distributed apply",
                            "bytes_per_launch": bytes_per_launch,
                            "us_per_launch": round(kern_s * 1e6, 3)}

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for bench.py on the GPU box (run through
+# gpurun).  Kernel-trace/stats and each PMC counter go in SEPARATE passes
+# (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2; gpurun
+# refuses --pmc mixed with tracing).  Output: gpurun_out/<tag>/...
+set -o pipefail
+TAG=${1:-prof_r1}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--no-cpu-baseline --steps 200 --warmup 20"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS --no-cg > $OUT/pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $ARGS --no-cg > $OUT/pmc_write.log 2>&1 || exit 1
+# calibration of FETCH_SIZE on a known byte count in a comparable access mix
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_membench -- python3 $ROOT/tools/membench.py 1000 > $OUT/pmc_fetch_membench.log 2>&1 || exit 1
+python3 $ROOT/tools/summarize_profile.py $OUT > $OUT/summary.md
+cat $OUT/summary.md
