@@ -191,6 +191,120 @@ int gkomi_implicit_residual_norm_f64(gkomi_stream_t s, int64_t nrhs,
 int gkomi_set_all_statuses(gkomi_stream_t s, int64_t nrhs, uint8_t stopping_id,
                            int set_finalized, uint8_t* stop_status);
 
+/* ---- ELL / SELL-P / COO / Hybrid SpMV (core/matrix/{ell,sellp,coo}_kernels.hpp,
+ *      core/matrix/hybrid.cpp:133-159) -------------------------------------- */
+/* alpha == beta == NULL: c = A b; otherwise c = alpha A b + beta c.
+ * ELL is column-major: entry (row, i) at row + i*stride, padding col == -1
+ * (reference/matrix/ell_kernels.cpp:57-157). */
+int gkomi_ell_spmv_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                           int64_t nrhs, int64_t num_stored_per_row,
+                           int64_t stride, const int32_t* col_idxs,
+                           const double* vals, const double* b,
+                           int64_t b_stride, double* c, int64_t c_stride,
+                           const double* alpha, const double* beta);
+/* SELL-P: entry (row r of slice s, i) at (slice_sets[s]+i)*slice_size + r;
+ * slice_sets/slice_lengths are size_type = 64-bit (sellp.hpp:382,
+ * reference/matrix/sellp_kernels.cpp:57-131). */
+int gkomi_sellp_spmv_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                             int64_t nrhs, int64_t slice_size,
+                             const uint64_t* slice_sets,
+                             const uint64_t* slice_lengths,
+                             const int32_t* col_idxs, const double* vals,
+                             const double* b, int64_t b_stride, double* c,
+                             int64_t c_stride, const double* alpha,
+                             const double* beta);
+/* coo::spmv / advanced_spmv = fill|scale + spmv2 (reference/matrix/coo_kernels.cpp:63-88) */
+int gkomi_coo_spmv_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                           int64_t nrhs, int64_t nnz, const int32_t* row_idxs,
+                           const int32_t* col_idxs, const double* vals,
+                           const double* b, int64_t b_stride, double* c,
+                           int64_t c_stride, const double* alpha,
+                           const double* beta);
+/* coo::spmv2 / advanced_spmv2: c += [alpha] A b (:92-131); alpha may be NULL */
+int gkomi_coo_spmv2_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                            int64_t nrhs, int64_t nnz, const int32_t* row_idxs,
+                            const int32_t* col_idxs, const double* vals,
+                            const double* b, int64_t b_stride, double* c,
+                            int64_t c_stride, const double* alpha);
+/* Hybrid::apply_impl: ELL apply then COO apply2 */
+int gkomi_hybrid_spmv_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                              int64_t nrhs, int64_t ell_num_stored_per_row,
+                              int64_t ell_stride, const int32_t* ell_col_idxs,
+                              const double* ell_vals, int64_t coo_nnz,
+                              const int32_t* coo_row_idxs,
+                              const int32_t* coo_col_idxs,
+                              const double* coo_vals, const double* b,
+                              int64_t b_stride, double* c, int64_t c_stride,
+                              const double* alpha, const double* beta);
+
+/* ---- index components and format conversions (bit-exact) ---------------- */
+/* components::prefix_sum: exclusive, in place
+ * (reference/components/prefix_sum_kernels.cpp:43-53) */
+size_t gkomi_prefix_sum_workspace_bytes(int64_t n);
+int gkomi_prefix_sum_i32(gkomi_stream_t s, int32_t* counts, int64_t n,
+                         void* workspace, size_t workspace_bytes);
+int gkomi_prefix_sum_i64(gkomi_stream_t s, int64_t* counts, int64_t n,
+                         void* workspace, size_t workspace_bytes);
+/* components::convert_ptrs_to_idxs / convert_idxs_to_ptrs / convert_ptrs_to_sizes
+ * (reference/components/format_conversion_kernels.cpp:50-92); idxs_to_ptrs
+ * needs prefix-sum scratch for num_blocks + 1 entries */
+int gkomi_convert_ptrs_to_idxs_i32(gkomi_stream_t s, const int32_t* ptrs,
+                                   int64_t num_blocks, int32_t* idxs);
+int gkomi_convert_idxs_to_ptrs_i32(gkomi_stream_t s, const int32_t* idxs,
+                                   int64_t num_idxs, int64_t num_blocks,
+                                   int32_t* ptrs, void* workspace,
+                                   size_t workspace_bytes);
+int gkomi_convert_ptrs_to_sizes_i32(gkomi_stream_t s, const int32_t* ptrs,
+                                    int64_t num_blocks, uint64_t* sizes);
+/* csr::convert_to_ell (reference/matrix/csr_kernels.cpp:431-459) */
+int gkomi_csr_convert_to_ell_f64_i32(gkomi_stream_t s, int64_t nrows,
+                                     const int32_t* row_ptrs,
+                                     const int32_t* col_idxs,
+                                     const double* vals,
+                                     int64_t num_stored_per_row,
+                                     int64_t stride, int32_t* ell_col_idxs,
+                                     double* ell_vals);
+/* sellp::compute_slice_sets (reference/matrix/sellp_kernels.cpp:134-159):
+ * slice_lengths[num_slices], slice_sets[num_slices + 1] */
+int gkomi_sellp_compute_slice_sets_i32(gkomi_stream_t s,
+                                       const int32_t* row_ptrs, int64_t nrows,
+                                       int64_t slice_size,
+                                       int64_t stride_factor,
+                                       uint64_t* slice_sets,
+                                       uint64_t* slice_lengths,
+                                       void* workspace, size_t workspace_bytes);
+/* csr::convert_to_sellp (reference/matrix/csr_kernels.cpp:385-425) */
+int gkomi_csr_convert_to_sellp_f64_i32(gkomi_stream_t s, int64_t nrows,
+                                       const int32_t* row_ptrs,
+                                       const int32_t* col_idxs,
+                                       const double* vals, int64_t slice_size,
+                                       const uint64_t* slice_sets,
+                                       const uint64_t* slice_lengths,
+                                       int32_t* out_col_idxs, double* out_vals);
+/* hybrid::compute_coo_row_ptrs (reference/matrix/hybrid_kernels.cpp:60-71): nrows + 1 entries */
+int gkomi_hybrid_compute_coo_row_ptrs_i32(gkomi_stream_t s,
+                                          const int32_t* row_ptrs,
+                                          int64_t nrows, int64_t ell_lim,
+                                          int64_t* coo_row_ptrs,
+                                          void* workspace,
+                                          size_t workspace_bytes);
+/* csr::convert_to_hybrid (reference/matrix/csr_kernels.cpp:768-812) */
+int gkomi_csr_convert_to_hybrid_f64_i32(
+    gkomi_stream_t s, int64_t nrows, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, const int64_t* coo_row_ptrs,
+    int64_t ell_lim, int64_t ell_stride, int32_t* ell_col_idxs,
+    double* ell_vals, int32_t* coo_row_idxs, int32_t* coo_col_idxs,
+    double* coo_vals);
+/* Hybrid strategy_type::compute_ell_num_stored_elements_per_row
+ * (include/ginkgo/core/matrix/hybrid.hpp:206-370), host side like the
+ * reference (blocking copy of row_ptrs).  kind: 0 column_limit(num_columns),
+ * 1 imbalance_limit(percent), 2 imbalance_bounded_limit(percent, ratio),
+ * 3 minimal_storage_limit, 4 automatic. */
+int gkomi_hybrid_ell_width_i32(gkomi_stream_t s, const int32_t* row_ptrs,
+                               int64_t nrows, int kind, double percent,
+                               double ratio, int64_t num_columns,
+                               int64_t* host_result);
+
 /* ---- CG solver driver (core/solver/cg.cpp:107-193) ----------------------- */
 /* Cg::apply_dense_impl for a CSR system matrix, an optional preconditioner
  * and the criteria Combined(Iteration(max_iters) [id 1], ResidualNorm(

@@ -1,0 +1,358 @@
+// ELL / SELL-P / COO / Hybrid SpMV for gfx950.  Replaces
+// gko::kernels::hip::{ell,sellp,coo}::{spmv, advanced_spmv, spmv2,
+// advanced_spmv2} (core/matrix/{ell,sellp,coo}_kernels.hpp) and the Hybrid
+// composition of core/matrix/hybrid.cpp:133-159.
+//
+// ELL / SELL-P: column-major storage makes the per-lane loads coalesced by
+// construction (8 B values + 4 B columns per lane); one thread owns one row
+// and accumulates in a register in storage order -> bit-identical to
+// reference/matrix/ell_kernels.cpp:57-157, sellp_kernels.cpp:57-131.
+// Algorithmic bytes: ELL 12*stride*K + 8*ncols + 8*nrows; SELL-P
+// 12*slice_size*total_cols + 16*num_slices + 8*ncols + 8*nrows.
+//
+// COO: 16 B/nonzero streamed with 8-/16-B per-lane loads into an LDS tile of
+// products + row ids; the thread that owns the first element of a row segment
+// adds the segment left to right and issues ONE fp64 atomic per segment.  For
+// row-sorted input every row that lies inside one tile is summed exactly in
+// the reference's order (coo_kernels.cpp:92-131); rows cut by a tile boundary
+// get two atomics (commutative: still deterministic); only rows spread over
+// three or more tiles depend on arrival order.
+#include "common.hpp"
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace gkomi {
+namespace {
+
+constexpr int block = 256;
+
+template <bool Advanced>
+__global__ __launch_bounds__(block) void ell_spmv_kernel(
+    int64_t nrows, int64_t num_stored, int64_t stride,
+    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
+    int64_t c_stride, const double* __restrict__ alpha_p,
+    const double* __restrict__ beta_p)
+{
+    b += blockIdx.y;
+    c += blockIdx.y;
+    double alpha = 1.0, beta = 0.0;
+    if (Advanced) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    const int64_t step = static_cast<int64_t>(gridDim.x) * block;
+    for (int64_t row = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
+         row < nrows; row += step) {
+        double result = Advanced ? c[row * c_stride] * beta : 0.0;
+        int64_t i = 0;
+        // 4 columns at a time: all 8 loads + 4 gathers in flight, then the
+        // in-order accumulation
+        for (; i + 4 <= num_stored; i += 4) {
+            double v[4];
+            int32_t col[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = vals[row + (i + u) * stride];
+                col[u] = col_idxs[row + (i + u) * stride];
+            }
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x[u] = b[max(col[u], 0) * b_stride];  // padding (-1) reads b[0], unused
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (col[u] != -1) {
+                    result += Advanced ? (alpha * v[u]) * x[u] : v[u] * x[u];
+                }
+            }
+        }
+        for (; i < num_stored; ++i) {
+            const double v = vals[row + i * stride];
+            const int32_t col = col_idxs[row + i * stride];
+            if (col != -1) {
+                const double x = b[col * b_stride];
+                result += Advanced ? (alpha * v) * x : v * x;
+            }
+        }
+        c[row * c_stride] = result;
+    }
+}
+
+template <bool Advanced>
+__global__ __launch_bounds__(block) void sellp_spmv_kernel(
+    int64_t nrows, int64_t slice_size, const uint64_t* __restrict__ slice_sets,
+    const uint64_t* __restrict__ slice_lengths,
+    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
+    int64_t c_stride, const double* __restrict__ alpha_p,
+    const double* __restrict__ beta_p)
+{
+    b += blockIdx.y;
+    c += blockIdx.y;
+    double alpha = 1.0, beta = 0.0;
+    if (Advanced) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    const int64_t step = static_cast<int64_t>(gridDim.x) * block;
+    for (int64_t row = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
+         row < nrows; row += step) {
+        const int64_t slice = row / slice_size;
+        const int64_t local = row % slice_size;
+        const int64_t len = static_cast<int64_t>(slice_lengths[slice]);
+        const int64_t base =
+            static_cast<int64_t>(slice_sets[slice]) * slice_size + local;
+        double result = Advanced ? c[row * c_stride] * beta : 0.0;
+        int64_t i = 0;
+        for (; i + 4 <= len; i += 4) {
+            double v[4];
+            int32_t col[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = vals[base + (i + u) * slice_size];
+                col[u] = col_idxs[base + (i + u) * slice_size];
+            }
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x[u] = b[max(col[u], 0) * b_stride];  // padding (-1) reads b[0], unused
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (col[u] != -1) {
+                    result += Advanced ? (alpha * v[u]) * x[u] : v[u] * x[u];
+                }
+            }
+        }
+        for (; i < len; ++i) {
+            const double v = vals[base + i * slice_size];
+            const int32_t col = col_idxs[base + i * slice_size];
+            if (col != -1) {
+                const double x = b[col * b_stride];
+                result += Advanced ? (alpha * v) * x : v * x;
+            }
+        }
+        c[row * c_stride] = result;
+    }
+}
+
+constexpr int coo_items = 6;
+constexpr int coo_tile = block * coo_items;  // 1536 nonzeros per workgroup
+
+template <bool Scaled, bool Vec>
+__global__ __launch_bounds__(block) void coo_spmv2_kernel(
+    int64_t nnz, const int32_t* __restrict__ row_idxs,
+    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
+    int64_t c_stride, const double* __restrict__ alpha_p)
+{
+    __shared__ __attribute__((aligned(16))) double prod[coo_tile];
+    __shared__ __attribute__((aligned(8))) int32_t rowid[coo_tile];
+    b += blockIdx.y;
+    c += blockIdx.y;
+    const double alpha = Scaled ? alpha_p[0] : 1.0;
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * coo_tile;
+    const int count = static_cast<int>(min(static_cast<int64_t>(coo_tile), nnz - base));
+    const int tid = threadIdx.x;
+    if (Vec) {
+        constexpr int pairs = coo_items / 2;
+        double2 v[pairs];
+        int2 r[pairs], cc[pairs];
+#pragma unroll
+        for (int u = 0; u < pairs; ++u) {
+            const int e = 2 * (tid + u * block);
+            v[u] = make_double2(0.0, 0.0);
+            r[u] = make_int2(0, 0);
+            cc[u] = make_int2(0, 0);
+            if (e + 1 < count) {
+                v[u] = *reinterpret_cast<const double2*>(vals + base + e);
+                r[u] = *reinterpret_cast<const int2*>(row_idxs + base + e);
+                cc[u] = *reinterpret_cast<const int2*>(col_idxs + base + e);
+            } else if (e < count) {
+                v[u].x = vals[base + e];
+                r[u].x = row_idxs[base + e];
+                cc[u].x = col_idxs[base + e];
+            }
+        }
+        double2 x[pairs];
+#pragma unroll
+        for (int u = 0; u < pairs; ++u) {
+            x[u].x = b[cc[u].x * b_stride];
+            x[u].y = b[cc[u].y * b_stride];
+        }
+#pragma unroll
+        for (int u = 0; u < pairs; ++u) {
+            const int e = 2 * (tid + u * block);
+            double2 pr;
+            pr.x = Scaled ? (alpha * v[u].x) * x[u].x : v[u].x * x[u].x;
+            pr.y = Scaled ? (alpha * v[u].y) * x[u].y : v[u].y * x[u].y;
+            *reinterpret_cast<double2*>(prod + e) = pr;
+            *reinterpret_cast<int2*>(rowid + e) = r[u];
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < coo_items; ++u) {
+            const int e = tid + u * block;
+            if (e < count) {
+                const double val = vals[base + e];
+                const double x = b[col_idxs[base + e] * b_stride];
+                prod[e] = Scaled ? (alpha * val) * x : val * x;
+                rowid[e] = row_idxs[base + e];
+            }
+        }
+    }
+    __syncthreads();
+    // segment heads inside this thread's run of coo_items elements
+    const int first = tid * coo_items;
+#pragma unroll
+    for (int u = 0; u < coo_items; ++u) {
+        const int e = first + u;
+        if (e < count) {
+            const int row = rowid[e];
+            if (e == 0 || rowid[e - 1] != row) {
+                double sum = prod[e];
+                int k = e + 1;
+                while (k < count && rowid[k] == row) {
+                    sum += prod[k];
+                    ++k;
+                }
+                unsafeAtomicAdd(c + row * c_stride, sum);
+            }
+        }
+    }
+}
+
+inline bool aligned_to(const void* p, size_t a)
+{
+    return reinterpret_cast<uintptr_t>(p) % a == 0;
+}
+
+int coo_launch(hipStream_t s, int64_t nrhs, int64_t nnz, const int32_t* rows,
+               const int32_t* cols, const double* vals, const double* b,
+               int64_t b_stride, double* c, int64_t c_stride,
+               const double* alpha)
+{
+    if (nnz == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    const int64_t nblocks = ceildiv(nnz, coo_tile);
+    if (nblocks > INT32_MAX) return GKOMI_ENOTSUPPORTED;
+    dim3 grid(static_cast<unsigned>(nblocks), static_cast<unsigned>(nrhs));
+    const bool vec = aligned_to(vals, 16) && aligned_to(rows, 8) && aligned_to(cols, 8);
+#define GKOMI_COO(SC, VE)                                                     \
+    hipLaunchKernelGGL((coo_spmv2_kernel<SC, VE>), grid, dim3(block), 0, s,   \
+                       nnz, rows, cols, vals, b, b_stride, c, c_stride, alpha)
+    if (alpha != nullptr) {
+        if (vec) GKOMI_COO(true, true); else GKOMI_COO(true, false);
+    } else {
+        if (vec) GKOMI_COO(false, true); else GKOMI_COO(false, false);
+    }
+#undef GKOMI_COO
+    return check_launch();
+}
+
+}  // namespace
+}  // namespace gkomi
+
+using namespace gkomi;
+
+extern "C" int gkomi_ell_spmv_f64_i32(
+    gkomi_stream_t s, int64_t nrows, int64_t ncols, int64_t nrhs,
+    int64_t num_stored_per_row, int64_t stride, const int32_t* col_idxs,
+    const double* vals, const double* b, int64_t b_stride, double* c,
+    int64_t c_stride, const double* alpha, const double* beta)
+{
+    if (nrows < 0 || ncols < 0 || nrhs < 0 || num_stored_per_row < 0) return GKOMI_EINVAL;
+    if ((alpha == nullptr) != (beta == nullptr)) return GKOMI_EINVAL;
+    if (nrows == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    if (stride < nrows || b_stride < nrhs || c_stride < nrhs) return GKOMI_EINVAL;
+    if (nrhs > 65535) return GKOMI_ENOTSUPPORTED;
+    dim3 grid(grid_for(nrows, block, 1 << 20), static_cast<unsigned>(nrhs));
+    if (alpha != nullptr) {
+        hipLaunchKernelGGL(ell_spmv_kernel<true>, grid, dim3(block), 0, to_stream(s), nrows,
+                           num_stored_per_row, stride, col_idxs, vals, b, b_stride, c, c_stride,
+                           alpha, beta);
+    } else {
+        hipLaunchKernelGGL(ell_spmv_kernel<false>, grid, dim3(block), 0, to_stream(s), nrows,
+                           num_stored_per_row, stride, col_idxs, vals, b, b_stride, c, c_stride,
+                           alpha, beta);
+    }
+    return check_launch();
+}
+
+extern "C" int gkomi_sellp_spmv_f64_i32(
+    gkomi_stream_t s, int64_t nrows, int64_t ncols, int64_t nrhs,
+    int64_t slice_size, const uint64_t* slice_sets,
+    const uint64_t* slice_lengths, const int32_t* col_idxs, const double* vals,
+    const double* b, int64_t b_stride, double* c, int64_t c_stride,
+    const double* alpha, const double* beta)
+{
+    if (nrows < 0 || ncols < 0 || nrhs < 0 || slice_size <= 0) return GKOMI_EINVAL;
+    if ((alpha == nullptr) != (beta == nullptr)) return GKOMI_EINVAL;
+    if (nrows == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    if (b_stride < nrhs || c_stride < nrhs) return GKOMI_EINVAL;
+    if (nrhs > 65535) return GKOMI_ENOTSUPPORTED;
+    dim3 grid(grid_for(nrows, block, 1 << 20), static_cast<unsigned>(nrhs));
+    if (alpha != nullptr) {
+        hipLaunchKernelGGL(sellp_spmv_kernel<true>, grid, dim3(block), 0, to_stream(s), nrows,
+                           slice_size, slice_sets, slice_lengths, col_idxs, vals, b, b_stride, c,
+                           c_stride, alpha, beta);
+    } else {
+        hipLaunchKernelGGL(sellp_spmv_kernel<false>, grid, dim3(block), 0, to_stream(s), nrows,
+                           slice_size, slice_sets, slice_lengths, col_idxs, vals, b, b_stride, c,
+                           c_stride, alpha, beta);
+    }
+    return check_launch();
+}
+
+extern "C" int gkomi_coo_spmv2_f64_i32(
+    gkomi_stream_t s, int64_t nrows, int64_t ncols, int64_t nrhs, int64_t nnz,
+    const int32_t* row_idxs, const int32_t* col_idxs, const double* vals,
+    const double* b, int64_t b_stride, double* c, int64_t c_stride,
+    const double* alpha)
+{
+    if (nrows < 0 || ncols < 0 || nrhs < 0 || nnz < 0) return GKOMI_EINVAL;
+    if (nrhs > 65535) return GKOMI_ENOTSUPPORTED;
+    if (nrows == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    if (b_stride < nrhs || c_stride < nrhs) return GKOMI_EINVAL;
+    return coo_launch(to_stream(s), nrhs, nnz, row_idxs, col_idxs, vals, b, b_stride, c, c_stride,
+                      alpha);
+}
+
+extern "C" int gkomi_coo_spmv_f64_i32(
+    gkomi_stream_t s, int64_t nrows, int64_t ncols, int64_t nrhs, int64_t nnz,
+    const int32_t* row_idxs, const int32_t* col_idxs, const double* vals,
+    const double* b, int64_t b_stride, double* c, int64_t c_stride,
+    const double* alpha, const double* beta)
+{
+    if ((alpha == nullptr) != (beta == nullptr)) return GKOMI_EINVAL;
+    if (nrows < 0 || nrhs < 0) return GKOMI_EINVAL;
+    if (nrows == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    int err;
+    if (alpha == nullptr) {
+        // spmv = dense::fill(c, 0) + spmv2 (reference/matrix/coo_kernels.cpp:63-71)
+        err = gkomi_dense_fill_f64(s, nrows, nrhs, c, c_stride, 0.0);
+    } else {
+        // advanced_spmv = dense::scale(beta, c) + advanced_spmv2 (:77-88)
+        err = gkomi_dense_scale_f64(s, nrows, nrhs, beta, 1, c, c_stride);
+    }
+    if (err) return err;
+    return gkomi_coo_spmv2_f64_i32(s, nrows, ncols, nrhs, nnz, row_idxs, col_idxs, vals, b,
+                                   b_stride, c, c_stride, alpha);
+}
+
+extern "C" int gkomi_hybrid_spmv_f64_i32(
+    gkomi_stream_t s, int64_t nrows, int64_t ncols, int64_t nrhs,
+    int64_t ell_num_stored_per_row, int64_t ell_stride,
+    const int32_t* ell_col_idxs, const double* ell_vals, int64_t coo_nnz,
+    const int32_t* coo_row_idxs, const int32_t* coo_col_idxs,
+    const double* coo_vals, const double* b, int64_t b_stride, double* c,
+    int64_t c_stride, const double* alpha, const double* beta)
+{
+    // ell->apply(b, x); coo->apply2(b, x)  (core/matrix/hybrid.cpp:133-159)
+    int err = gkomi_ell_spmv_f64_i32(s, nrows, ncols, nrhs, ell_num_stored_per_row, ell_stride,
+                                     ell_col_idxs, ell_vals, b, b_stride, c, c_stride, alpha, beta);
+    if (err) return err;
+    return gkomi_coo_spmv2_f64_i32(s, nrows, ncols, nrhs, coo_nnz, coo_row_idxs, coo_col_idxs,
+                                   coo_vals, b, b_stride, c, c_stride, alpha);
+}

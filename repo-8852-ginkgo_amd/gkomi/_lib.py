@@ -31,6 +31,7 @@ _SCALARS = {
     "int32_t": ctypes.c_int32,
     "int64_t": ctypes.c_int64,
     "uint8_t": ctypes.c_uint8,
+    "uint64_t": ctypes.c_uint64,
     "size_t": ctypes.c_size_t,
     "double": ctypes.c_double,
     "float": ctypes.c_float,
