@@ -305,6 +305,57 @@ int gkomi_hybrid_ell_width_i32(gkomi_stream_t s, const int32_t* row_ptrs,
                                double ratio, int64_t num_columns,
                                int64_t* host_result);
 
+/* ---- block-Jacobi preconditioner (core/preconditioner/jacobi_kernels.hpp:50-190)
+ * fp64 block storage (precision_reduction(0,0)); blocks use the reference's
+ * block_interleaved_storage_scheme with max_block_stride = 64, the HIP
+ * wavefront size (include/ginkgo/core/preconditioner/jacobi.hpp:62-167,
+ * 578-609).  1 <= max_block_size <= 32. ---------------------------------- */
+/* out = {block_offset, group_offset, group_power, stride} */
+int gkomi_jacobi_storage_scheme(int max_block_size, int64_t out[4]);
+/* storage_scheme.compute_storage_space(num_blocks), in values */
+size_t gkomi_jacobi_storage_elements(int max_block_size, int64_t num_blocks);
+/* jacobi::find_blocks (reference/preconditioner/jacobi_kernels.cpp:66-151):
+ * block_ptrs has nrows + 1 entries; the count goes to num_blocks_device
+ * (device int64) and, if host_num_blocks != NULL, to the host (blocking).
+ * workspace: nrows + 8 bytes. */
+int gkomi_jacobi_find_blocks_i32(gkomi_stream_t s, int64_t nrows,
+                                 const int32_t* row_ptrs,
+                                 const int32_t* col_idxs, int max_block_size,
+                                 int32_t* block_ptrs,
+                                 int64_t* num_blocks_device, void* workspace,
+                                 size_t workspace_bytes,
+                                 int64_t* host_num_blocks);
+/* jacobi::generate (:339-441): inverts every diagonal block (Gauss-Jordan,
+ * implicit row pivoting) into `blocks`; conditioning (may be NULL) receives
+ * ||D||_inf * ||D^-1||_inf per block as the reference computes it. */
+int gkomi_jacobi_generate_f64_i32(gkomi_stream_t s, int64_t nrows,
+                                  const int32_t* row_ptrs,
+                                  const int32_t* col_idxs, const double* vals,
+                                  int64_t num_blocks, int max_block_size,
+                                  const int32_t* block_ptrs,
+                                  double* conditioning, double* blocks);
+/* jacobi::simple_apply (alpha == beta == NULL) / jacobi::apply (:505-561) */
+int gkomi_jacobi_apply_f64_i32(gkomi_stream_t s, int64_t num_blocks,
+                               int max_block_size, const int32_t* block_ptrs,
+                               const double* blocks, int64_t nrhs,
+                               const double* alpha, const double* b,
+                               int64_t b_stride, const double* beta, double* x,
+                               int64_t x_stride);
+/* scalar Jacobi (max_block_size == 1): csr::extract_diagonal
+ * (reference/matrix/csr_kernels.cpp:1016-1034), jacobi::invert_diagonal
+ * (:608-620), simple_scalar_apply / scalar_apply (:565-594) */
+int gkomi_csr_extract_diagonal_f64_i32(gkomi_stream_t s, int64_t nrows,
+                                       const int32_t* row_ptrs,
+                                       const int32_t* col_idxs,
+                                       const double* vals, double* diag);
+int gkomi_jacobi_invert_diagonal_f64(gkomi_stream_t s, int64_t n,
+                                     const double* diag, double* inv_diag);
+int gkomi_jacobi_scalar_apply_f64(gkomi_stream_t s, int64_t nrows,
+                                  int64_t nrhs, const double* inv_diag,
+                                  const double* alpha, const double* b,
+                                  int64_t b_stride, const double* beta,
+                                  double* x, int64_t x_stride);
+
 /* ---- CG solver driver (core/solver/cg.cpp:107-193) ----------------------- */
 /* Cg::apply_dense_impl for a CSR system matrix, an optional preconditioner
  * and the criteria Combined(Iteration(max_iters) [id 1], ResidualNorm(

@@ -1,0 +1,525 @@
+// Block-Jacobi preconditioner for gfx950.  Replaces
+// gko::kernels::hip::jacobi::{find_blocks, generate, apply, simple_apply,
+// scalar_apply, simple_scalar_apply, invert_diagonal}
+// (core/preconditioner/jacobi_kernels.hpp:50-190) and csr::extract_diagonal;
+// semantics = reference/preconditioner/jacobi_kernels.cpp:66-625.
+// Full-precision (fp64) block storage; the adaptive-precision storage
+// optimisation is outside the fp64 scope.
+//
+// Storage = the reference's block_interleaved_storage_scheme with the HIP
+// choice max_block_stride = wavefront size = 64 (jacobi.hpp:578-609): with
+// S = pow2ceil(max_block_size), a group holds 64/S blocks, element (r, c) of
+// block b sits at group_offset*(b / gs) + block_offset*(b % gs) + r + c*stride.
+// One wave owns one group, lane = (block in group)*S + row: for a fixed column
+// the 64 lanes of a wave read 64*8 consecutive bytes.
+//
+// apply: HBM-bound on the block storage (8*bs^2 B per block vs 16*bs B of
+// vector): every lane streams its row of the inverse (one coalesced 8-B load
+// per column, all issued up front), b is broadcast by shuffle, and the row sum
+// is formed in the reference's `inner` order -> bit-identical results.
+// generate: Gauss-Jordan with the reference's implicit row pivoting, each
+// block in LDS, one lane per row; every element sees the same operations in
+// the same order as reference invert_block -> bit-identical inverse.
+#include "common.hpp"
+
+namespace gkomi {
+namespace {
+
+constexpr int block = 256;
+
+struct scheme_t {
+    int64_t block_offset, group_offset;
+    int group_power;
+    __host__ __device__ int64_t stride() const { return block_offset << group_power; }
+    __host__ __device__ int64_t global_offset(int64_t b) const
+    {
+        return group_offset * (b >> group_power) +
+               block_offset * (b & ((int64_t{1} << group_power) - 1));
+    }
+};
+
+// ---- find_blocks ----------------------------------------------------------
+
+// same[i] = row i has the sparsity pattern of row i-1 (same[0] = 0)
+__global__ __launch_bounds__(block) void compare_rows_kernel(
+    int64_t nrows, const int32_t* __restrict__ row_ptrs,
+    const int32_t* __restrict__ col_idxs, uint8_t* __restrict__ same)
+{
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; i < nrows;
+         i += static_cast<int64_t>(gridDim.x) * block) {
+        uint8_t s = 0;
+        if (i > 0) {
+            const int32_t p0 = row_ptrs[i - 1], p1 = row_ptrs[i], p2 = row_ptrs[i + 1];
+            if (p2 - p1 == p1 - p0) {
+                s = 1;
+                for (int32_t k = 0; k < p2 - p1; ++k) {
+                    if (col_idxs[p0 + k] != col_idxs[p1 + k]) {
+                        s = 0;
+                        break;
+                    }
+                }
+            }
+        }
+        same[i] = s;
+    }
+}
+
+// The greedy natural-block + agglomeration recurrences are sequential; one wave
+// streams the flags (ballot -> 64-bit mask per 64 rows) and walks the bits
+// with wave-uniform state, fusing both passes of the reference: when natural
+// block k closes it is handed to the agglomerator at once.
+__global__ __launch_bounds__(64) void find_blocks_serial_kernel(
+    int64_t nrows, const uint8_t* __restrict__ same, int max_block_size,
+    int32_t* __restrict__ block_ptrs, int64_t* __restrict__ num_blocks_out)
+{
+    const int lane = threadIdx.x;
+    if (nrows == 0) {
+        if (lane == 0) {
+            block_ptrs[0] = 0;
+            *num_blocks_out = 0;
+        }
+        return;
+    }
+    int64_t nout = 1;          // entries written to block_ptrs so far (ptrs[0] = 0)
+    int cur = 1;               // size of the open natural block (row 0 opened it)
+    int64_t nat_start = 0;     // first row of the open natural block
+    int acc = -1;              // size of the open agglomerated block, -1 = none yet
+    if (lane == 0) block_ptrs[0] = 0;
+    for (int64_t base = 0; base < nrows; base += 64) {
+        const int64_t i = base + lane;
+        const bool flag = i < nrows && i > 0 && same[i] != 0;
+        const unsigned long long mask = __ballot(flag);
+        const int count = static_cast<int>(min(int64_t{64}, nrows - base));
+        for (int j = (base == 0 ? 1 : 0); j < count; ++j) {
+            const bool s = (mask >> j) & 1ull;
+            if (cur < max_block_size && s) {
+                ++cur;
+            } else {
+                // natural block [nat_start, nat_start + cur) closes
+                if (acc < 0) {
+                    acc = cur;
+                } else if (acc + cur <= max_block_size) {
+                    acc += cur;
+                } else {
+                    if (lane == 0) block_ptrs[nout] = static_cast<int32_t>(nat_start);
+                    ++nout;
+                    acc = cur;
+                }
+                nat_start = base + j;
+                cur = 1;
+            }
+        }
+    }
+    // the last natural block closes at the end
+    if (acc >= 0 && acc + cur > max_block_size) {
+        if (lane == 0) block_ptrs[nout] = static_cast<int32_t>(nat_start);
+        ++nout;
+    }
+    if (lane == 0) {
+        block_ptrs[nout] = static_cast<int32_t>(nrows);
+        *num_blocks_out = nout;
+    }
+}
+
+// ---- generate ---------------------------------------------------------------
+
+template <int S>
+__global__ __launch_bounds__(64) void jacobi_generate_kernel(
+    const int32_t* __restrict__ row_ptrs, const int32_t* __restrict__ col_idxs,
+    const double* __restrict__ vals, int64_t num_blocks, scheme_t scheme,
+    const int32_t* __restrict__ block_ptrs, double* __restrict__ conditioning,
+    double* __restrict__ blocks)
+{
+    constexpr int gs = 64 / S;        // blocks per group = per wave
+    constexpr int ld = S + 1;         // padded leading dimension: conflict-free column walks
+    __shared__ double sblk[gs * S * ld];
+    __shared__ int sperm[gs * S];
+    __shared__ double scol[gs * S];   // |pivot candidates| / column sums
+    const int lane = threadIdx.x;
+    const int g = lane / S;           // block within the group
+    const int r = lane % S;           // row (or column) handled by this lane
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * gs + g;
+    const bool have = b < num_blocks;
+    const int start = have ? block_ptrs[b] : 0;
+    const int bs = have ? block_ptrs[b + 1] - start : 0;
+    double* blk = sblk + g * S * ld;
+    int* perm = sperm + g * S;
+    double* col = scol + g * S;
+    const bool row_active = r < bs;
+
+    // extract_block (:163-183)
+    for (int j = 0; j < S; ++j) blk[r * ld + j] = 0.0;
+    perm[r] = r;
+    if (row_active) {
+        const int end = row_ptrs[start + r + 1];
+        for (int k = row_ptrs[start + r]; k < end; ++k) {
+            const int c = col_idxs[k] - start;
+            if (0 <= c && c < bs) blk[r * ld + c] = vals[k];
+        }
+    }
+    __syncthreads();
+    // compute_inf_norm as the reference calls it on the row-major block:
+    // max_i sum_j |m[i + j*bs]| (matrix_operations.hpp:51-66)
+    double cond = 0.0;
+    if (conditioning != nullptr) {
+        double t = 0.0;
+        if (row_active)
+            for (int j = 0; j < bs; ++j) t += fabs(blk[j * ld + r]);
+        col[r] = row_active ? t : 0.0;
+        __syncthreads();
+        for (int i = 0; i < bs; ++i) cond = fmax(cond, col[i]);
+        __syncthreads();
+    }
+
+    // invert_block (:295-312); `ok` turns false at a zero pivot like the
+    // reference's early return (the block then keeps its partial state)
+    bool ok = true;
+    int max_bs = bs;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) max_bs = max(max_bs, __shfl_xor(max_bs, off, 64));
+    for (int k = 0; k < max_bs; ++k) {
+        const bool step = ok && k < bs;
+        // choose_pivot: first row i >= k with the largest |blk[i][k]|
+        int cp = k;
+        if (step) {
+            double best = fabs(blk[k * ld + k]);
+            for (int i = k + 1; i < bs; ++i) {
+                const double cand = fabs(blk[i * ld + k]);
+                if (best < cand) {
+                    best = cand;
+                    cp = i;
+                }
+            }
+        }
+        // swap_rows(k, cp) and the permutation: lane r handles column r
+        if (step && row_active && cp != k) {
+            const double t = blk[k * ld + r];
+            blk[k * ld + r] = blk[cp * ld + r];
+            blk[cp * ld + r] = t;
+            if (r == 0) {
+                const int tp = perm[k];
+                perm[k] = perm[cp];
+                perm[cp] = tp;
+            }
+        }
+        __syncthreads();
+        const double d = step ? blk[k * ld + k] : 1.0;
+        if (step && d == 0.0) ok = false;
+        const bool go = step && ok;
+        __syncthreads();
+        // apply_gauss_jordan_transform(k, k) (:217-240)
+        if (go && row_active) blk[r * ld + k] /= -d;
+        __syncthreads();
+        if (go && r == k) blk[k * ld + k] = 0.0;
+        __syncthreads();
+        if (go && row_active && r != k) {
+            // row k adds 0 * row k to itself in the reference: left untouched here
+            const double f = blk[r * ld + k];
+            for (int j = 0; j < bs; ++j) blk[r * ld + j] += f * blk[k * ld + j];
+        }
+        __syncthreads();
+        if (go && row_active) blk[k * ld + r] /= d;
+        __syncthreads();
+        if (go && r == k) blk[k * ld + k] = 1.0 / d;
+        __syncthreads();
+    }
+
+    if (conditioning != nullptr) {
+        double t = 0.0;
+        if (row_active)
+            for (int j = 0; j < bs; ++j) t += fabs(blk[j * ld + r]);
+        col[r] = row_active ? t : 0.0;
+        __syncthreads();
+        double inv_norm = 0.0;
+        for (int i = 0; i < bs; ++i) inv_norm = fmax(inv_norm, col[i]);
+        if (have && r == 0) conditioning[b] = cond * inv_norm;
+    }
+    // permute_and_transpose_block (:277-292): out[i + perm[j]*stride] = blk[i][j]
+    if (row_active) {
+        double* out = blocks + scheme.global_offset(b);
+        const int64_t stride = scheme.stride();
+        for (int j = 0; j < bs; ++j) out[r + perm[j] * stride] = blk[r * ld + j];
+    }
+}
+
+// ---- apply --------------------------------------------------------------------
+
+template <int S, bool Advanced>
+__global__ __launch_bounds__(block) void jacobi_apply_kernel(
+    int64_t num_blocks, scheme_t scheme, const int32_t* __restrict__ block_ptrs,
+    const double* __restrict__ blocks, int64_t nrhs, const double* __restrict__ alpha_p,
+    const double* __restrict__ b, int64_t b_stride, const double* __restrict__ beta_p,
+    double* __restrict__ x, int64_t x_stride)
+{
+    constexpr int gs = 64 / S;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / S, r = lane % S;
+    const int64_t group = blockIdx.x * static_cast<int64_t>(block / 64) + (threadIdx.x >> 6);
+    const int64_t blk_id = group * gs + g;
+    const bool have = blk_id < num_blocks;
+    const int start = have ? block_ptrs[blk_id] : 0;
+    const int bs = have ? block_ptrs[blk_id + 1] - start : 0;
+    const bool active = r < bs;
+    double alpha = 1.0, beta = 0.0;
+    if (Advanced) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    // this lane's row of the inverse: one coalesced 8-B load per column
+    const double* src = blocks + (have ? scheme.global_offset(blk_id) : 0) + r;
+    const int64_t stride = scheme.stride();
+    double rowv[S];
+#pragma unroll
+    for (int inner = 0; inner < S; ++inner) {
+        rowv[inner] = (active && inner < bs) ? src[inner * stride] : 0.0;
+    }
+    for (int64_t j = 0; j < nrhs; ++j) {
+        const double bv = active ? b[(start + r) * b_stride + j] : 0.0;
+        double acc = 0.0;
+        if (Advanced && active && beta != 0.0) acc = x[(start + r) * x_stride + j] * beta;
+#pragma unroll
+        for (int inner = 0; inner < S; ++inner) {
+            const double bi = __shfl(bv, g * S + inner, 64);
+            if (inner < bs) {
+                acc += Advanced ? (alpha * rowv[inner]) * bi : rowv[inner] * bi;
+            }
+        }
+        if (active) x[(start + r) * x_stride + j] = acc;
+    }
+}
+
+// ---- scalar Jacobi --------------------------------------------------------------
+
+__global__ __launch_bounds__(block) void extract_diagonal_kernel(
+    int64_t nrows, const int32_t* __restrict__ row_ptrs,
+    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    double* __restrict__ diag)
+{
+    for (int64_t row = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; row < nrows;
+         row += static_cast<int64_t>(gridDim.x) * block) {
+        double d = 0.0;
+        const int32_t end = row_ptrs[row + 1];
+        for (int32_t k = row_ptrs[row]; k < end; ++k) {
+            if (col_idxs[k] == row) {
+                d = vals[k];
+                break;
+            }
+        }
+        diag[row] = d;
+    }
+}
+
+__global__ __launch_bounds__(block) void invert_diagonal_kernel(int64_t n,
+                                                               const double* __restrict__ diag,
+                                                               double* __restrict__ inv)
+{
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * block) {
+        const double d = diag[i];
+        inv[i] = 1.0 / (d == 0.0 ? 1.0 : d);
+    }
+}
+
+template <bool Advanced>
+__global__ __launch_bounds__(block) void scalar_apply_kernel(
+    int64_t nrows, int64_t nrhs, const double* __restrict__ diag,
+    const double* __restrict__ alpha_p, const double* __restrict__ b, int64_t b_stride,
+    const double* __restrict__ beta_p, double* __restrict__ x, int64_t x_stride)
+{
+    const double alpha = Advanced ? alpha_p[0] : 1.0;
+    const double beta = Advanced ? beta_p[0] : 0.0;
+    const int64_t total = nrows * nrhs;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * block) {
+        const int64_t row = i / nrhs, col = i % nrhs;
+        const double bv = b[row * b_stride + col];
+        double* xp = x + row * x_stride + col;
+        // reference :565-594
+        *xp = Advanced ? beta * (*xp) + (alpha * bv) * diag[row] : bv * diag[row];
+    }
+}
+
+int pow2ceil(int v)
+{
+    int p = 1;
+    while (p < v) p *= 2;
+    return p;
+}
+
+scheme_t make_scheme(int max_block_size)
+{
+    const int s = pow2ceil(max_block_size);
+    const int group_size = 64 / s;
+    scheme_t sc;
+    sc.block_offset = max_block_size;
+    sc.group_offset = static_cast<int64_t>(max_block_size) * group_size * max_block_size;
+    sc.group_power = 0;
+    while ((1 << (sc.group_power + 1)) <= group_size) ++sc.group_power;
+    return sc;
+}
+
+}  // namespace
+}  // namespace gkomi
+
+using namespace gkomi;
+
+extern "C" int gkomi_jacobi_storage_scheme(int max_block_size, int64_t out[4])
+{
+    if (out == nullptr || max_block_size < 1 || max_block_size > 32) return GKOMI_EINVAL;
+    const scheme_t sc = make_scheme(max_block_size);
+    out[0] = sc.block_offset;
+    out[1] = sc.group_offset;
+    out[2] = sc.group_power;
+    out[3] = sc.stride();
+    return GKOMI_SUCCESS;
+}
+
+extern "C" size_t gkomi_jacobi_storage_elements(int max_block_size, int64_t num_blocks)
+{
+    if (max_block_size < 1 || max_block_size > 32 || num_blocks < 0) return 0;
+    const scheme_t sc = make_scheme(max_block_size);
+    const int64_t gs = int64_t{1} << sc.group_power;
+    return static_cast<size_t>(ceildiv(num_blocks, gs) * sc.group_offset);
+}
+
+extern "C" int gkomi_jacobi_find_blocks_i32(gkomi_stream_t s, int64_t nrows,
+                                            const int32_t* row_ptrs, const int32_t* col_idxs,
+                                            int max_block_size, int32_t* block_ptrs,
+                                            int64_t* num_blocks_device, void* workspace,
+                                            size_t workspace_bytes, int64_t* host_num_blocks)
+{
+    if (nrows < 0 || max_block_size < 1 || max_block_size > 32) return GKOMI_EINVAL;
+    if (workspace_bytes < static_cast<size_t>(nrows) + 8 || (workspace == nullptr && nrows > 0)) {
+        return GKOMI_EWORKSPACE;
+    }
+    hipStream_t stream = to_stream(s);
+    uint8_t* same = static_cast<uint8_t*>(workspace);
+    if (nrows > 0) {
+        hipLaunchKernelGGL(compare_rows_kernel, dim3(grid_for(nrows, block, 1 << 16)), dim3(block),
+                           0, stream, nrows, row_ptrs, col_idxs, same);
+    }
+    hipLaunchKernelGGL(find_blocks_serial_kernel, dim3(1), dim3(64), 0, stream, nrows, same,
+                       max_block_size, block_ptrs, num_blocks_device);
+    int err = check_launch();
+    if (err) return err;
+    if (host_num_blocks != nullptr) {
+        err = static_cast<int>(hipMemcpyAsync(host_num_blocks, num_blocks_device, sizeof(int64_t),
+                                              hipMemcpyDeviceToHost, stream));
+        if (err) return err;
+        err = static_cast<int>(hipStreamSynchronize(stream));
+    }
+    return err;
+}
+
+extern "C" int gkomi_jacobi_generate_f64_i32(gkomi_stream_t s, int64_t nrows,
+                                             const int32_t* row_ptrs, const int32_t* col_idxs,
+                                             const double* vals, int64_t num_blocks,
+                                             int max_block_size, const int32_t* block_ptrs,
+                                             double* conditioning, double* blocks)
+{
+    if (nrows < 0 || num_blocks < 0 || max_block_size < 1 || max_block_size > 32) return GKOMI_EINVAL;
+    if (num_blocks == 0) return GKOMI_SUCCESS;
+    const scheme_t sc = make_scheme(max_block_size);
+    const int sw = pow2ceil(max_block_size);
+    const int64_t groups = ceildiv(num_blocks, 64 / sw);
+    if (groups > INT32_MAX) return GKOMI_ENOTSUPPORTED;
+    hipStream_t stream = to_stream(s);
+    // padding entries of the storage are never read by apply, but keep them defined
+    int err = static_cast<int>(hipMemsetAsync(
+        blocks, 0, sizeof(double) * gkomi_jacobi_storage_elements(max_block_size, num_blocks), stream));
+    if (err) return err;
+#define GKOMI_GEN(S)                                                                          \
+    hipLaunchKernelGGL(jacobi_generate_kernel<S>, dim3(static_cast<unsigned>(groups)), dim3(64), \
+                       0, stream, row_ptrs, col_idxs, vals, num_blocks, sc, block_ptrs,        \
+                       conditioning, blocks)
+    switch (sw) {
+    case 1: GKOMI_GEN(1); break;
+    case 2: GKOMI_GEN(2); break;
+    case 4: GKOMI_GEN(4); break;
+    case 8: GKOMI_GEN(8); break;
+    case 16: GKOMI_GEN(16); break;
+    default: GKOMI_GEN(32); break;
+    }
+#undef GKOMI_GEN
+    return check_launch();
+}
+
+extern "C" int gkomi_jacobi_apply_f64_i32(gkomi_stream_t s, int64_t num_blocks,
+                                          int max_block_size, const int32_t* block_ptrs,
+                                          const double* blocks, int64_t nrhs, const double* alpha,
+                                          const double* b, int64_t b_stride, const double* beta,
+                                          double* x, int64_t x_stride)
+{
+    if (num_blocks < 0 || nrhs < 0 || max_block_size < 1 || max_block_size > 32) return GKOMI_EINVAL;
+    if ((alpha == nullptr) != (beta == nullptr)) return GKOMI_EINVAL;
+    if (num_blocks == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    const scheme_t sc = make_scheme(max_block_size);
+    const int sw = pow2ceil(max_block_size);
+    const int64_t groups = ceildiv(num_blocks, 64 / sw);
+    const int64_t grid = ceildiv(groups, block / 64);
+    if (grid > INT32_MAX) return GKOMI_ENOTSUPPORTED;
+    hipStream_t stream = to_stream(s);
+#define GKOMI_APPLY(S)                                                                        \
+    do {                                                                                      \
+        if (alpha != nullptr) {                                                               \
+            hipLaunchKernelGGL((jacobi_apply_kernel<S, true>), dim3(static_cast<unsigned>(grid)), \
+                               dim3(block), 0, stream, num_blocks, sc, block_ptrs, blocks, nrhs, \
+                               alpha, b, b_stride, beta, x, x_stride);                        \
+        } else {                                                                              \
+            hipLaunchKernelGGL((jacobi_apply_kernel<S, false>), dim3(static_cast<unsigned>(grid)), \
+                               dim3(block), 0, stream, num_blocks, sc, block_ptrs, blocks, nrhs, \
+                               alpha, b, b_stride, beta, x, x_stride);                        \
+        }                                                                                     \
+    } while (0)
+    switch (sw) {
+    case 1: GKOMI_APPLY(1); break;
+    case 2: GKOMI_APPLY(2); break;
+    case 4: GKOMI_APPLY(4); break;
+    case 8: GKOMI_APPLY(8); break;
+    case 16: GKOMI_APPLY(16); break;
+    default: GKOMI_APPLY(32); break;
+    }
+#undef GKOMI_APPLY
+    return check_launch();
+}
+
+extern "C" int gkomi_csr_extract_diagonal_f64_i32(gkomi_stream_t s, int64_t nrows,
+                                                  const int32_t* row_ptrs,
+                                                  const int32_t* col_idxs, const double* vals,
+                                                  double* diag)
+{
+    if (nrows < 0) return GKOMI_EINVAL;
+    if (nrows == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(extract_diagonal_kernel, dim3(grid_for(nrows, block, 1 << 16)), dim3(block),
+                       0, to_stream(s), nrows, row_ptrs, col_idxs, vals, diag);
+    return check_launch();
+}
+
+extern "C" int gkomi_jacobi_invert_diagonal_f64(gkomi_stream_t s, int64_t n, const double* diag,
+                                                double* inv_diag)
+{
+    if (n < 0) return GKOMI_EINVAL;
+    if (n == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(invert_diagonal_kernel, dim3(grid_for(n, block)), dim3(block), 0,
+                       to_stream(s), n, diag, inv_diag);
+    return check_launch();
+}
+
+extern "C" int gkomi_jacobi_scalar_apply_f64(gkomi_stream_t s, int64_t nrows, int64_t nrhs,
+                                             const double* inv_diag, const double* alpha,
+                                             const double* b, int64_t b_stride,
+                                             const double* beta, double* x, int64_t x_stride)
+{
+    if (nrows < 0 || nrhs < 0) return GKOMI_EINVAL;
+    if ((alpha == nullptr) != (beta == nullptr)) return GKOMI_EINVAL;
+    if (nrows == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    dim3 grid(grid_for(nrows * nrhs, block));
+    if (alpha != nullptr) {
+        hipLaunchKernelGGL(scalar_apply_kernel<true>, grid, dim3(block), 0, to_stream(s), nrows,
+                           nrhs, inv_diag, alpha, b, b_stride, beta, x, x_stride);
+    } else {
+        hipLaunchKernelGGL(scalar_apply_kernel<false>, grid, dim3(block), 0, to_stream(s), nrows,
+                           nrhs, inv_diag, alpha, b, b_stride, beta, x, x_stride);
+    }
+    return check_launch();
+}

@@ -1,0 +1,204 @@
+"""GPU parity tests (C ABI) of block-Jacobi against the oracle: known answers
+of reference/test/preconditioner/jacobi_kernels.cpp, then random block-diagonal
+dominant matrices (the reference's cross-executor tests,
+test/preconditioner/jacobi_kernels.cpp).  find_blocks bit-exact; generate and
+apply bit-exact (same operations in the same order per element)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import matgen
+from gpu_util import dev, host, stream_ptr
+from test_oracle_jacobi import _strided, block_of
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jacobi.json")))
+R = G["tol"]
+
+
+def mtx():
+    m = G["mtx"]
+    return m["n"], np.array(m["row_ptrs"], np.int32), np.array(m["col_idxs"], np.int32), np.array(m["vals"])
+
+
+def gpu_scheme(gk, max_bs):
+    import ctypes
+    out = (ctypes.c_int64 * 4)()
+    gk.jacobi_storage_scheme(max_bs, ctypes.addressof(out))
+    return np.array(list(out), np.int64)
+
+
+def gpu_find_blocks(gk, n, rpd, cid, max_bs):
+    import ctypes
+    ptrs = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda:0")
+    nbd = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    ws = torch.empty(n + 8, dtype=torch.uint8, device="cuda:0")
+    hn = ctypes.c_int64(-1)
+    gk.jacobi_find_blocks_i32(stream_ptr(), n, rpd, cid, max_bs, ptrs, nbd, ws, n + 8, ctypes.addressof(hn))
+    return int(hn.value), ptrs
+
+
+def gpu_generate(gk, n, rpd, cid, vd, ptrs_d, nb, max_bs, cond=False):
+    nel = gk.jacobi_storage_elements(max_bs, nb)
+    blocks = torch.full((max(nel, 1),), float("nan"), dtype=torch.float64, device="cuda:0")
+    c = torch.zeros(max(nb, 1), dtype=torch.float64, device="cuda:0") if cond else None
+    gk.jacobi_generate_f64_i32(stream_ptr(), n, rpd, cid, vd, nb, max_bs, ptrs_d, c, blocks)
+    return blocks, c
+
+
+def test_storage_scheme_matches_reference_formula(gk, oracle):
+    for max_bs in range(1, 33):
+        e = np.zeros(3, np.int64)
+        oracle.ref_jacobi_storage_scheme(max_bs, 64, e)  # HIP: warp size 64 (jacobi.hpp:581-586)
+        s = gpu_scheme(gk, max_bs)
+        assert list(s[:3]) == list(e) and s[3] == e[0] << e[2]
+        for nb in (0, 1, 5, 64, 1000):
+            assert gk.jacobi_storage_elements(max_bs, nb) == oracle.ref_jacobi_storage_space(e, nb)
+
+
+@pytest.mark.parametrize("case", G["find_blocks"], ids=lambda c: c["name"])
+def test_find_blocks_known_answers(gk, case):
+    if case.get("use_mtx"):
+        n, rp, ci, _ = mtx()
+    else:
+        n, rp, ci = case["n"], np.array(case["row_ptrs"], np.int32), np.array(case["col_idxs"], np.int32)
+    nb, ptrs = gpu_find_blocks(gk, n, dev(rp), dev(ci), case["max_block_size"])
+    assert list(host(ptrs)[:nb + 1]) == case["expect"]
+
+
+def test_known_inverses_condition_numbers_and_applies(gk):
+    n, rp, ci, v = mtx()
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    ptrs = dev(np.array(G["block_pointers"], np.int32))
+    blocks, cond = gpu_generate(gk, n, rpd, cid, vd, ptrs, 2, 3, cond=True)
+    s = gpu_scheme(gk, 3)
+    hb = host(blocks)
+    assert np.allclose(block_of(s, hb, 0, 2), G["inverse_blocks"]["b1"], rtol=0, atol=R)
+    assert np.allclose(block_of(s, hb, 1, 3), G["inverse_blocks"]["b2"], rtol=0, atol=R)
+    assert np.allclose(host(cond), G["conditioning"]["expect"], rtol=0, atol=G["conditioning"]["tol"])
+    for case in G["applies"]:
+        st = case.get("stride")
+        x, b = dev(_strided(case["x"], st)), dev(_strided(case["b"], st))
+        nrhs = np.array(case["x"]).shape[1]
+        al = dev(np.array([case["alpha"]])) if "alpha" in case else None
+        be = dev(np.array([case["beta"]])) if "alpha" in case else None
+        gk.jacobi_apply_f64_i32(stream_ptr(), 2, 3, ptrs, blocks, nrhs, al, b, b.shape[1], be, x, x.shape[1])
+        assert matgen.rel_err(host(x)[:, :nrhs], case["expect"]) <= R, case["name"]
+        assert np.all(host(x)[:, nrhs:] == -9.0)
+    p = G["pivoting"]
+    blocks, _ = gpu_generate(gk, 3, dev(np.array(p["row_ptrs"], np.int32)), dev(np.array(p["col_idxs"], np.int32)),
+                             dev(np.array(p["vals"])), dev(np.array(p["block_pointers"], np.int32)), 1, 3)
+    assert np.allclose(block_of(gpu_scheme(gk, 3), host(blocks), 0, 3), p["inverse"], rtol=0, atol=R)
+
+
+@pytest.mark.parametrize("case", G["scalar_applies"], ids=lambda c: c["name"])
+def test_scalar_jacobi_known_answers(gk, case):
+    n, rp, ci, v = mtx()
+    d = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    gk.csr_extract_diagonal_f64_i32(stream_ptr(), n, dev(rp), dev(ci), dev(v), d)
+    inv = torch.zeros_like(d)
+    gk.jacobi_invert_diagonal_f64(stream_ptr(), n, d, inv)
+    assert np.array_equal(host(inv), np.full(n, 0.25))
+    st = case.get("stride")
+    x, b = dev(_strided(case["x"], st)), dev(_strided(case["b"], st))
+    nrhs = np.array(case["x"]).shape[1]
+    al = dev(np.array([case["alpha"]])) if "alpha" in case else None
+    be = dev(np.array([case["beta"]])) if "alpha" in case else None
+    gk.jacobi_scalar_apply_f64(stream_ptr(), n, nrhs, inv, al, b, b.shape[1], be, x, x.shape[1])
+    assert matgen.rel_err(host(x)[:, :nrhs], case["expect"]) <= R
+
+
+def block_structured_matrix(nblocks, max_bs, seed, fill=0.6):
+    """Random matrix with dense-ish diagonal blocks of random sizes <= max_bs
+    (rows inside a block share their pattern so that find_blocks detects them),
+    diagonally dominant, plus off-block coupling."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(1, max_bs + 1, size=nblocks)
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(starts[-1])
+    rp, ci, v = [0], [], []
+    for b in range(nblocks):
+        s0, bs = int(starts[b]), int(sizes[b])
+        cols_in = [c for c in range(s0, s0 + bs) if rng.random() < fill]
+        extra = sorted(set(int(c) for c in rng.integers(0, n, size=2)) - set(range(s0, s0 + bs)))
+        for r in range(s0, s0 + bs):
+            cols = sorted(set(cols_in) | {r} | set(extra)) if bs > 1 else sorted({r} | set(extra))
+            for c in cols:
+                ci.append(c)
+                v.append(rng.standard_normal() + (bs + 3.0 if c == r else 0.0))
+            rp.append(len(ci))
+    return n, np.array(rp, np.int32), np.array(ci, np.int32), np.array(v), starts.astype(np.int32)
+
+
+@pytest.mark.parametrize("max_bs", [1, 2, 3, 4, 7, 8, 13, 16, 17, 31, 32])
+def test_find_generate_apply_bitexact_vs_oracle(gk, oracle, max_bs):
+    n, rp, ci, v, _ = block_structured_matrix(257, max_bs, seed=max_bs)
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    eptrs = np.zeros(n + 1, np.int32)
+    enb = oracle.ref_jacobi_find_blocks(n, rp, ci, max_bs, eptrs)
+    nb, ptrs = gpu_find_blocks(gk, n, rpd, cid, max_bs)
+    assert nb == enb and np.array_equal(host(ptrs)[:nb + 1], eptrs[:nb + 1])
+    es = np.zeros(3, np.int64)
+    oracle.ref_jacobi_storage_scheme(max_bs, 64, es)
+    eblocks = np.zeros(int(oracle.ref_jacobi_storage_space(es, nb)))
+    econd = np.zeros(nb)
+    oracle.ref_jacobi_generate(n, rp, ci, v, nb, es, eptrs, econd, eblocks)
+    blocks, cond = gpu_generate(gk, n, rpd, cid, vd, ptrs, nb, max_bs, cond=True)
+    assert np.array_equal(host(blocks), eblocks)
+    assert np.array_equal(host(cond)[:nb], econd)
+    rng = np.random.default_rng(99)
+    for nrhs in (1, 3):
+        b = rng.standard_normal((n, nrhs))
+        x0 = rng.standard_normal((n, nrhs))
+        ex = x0.copy()
+        oracle.ref_jacobi_simple_apply(nb, es, eptrs, eblocks, nrhs, b, nrhs, ex, nrhs)
+        x = dev(x0)
+        gk.jacobi_apply_f64_i32(stream_ptr(), nb, max_bs, ptrs, blocks, nrhs, None, dev(b), nrhs, None, x, nrhs)
+        assert np.array_equal(host(x), ex)
+        for beta in (-1.0, 0.0):
+            ex = x0.copy()
+            oracle.ref_jacobi_apply(nb, es, eptrs, eblocks, nrhs, 2.0, b, nrhs, beta, ex, nrhs)
+            x = dev(x0)
+            gk.jacobi_apply_f64_i32(stream_ptr(), nb, max_bs, ptrs, blocks, nrhs, dev(np.array([2.0])), dev(b), nrhs,
+                                    dev(np.array([beta])), x, nrhs)
+            assert np.array_equal(host(x), ex)
+
+
+def test_singular_block_stops_like_the_reference(gk, oracle):
+    # a zero pivot: the reference's invert_block returns early and stores the
+    # partially transformed block; the kernel must do the same (bit-exact)
+    rp = np.array([0, 2, 4, 5], np.int32)
+    ci = np.array([0, 1, 0, 1, 2], np.int32)
+    v = np.array([1.0, 2.0, 2.0, 4.0, 3.0])
+    ptrs = np.array([0, 2, 3], np.int32)
+    es = np.zeros(3, np.int64)
+    oracle.ref_jacobi_storage_scheme(2, 64, es)
+    eb = np.zeros(int(oracle.ref_jacobi_storage_space(es, 2)))
+    oracle.ref_jacobi_generate(3, rp, ci, v, 2, es, ptrs, None, eb)
+    blocks, _ = gpu_generate(gk, 3, dev(rp), dev(ci), dev(v), dev(ptrs), 2, 2)
+    assert np.array_equal(host(blocks), eb, equal_nan=True)
+
+
+def test_find_blocks_large_poisson_and_identity_patterns(gk, oracle):
+    # 1M rows: no two consecutive rows share a pattern -> blocks of max_bs rows
+    n, rp, ci, v = matgen.poisson_2d_5pt(1000)
+    eptrs = np.zeros(n + 1, np.int32)
+    enb = oracle.ref_jacobi_find_blocks(n, rp, ci, 32, eptrs)
+    nb, ptrs = gpu_find_blocks(gk, n, dev(rp), dev(ci), 32)
+    assert nb == enb == 31250 and np.array_equal(host(ptrs)[:nb + 1], eptrs[:nb + 1])
+    # generate + apply at that size agree with the oracle bit for bit
+    es = np.zeros(3, np.int64)
+    oracle.ref_jacobi_storage_scheme(32, 64, es)
+    eblocks = np.zeros(int(oracle.ref_jacobi_storage_space(es, nb)))
+    oracle.ref_jacobi_generate(n, rp, ci, v, nb, es, eptrs, None, eblocks)
+    blocks, _ = gpu_generate(gk, n, dev(rp), dev(ci), dev(v), ptrs, nb, 32)
+    assert np.array_equal(host(blocks), eblocks)
+    b = np.sin(0.01 * np.arange(n)).reshape(n, 1)
+    ex = np.zeros((n, 1))
+    oracle.ref_jacobi_simple_apply(nb, es, eptrs, eblocks, 1, b, 1, ex, 1)
+    x = torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")
+    gk.jacobi_apply_f64_i32(stream_ptr(), nb, 32, ptrs, blocks, 1, None, dev(b), 1, None, x, 1)
+    assert np.array_equal(host(x), ex)
