@@ -356,6 +356,75 @@ int gkomi_jacobi_scalar_apply_f64(gkomi_stream_t s, int64_t nrows,
                                   int64_t b_stride, const double* beta,
                                   double* x, int64_t x_stride);
 
+/* ---- sparse triangular solves = ILU apply (core/solver/{lower,upper}_trs_kernels.hpp;
+ *      composition include/ginkgo/core/preconditioner/ilu.hpp:265-305) ------ */
+/* x = L^-1 b / x = U^-1 b for a CSR matrix whose other triangle (if stored) is
+ * ignored; unit_diag as solver::LowerTrs/UpperTrs::parameters (triangular.hpp:117-132).
+ * x and b must not alias.  workspace: gkomi_trs_workspace_bytes() bytes of
+ * device memory (the reference's SolveStruct; generate() needs no analysis
+ * here).  reference/solver/lower_trs_kernels.cpp:90-120, upper_trs_kernels.cpp:90-123 */
+size_t gkomi_trs_workspace_bytes(void);
+int gkomi_lower_trs_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                                  const int32_t* row_ptrs,
+                                  const int32_t* col_idxs, const double* vals,
+                                  int unit_diag, const double* b,
+                                  int64_t b_stride, double* x, int64_t x_stride,
+                                  void* workspace, size_t workspace_bytes);
+int gkomi_upper_trs_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                                  const int32_t* row_ptrs,
+                                  const int32_t* col_idxs, const double* vals,
+                                  int unit_diag, const double* b,
+                                  int64_t b_stride, double* x, int64_t x_stride,
+                                  void* workspace, size_t workspace_bytes);
+/* *host_flag != 0 if the last solve on this workspace hit its spin bound
+ * (the role of the nan_produced guard, cuda/solver/common_trs_kernels.cuh:444-449) */
+int gkomi_trs_check_overrun(gkomi_stream_t s, const void* workspace,
+                            int* host_flag);
+
+/* ---- ParILU(0) (core/factorization/par_ilu.cpp:74-163) -------------------- */
+size_t gkomi_factorization_workspace_bytes(int64_t nrows);
+/* factorization::add_diagonal_elements in two phases because the caller owns
+ * the allocation (reference/factorization/factorization_kernels.cpp:54-160):
+ * count (blocking copy of the count to *host_missing), then fill arrays of
+ * nnz + missing entries and shift row_ptrs in place.  Same workspace for both. */
+int gkomi_factorization_count_missing_diagonal_i32(
+    gkomi_stream_t s, int64_t nrows, int64_t ncols, const int32_t* row_ptrs,
+    const int32_t* col_idxs, void* workspace, size_t workspace_bytes,
+    int64_t* host_missing);
+int gkomi_factorization_add_diagonal_elements_f64_i32(
+    gkomi_stream_t s, int64_t nrows, int64_t ncols, int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, int32_t* new_col_idxs,
+    double* new_vals, const void* workspace);
+/* factorization::initialize_row_ptrs_l_u (:166-192); workspace = prefix-sum scratch for n + 1 */
+int gkomi_factorization_initialize_row_ptrs_l_u_i32(
+    gkomi_stream_t s, int64_t n, const int32_t* row_ptrs,
+    const int32_t* col_idxs, int32_t* l_row_ptrs, int32_t* u_row_ptrs,
+    void* workspace, size_t workspace_bytes);
+/* factorization::initialize_l_u (:198-245) */
+int gkomi_factorization_initialize_l_u_f64_i32(
+    gkomi_stream_t s, int64_t n, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, const int32_t* l_row_ptrs,
+    int32_t* l_col_idxs, double* l_vals, const int32_t* u_row_ptrs,
+    int32_t* u_col_idxs, double* u_vals);
+/* par_ilu_factorization::compute_l_u_factors
+ * (reference/factorization/par_ilu_kernels.cpp:54-120): `iterations`
+ * asynchronous sweeps over the COO entries of A; U is passed transposed (CSC of
+ * U = CSR of U^T).  iterations == 0 ("Auto") = 10 sweeps, the reference's HIP choice. */
+int gkomi_par_ilu_compute_l_u_factors_f64_i32(
+    gkomi_stream_t s, int64_t iterations, int64_t nnz,
+    const int32_t* coo_row_idxs, const int32_t* coo_col_idxs,
+    const double* coo_vals, const int32_t* l_row_ptrs,
+    const int32_t* l_col_idxs, double* l_vals, const int32_t* ut_row_ptrs,
+    const int32_t* ut_col_idxs, double* ut_vals);
+/* csr::transpose (reference/matrix/csr_kernels.cpp:551-586) */
+size_t gkomi_csr_transpose_workspace_bytes(int64_t ncols);
+int gkomi_csr_transpose_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                                int64_t nnz, const int32_t* row_ptrs,
+                                const int32_t* col_idxs, const double* vals,
+                                int32_t* t_row_ptrs, int32_t* t_col_idxs,
+                                double* t_vals, void* workspace,
+                                size_t workspace_bytes);
+
 /* ---- CG solver driver (core/solver/cg.cpp:107-193) ----------------------- */
 /* Cg::apply_dense_impl for a CSR system matrix, an optional preconditioner
  * and the criteria Combined(Iteration(max_iters) [id 1], ResidualNorm(

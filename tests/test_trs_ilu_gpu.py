@@ -1,0 +1,200 @@
+"""GPU parity tests (C ABI) of the sparse triangular solves (= ILU apply),
+the ParILU chain and csr::transpose against the oracle.  Triangular solves
+are bit-exact (per row the subtractions run in storage order).  ParILU sweeps
+are asynchronous: parity by tolerance after enough sweeps, like
+test/factorization/par_ilu_kernels.cpp:277-309."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ilu_util
+import matgen
+from gpu_util import dev, host, stream_ptr
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trs_ilu.json")))
+
+
+def trs(gk, which, n, rp, ci, v, unit, b):
+    fn = gk.lower_trs_solve_f64_i32 if which == "lower" else gk.upper_trs_solve_f64_i32
+    nrhs = b.shape[1]
+    x = torch.full((n, nrhs), 777.0, dtype=torch.float64, device="cuda:0")
+    nb = gk.trs_workspace_bytes()
+    ws = torch.zeros(nb, dtype=torch.uint8, device="cuda:0")
+    fn(stream_ptr(), n, nrhs, dev(rp), dev(ci), dev(v), int(unit), dev(b), nrhs, x, nrhs, ws, nb)
+    flag = ctypes.c_int(-1)
+    gk.trs_check_overrun(stream_ptr(), ws, ctypes.addressof(flag))
+    assert flag.value == 0, "triangular solve hit its spin bound"
+    return host(x)
+
+
+@pytest.mark.parametrize("which", ["lower", "upper"])
+def test_trs_known_answers(gk, which):
+    g = G[which]
+    for case in g["cases"]:
+        rp, ci, v = matgen.dense_to_csr(g[case["matrix"]])
+        b = np.array(case["b"], np.float64)
+        x = trs(gk, which, len(b), rp, ci, v, case["unit"], b)
+        assert matgen.rel_err(x, case["expect"]) <= case["tol"], case["name"]
+
+
+def random_triangular(n, lower, seed, max_off=6, band=None):
+    """Well-conditioned random triangular CSR with the other triangle partly
+    filled (must be ignored) and entries in a random order inside each row."""
+    rng = np.random.default_rng(seed)
+    rp, ci, v = [0], [], []
+    for r in range(n):
+        lo, hi = (0, r) if lower else (r + 1, n)
+        if band is not None:
+            lo, hi = (max(0, r - band), r) if lower else (r + 1, min(n, r + 1 + band))
+        cnt = min(hi - lo, int(rng.integers(0, max_off + 1)))
+        deps = list(rng.choice(np.arange(lo, hi), size=cnt, replace=False)) if cnt else []
+        olo, ohi = (r + 1, n) if lower else (0, r)
+        other = list(rng.choice(np.arange(olo, ohi), size=min(2, ohi - olo), replace=False)) if ohi > olo else []
+        cols = deps + other + [r]
+        rng.shuffle(cols)
+        for c in cols:
+            ci.append(int(c))
+            v.append(float(rng.standard_normal() * 0.3 + (4.0 if c == r else 0.0)))
+        rp.append(len(ci))
+    return np.array(rp, np.int32), np.array(ci, np.int32), np.array(v)
+
+
+@pytest.mark.parametrize("which", ["lower", "upper"])
+@pytest.mark.parametrize("n,band", [(1, None), (63, None), (257, None), (5000, 40), (100_000, 700)])
+@pytest.mark.parametrize("unit", [False, True])
+def test_trs_bitexact_vs_oracle(gk, oracle, which, n, band, unit):
+    rp, ci, v = random_triangular(n, which == "lower", seed=n + unit, band=band)
+    rng = np.random.default_rng(5)
+    for nrhs in (1, 2):
+        b = rng.standard_normal((n, nrhs))
+        e = np.zeros_like(b)
+        (oracle.ref_lower_trs_solve if which == "lower" else oracle.ref_upper_trs_solve)(
+            n, nrhs, rp, ci, v, int(unit), b, nrhs, e, nrhs)
+        x = trs(gk, which, n, rp, ci, v, unit, b)
+        assert np.array_equal(x, e)
+
+
+def test_trs_long_dependency_chain(gk, oracle):
+    # bidiagonal: every row waits for the previous one (worst case for a
+    # sync-free solve: 20000 sequential hand-offs, many inside one wave)
+    n = 20000
+    rp = np.arange(0, 2 * n + 1, 2, dtype=np.int32) - 1
+    rp[0] = 0
+    ci = np.empty(2 * n - 1, np.int32)
+    v = np.empty(2 * n - 1)
+    ci[0], v[0] = 0, 2.0
+    ci[1::2], v[1::2] = np.arange(0, n - 1), -1.0
+    ci[2::2], v[2::2] = np.arange(1, n), 2.0
+    b = np.ones((n, 1))
+    e = np.zeros_like(b)
+    oracle.ref_lower_trs_solve(n, 1, rp, ci, v, 0, b, 1, e, 1)
+    assert np.array_equal(trs(gk, "lower", n, rp, ci, v, False, b), e)
+
+
+def test_trs_nan_results_do_not_hang(gk, oracle):
+    # 0/0 on the diagonal gives NaN; later rows must still complete
+    rp, ci, v = matgen.dense_to_csr([[1e-300, 0, 0], [1.0, 2.0, 0], [1.0, 1.0, 3.0]])
+    v = v.copy()
+    v[0] = 0.0
+    b = np.zeros((3, 1))
+    x = trs(gk, "lower", 3, rp, ci, v, False, b)
+    assert np.isnan(x).all()
+
+
+def test_ilu0_apply_on_poisson_matches_oracle(gk, oracle):
+    """Ilu::apply = L^-1 then U^-1 (ilu.hpp:265-286) with the exact ILU(0)
+    factors of a 3-D 7-pt stencil (config 4's structure: ~3*grid levels)."""
+    n, rp, ci, v = matgen.poisson_3d_7pt(24)
+    f = ilu_util.oracle_par_ilu(oracle, n, rp, ci, v)
+    lrp, lc, lv = f["L"]
+    urp, uc, uv = f["U"]
+    b = np.sin(0.1 * np.arange(n)).reshape(n, 1)
+    y = np.zeros_like(b)
+    oracle.ref_lower_trs_solve(n, 1, lrp, lc, lv, 0, b, 1, y, 1)
+    e = np.zeros_like(b)
+    oracle.ref_upper_trs_solve(n, 1, urp, uc, uv, 0, y, 1, e, 1)
+    yg = trs(gk, "lower", n, lrp, lc, lv, False, b)
+    assert np.array_equal(yg, y)
+    assert np.array_equal(trs(gk, "upper", n, urp, uc, uv, False, yg), e)
+
+
+@pytest.mark.parametrize("case", G["add_diagonal"], ids=lambda c: c["name"])
+def test_add_diagonal_known_answers(gk, case):
+    n, m = case["nrows"], case["ncols"]
+    rpd = dev(np.array(case["row_ptrs"], np.int32))
+    cid = dev(np.array(case["col_idxs"] or [0], np.int32))
+    vd = dev(np.array(case["vals"] or [0.0]))
+    nb = gk.factorization_workspace_bytes(n)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
+    missing = ctypes.c_int64(-1)
+    gk.factorization_count_missing_diagonal_i32(stream_ptr(), n, m, rpd, cid, ws, nb, ctypes.addressof(missing))
+    total = len(case["expect_vals"])
+    assert missing.value == total - len(case["vals"])
+    nc = torch.zeros(total, dtype=torch.int32, device="cuda:0")
+    nv = torch.zeros(total, dtype=torch.float64, device="cuda:0")
+    gk.factorization_add_diagonal_elements_f64_i32(stream_ptr(), n, m, rpd, cid, vd, nc, nv, ws)
+    assert list(host(rpd)) == case["expect_row_ptrs"]
+    assert list(host(nc)) == case["expect_col_idxs"] and list(host(nv)) == case["expect_vals"]
+
+
+@pytest.mark.parametrize("case", G["par_ilu"]["cases"], ids=lambda c: c["name"])
+def test_par_ilu_known_factors(gk, case):
+    a = np.array(case["A"], np.float64)
+    n = a.shape[0]
+    rp, ci, v = matgen.dense_to_csr(a)
+    f = ilu_util.gpu_par_ilu(gk, torch, n, dev(rp), dev(ci), dev(v), iterations=30)
+    L = ilu_util.csr_to_dense(n, n, *[host(t) for t in f["L"]])
+    U = ilu_util.csr_to_dense(n, n, *[host(t) for t in f["U"]])
+    assert matgen.rel_err(L, case["L"]) <= max(case["tol"], 1e-14)
+    assert matgen.rel_err(U, case["U"]) <= max(case["tol"], 1e-14)
+
+
+@pytest.mark.parametrize("name", ["poisson2d", "poisson3d", "random_dd"])
+def test_par_ilu_chain_vs_oracle(gk, oracle, name):
+    if name == "poisson2d":
+        n, rp, ci, v = matgen.poisson_2d_5pt(40, 37)
+    elif name == "poisson3d":
+        n, rp, ci, v = matgen.poisson_3d_7pt(12, 11, 13)
+    else:
+        n = 400
+        rp, ci, v = matgen.random_csr(n, n, 2, 9, seed=12)
+        # diagonally dominant, some rows without a stored diagonal
+        a = ilu_util.csr_to_dense(n, n, rp, ci, v) * 0.1
+        a[np.arange(n), np.arange(n)] = 3.0
+        a[7, 7] = 0.0
+        a[123, 123] = 0.0
+        rp, ci, v = matgen.dense_to_csr(a)
+    e = ilu_util.oracle_par_ilu(oracle, n, rp, ci, v)
+    f = ilu_util.gpu_par_ilu(gk, torch, n, dev(rp), dev(ci), dev(v), iterations=60)
+    # integer parts of the chain: bit-exact
+    for key in ("A", "L", "U"):
+        assert np.array_equal(host(f[key][0]), e[key][0]), key
+        assert np.array_equal(host(f[key][1]), e[key][1]), key
+    assert np.array_equal(host(f["A"][2]), e["A"][2])
+    # factors: converged fixed point == the sequential sweep
+    assert matgen.rel_err(host(f["L"][2]), e["L"][2]) <= 1e-12
+    assert matgen.rel_err(host(f["U"][2]), e["U"][2]) <= 1e-12
+    # the reference's own bar for the default sweep count: 5e-2
+    f10 = ilu_util.gpu_par_ilu(gk, torch, n, dev(rp), dev(ci), dev(v), iterations=0)
+    assert matgen.rel_err(host(f10["L"][2]), e["L"][2]) <= 5e-2
+    assert matgen.rel_err(host(f10["U"][2]), e["U"][2]) <= 5e-2
+
+
+def test_transpose_bitexact_vs_oracle(gk, oracle):
+    for (nr, nc, seed) in ((37, 23, 2), (1000, 1000, 3), (5, 2000, 4)):
+        rp, ci, v = matgen.random_csr(nr, nc, 0, 9, seed=seed)
+        nnz = len(ci)
+        etrp, etc_, etv = np.zeros(nc + 1, np.int32), np.zeros(nnz, np.int32), np.zeros(nnz)
+        oracle.ref_csr_transpose(nr, nc, rp, ci, v, etrp, etc_, etv)
+        nb = gk.csr_transpose_workspace_bytes(nc)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
+        trp = torch.zeros(nc + 1, dtype=torch.int32, device="cuda:0")
+        tc = torch.zeros(nnz, dtype=torch.int32, device="cuda:0")
+        tv = torch.zeros(nnz, dtype=torch.float64, device="cuda:0")
+        gk.csr_transpose_f64_i32(stream_ptr(), nr, nc, nnz, dev(rp), dev(ci), dev(v), trp, tc, tv, ws, nb)
+        assert np.array_equal(host(trp), etrp) and np.array_equal(host(tc), etc_) and np.array_equal(host(tv), etv)
