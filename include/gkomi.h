@@ -460,6 +460,92 @@ int gkomi_cg_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
                            int check_every, void* workspace,
                            size_t workspace_bytes, double* host_info);
 
+/* ---- preconditioners as solver callbacks ---------------------------------
+ * Ready-made gkomi_apply_fn implementations and their context records, the
+ * generated state of preconditioner::Jacobi / preconditioner::Ilu.  All
+ * pointers are device pointers; the records themselves live on the host. */
+typedef struct gkomi_jacobi_ctx {
+    int64_t n;               /* rows */
+    int64_t nrhs;            /* columns of the vectors (stride == nrhs) */
+    int64_t num_blocks;
+    int32_t max_block_size;  /* 1: scalar Jacobi, blocks = inverted diagonal */
+    int32_t pad_;
+    const int32_t* block_ptrs;
+    const double* blocks;
+} gkomi_jacobi_ctx;
+typedef struct gkomi_ilu_ctx {
+    int64_t n;
+    int64_t nrhs;
+    const int32_t* l_row_ptrs;
+    const int32_t* l_col_idxs;
+    const double* l_vals;
+    const int32_t* u_row_ptrs;
+    const int32_t* u_col_idxs;
+    const double* u_vals;
+    double* intermediate;    /* n x nrhs scratch (Ilu's cached intermediate) */
+    void* trs_workspace;
+    size_t trs_workspace_bytes;
+    int32_t l_unit_diag;     /* ParIlu stores the unit diagonal of L explicitly: 0 */
+    int32_t pad_;
+} gkomi_ilu_ctx;
+int gkomi_jacobi_apply_cb(void* ctx, gkomi_stream_t s, const double* in,
+                          double* out);
+int gkomi_ilu_apply_cb(void* ctx, gkomi_stream_t s, const double* in,
+                       double* out);
+
+/* ---- GMRES (core/solver/common_gmres_kernels.hpp, core/solver/gmres_kernels.hpp,
+ *      driver core/solver/gmres.cpp:139-372) ------------------------------ */
+/* givens_sin/cos: krylov_dim x nrhs, residual_norm_collection: (krylov_dim+1) x nrhs,
+ * y: krylov_dim x nrhs (all row stride nrhs); hessenberg: (krylov_dim+1) x
+ * (krylov_dim*nrhs), entry (i, j*nrhs + k); krylov_bases: ((krylov_dim+1)*n) x nrhs;
+ * final_iter_nums: size_type (64-bit) per rhs.
+ * reference/solver/common_gmres_kernels.cpp:140-217, gmres_kernels.cpp:55-100 */
+int gkomi_gmres_initialize_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                               int64_t krylov_dim, const double* b,
+                               int64_t b_stride, double* residual,
+                               int64_t r_stride, double* givens_sin,
+                               double* givens_cos, uint8_t* stop_status);
+int gkomi_gmres_restart_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                            const double* residual, int64_t r_stride,
+                            const double* residual_norm,
+                            double* residual_norm_collection,
+                            double* krylov_bases, int64_t kb_stride,
+                            uint64_t* final_iter_nums);
+/* hessenberg_iter = column block `iter` of the Hessenberg matrix (entry (row, rhs)
+ * at row*h_stride + rhs), as Gmres passes its create_submatrix view */
+int gkomi_gmres_hessenberg_qr_f64(gkomi_stream_t s, int64_t nrhs,
+                                  double* givens_sin, double* givens_cos,
+                                  double* residual_norm,
+                                  double* residual_norm_collection,
+                                  double* hessenberg_iter, int64_t h_stride,
+                                  int64_t iter, uint64_t* final_iter_nums,
+                                  const uint8_t* stop_status);
+int gkomi_gmres_solve_krylov_f64(gkomi_stream_t s, int64_t nrhs,
+                                 const double* residual_norm_collection,
+                                 const double* hessenberg, int64_t h_stride,
+                                 double* y, const uint64_t* final_iter_nums,
+                                 const uint8_t* stop_status);
+int gkomi_gmres_multi_axpy_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                               const double* krylov_bases, int64_t kb_stride,
+                               const double* y, double* before_preconditioner,
+                               int64_t bp_stride,
+                               const uint64_t* final_iter_nums,
+                               uint8_t* stop_status);
+/* Gmres::apply_dense_impl for a CSR matrix, optional (right) preconditioner and
+ * Combined(Iteration(max_iters) [id 1], ResidualNorm(reduction, baseline) [id 2]);
+ * the criterion is fed the implicit residual norm, checked on the host every
+ * iteration.  host_info as for gkomi_cg_solve_f64_i32.  Blocks until done. */
+size_t gkomi_gmres_workspace_bytes(int64_t n, int64_t nrhs, int64_t krylov_dim);
+int gkomi_gmres_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                              int64_t nnz, const int32_t* row_ptrs,
+                              const int32_t* col_idxs, const double* vals,
+                              int spmv_strategy, int64_t max_row_nnz_hint,
+                              gkomi_apply_fn precond, void* precond_ctx,
+                              const double* b, double* x, int64_t krylov_dim,
+                              int64_t max_iters, double reduction_factor,
+                              int baseline, void* workspace,
+                              size_t workspace_bytes, double* host_info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,399 @@
+// GMRES for gfx950: the step kernels of core/solver/{common_gmres,gmres}_kernels.hpp
+// (initialize, restart, hessenberg_qr, solve_krylov, multi_axpy; semantics =
+// reference/solver/common_gmres_kernels.cpp:60-217, gmres_kernels.cpp:55-100)
+// and a native driver for Gmres::apply_dense_impl (core/solver/gmres.cpp:139-372).
+//
+// The Arnoldi step keeps the reference's modified Gram-Schmidt order (dot,
+// axpy, dot, axpy ...), so the Hessenberg entries agree with the reference up
+// to the reduction order of each dot.  The small-matrix kernels (Givens QR on
+// one Hessenberg column, triangular solve) run one thread per right-hand
+// side exactly like the reference loops -> bit-identical given equal inputs.
+// HBM: step k moves (5k+8) n values (core/solver/gmres.cpp:217-222).
+#include "internal.hpp"
+
+#include <cmath>
+#include <utility>
+
+namespace gkomi {
+namespace {
+
+constexpr int block = 256;
+
+__global__ __launch_bounds__(block) void gmres_initialize_kernel(
+    int64_t n, int64_t nrhs, int64_t krylov_dim, const double* __restrict__ b, int64_t b_stride,
+    double* __restrict__ residual, int64_t r_stride, double* __restrict__ gsin,
+    double* __restrict__ gcos, uint8_t* __restrict__ stop_status)
+{
+    const int64_t gid = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * block;
+    for (int64_t i = gid; i < krylov_dim * nrhs; i += step) {
+        gsin[i] = 0.0;
+        gcos[i] = 0.0;
+    }
+    for (int64_t i = gid; i < nrhs; i += step) stop_status[i] = 0;
+    for (int64_t i = gid; i < n * nrhs; i += step) {
+        const int64_t row = i / nrhs, col = i % nrhs;
+        residual[row * r_stride + col] = b[row * b_stride + col];
+    }
+}
+
+__global__ __launch_bounds__(block) void gmres_restart_kernel(
+    int64_t n, int64_t nrhs, const double* __restrict__ residual, int64_t r_stride,
+    const double* __restrict__ residual_norm, double* __restrict__ rnc,
+    double* __restrict__ krylov_bases, int64_t kb_stride, uint64_t* __restrict__ final_iter_nums)
+{
+    const int64_t gid = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * block;
+    for (int64_t i = gid; i < nrhs; i += step) {
+        rnc[i] = residual_norm[i];
+        final_iter_nums[i] = 0;
+    }
+    for (int64_t i = gid; i < n * nrhs; i += step) {
+        const int64_t row = i / nrhs, col = i % nrhs;
+        krylov_bases[row * kb_stride + col] = residual[row * r_stride + col] / residual_norm[col];
+    }
+}
+
+// one thread per right-hand side; the loop body is the reference's
+__global__ __launch_bounds__(block) void gmres_hessenberg_qr_kernel(
+    int64_t nrhs, double* __restrict__ gsin, double* __restrict__ gcos,
+    double* __restrict__ residual_norm, double* __restrict__ rnc, double* __restrict__ hess,
+    int64_t h_stride, int64_t iter, uint64_t* __restrict__ final_iter_nums,
+    const uint8_t* __restrict__ stop_status)
+{
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; i < nrhs;
+         i += static_cast<int64_t>(gridDim.x) * block) {
+        if (status_has_stopped(stop_status[i])) continue;
+        final_iter_nums[i]++;
+        for (int64_t j = 0; j < iter; ++j) {
+            const double c = gcos[j * nrhs + i], s = gsin[j * nrhs + i];
+            const double h0 = hess[j * h_stride + i], h1 = hess[(j + 1) * h_stride + i];
+            const double temp = c * h0 + s * h1;
+            hess[(j + 1) * h_stride + i] = -s * h0 + c * h1;
+            hess[j * h_stride + i] = temp;
+        }
+        const double this_h = hess[iter * h_stride + i];
+        const double next_h = hess[(iter + 1) * h_stride + i];
+        double c, s;
+        if (this_h == 0.0) {
+            c = 0.0;
+            s = 1.0;
+        } else {
+            const double scale = fabs(this_h) + fabs(next_h);
+            const double hyp = scale * sqrt(fabs(this_h / scale) * fabs(this_h / scale) +
+                                            fabs(next_h / scale) * fabs(next_h / scale));
+            c = this_h / hyp;
+            s = next_h / hyp;
+        }
+        gcos[iter * nrhs + i] = c;
+        gsin[iter * nrhs + i] = s;
+        hess[iter * h_stride + i] = c * this_h + s * next_h;
+        hess[(iter + 1) * h_stride + i] = 0.0;
+        const double r = rnc[iter * nrhs + i];
+        const double next_r = -s * r;
+        rnc[(iter + 1) * nrhs + i] = next_r;
+        rnc[iter * nrhs + i] = c * r;
+        residual_norm[i] = fabs(next_r);
+    }
+}
+
+__global__ __launch_bounds__(block) void gmres_solve_krylov_kernel(
+    int64_t nrhs, const double* __restrict__ rnc, const double* __restrict__ hessenberg,
+    int64_t h_stride, double* __restrict__ y, const uint64_t* __restrict__ final_iter_nums,
+    const uint8_t* __restrict__ stop_status)
+{
+    for (int64_t k = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; k < nrhs;
+         k += static_cast<int64_t>(gridDim.x) * block) {
+        if (stop_status[k] & GKOMI_STATUS_FINALIZED) continue;
+        const int64_t m = static_cast<int64_t>(final_iter_nums[k]);
+        for (int64_t i = m - 1; i >= 0; --i) {
+            double temp = rnc[i * nrhs + k];
+            for (int64_t j = i + 1; j < m; ++j) {
+                temp -= hessenberg[i * h_stride + j * nrhs + k] * y[j * nrhs + k];
+            }
+            y[i * nrhs + k] = temp / hessenberg[i * h_stride + i * nrhs + k];
+        }
+    }
+}
+
+// before_preconditioner = V y: each thread owns one (row, rhs) entry and adds
+// the Krylov vectors in index order, like the reference
+__global__ __launch_bounds__(block) void gmres_multi_axpy_kernel(
+    int64_t n, int64_t nrhs, const double* __restrict__ krylov_bases, int64_t kb_stride,
+    const double* __restrict__ y, double* __restrict__ before, int64_t bp_stride,
+    const uint64_t* __restrict__ final_iter_nums, const uint8_t* __restrict__ stop_status)
+{
+    const int64_t total = n * nrhs;
+    for (int64_t idx = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; idx < total;
+         idx += static_cast<int64_t>(gridDim.x) * block) {
+        const int64_t i = idx / nrhs, k = idx % nrhs;
+        if (stop_status[k] & GKOMI_STATUS_FINALIZED) continue;
+        const int64_t m = static_cast<int64_t>(final_iter_nums[k]);
+        double acc = 0.0;
+        for (int64_t j = 0; j < m; ++j) {
+            acc += krylov_bases[(i + j * n) * kb_stride + k] * y[j * nrhs + k];
+        }
+        before[i * bp_stride + k] = acc;
+    }
+}
+
+__global__ __launch_bounds__(block) void gmres_finalize_status_kernel(
+    int64_t nrhs, uint8_t* __restrict__ stop_status)
+{
+    for (int64_t k = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; k < nrhs;
+         k += static_cast<int64_t>(gridDim.x) * block) {
+        const uint8_t st = stop_status[k];
+        if (!(st & GKOMI_STATUS_FINALIZED) && status_has_stopped(st)) {
+            stop_status[k] = st | GKOMI_STATUS_FINALIZED;
+        }
+    }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct gmres_layout {
+    size_t residual, pv, before, after, kb, hess, gsin, gcos, rnc, y, small, fin, red, total;
+};
+
+gmres_layout make_layout(int64_t n, int64_t nrhs, int64_t d)
+{
+    gmres_layout l{};
+    const size_t vec = align_up(sizeof(double) * static_cast<size_t>(n) * nrhs, 256);
+    size_t off = 0;
+    l.residual = off; off += vec;
+    l.pv = off; off += vec;
+    l.before = off; off += vec;
+    l.after = off; off += vec;
+    l.kb = off; off += align_up(sizeof(double) * static_cast<size_t>(n) * nrhs * (d + 1), 256);
+    l.hess = off; off += align_up(sizeof(double) * static_cast<size_t>((d + 1) * d * nrhs), 256);
+    l.gsin = off; off += align_up(sizeof(double) * static_cast<size_t>(d * nrhs), 256);
+    l.gcos = off; off += align_up(sizeof(double) * static_cast<size_t>(d * nrhs), 256);
+    l.rnc = off; off += align_up(sizeof(double) * static_cast<size_t>((d + 1) * nrhs), 256);
+    l.y = off; off += align_up(sizeof(double) * static_cast<size_t>(d * nrhs), 256);
+    // residual_norm, orig_tau, one, neg_one (nrhs each), then stop_status + flags
+    l.small = off; off += align_up(sizeof(double) * 4 * static_cast<size_t>(nrhs) + nrhs + 16, 256);
+    l.fin = off; off += align_up(sizeof(uint64_t) * static_cast<size_t>(nrhs), 256);
+    l.red = off; off += align_up(gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8, 256);
+    l.total = off;
+    return l;
+}
+
+#define GKOMI_TRY(expr)        \
+    do {                       \
+        int err_ = (expr);     \
+        if (err_) return err_; \
+    } while (0)
+
+}  // namespace
+}  // namespace gkomi
+
+using namespace gkomi;
+
+extern "C" int gkomi_gmres_initialize_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                                          int64_t krylov_dim, const double* b, int64_t b_stride,
+                                          double* residual, int64_t r_stride, double* givens_sin,
+                                          double* givens_cos, uint8_t* stop_status)
+{
+    if (n < 0 || nrhs < 0 || krylov_dim < 0) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    const int64_t work = std::max<int64_t>(n * nrhs, krylov_dim * nrhs);
+    hipLaunchKernelGGL(gmres_initialize_kernel, dim3(grid_for(work, block)), dim3(block), 0,
+                       to_stream(s), n, nrhs, krylov_dim, b, b_stride, residual, r_stride,
+                       givens_sin, givens_cos, stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_gmres_restart_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                                       const double* residual, int64_t r_stride,
+                                       const double* residual_norm,
+                                       double* residual_norm_collection, double* krylov_bases,
+                                       int64_t kb_stride, uint64_t* final_iter_nums)
+{
+    if (n < 0 || nrhs < 0) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(gmres_restart_kernel, dim3(grid_for(std::max<int64_t>(n * nrhs, nrhs), block)),
+                       dim3(block), 0, to_stream(s), n, nrhs, residual, r_stride, residual_norm,
+                       residual_norm_collection, krylov_bases, kb_stride, final_iter_nums);
+    return check_launch();
+}
+
+extern "C" int gkomi_gmres_hessenberg_qr_f64(gkomi_stream_t s, int64_t nrhs, double* givens_sin,
+                                             double* givens_cos, double* residual_norm,
+                                             double* residual_norm_collection,
+                                             double* hessenberg_iter, int64_t h_stride,
+                                             int64_t iter, uint64_t* final_iter_nums,
+                                             const uint8_t* stop_status)
+{
+    if (nrhs < 0 || iter < 0) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(gmres_hessenberg_qr_kernel, dim3(grid_for(nrhs, block)), dim3(block), 0,
+                       to_stream(s), nrhs, givens_sin, givens_cos, residual_norm,
+                       residual_norm_collection, hessenberg_iter, h_stride, iter, final_iter_nums,
+                       stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_gmres_solve_krylov_f64(gkomi_stream_t s, int64_t nrhs,
+                                            const double* residual_norm_collection,
+                                            const double* hessenberg, int64_t h_stride, double* y,
+                                            const uint64_t* final_iter_nums,
+                                            const uint8_t* stop_status)
+{
+    if (nrhs < 0) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(gmres_solve_krylov_kernel, dim3(grid_for(nrhs, block)), dim3(block), 0,
+                       to_stream(s), nrhs, residual_norm_collection, hessenberg, h_stride, y,
+                       final_iter_nums, stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_gmres_multi_axpy_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                                          const double* krylov_bases, int64_t kb_stride,
+                                          const double* y, double* before_preconditioner,
+                                          int64_t bp_stride, const uint64_t* final_iter_nums,
+                                          uint8_t* stop_status)
+{
+    if (n < 0 || nrhs < 0) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    hipStream_t stream = to_stream(s);
+    if (n > 0) {
+        hipLaunchKernelGGL(gmres_multi_axpy_kernel, dim3(grid_for(n * nrhs, block)), dim3(block), 0,
+                           stream, n, nrhs, krylov_bases, kb_stride, y, before_preconditioner,
+                           bp_stride, final_iter_nums, stop_status);
+    }
+    // "if has_stopped: finalize" after the column is done (gmres_kernels.cpp:95-97)
+    hipLaunchKernelGGL(gmres_finalize_status_kernel, dim3(grid_for(nrhs, block)), dim3(block), 0,
+                       stream, nrhs, stop_status);
+    return check_launch();
+}
+
+extern "C" size_t gkomi_gmres_workspace_bytes(int64_t n, int64_t nrhs, int64_t krylov_dim)
+{
+    if (n < 0 || nrhs <= 0 || krylov_dim <= 0) return 0;
+    return make_layout(n, nrhs, krylov_dim).total;
+}
+
+extern "C" int gkomi_gmres_solve_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
+    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t krylov_dim,
+    int64_t max_iters, double reduction_factor, int baseline, void* workspace,
+    size_t workspace_bytes, double* host_info)
+{
+    if (n < 0 || nrhs <= 0 || krylov_dim <= 0 || max_iters < 0) return GKOMI_EINVAL;
+    if (baseline < 0 || baseline > 2) return GKOMI_EINVAL;
+    const gmres_layout l = make_layout(n, nrhs, krylov_dim);
+    if (workspace == nullptr || workspace_bytes < l.total) return GKOMI_EWORKSPACE;
+    hipStream_t stream = to_stream(s);
+    char* ws = static_cast<char*>(workspace);
+    auto D = [&](size_t off) { return reinterpret_cast<double*>(ws + off); };
+    double *residual = D(l.residual), *pv = D(l.pv), *before = D(l.before), *after = D(l.after);
+    double *kb = D(l.kb), *hess = D(l.hess), *gsin = D(l.gsin), *gcos = D(l.gcos);
+    double *rnc = D(l.rnc), *y = D(l.y);
+    double* small = D(l.small);
+    double *residual_norm = small, *orig_tau = small + nrhs, *one = small + 2 * nrhs,
+           *neg_one = small + 3 * nrhs;
+    uint8_t* stop_status = reinterpret_cast<uint8_t*>(small + 4 * nrhs);
+    uint8_t* dev_flags = stop_status + nrhs + (8 - nrhs % 8) % 8;
+    uint64_t* final_iter_nums = reinterpret_cast<uint64_t*>(ws + l.fin);
+    void* red = ws + l.red;
+    const size_t red_bytes = gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8;
+    const int64_t h_stride = krylov_dim * nrhs;
+    constexpr uint8_t id_iteration = 1, id_residual = 2;
+
+    auto apply_precond = [&](const double* in, double* out) -> int {
+        if (precond == nullptr) return gkomi_dense_copy_f64(s, n, nrhs, in, nrhs, out, nrhs);
+        return precond(precond_ctx, s, in, out);
+    };
+    auto residual_and_restart = [&]() -> int {
+        // residual = b - A x; residual_norm; restart (gmres.cpp:184-195 / 260-275)
+        GKOMI_TRY(gkomi_dense_copy_f64(s, n, nrhs, b, nrhs, residual, nrhs));
+        GKOMI_TRY(gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, x, nrhs,
+                                         residual, nrhs, neg_one, one, spmv_strategy,
+                                         max_row_nnz_hint));
+        GKOMI_TRY(gkomi_dense_compute_norm2_f64(s, n, nrhs, residual, nrhs, residual_norm, red,
+                                                red_bytes));
+        return gkomi_gmres_restart_f64(s, n, nrhs, residual, nrhs, residual_norm, rnc, kb, nrhs,
+                                       final_iter_nums);
+    };
+    auto update_solution = [&](int64_t) -> int {
+        GKOMI_TRY(gkomi_gmres_solve_krylov_f64(s, nrhs, rnc, hess, h_stride, y, final_iter_nums,
+                                               stop_status));
+        GKOMI_TRY(gkomi_gmres_multi_axpy_f64(s, n, nrhs, kb, nrhs, y, before, nrhs,
+                                             final_iter_nums, stop_status));
+        GKOMI_TRY(apply_precond(before, after));
+        return gkomi_dense_add_scaled_f64(s, n, nrhs, one, 1, after, nrhs, x, nrhs);
+    };
+
+    GKOMI_TRY(gkomi_dense_fill_f64(s, 1, nrhs, one, nrhs, 1.0));
+    GKOMI_TRY(gkomi_dense_fill_f64(s, 1, nrhs, neg_one, nrhs, -1.0));
+    GKOMI_TRY(gkomi_dense_fill_f64(s, krylov_dim + 1, h_stride, hess, h_stride, 0.0));
+    GKOMI_TRY(gkomi_gmres_initialize_f64(s, n, nrhs, krylov_dim, b, nrhs, residual, nrhs, gsin,
+                                         gcos, stop_status));
+    GKOMI_TRY(residual_and_restart());
+    if (baseline == 0) {
+        GKOMI_TRY(gkomi_dense_compute_norm2_f64(s, n, nrhs, b, nrhs, orig_tau, red, red_bytes));
+    } else if (baseline == 1) {
+        GKOMI_TRY(gkomi_dense_copy_f64(s, 1, nrhs, residual_norm, nrhs, orig_tau, nrhs));
+    } else {
+        GKOMI_TRY(gkomi_dense_fill_f64(s, 1, nrhs, orig_tau, nrhs, 1.0));
+    }
+
+    long long total_iter = -1;
+    int64_t restart_iter = 0;
+    int converged = 0;
+    uint8_t host_flags[2] = {0, 0};
+    while (true) {
+        ++total_iter;
+        bool stop = false;
+        if (total_iter >= max_iters) {
+            GKOMI_TRY(gkomi_set_all_statuses(s, nrhs, id_iteration, 0, stop_status));
+            stop = true;
+        } else {
+            // the criterion gets residual_norm directly (gmres.cpp:240-246), not finalized
+            GKOMI_TRY(gkomi_residual_norm_f64(s, nrhs, residual_norm, orig_tau, reduction_factor,
+                                              id_residual, 0, stop_status, dev_flags, host_flags));
+            stop = host_flags[0] != 0;
+            converged = stop ? 1 : 0;
+        }
+        if (stop) break;
+        if (restart_iter == krylov_dim) {
+            GKOMI_TRY(update_solution(restart_iter));
+            GKOMI_TRY(residual_and_restart());
+            restart_iter = 0;
+        }
+        double* this_k = kb + n * nrhs * restart_iter;
+        double* next_k = kb + n * nrhs * (restart_iter + 1);
+        GKOMI_TRY(apply_precond(this_k, pv));
+        double* hess_iter = hess + nrhs * restart_iter;
+        GKOMI_TRY(gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, pv, nrhs,
+                                         next_k, nrhs, nullptr, nullptr, spmv_strategy,
+                                         max_row_nnz_hint));
+        for (int64_t i = 0; i <= restart_iter; ++i) {
+            double* h = hess_iter + i * h_stride;
+            const double* basis = kb + n * nrhs * i;
+            GKOMI_TRY(gkomi_dense_compute_dot_f64(s, n, nrhs, next_k, nrhs, basis, nrhs, h, red,
+                                                  red_bytes));
+            GKOMI_TRY(gkomi_dense_sub_scaled_f64(s, n, nrhs, h, nrhs, basis, nrhs, next_k, nrhs));
+        }
+        double* hn = hess_iter + (restart_iter + 1) * h_stride;
+        GKOMI_TRY(gkomi_dense_compute_norm2_f64(s, n, nrhs, next_k, nrhs, hn, red, red_bytes));
+        GKOMI_TRY(gkomi_dense_inv_scale_f64(s, n, nrhs, hn, nrhs, next_k, nrhs));
+        GKOMI_TRY(gkomi_gmres_hessenberg_qr_f64(s, nrhs, gsin, gcos, residual_norm, rnc, hess_iter,
+                                                h_stride, restart_iter, final_iter_nums,
+                                                stop_status));
+        restart_iter++;
+    }
+    GKOMI_TRY(update_solution(restart_iter));
+    if (host_info != nullptr) {
+        for (int64_t j = 0; j < nrhs; ++j) {
+            GKOMI_TRY(static_cast<int>(hipMemcpyAsync(host_info + 2 + 2 * j, residual_norm + j,
+                                                      sizeof(double), hipMemcpyDeviceToHost, stream)));
+            GKOMI_TRY(static_cast<int>(hipMemcpyAsync(host_info + 3 + 2 * j, orig_tau + j,
+                                                      sizeof(double), hipMemcpyDeviceToHost, stream)));
+        }
+        host_info[0] = static_cast<double>(total_iter);
+        host_info[1] = static_cast<double>(converged);
+    }
+    return static_cast<int>(hipStreamSynchronize(stream));
+}

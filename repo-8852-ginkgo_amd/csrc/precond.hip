@@ -1,0 +1,32 @@
+// Preconditioner apply callbacks (gkomi_apply_fn) for the native solver
+// drivers: the LinOp::apply of preconditioner::Jacobi
+// (core/preconditioner/jacobi.cpp apply_impl -> jacobi::simple_apply) and of
+// preconditioner::Ilu (include/ginkgo/core/preconditioner/ilu.hpp:265-286:
+// L^-1 into a cached intermediate, then U^-1).
+#include "common.hpp"
+
+extern "C" int gkomi_jacobi_apply_cb(void* ctx_, gkomi_stream_t s, const double* in, double* out)
+{
+    const gkomi_jacobi_ctx* c = static_cast<const gkomi_jacobi_ctx*>(ctx_);
+    if (c == nullptr) return GKOMI_EINVAL;
+    if (c->max_block_size == 1) {
+        return gkomi_jacobi_scalar_apply_f64(s, c->n, c->nrhs, c->blocks, nullptr, in, c->nrhs,
+                                             nullptr, out, c->nrhs);
+    }
+    return gkomi_jacobi_apply_f64_i32(s, c->num_blocks, c->max_block_size, c->block_ptrs,
+                                      c->blocks, c->nrhs, nullptr, in, c->nrhs, nullptr, out,
+                                      c->nrhs);
+}
+
+extern "C" int gkomi_ilu_apply_cb(void* ctx_, gkomi_stream_t s, const double* in, double* out)
+{
+    const gkomi_ilu_ctx* c = static_cast<const gkomi_ilu_ctx*>(ctx_);
+    if (c == nullptr) return GKOMI_EINVAL;
+    int err = gkomi_lower_trs_solve_f64_i32(s, c->n, c->nrhs, c->l_row_ptrs, c->l_col_idxs,
+                                            c->l_vals, c->l_unit_diag, in, c->nrhs, c->intermediate,
+                                            c->nrhs, c->trs_workspace, c->trs_workspace_bytes);
+    if (err) return err;
+    return gkomi_upper_trs_solve_f64_i32(s, c->n, c->nrhs, c->u_row_ptrs, c->u_col_idxs, c->u_vals,
+                                         0, c->intermediate, c->nrhs, out, c->nrhs,
+                                         c->trs_workspace, c->trs_workspace_bytes);
+}

@@ -32,7 +32,9 @@ def cg_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reducti
     info = np.zeros(2 + 2 * nrhs, dtype=np.float64)
     stream = torch.cuda.current_stream().cuda_stream
     pc = None
-    if precond is not None:
+    if precond is not None and hasattr(precond, "ctx_ptr"):
+        pc, precond_ctx = precond.fn, precond.ctx_ptr
+    elif precond is not None:
         pc = ctypes.cast(precond, ctypes.c_void_p).value if not isinstance(precond, int) else precond
     gk.cg_solve_f64_i32(stream, n, nrhs, nnz, row_ptrs, col_idxs, vals, strategy, max_row_nnz,
                         pc, precond_ctx, b2, x2, max_iters, reduction, BASELINES[baseline], mode,
@@ -41,4 +43,91 @@ def cg_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reducti
     base = info[3::2].copy()
     return {"x": x2 if b.dim() > 1 else x2.reshape(n), "iterations": int(info[0]),
             "converged": bool(info[1]), "residual_norm": res, "baseline_norm": base,
+            "rel_residual": float(np.max(res / np.where(base == 0, 1.0, base)))}
+
+
+class JacobiCtx(ctypes.Structure):
+    """gkomi_jacobi_ctx (include/gkomi.h)."""
+    _fields_ = [("n", ctypes.c_int64), ("nrhs", ctypes.c_int64), ("num_blocks", ctypes.c_int64),
+                ("max_block_size", ctypes.c_int32), ("pad_", ctypes.c_int32),
+                ("block_ptrs", ctypes.c_void_p), ("blocks", ctypes.c_void_p)]
+
+
+class IluCtx(ctypes.Structure):
+    """gkomi_ilu_ctx (include/gkomi.h)."""
+    _fields_ = [("n", ctypes.c_int64), ("nrhs", ctypes.c_int64),
+                ("l_row_ptrs", ctypes.c_void_p), ("l_col_idxs", ctypes.c_void_p), ("l_vals", ctypes.c_void_p),
+                ("u_row_ptrs", ctypes.c_void_p), ("u_col_idxs", ctypes.c_void_p), ("u_vals", ctypes.c_void_p),
+                ("intermediate", ctypes.c_void_p), ("trs_workspace", ctypes.c_void_p),
+                ("trs_workspace_bytes", ctypes.c_size_t), ("l_unit_diag", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class Preconditioner:
+    """A native gkomi_apply_fn + its context; keeps the device buffers alive."""
+
+    def __init__(self, gk, name, ctx, keep):
+        self.fn = ctypes.cast(getattr(gk._cdll, name), ctypes.c_void_p).value
+        self.ctx = ctx
+        self.ctx_ptr = ctypes.addressof(ctx)
+        self.keep = keep
+
+
+def jacobi_generate(gk, n, row_ptrs, col_idxs, vals, max_block_size=32, nrhs=1):
+    """preconditioner::Jacobi::generate (core/preconditioner/jacobi.cpp:300-370):
+    detect_blocks + generate, or extract/invert the diagonal for max_block_size 1."""
+    dv = vals.device
+    s = torch.cuda.current_stream().cuda_stream
+    if max_block_size == 1:
+        diag = torch.zeros(n, dtype=torch.float64, device=dv)
+        gk.csr_extract_diagonal_f64_i32(s, n, row_ptrs, col_idxs, vals, diag)
+        inv = torch.zeros_like(diag)
+        gk.jacobi_invert_diagonal_f64(s, n, diag, inv)
+        ctx = JacobiCtx(n, nrhs, n, 1, 0, 0, inv.data_ptr())
+        return Preconditioner(gk, "gkomi_jacobi_apply_cb", ctx, (inv,))
+    ptrs = torch.zeros(n + 1, dtype=torch.int32, device=dv)
+    nbd = torch.zeros(1, dtype=torch.int64, device=dv)
+    ws = torch.empty(n + 8, dtype=torch.uint8, device=dv)
+    hn = ctypes.c_int64(0)
+    gk.jacobi_find_blocks_i32(s, n, row_ptrs, col_idxs, max_block_size, ptrs, nbd, ws, n + 8, ctypes.addressof(hn))
+    nb = int(hn.value)
+    blocks = torch.zeros(max(gk.jacobi_storage_elements(max_block_size, nb), 1), dtype=torch.float64, device=dv)
+    gk.jacobi_generate_f64_i32(s, n, row_ptrs, col_idxs, vals, nb, max_block_size, ptrs, None, blocks)
+    ctx = JacobiCtx(n, nrhs, nb, max_block_size, 0, ptrs.data_ptr(), blocks.data_ptr())
+    p = Preconditioner(gk, "gkomi_jacobi_apply_cb", ctx, (ptrs, blocks))
+    p.num_blocks, p.block_ptrs, p.blocks = nb, ptrs, blocks
+    return p
+
+
+def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False):
+    """preconditioner::Ilu over given CSR factors L = (row_ptrs, col_idxs, vals), U likewise."""
+    dv = L[2].device
+    inter = torch.zeros((n, nrhs), dtype=torch.float64, device=dv)
+    nb = gk.trs_workspace_bytes()
+    tws = torch.zeros(nb, dtype=torch.uint8, device=dv)
+    ctx = IluCtx(n, nrhs, L[0].data_ptr(), L[1].data_ptr(), L[2].data_ptr(), U[0].data_ptr(), U[1].data_ptr(),
+                 U[2].data_ptr(), inter.data_ptr(), tws.data_ptr(), nb, int(l_unit_diag), 0)
+    return Preconditioner(gk, "gkomi_ilu_apply_cb", ctx, (L, U, inter, tws))
+
+
+def gmres_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, krylov_dim=100, max_iters=1000, reduction=1e-10,
+                baseline="rhs_norm", strategy=0, max_row_nnz=-1, precond=None):
+    """Gmres with Combined(Iteration(max_iters), ResidualNorm(reduction, baseline)).
+    precond: None or a Preconditioner."""
+    b2 = b.reshape(n, -1)
+    nrhs = b2.shape[1]
+    if x is None:
+        x = torch.zeros_like(b2)
+    x2 = x.reshape(n, nrhs)
+    nnz = int(vals.numel())
+    nbytes = gk.gmres_workspace_bytes(n, nrhs, krylov_dim)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+    info = np.zeros(2 + 2 * nrhs, dtype=np.float64)
+    stream = torch.cuda.current_stream().cuda_stream
+    fn = precond.fn if precond is not None else None
+    ctx = precond.ctx_ptr if precond is not None else None
+    gk.gmres_solve_f64_i32(stream, n, nrhs, nnz, row_ptrs, col_idxs, vals, strategy, max_row_nnz, fn, ctx, b2, x2,
+                           krylov_dim, max_iters, reduction, BASELINES[baseline], ws, nbytes, info)
+    res, base = info[2::2].copy(), info[3::2].copy()
+    return {"x": x2 if b.dim() > 1 else x2.reshape(n), "iterations": int(info[0]), "converged": bool(info[1]),
+            "residual_norm": res, "baseline_norm": base,
             "rel_residual": float(np.max(res / np.where(base == 0, 1.0, base)))}
