@@ -460,6 +460,56 @@ int gkomi_cg_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
                            int check_every, void* workspace,
                            size_t workspace_bytes, double* host_info);
 
+/* ---- row-partitioned distributed matrix (core/distributed/{partition,matrix}_kernels.hpp) */
+/* Partition metadata on HOST arrays (O(#ranges); core/distributed/matrix.cpp
+ * consumes it on the host for the communication plan):
+ * reference/distributed/partition_kernels.cpp:42-135.
+ * ranges: num_parts + 1; range_bounds: num_ranges + 1; part_ids, starting
+ * indices: num_ranges; part_sizes: num_parts. */
+int gkomi_partition_build_ranges_from_global_size(int64_t num_parts,
+                                                  int64_t global_size,
+                                                  int64_t* host_ranges);
+int gkomi_partition_build_from_contiguous(int64_t num_parts,
+                                          const int64_t* host_ranges,
+                                          int64_t* host_range_bounds,
+                                          int32_t* host_part_ids);
+int gkomi_partition_build_from_mapping(int64_t n, const int32_t* host_mapping,
+                                       int64_t* host_range_bounds,
+                                       int32_t* host_part_ids,
+                                       int64_t* host_num_ranges);
+int gkomi_partition_build_starting_indices(const int64_t* host_range_bounds,
+                                           const int32_t* host_part_ids,
+                                           int64_t num_ranges,
+                                           int64_t num_parts,
+                                           int32_t* host_starting_indices,
+                                           int32_t* host_part_sizes,
+                                           int64_t* host_num_empty_parts);
+/* distributed_matrix::build_local_nonlocal
+ * (reference/distributed/matrix_kernels.cpp:49-190) on device-resident COO
+ * input with 64-bit global indices; partition arrays are device copies of the
+ * metadata above.  Two phases because the caller allocates the outputs:
+ * sizes -> host_sizes = {num_local, num_non_local, num_unique_non_local_cols}
+ * (blocking), then fill with the SAME workspace.  Global columns < 2^40. */
+size_t gkomi_dist_build_workspace_bytes(int64_t nnz);
+int gkomi_dist_build_local_nonlocal_sizes(
+    gkomi_stream_t s, int64_t nnz, const int64_t* rows, const int64_t* cols,
+    const int64_t* row_range_bounds, const int32_t* row_part_ids,
+    const int32_t* row_starts, int64_t row_num_ranges,
+    const int64_t* col_range_bounds, const int32_t* col_part_ids,
+    const int32_t* col_starts, int64_t col_num_ranges, int32_t local_part,
+    void* workspace, size_t workspace_bytes, int64_t host_sizes[3]);
+int gkomi_dist_build_local_nonlocal_fill(
+    gkomi_stream_t s, int64_t nnz, const int64_t* rows, const int64_t* cols,
+    const double* vals, const int64_t* row_range_bounds,
+    const int32_t* row_part_ids, const int32_t* row_starts,
+    int64_t row_num_ranges, const int64_t* col_range_bounds,
+    const int32_t* col_part_ids, const int32_t* col_starts,
+    int64_t col_num_ranges, int64_t num_parts, const void* workspace,
+    int64_t num_unique, int32_t* local_row_idxs, int32_t* local_col_idxs,
+    double* local_vals, int32_t* non_local_row_idxs,
+    int32_t* non_local_col_idxs, double* non_local_vals, int32_t* gather_idxs,
+    int32_t* recv_sizes, int64_t* non_local_to_global);
+
 /* ---- preconditioners as solver callbacks ---------------------------------
  * Ready-made gkomi_apply_fn implementations and their context records, the
  * generated state of preconditioner::Jacobi / preconditioner::Ilu.  All

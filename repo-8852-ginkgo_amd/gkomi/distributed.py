@@ -1,0 +1,319 @@
+"""Row-partitioned distributed matrix / vector / CG over torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPUs; "gloo" on CPUs for the logic
+tests).  Mirrors gko::experimental::distributed::{Partition, Matrix, Vector}
+(core/distributed/{partition,matrix,vector}.cpp) for the hot path:
+
+  read_distributed : build_local_nonlocal on the device, then the two setup
+                     exchanges of matrix.cpp:198-224 (counts, gather indices);
+  apply            : row_gather pack -> asynchronous all-to-all-v of the halo
+                     values on a side stream || local SpMV -> non-local
+                     advanced SpMV (matrix.cpp:263-335);
+  dot / norm2      : local two-stage reduction + all-reduce of the device
+                     scalar (vector.cpp:317-409), no host round trip.
+
+All compute goes through an `ops` object; the product one (GpuOps) is the C ABI
+on device tensors and refuses to run without the HIP library.  Tests inject
+their own ops to exercise the communication logic on CPUs.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class Partition:
+    """Host-side partition metadata (O(#ranges)), as
+    experimental::distributed::Partition keeps it."""
+
+    def __init__(self, range_bounds, part_ids, starts, part_sizes):
+        self.range_bounds = np.ascontiguousarray(range_bounds, np.int64)
+        self.part_ids = np.ascontiguousarray(part_ids, np.int32)
+        self.starts = np.ascontiguousarray(starts, np.int32)
+        self.part_sizes = np.ascontiguousarray(part_sizes, np.int32)
+        self.num_parts = len(self.part_sizes)
+        self.num_ranges = len(self.part_ids)
+        self.size = int(self.range_bounds[-1])
+
+    @staticmethod
+    def _finish(gk, bounds, ids, num_parts):
+        nr = len(ids)
+        starts = np.zeros(nr, np.int32)
+        sizes = np.zeros(num_parts, np.int32)
+        gk.partition_build_starting_indices(bounds, ids, nr, num_parts, starts, sizes, None)
+        return Partition(bounds, ids, starts, sizes)
+
+    @staticmethod
+    def build_from_global_size_uniform(gk, num_parts, global_size):
+        ranges = np.zeros(num_parts + 1, np.int64)
+        gk.partition_build_ranges_from_global_size(num_parts, global_size, ranges)
+        bounds = np.zeros(num_parts + 1, np.int64)
+        ids = np.zeros(num_parts, np.int32)
+        gk.partition_build_from_contiguous(num_parts, ranges, bounds, ids)
+        return Partition._finish(gk, bounds, ids, num_parts)
+
+    @staticmethod
+    def build_from_mapping(gk, mapping, num_parts):
+        mapping = np.ascontiguousarray(mapping, np.int32)
+        n = len(mapping)
+        bounds = np.zeros(n + 1, np.int64)
+        ids = np.zeros(max(n, 1), np.int32)
+        nr = ctypes.c_int64(0)
+        gk.partition_build_from_mapping(n, mapping, bounds, ids, ctypes.addressof(nr))
+        return Partition._finish(gk, bounds[:nr.value + 1].copy(), ids[:nr.value].copy(), num_parts)
+
+
+class GpuOps:
+    """The product compute path: C ABI kernels on device tensors."""
+
+    def __init__(self, gk, device):
+        self.gk = gk
+        self.device = torch.device(device)
+        assert self.device.type == "cuda", "GpuOps needs a GPU; there is no CPU fallback"
+
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def tensor(self, a, dtype=None):
+        t = torch.as_tensor(np.ascontiguousarray(a)).to(self.device)
+        return t if dtype is None else t.to(dtype)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def build_local_nonlocal(self, rows, cols, vals, row_part, col_part, local_part):
+        gk, s = self.gk, self.stream()
+        nnz = int(rows.numel())
+        nb = gk.dist_build_workspace_bytes(nnz)
+        ws = self.empty(nb, torch.uint8)
+        rb, rid, rst = self.tensor(row_part.range_bounds), self.tensor(row_part.part_ids), self.tensor(row_part.starts)
+        cb, cid, cst = self.tensor(col_part.range_bounds), self.tensor(col_part.part_ids), self.tensor(col_part.starts)
+        sizes = (ctypes.c_int64 * 3)()
+        gk.dist_build_local_nonlocal_sizes(s, nnz, rows, cols, rb, rid, rst, row_part.num_ranges, cb, cid, cst,
+                                           col_part.num_ranges, local_part, ws, nb, ctypes.addressof(sizes))
+        nl, nn, nu = (int(v) for v in sizes)
+        i32, f64 = torch.int32, torch.float64
+        out = dict(l_rows=self.empty(max(nl, 1), i32), l_cols=self.empty(max(nl, 1), i32), l_vals=self.empty(max(nl, 1), f64),
+                   nl_rows=self.empty(max(nn, 1), i32), nl_cols=self.empty(max(nn, 1), i32), nl_vals=self.empty(max(nn, 1), f64),
+                   gather_idxs=self.empty(max(nu, 1), i32), recv_sizes=self.empty(row_part.num_parts, i32),
+                   non_local_to_global=self.empty(max(nu, 1), torch.int64), num_local=nl, num_non_local=nn, num_unique=nu)
+        gk.dist_build_local_nonlocal_fill(s, nnz, rows, cols, vals, rb, rid, rst, row_part.num_ranges, cb, cid, cst,
+                                          col_part.num_ranges, row_part.num_parts, ws, nu, out["l_rows"], out["l_cols"],
+                                          out["l_vals"], out["nl_rows"], out["nl_cols"], out["nl_vals"],
+                                          out["gather_idxs"], out["recv_sizes"], out["non_local_to_global"])
+        return out
+
+    def coo_to_csr(self, nrows, row_idxs, nnz):
+        # Csr::read(device_matrix_data): convert_idxs_to_ptrs (core/matrix/csr.cpp:453-470)
+        ptrs = self.empty(nrows + 1, torch.int32)
+        nb = self.gk.prefix_sum_workspace_bytes(nrows + 1)
+        ws = self.empty(max(nb, 8), torch.uint8)
+        self.gk.convert_idxs_to_ptrs_i32(self.stream(), row_idxs, nnz, nrows, ptrs, ws, nb)
+        return ptrs
+
+    def spmv(self, csr, b, x, alpha=None, beta=None):
+        nrows, ncols, nnz, rp, ci, v = csr
+        self.gk.csr_spmv_f64_i32(self.stream(), nrows, ncols, b.shape[1], nnz, rp, ci, v, b, b.stride(0), x,
+                                 x.stride(0), alpha, beta, 0, -1)
+
+    def row_gather(self, idxs, count, src, out):
+        self.gk.dense_row_gather_f64_i32(self.stream(), count, src.shape[1], idxs, src, src.stride(0), out, out.stride(0))
+
+    def local_dot(self, x, y, result, ws):
+        self.gk.dense_compute_dot_f64(self.stream(), x.shape[0], x.shape[1], x, x.stride(0), y, y.stride(0), result,
+                                      ws, ws.numel())
+
+    def local_squared_norm2(self, x, result, ws):
+        self.gk.dense_compute_squared_norm2_f64(self.stream(), x.shape[0], x.shape[1], x, x.stride(0), result, ws,
+                                                ws.numel())
+
+    def reduction_workspace(self, nrows, ncols):
+        return self.empty(max(self.gk.dense_reduction_workspace_bytes(nrows, ncols), 8), torch.uint8)
+
+    def sqrt_(self, t):
+        self.gk.dense_compute_sqrt_f64(self.stream(), 1, t.numel(), t, t.numel())
+
+    def cg_initialize(self, b, r, z, p, q, prev_rho, rho, stop):
+        n, k = b.shape
+        self.gk.cg_initialize_f64(self.stream(), n, k, b, k, r, k, z, k, p, k, q, k, prev_rho, rho, stop)
+
+    def cg_step_1(self, p, z, rho, prev_rho, stop):
+        n, k = p.shape
+        self.gk.cg_step_1_f64(self.stream(), n, k, p, k, z, k, rho, prev_rho, stop)
+
+    def cg_step_2(self, x, r, p, q, beta, rho, stop):
+        n, k = x.shape
+        self.gk.cg_step_2_f64(self.stream(), n, k, x, k, r, k, p, k, q, k, beta, rho, stop)
+
+    def copy(self, src, dst):
+        n, k = src.shape
+        self.gk.dense_copy_f64(self.stream(), n, k, src, src.stride(0), dst, dst.stride(0))
+
+    def sub_scaled(self, alpha, x, y):
+        n, k = x.shape
+        self.gk.dense_sub_scaled_f64(self.stream(), n, k, alpha, alpha.numel(), x, x.stride(0), y, y.stride(0))
+
+    def fill(self, x, value):
+        n, k = x.shape
+        self.gk.dense_fill_f64(self.stream(), n, k, x, x.stride(0), value)
+
+    def residual_check(self, tau, orig_tau, reduction, stop, flags):
+        """ResidualNorm::check_impl: returns all_converged (blocking 2-byte copy)."""
+        host = np.zeros(2, np.uint8)
+        self.gk.residual_norm_f64(self.stream(), tau.numel(), tau, orig_tau, reduction, 2, 1, stop, flags, host)
+        return bool(host[0])
+
+    def side_stream(self):
+        return torch.cuda.Stream(self.device)
+
+
+class Matrix:
+    """experimental::distributed::Matrix for the hot path."""
+
+    def __init__(self, ops, group=None):
+        self.ops = ops
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def read_distributed(self, rows, cols, vals, row_partition, col_partition=None):
+        """rows/cols: int64 global indices of this rank's entries (any rows may
+        be passed; entries of other parts are dropped like the reference does),
+        in row-major order; vals float64."""
+        ops = self.ops
+        col_partition = col_partition or row_partition
+        assert row_partition.num_parts == self.world
+        rows, cols, vals = ops.tensor(rows, torch.int64), ops.tensor(cols, torch.int64), ops.tensor(vals, torch.float64)
+        o = ops.build_local_nonlocal(rows, cols, vals, row_partition, col_partition, self.rank)
+        self.num_local_rows = int(row_partition.part_sizes[self.rank])
+        self.num_local_cols = int(col_partition.part_sizes[self.rank])
+        nl, nn, nu = o["num_local"], o["num_non_local"], o["num_unique"]
+        self.local = (self.num_local_rows, self.num_local_cols, nl,
+                      ops.coo_to_csr(self.num_local_rows, o["l_rows"], nl), o["l_cols"], o["l_vals"])
+        self.non_local = (self.num_local_rows, nu, nn,
+                          ops.coo_to_csr(self.num_local_rows, o["nl_rows"], nn), o["nl_cols"], o["nl_vals"])
+        self.non_local_to_global = o["non_local_to_global"][:nu]
+        # exchange step 1: counts (matrix.cpp:198-209)
+        recv_sizes = o["recv_sizes"].to(torch.int64)
+        send_sizes = torch.empty_like(recv_sizes)
+        dist.all_to_all_single(send_sizes, recv_sizes, group=self.group)
+        self.recv_sizes = [int(v) for v in recv_sizes.cpu()]
+        self.send_sizes = [int(v) for v in send_sizes.cpu()]
+        # exchange step 2: receivers tell senders which local rows they need (:211-224)
+        recv_gather = o["gather_idxs"][:nu].contiguous()
+        self.gather_idxs = ops.empty(max(sum(self.send_sizes), 1), torch.int32)[:sum(self.send_sizes)]
+        dist.all_to_all_single(self.gather_idxs, recv_gather, self.send_sizes, self.recv_sizes, group=self.group)
+        self.send_count, self.recv_count = sum(self.send_sizes), sum(self.recv_sizes)
+        self._bufs = {}
+        self._one = ops.tensor(np.array([1.0]))
+        self._comm_stream = ops.side_stream() if hasattr(ops, "side_stream") else None
+        return self
+
+    def _buffers(self, nrhs):
+        if nrhs not in self._bufs:
+            self._bufs[nrhs] = (self.ops.empty((max(self.send_count, 1), nrhs), torch.float64),
+                                self.ops.empty((max(self.recv_count, 1), nrhs), torch.float64))
+        return self._bufs[nrhs]
+
+    def apply(self, b, x):
+        """x = A b on the local rows.  b, x: (num_local_*, nrhs) tensors."""
+        ops = self.ops
+        nrhs = b.shape[1]
+        send, recv = self._buffers(nrhs)
+        ops.row_gather(self.gather_idxs, self.send_count, b, send)
+        split = lambda sizes: [s * 1 for s in sizes]
+        if self._comm_stream is not None:
+            # halo exchange on a side stream, overlapped with the local SpMV
+            self._comm_stream.wait_stream(torch.cuda.current_stream(ops.device))
+            with torch.cuda.stream(self._comm_stream):
+                work = dist.all_to_all_single(recv[:self.recv_count], send[:self.send_count], split(self.recv_sizes),
+                                              split(self.send_sizes), group=self.group, async_op=True)
+            ops.spmv(self.local, b, x)
+            work.wait()
+            torch.cuda.current_stream(ops.device).wait_stream(self._comm_stream)
+        else:
+            work = dist.all_to_all_single(recv[:self.recv_count], send[:self.send_count], split(self.recv_sizes),
+                                          split(self.send_sizes), group=self.group, async_op=True)
+            ops.spmv(self.local, b, x)
+            work.wait()
+        if self.non_local[2] > 0:
+            ops.spmv(self.non_local, recv, x, self._one, self._one)
+        return x
+
+
+class VectorOps:
+    """experimental::distributed::Vector reductions (vector.cpp:317-409)."""
+
+    def __init__(self, ops, nrows, nrhs, group=None):
+        self.ops, self.group = ops, group
+        self.ws = ops.reduction_workspace(nrows, nrhs)
+
+    def dot(self, x, y, result):
+        self.ops.local_dot(x, y, result, self.ws)
+        dist.all_reduce(result, op=dist.ReduceOp.SUM, group=self.group)
+        return result
+
+    def norm2(self, x, result):
+        self.ops.local_squared_norm2(x, result, self.ws)
+        dist.all_reduce(result, op=dist.ReduceOp.SUM, group=self.group)
+        self.ops.sqrt_(result)
+        return result
+
+
+def cg(matrix, b, x, max_iters=1000, reduction=1e-10):
+    """Cg::apply_dense_impl on distributed vectors (core/solver/cg.cpp:107-193
+    with detail::get_local for the step kernels), Identity preconditioner,
+    Combined(Iteration, ResidualNorm(rhs_norm)).  Returns (iterations, converged)."""
+    ops = matrix.ops
+    n, k = b.shape
+    r, z, p, q = (ops.empty((n, k), torch.float64) for _ in range(4))
+    f = lambda: ops.empty((k,), torch.float64)
+    prev_rho, rho, beta, tau, orig = f(), f(), f(), f(), f()
+    stop = ops.empty((k,), torch.uint8)
+    vec = VectorOps(ops, n, k, matrix.group)
+    flags = ops.empty((2,), torch.uint8)
+    one = ops.tensor(np.ones(1))
+    ops.cg_initialize(b, r, z, p, q, prev_rho, rho, stop)
+    matrix.apply(x, q)                       # r = b - A x
+    ops.sub_scaled(one, q, r)
+    ops.fill(q, 0.0)
+    vec.norm2(b, orig)
+    it = -1
+    while True:
+        ops.copy(r, z)
+        vec.dot(r, z, rho)
+        it += 1
+        if it >= max_iters:
+            return it, False
+        vec.norm2(r, tau)
+        if ops.residual_check(tau, orig, reduction, stop, flags):
+            return it, True
+        ops.cg_step_1(p, z, rho, prev_rho, stop)
+        matrix.apply(p, q)
+        vec.dot(p, q, beta)
+        ops.cg_step_2(x, r, p, q, beta, rho, stop)
+        prev_rho, rho = rho, prev_rho
+
+
+def poisson_slab_rows(grid, rank, world):
+    """COO entries (global int64 indices, row-major) of rank's rows of the 5-pt
+    Poisson matrix on a (grid*world) x grid mesh, row = i*grid + j: the bench's
+    weak-scaling workload (one 1000 x 1000 slab per GPU)."""
+    nx, ny = grid * world, grid
+    i0 = rank * grid
+    i, j = np.meshgrid(np.arange(i0, i0 + grid, dtype=np.int64), np.arange(ny, dtype=np.int64), indexing="ij")
+    i, j = i.ravel(), j.ravel()
+    row = i * ny + j
+    cols = np.stack([row - ny, row - 1, row, row + 1, row + ny], axis=1)
+    valid = np.stack([i > 0, j > 0, np.ones_like(i, bool), j < ny - 1, i < nx - 1], axis=1)
+    vals = np.broadcast_to(np.array([-1.0, -1.0, 4.0, -1.0, -1.0]), cols.shape)
+    rows = np.broadcast_to(row[:, None], cols.shape)
+    return rows[valid], cols[valid], np.ascontiguousarray(vals[valid]), nx * ny
+
+
+def poisson_slab_matrix(gk, grid, rank, world, device, group=None):
+    rows, cols, vals, n_global = poisson_slab_rows(grid, rank, world)
+    part = Partition.build_from_global_size_uniform(gk, world, n_global)
+    m = Matrix(GpuOps(gk, device), group).read_distributed(rows, cols, vals, part)
+    m.global_nnz_local_rows = len(vals)
+    return m
