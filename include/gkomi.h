@@ -63,6 +63,15 @@ int gkomi_synchronize(gkomi_stream_t stream);
 /* readable name of the last HIP error code returned (Hip*Error::get_error) */
 const char* gkomi_error_string(int code);
 
+/* HipExecutor memory interface (hip/base/executor.hip.cpp: raw_alloc, raw_free,
+ * raw_copy_to x4, core/device_hooks/hip_hooks.cpp:66-112) so that a host
+ * program needs no HIP headers.  kind: 0 host->device, 1 device->host,
+ * 2 device->device; copies are synchronous like the reference's hipMemcpy. */
+int gkomi_set_device(int device);
+int gkomi_raw_alloc(size_t num_bytes, void** out_ptr);
+int gkomi_raw_free(void* ptr);
+int gkomi_raw_copy(void* dst, const void* src, size_t num_bytes, int kind);
+
 /* ---- CSR SpMV (core/matrix/csr_kernels.hpp:58-75) ----------------------- */
 
 /* Kernel selection, the role of Csr::strategy_type / srow

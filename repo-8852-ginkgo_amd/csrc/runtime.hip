@@ -48,3 +48,32 @@ extern "C" const char* gkomi_error_string(int code)
     if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
     return "gkomi: unknown error";
 }
+
+extern "C" int gkomi_set_device(int device) { return static_cast<int>(hipSetDevice(device)); }
+
+extern "C" int gkomi_raw_alloc(size_t num_bytes, void** out_ptr)
+{
+    if (out_ptr == nullptr) return GKOMI_EINVAL;
+    *out_ptr = nullptr;
+    if (num_bytes == 0) return GKOMI_SUCCESS;
+    return static_cast<int>(hipMalloc(out_ptr, num_bytes));
+}
+
+extern "C" int gkomi_raw_free(void* ptr)
+{
+    if (ptr == nullptr) return GKOMI_SUCCESS;
+    return static_cast<int>(hipFree(ptr));
+}
+
+extern "C" int gkomi_raw_copy(void* dst, const void* src, size_t num_bytes, int kind)
+{
+    if (num_bytes == 0) return GKOMI_SUCCESS;
+    hipMemcpyKind k;
+    switch (kind) {
+    case 0: k = hipMemcpyHostToDevice; break;
+    case 1: k = hipMemcpyDeviceToHost; break;
+    case 2: k = hipMemcpyDeviceToDevice; break;
+    default: return GKOMI_EINVAL;
+    }
+    return static_cast<int>(hipMemcpy(dst, src, num_bytes, k));
+}

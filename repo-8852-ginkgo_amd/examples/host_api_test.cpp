@@ -1,0 +1,50 @@
+// CPU-only checks of the gko:: mirror: memory spaces, arrays, MatrixMarket
+// reading, dimension validation, and that kernels on host executors raise
+// gko::NotCompiled (a build without the reference/omp modules).
+#include <ginkgo/ginkgo.hpp>
+
+#include <iostream>
+#include <sstream>
+
+#define CHECK(cond) do { if (!(cond)) { std::cerr << "FAILED: " #cond " at line " << __LINE__ << "\n"; return 1; } } while (0)
+
+int main()
+{
+    using vec = gko::matrix::Dense<double>;
+    using csr = gko::matrix::Csr<double, int>;
+    auto ref = gko::ReferenceExecutor::create();
+    auto omp = gko::OmpExecutor::create();
+    CHECK(ref->get_master() == ref);
+    gko::array<int> a(ref, {1, 2, 3});
+    gko::array<int> c(omp, a);
+    CHECK(c.get_num_elems() == 3 && c.get_const_data()[2] == 3);
+    std::istringstream mm("%%MatrixMarket matrix coordinate real symmetric\n% c\n3 3 4\n1 1 2.0\n2 1 -1.0\n2 2 2.0\n3 3 5.0\n");
+    auto A = gko::share(gko::read<csr>(mm, ref));
+    CHECK(A->get_size() == gko::dim<2>(3, 3) && A->get_num_stored_elements() == 5);
+    CHECK(A->get_const_row_ptrs()[1] == 2 && A->get_const_col_idxs()[1] == 1 && A->get_const_values()[1] == -1.0);
+    CHECK(A->get_strategy()->get_name() == "automatical");
+    std::istringstream arr("%%MatrixMarket matrix array real general\n3 1\n1\n2\n3\n");
+    auto b = gko::read<vec>(arr, ref);
+    CHECK(b->get_size() == gko::dim<2>(3, 1) && b->at(2) == 3.0);
+    auto x = vec::create(ref, gko::dim<2>(3, 1));
+    bool not_compiled = false;
+    try { A->apply(b.get(), x.get()); } catch (const gko::NotCompiled&) { not_compiled = true; }
+    CHECK(not_compiled);
+    bool mismatch = false;
+    try { auto bad = vec::create(ref, gko::dim<2>(4, 1)); A->apply(bad.get(), x.get()); } catch (const gko::DimensionMismatch&) { mismatch = true; }
+    CHECK(mismatch);
+    bool cuda_missing = false;
+    try { gko::CudaExecutor::create(0, omp); } catch (const gko::NotCompiled&) { cuda_missing = true; }
+    CHECK(cuda_missing);
+    std::ostringstream os;
+    gko::write(os, b.get());
+    CHECK(os.str().find("3 1") != std::string::npos);
+    auto solver = gko::solver::Cg<double>::build()
+                      .with_criteria(gko::stop::Iteration::build().with_max_iters(5u).on(ref))
+                      .on(ref)->generate(A);
+    bool solver_not_compiled = false;
+    try { solver->apply(b.get(), x.get()); } catch (const gko::NotCompiled&) { solver_not_compiled = true; }
+    CHECK(solver_not_compiled);
+    std::cout << "host api ok\n";
+    return 0;
+}

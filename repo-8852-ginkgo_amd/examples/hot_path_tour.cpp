@@ -1,0 +1,123 @@
+// Exercises the rest of the gko:: mirror on a HipExecutor: format conversions
+// and every format's apply, block-Jacobi-preconditioned CG, ParILU-preconditioned
+// GMRES(30), on an n x n 5-pt Poisson / convection-diffusion matrix built in
+// place.  Prints "name value" lines that tests/test_cpp_mirror.py checks.
+#include <ginkgo/ginkgo.hpp>
+
+#include <cmath>
+#include <iostream>
+
+using vec = gko::matrix::Dense<double>;
+using csr = gko::matrix::Csr<double, int>;
+
+static gko::matrix_data<double, int> stencil(int g, double upwind)
+{
+    gko::matrix_data<double, int> d;
+    d.size = gko::dim<2>(g * g, g * g);
+    for (int i = 0; i < g; ++i) {
+        for (int j = 0; j < g; ++j) {
+            const int r = i * g + j;
+            if (i > 0) d.nonzeros.push_back({r, r - g, -1.0});
+            if (j > 0) d.nonzeros.push_back({r, r - 1, -1.0 - upwind});
+            d.nonzeros.push_back({r, r, 4.0 + upwind});
+            if (j < g - 1) d.nonzeros.push_back({r, r + 1, -1.0});
+            if (i < g - 1) d.nonzeros.push_back({r, r + g, -1.0});
+        }
+    }
+    return d;
+}
+
+static double diff_norm(std::shared_ptr<const gko::Executor> exec, const vec* a, const vec* b)
+{
+    auto d = a->clone();
+    auto neg = gko::initialize<vec>({-1.0}, exec);
+    d->add_scaled(neg.get(), b);
+    auto n = vec::create(exec, gko::dim<2>(1, 1));
+    d->compute_norm2(n.get());
+    return exec->copy_val_to_host(n->get_const_values());
+}
+
+int main()
+{
+    try {
+        auto exec = gko::HipExecutor::create(0, gko::OmpExecutor::create());
+        const int g = 96, n = g * g;
+        auto A = gko::share(csr::create(exec));
+        A->read(stencil(g, 0.0));
+        auto host_x = vec::create(exec->get_master(), gko::dim<2>(n, 1));
+        for (int i = 0; i < n; ++i) host_x->at(i) = std::sin(0.01 * i);
+        auto x = host_x->clone(exec);
+        auto y = vec::create(exec, gko::dim<2>(n, 1));
+        A->apply(x.get(), y.get());
+        // every format agrees with CSR
+        auto y2 = vec::create(exec, gko::dim<2>(n, 1));
+        auto ell = gko::matrix::Ell<double, int>::create(exec);
+        A->convert_to(ell.get());
+        ell->apply(x.get(), y2.get());
+        std::cout << "ell_diff " << diff_norm(exec, y.get(), y2.get()) << "\n";
+        auto sellp = gko::matrix::Sellp<double, int>::create(exec);
+        A->convert_to(sellp.get());
+        sellp->apply(x.get(), y2.get());
+        std::cout << "sellp_diff " << diff_norm(exec, y.get(), y2.get()) << "\n";
+        auto coo = gko::matrix::Coo<double, int>::create(exec);
+        A->convert_to(coo.get());
+        coo->apply(x.get(), y2.get());
+        std::cout << "coo_diff " << diff_norm(exec, y.get(), y2.get()) << "\n";
+        auto hyb = gko::matrix::Hybrid<double, int>::create(exec, std::make_shared<gko::matrix::Hybrid<double, int>::column_limit>(3));
+        A->convert_to(hyb.get());
+        hyb->apply(x.get(), y2.get());
+        std::cout << "hybrid_diff " << diff_norm(exec, y.get(), y2.get()) << " coo_nnz " << hyb->get_coo_num_stored_elements() << "\n";
+
+        // CG + block-Jacobi
+        auto b = vec::create(exec, gko::dim<2>(n, 1));
+        b->fill(1.0);
+        auto sol = vec::create(exec, gko::dim<2>(n, 1));
+        sol->fill(0.0);
+        auto cg = gko::solver::Cg<double>::build()
+                      .with_criteria(gko::stop::Iteration::build().with_max_iters(2000u).on(exec),
+                                     gko::stop::ResidualNorm<double>::build().with_reduction_factor(1e-10).on(exec))
+                      .with_preconditioner(gko::preconditioner::Jacobi<double, int>::build().with_max_block_size(8u).on(exec))
+                      .on(exec)
+                      ->generate(A);
+        cg->apply(b.get(), sol.get());
+        auto r = b->clone();
+        auto one = gko::initialize<vec>({1.0}, exec);
+        auto neg = gko::initialize<vec>({-1.0}, exec);
+        A->apply(neg.get(), sol.get(), one.get(), r.get());
+        auto rn = vec::create(exec, gko::dim<2>(1, 1));
+        r->compute_norm2(rn.get());
+        std::cout << "cg_jacobi_iters " << cg->get_last_iteration_count() << " converged " << cg->has_converged()
+                  << " true_residual " << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
+
+        // GMRES(30) + ParILU on the nonsymmetric variant
+        auto B = gko::share(csr::create(exec));
+        B->read(stencil(g, 0.5));
+        sol->fill(0.0);
+        auto gm = gko::solver::Gmres<double>::build()
+                      .with_krylov_dim(30u)
+                      .with_criteria(gko::stop::Iteration::build().with_max_iters(1000u).on(exec),
+                                     gko::stop::ResidualNorm<double>::build().with_reduction_factor(1e-10).on(exec))
+                      .with_preconditioner(gko::preconditioner::Ilu<double, int>::build().with_factorization_iterations(20u).on(exec))
+                      .on(exec)
+                      ->generate(B);
+        gm->apply(b.get(), sol.get());
+        r->copy_from(b.get());
+        B->apply(neg.get(), sol.get(), one.get(), r.get());
+        r->compute_norm2(rn.get());
+        std::cout << "gmres_ilu_iters " << gm->get_last_iteration_count() << " converged " << gm->has_converged()
+                  << " true_residual " << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
+
+        // error behaviour: dimension mismatch is caught before the boundary
+        try {
+            auto bad = vec::create(exec, gko::dim<2>(n + 1, 1));
+            A->apply(bad.get(), y.get());
+            std::cout << "dimension_check missing\n";
+        } catch (const gko::DimensionMismatch&) {
+            std::cout << "dimension_check ok\n";
+        }
+    } catch (const gko::Error& e) {
+        std::cerr << "gko::Error: " << e.what() << std::endl;
+        return 3;
+    }
+    return 0;
+}
