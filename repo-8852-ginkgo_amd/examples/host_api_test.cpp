@@ -18,6 +18,10 @@ int main()
     gko::array<int> a(ref, {1, 2, 3});
     gko::array<int> c(omp, a);
     CHECK(c.get_num_elems() == 3 && c.get_const_data()[2] == 3);
+    // set_executor moves the data into the other memory space and relabels it
+    gko::array<int> moved(ref, {7, 8});
+    moved.set_executor(omp);
+    CHECK(moved.get_executor() == omp && moved.get_const_data()[1] == 8);
     std::istringstream mm("%%MatrixMarket matrix coordinate real symmetric\n% c\n3 3 4\n1 1 2.0\n2 1 -1.0\n2 2 2.0\n3 3 5.0\n");
     auto A = gko::share(gko::read<csr>(mm, ref));
     CHECK(A->get_size() == gko::dim<2>(3, 3) && A->get_num_stored_elements() == 5);

@@ -334,9 +334,11 @@ public:
     void set_executor(std::shared_ptr<const Executor> exec)
     {
         if (exec == exec_) return;
-        array tmp(exec, *this);
-        *this = std::move(tmp);
-        exec_ = exec;
+        array tmp(exec, *this);  // copy of the data in the new memory space
+        clear();
+        exec_ = std::move(exec);
+        data_ = tmp.data_; n_ = tmp.n_; owns_ = true;
+        tmp.data_ = nullptr; tmp.n_ = 0;
     }
     T* get_data() noexcept { return data_; }
     const T* get_const_data() const noexcept { return data_; }
