@@ -29,7 +29,10 @@
 namespace gkomi {
 namespace {
 
-constexpr int block = 256;
+// the fused kernels use 1024-thread workgroups: same thread count on the chip,
+// 4x fewer partials for every consumer workgroup to re-add (K3 re-reads the
+// ~3900 p.q partials of K2: 15 MB of L2 traffic instead of 61 MB)
+constexpr int fblock = 1024;
 constexpr int max_parts = 1024;
 constexpr uint8_t id_iteration = 1;  // Combined: ids count from 1 in criteria order
 constexpr uint8_t id_residual = 2;
@@ -49,7 +52,7 @@ __device__ __forceinline__ double sum_partials(const double* __restrict__ part,
                                                int nparts, double* smem)
 {
     double acc = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += block) acc += part[i];
+    for (int i = threadIdx.x; i < nparts; i += fblock) acc += part[i];
     acc = wave_reduce_sum(acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
@@ -57,20 +60,30 @@ __device__ __forceinline__ double sum_partials(const double* __restrict__ part,
     __syncthreads();
     double total = 0.0;
 #pragma unroll
-    for (int w = 0; w < block / wave_size; ++w) total += smem[w];
+    for (int w = 0; w < fblock / wave_size; ++w) total += smem[w];
     return total;  // identical in every thread of every workgroup
 }
 
 // K1.  rho_part/tau_part may alias (Identity preconditioner: z == r).
-__global__ __launch_bounds__(block) void cg_fused_step1_kernel(
+__global__ __launch_bounds__(fblock) void cg_fused_step1_kernel(
     int64_t n, double* __restrict__ p, const double* __restrict__ z,
     const double* __restrict__ rho_part, int n_rho,
     const double* __restrict__ tau_part, int n_tau, cg_scalars* scal,
     long long it, long long max_iters, double goal)
 {
-    __shared__ double smem[block / wave_size];
+    __shared__ double smem[fblock / wave_size];
     const bool stopped_before = status_has_stopped(scal->status);
     if (stopped_before) return;
+    // the first sweep's loads do not depend on the scalars: issue them before
+    // the partial sums so their latency hides behind the reduction
+    const int64_t n2 = n / 2;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * fblock;
+    const int64_t i0 = blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x;
+    double2 z0 = make_double2(0.0, 0.0), p0 = make_double2(0.0, 0.0);
+    if (i0 < n2) {
+        z0 = reinterpret_cast<const double2*>(z)[i0];
+        p0 = reinterpret_cast<const double2*>(p)[i0];
+    }
     const double rho = sum_partials(rho_part, n_rho, smem);
     const double tau2 = rho_part == tau_part ? rho : sum_partials(tau_part, n_tau, smem);
     const double tau = sqrt(tau2);
@@ -94,12 +107,16 @@ __global__ __launch_bounds__(block) void cg_fused_step1_kernel(
     const double prev = scal->rho[(it + 1) & 1];
     const bool restart = prev == 0.0;
     const double tmp = restart ? 0.0 : rho / prev;
-    const int64_t n2 = n / 2;
-    const int64_t step = static_cast<int64_t>(gridDim.x) * block;
     double2* p2 = reinterpret_cast<double2*>(p);
     const double2* z2 = reinterpret_cast<const double2*>(z);
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
-         i < n2; i += step) {
+    if (i0 < n2) {
+        if (!restart) {
+            z0.x = z0.x + tmp * p0.x;
+            z0.y = z0.y + tmp * p0.y;
+        }
+        p2[i0] = z0;
+    }
+    for (int64_t i = i0 + step; i < n2; i += step) {
         double2 zv = z2[i];
         if (!restart) {
             const double2 pv = p2[i];
@@ -114,28 +131,48 @@ __global__ __launch_bounds__(block) void cg_fused_step1_kernel(
 }
 
 // K3.  Leaves partial[blockIdx.x] = sum of r_new^2 over this workgroup's share.
-__global__ __launch_bounds__(block) void cg_fused_step2_kernel(
+__global__ __launch_bounds__(fblock) void cg_fused_step2_kernel(
     int64_t n, double* __restrict__ x, double* __restrict__ r,
     const double* __restrict__ p, const double* __restrict__ q,
     const double* __restrict__ beta_part, int n_beta, cg_scalars* scal,
     long long it, double* __restrict__ rr_part)
 {
-    __shared__ double smem[block / wave_size];
+    __shared__ double smem[fblock / wave_size];
     if (status_has_stopped(scal->status)) return;
+    const int64_t n2 = n / 2;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * fblock;
+    const int64_t i0 = blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x;
+    double2* x2 = reinterpret_cast<double2*>(x);
+    double2* r2 = reinterpret_cast<double2*>(r);
+    const double2* p2 = reinterpret_cast<const double2*>(p);
+    const double2* q2 = reinterpret_cast<const double2*>(q);
+    // first sweep's loads before the partial sums (independent of beta)
+    double2 x0 = make_double2(0.0, 0.0), r0 = x0, p0 = x0, q0 = x0;
+    if (i0 < n2) {
+        x0 = x2[i0];
+        r0 = r2[i0];
+        p0 = p2[i0];
+        q0 = q2[i0];
+    }
     const double beta = sum_partials(beta_part, n_beta, smem);
     const double rho = scal->rho[it & 1];
     const bool update = beta != 0.0;
     const double tmp = update ? rho / beta : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) scal->beta = beta;
-    const int64_t n2 = n / 2;
-    const int64_t step = static_cast<int64_t>(gridDim.x) * block;
-    double2* x2 = reinterpret_cast<double2*>(x);
-    double2* r2 = reinterpret_cast<double2*>(r);
-    const double2* p2 = reinterpret_cast<const double2*>(p);
-    const double2* q2 = reinterpret_cast<const double2*>(q);
     double acc0 = 0.0, acc1 = 0.0;
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
-         i < n2; i += step) {
+    if (i0 < n2) {
+        if (update) {
+            x0.x += tmp * p0.x;
+            x0.y += tmp * p0.y;
+            r0.x -= tmp * q0.x;
+            r0.y -= tmp * q0.y;
+            x2[i0] = x0;
+            r2[i0] = r0;
+        }
+        acc0 += r0.x * r0.x;
+        acc1 += r0.y * r0.y;
+    }
+    for (int64_t i = i0 + step; i < n2; i += step) {
         double2 rv = r2[i];
         if (update) {
             double2 xv = x2[i];
@@ -158,30 +195,30 @@ __global__ __launch_bounds__(block) void cg_fused_step2_kernel(
         acc0 += r[n - 1] * r[n - 1];
     }
     __syncthreads();
-    const double total = block_reduce_sum<block>(acc0 + acc1, smem);
+    const double total = block_reduce_sum<fblock>(acc0 + acc1, smem);
     if (threadIdx.x == 0) rr_part[blockIdx.x] = total;
 }
 
 // partial[blockIdx.x] = sum x*y over the workgroup's share; two outputs so that
 // r.z and r.r come from one pass when a preconditioner is present
-__global__ __launch_bounds__(block) void cg_dot2_partials_kernel(
+__global__ __launch_bounds__(fblock) void cg_dot2_partials_kernel(
     int64_t n, const double* __restrict__ r, const double* __restrict__ z,
     const cg_scalars* scal, double* __restrict__ rz_part,
     double* __restrict__ rr_part)
 {
-    __shared__ double smem[block / wave_size];
+    __shared__ double smem[fblock / wave_size];
     if (scal != nullptr && status_has_stopped(scal->status)) return;
-    const int64_t step = static_cast<int64_t>(gridDim.x) * block;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * fblock;
     double a = 0.0, bb = 0.0;
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x;
          i < n; i += step) {
         const double rv = r[i];
         a += rv * z[i];
         bb += rv * rv;
     }
-    const double ta = block_reduce_sum<block>(a, smem);
+    const double ta = block_reduce_sum<fblock>(a, smem);
     __syncthreads();
-    const double tb = block_reduce_sum<block>(bb, smem);
+    const double tb = block_reduce_sum<fblock>(bb, smem);
     if (threadIdx.x == 0) {
         rz_part[blockIdx.x] = ta;
         if (rr_part != nullptr) rr_part[blockIdx.x] = tb;
@@ -202,7 +239,7 @@ __global__ void cg_init_scalars_kernel(cg_scalars* scal, const double* orig_tau,
 
 int vec_grid(int64_t n)
 {
-    int64_t g = ceildiv(n / 2 + 1, block);
+    int64_t g = ceildiv(n / 2 + 1, fblock);
     if (g > max_parts) g = max_parts;
     if (g < 1) g = 1;
     return static_cast<int>(g);
@@ -390,7 +427,7 @@ extern "C" int gkomi_cg_solve_f64_i32(
         // partials of r.z (and r.r) for the first check
         const double* zz = precond == nullptr ? r : z;
         if (precond != nullptr) GKOMI_TRY(precond(precond_ctx, s, r, z));
-        hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(block), 0, stream, n, r, zz,
+        hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r, zz,
                            static_cast<const cg_scalars*>(nullptr), part_a,
                            precond == nullptr ? nullptr : part_b);
         GKOMI_TRY(check_launch());
@@ -399,16 +436,16 @@ extern "C" int gkomi_cg_solve_f64_i32(
         bool done = false;
         while (!done) {
             for (int c = 0; c < check_every; ++c, ++it) {
-                hipLaunchKernelGGL(cg_fused_step1_kernel, dim3(g), dim3(block), 0, stream, n, p, zz,
+                hipLaunchKernelGGL(cg_fused_step1_kernel, dim3(g), dim3(fblock), 0, stream, n, p, zz,
                                    part_a, g, tau_part, g, scal, it,
                                    static_cast<long long>(max_iters), reduction_factor);
                 GKOMI_TRY(csr_spmv_dot_launch(stream, static_cast<int>(n), nnz, row_ptrs, col_idxs,
                                               vals, p, q, part_c, &scal->status, swizzle));
-                hipLaunchKernelGGL(cg_fused_step2_kernel, dim3(g), dim3(block), 0, stream, n, x, r, p,
+                hipLaunchKernelGGL(cg_fused_step2_kernel, dim3(g), dim3(fblock), 0, stream, n, x, r, p,
                                    q, part_c, nb, scal, it, precond == nullptr ? part_a : part_b);
                 if (precond != nullptr) {
                     GKOMI_TRY(precond(precond_ctx, s, r, z));
-                    hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(block), 0, stream, n, r,
+                    hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r,
                                        z, static_cast<const cg_scalars*>(scal), part_a,
                                        static_cast<double*>(nullptr));
                 }

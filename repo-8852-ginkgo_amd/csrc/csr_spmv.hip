@@ -21,6 +21,8 @@
 // from L2) + 8 = 80 B.
 #include "common.hpp"
 
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
 namespace gkomi {
 namespace {
 
@@ -32,7 +34,13 @@ constexpr int num_xcd = 8;
 // launch grid is 8*per, surplus ids exit; pure speed, never correctness.
 __device__ __forceinline__ int xcd_chunked_block(int bid, int per)
 {
-    return (bid % num_xcd) * per + bid / num_xcd;
+    // groups of 8*per consecutive ids; inside a group XCD k owns `per`
+    // consecutive logical blocks.  per = ceil(nblocks / 8) gives every XCD one
+    // contiguous eighth of the matrix; a smaller per keeps the 8 XCDs streaming
+    // from neighbouring addresses.
+    const int group = bid / (num_xcd * per);
+    const int w = bid - group * num_xcd * per;
+    return group * num_xcd * per + (w % num_xcd) * per + w / num_xcd;
 }
 
 // Dot = true adds the CG epilogue: partial[logical block] = sum over the
@@ -165,6 +173,109 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
 }
 
 
+// ---- load-balanced kernel ("load_balance", csr.hpp:356-524) -------------------
+//
+// For matrices whose row lengths vary wildly the work is split by NONZEROS, not
+// rows: workgroup b owns nonzeros [b*Tile, (b+1)*Tile).  The (vals, col_idxs)
+// loads depend only on b, so they are issued first; while they are in flight
+// the wave finds the rows that intersect the tile with a 64-ary search over
+// row_ptrs (4 dependent probes for 16M rows instead of 24 binary-search steps).
+// Products go through the same LDS tile as the stream kernel; one thread per
+// intersecting row adds its part left to right and issues one fp64 atomic
+// (`c` is pre-set to 0 or beta*c by the caller-side fill/scale, like the
+// reference's dense::fill + atomic_add).  A row spanning k tiles gets k atomics.
+
+// largest r in [0, nrows] with row_ptrs[r] <= target (row containing nonzero
+// `target`, skipping empty rows); wave-cooperative, result in every lane
+__device__ __forceinline__ int wave_find_row(const int32_t* __restrict__ row_ptrs,
+                                             int nrows, int target)
+{
+    int lo = 0, hi = nrows;  // invariant: row_ptrs[lo] <= target, answer in [lo, hi]
+    const int lane = threadIdx.x & 63;
+    while (hi - lo > 0) {
+        const int span = hi - lo;
+        const int stepw = (span + 63) / 64;
+        const int probe = min(lo + (lane + 1) * stepw, hi);
+        const bool le = row_ptrs[probe] <= target;
+        // lanes probe increasing positions: count how many are still <= target
+        const unsigned long long mask = __ballot(le);
+        const int cnt = __popcll(mask);
+        const int new_lo = cnt == 0 ? lo : min(lo + cnt * stepw, hi);
+        const int new_hi = cnt == 64 ? hi : min(lo + (cnt + 1) * stepw, hi) - 1;
+        // new_hi: the first failing probe sits at lo + (cnt+1)*stepw, the answer is below it
+        lo = new_lo;
+        hi = max(new_hi, new_lo);
+        if (stepw == 1) break;
+    }
+    return lo;
+}
+
+template <int Block, int Tile, bool Advanced>
+__global__ __launch_bounds__(Block) void csr_balanced_kernel(
+    int nrows, int nnz_total, const int32_t* __restrict__ row_ptrs,
+    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
+    int64_t c_stride, const double* __restrict__ alpha_p)
+{
+    constexpr int pairs = Tile / (2 * Block);
+    __shared__ __attribute__((aligned(16))) double prod[Tile];
+    __shared__ int s_rows[2];
+    b += blockIdx.y;
+    c += blockIdx.y;
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * Tile;
+    const int t1 = min(t0 + Tile, nnz_total);
+    const double alpha = Advanced ? alpha_p[0] : 1.0;
+    double2 v[pairs];
+    int2 ci[pairs];
+#pragma unroll
+    for (int u = 0; u < pairs; ++u) {
+        const int k = t0 + 2 * (tid + u * Block);
+        v[u] = make_double2(0.0, 0.0);
+        ci[u] = make_int2(0, 0);
+        if (k + 1 < t1) {
+            v[u] = *reinterpret_cast<const double2*>(vals + k);
+            ci[u] = *reinterpret_cast<const int2*>(col_idxs + k);
+        } else if (k < t1) {
+            v[u].x = vals[k];
+            ci[u].x = col_idxs[k];
+        }
+    }
+    // rows intersecting the tile (wave 0 searches while the loads fly)
+    if (tid < 64) {
+        const int first = wave_find_row(row_ptrs, nrows, t0);
+        const int last = wave_find_row(row_ptrs, nrows, t1 - 1);
+        if (tid == 0) {
+            s_rows[0] = first;
+            s_rows[1] = last;
+        }
+    }
+    double2 xv[pairs];
+#pragma unroll
+    for (int u = 0; u < pairs; ++u) {
+        xv[u].x = b[ci[u].x * b_stride];
+        xv[u].y = b[ci[u].y * b_stride];
+    }
+#pragma unroll
+    for (int u = 0; u < pairs; ++u) {
+        double2 pr;
+        pr.x = Advanced ? (alpha * v[u].x) * xv[u].x : v[u].x * xv[u].x;
+        pr.y = Advanced ? (alpha * v[u].y) * xv[u].y : v[u].y * xv[u].y;
+        *reinterpret_cast<double2*>(prod + 2 * (tid + u * Block)) = pr;
+    }
+    __syncthreads();
+    const int first = s_rows[0], last = min(s_rows[1], nrows - 1);
+    for (int row = first + tid; row <= last; row += Block) {
+        const int lo = max(row_ptrs[row], t0);
+        const int hi = min(row_ptrs[row + 1], t1);
+        if (lo < hi) {
+            double sum = prod[lo - t0];
+            for (int k = lo + 1; k < hi; ++k) sum += prod[k - t0];
+            unsafeAtomicAdd(c + row * c_stride, sum);
+        }
+    }
+}
+
 // Variant of the stream kernel's staging for arrays whose base pointers are
 // not 16-/8-byte aligned is not needed: misaligned inputs take the vector
 // kernel, which only uses natural-width loads.
@@ -230,7 +341,7 @@ __global__ __launch_bounds__(256) void csr_max_row_nnz_kernel(
 }
 
 template <int Block, int RowsPerThread, int Tile>
-int launch_stream(hipStream_t stream, bool swizzle, int nrows, int nrhs,
+int launch_stream(hipStream_t stream, bool swizzle, int chunk, int nrows, int nrhs,
                   const int32_t* row_ptrs, const int32_t* col_idxs,
                   const double* vals, const double* b, int64_t b_stride,
                   double* c, int64_t c_stride, const double* alpha,
@@ -238,10 +349,12 @@ int launch_stream(hipStream_t stream, bool swizzle, int nrows, int nrhs,
 {
     constexpr int rows_per_block = Block * RowsPerThread;
     const int nblocks = static_cast<int>(ceildiv(nrows, rows_per_block));
-    const int per = static_cast<int>(ceildiv(nblocks, num_xcd));
+    int per = static_cast<int>(ceildiv(nblocks, num_xcd));
+    if (chunk > 0 && chunk < per) per = chunk;
     const bool advanced = alpha != nullptr;
     const bool swz = swizzle && nblocks >= 2 * num_xcd;
-    dim3 grid(swz ? per * num_xcd : nblocks, nrhs);
+    const int groups = static_cast<int>(ceildiv(nblocks, per * num_xcd));
+    dim3 grid(swz ? groups * per * num_xcd : nblocks, nrhs);
 #define GKOMI_LAUNCH(ADV, SWZ)                                                 \
     hipLaunchKernelGGL(                                                        \
         (csr_stream_kernel<Block, RowsPerThread, Tile, ADV, SWZ>), grid,       \
@@ -350,17 +463,25 @@ extern "C" int gkomi_csr_spmv_f64_i32(
     int kind = strategy & 0xff;
     int variant = (strategy >> 8) & 0xff;
     bool no_swizzle = (strategy >> 16) & 1;
+    const int chunk_code = (strategy >> 17) & 0x7f;  // XCD chunk = 2^(code-1) row blocks, 0 = one eighth each
+    const int chunk = chunk_code ? 1 << (chunk_code - 1) : 0;
     const bool automatic = kind == GKOMI_CSR_AUTO;
     const bool aligned = (reinterpret_cast<uintptr_t>(vals) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(col_idxs) % 8 == 0);
     if (kind == GKOMI_CSR_AUTO) {
         // the role of Csr::automatical (csr.hpp:526-705): short rows stream,
         // long rows go one sub-wave per row
-        kind = (max_row_nnz_hint < 0 || max_row_nnz_hint <= 256)
-                   ? GKOMI_CSR_STREAM
-                   : GKOMI_CSR_VECTOR;
+        // short rows stream; long rows one sub-wave per row; when a few rows
+        // dwarf the average (max > 64 x mean) split by nonzeros instead
+        if (max_row_nnz_hint < 0 || max_row_nnz_hint <= 256) {
+            kind = GKOMI_CSR_STREAM;
+        } else if (nnz > 0 && max_row_nnz_hint > 64 * (nnz / nrows + 1)) {
+            kind = GKOMI_CSR_BALANCED;
+        } else {
+            kind = GKOMI_CSR_VECTOR;
+        }
     }
-    if (kind == GKOMI_CSR_BALANCED) kind = GKOMI_CSR_VECTOR;
+    if (kind == GKOMI_CSR_BALANCED && (!aligned || nnz < 0)) kind = GKOMI_CSR_VECTOR;
     if (kind == GKOMI_CSR_STREAM && !aligned) kind = GKOMI_CSR_VECTOR;
     if (automatic) {
         // 256 threads, 256 rows, 1536-nonzero tile: fastest measured
@@ -372,21 +493,42 @@ extern "C" int gkomi_csr_spmv_f64_i32(
     n, r, row_ptrs, col_idxs, vals, b, b_stride, c, c_stride, alpha, beta
     if (kind == GKOMI_CSR_STREAM) {
         switch (variant) {
-        case 1: return launch_stream<256, 2, 4096>(stream, !no_swizzle, GKOMI_ARGS);
-        case 2: return launch_stream<512, 1, 4096>(stream, !no_swizzle, GKOMI_ARGS);
-        case 3: return launch_stream<256, 4, 8192>(stream, !no_swizzle, GKOMI_ARGS);
-        case 4: return launch_stream<128, 1, 1024>(stream, !no_swizzle, GKOMI_ARGS);
-        case 5: return launch_stream<256, 1, 1536>(stream, !no_swizzle, GKOMI_ARGS);
-        case 6: return launch_stream<512, 1, 3072>(stream, !no_swizzle, GKOMI_ARGS);
-        case 7: return launch_stream<1024, 1, 6144>(stream, !no_swizzle, GKOMI_ARGS);
-        case 8: return launch_stream<64, 1, 384>(stream, !no_swizzle, GKOMI_ARGS);
-        case 9: return launch_stream<192, 1, 1152>(stream, !no_swizzle, GKOMI_ARGS);
-        case 10: return launch_stream<320, 1, 1920>(stream, !no_swizzle, GKOMI_ARGS);
-        case 11: return launch_stream<128, 1, 768>(stream, !no_swizzle, GKOMI_ARGS);
-        case 12: return launch_stream<256, 1, 1024>(stream, !no_swizzle, GKOMI_ARGS);
-        case 13: return launch_stream<384, 1, 2304>(stream, !no_swizzle, GKOMI_ARGS);
-        default: return launch_stream<256, 1, 2048>(stream, !no_swizzle, GKOMI_ARGS);
+        case 1: return launch_stream<256, 2, 4096>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 2: return launch_stream<512, 1, 4096>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 3: return launch_stream<256, 4, 8192>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 4: return launch_stream<128, 1, 1024>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 5: return launch_stream<256, 1, 1536>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 6: return launch_stream<512, 1, 3072>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 7: return launch_stream<1024, 1, 6144>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 8: return launch_stream<64, 1, 384>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 9: return launch_stream<192, 1, 1152>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 10: return launch_stream<320, 1, 1920>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 11: return launch_stream<128, 1, 768>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 12: return launch_stream<256, 1, 1024>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 13: return launch_stream<384, 1, 2304>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        default: return launch_stream<256, 1, 2048>(stream, !no_swizzle, chunk, GKOMI_ARGS);
         }
+    }
+    if (kind == GKOMI_CSR_BALANCED) {
+        // c = 0 (or beta * c) first, then atomics: reference load_balance does
+        // dense::fill + atomic_add (hip/matrix/csr_kernels.hip.cpp:293-309)
+        int err = alpha == nullptr
+                      ? gkomi_dense_fill_f64(stream_, nrows, nrhs, c, c_stride, 0.0)
+                      : gkomi_dense_scale_f64(stream_, nrows, nrhs, beta, 1, c, c_stride);
+        if (err) return err;
+        if (nnz == 0) return GKOMI_SUCCESS;
+        constexpr int Block = 256, Tile = 1536;
+        dim3 grid(static_cast<unsigned>(ceildiv(nnz, Tile)), r);
+        if (alpha != nullptr) {
+            hipLaunchKernelGGL((csr_balanced_kernel<Block, Tile, true>), grid, dim3(Block), 0, stream, n,
+                               static_cast<int>(nnz), row_ptrs, col_idxs, vals, b, b_stride, c, c_stride,
+                               alpha);
+        } else {
+            hipLaunchKernelGGL((csr_balanced_kernel<Block, Tile, false>), grid, dim3(Block), 0, stream, n,
+                               static_cast<int>(nnz), row_ptrs, col_idxs, vals, b, b_stride, c, c_stride,
+                               alpha);
+        }
+        return check_launch();
     }
     if (kind == GKOMI_CSR_VECTOR) {
         int64_t len = max_row_nnz_hint;

@@ -17,7 +17,7 @@ namespace gkomi {
 namespace {
 
 constexpr int block = 256;
-constexpr int red_max_blocks = 1024;
+constexpr int red_max_blocks = 2048;
 
 enum class ew_op { scale, inv_scale, add_scaled, sub_scaled };
 
@@ -266,8 +266,9 @@ __global__ __launch_bounds__(block) void reduce_final_kernel(
 
 int reduction_blocks(int64_t nrows)
 {
-    // ~8 KiB of 16-B loads per thread before it pays to add a block
-    int64_t g = ceildiv(nrows, static_cast<int64_t>(block) * 2 * 4);
+    // two 16-B loads per thread before it pays to add a workgroup (short
+    // vectors are latency-bound: more workgroups = more loads in flight)
+    int64_t g = ceildiv(nrows, static_cast<int64_t>(block) * 2 * 2);
     if (g < 1) g = 1;
     if (g > red_max_blocks) g = red_max_blocks;
     return static_cast<int>(g);

@@ -60,7 +60,7 @@ def test_reduction_workspace_size(gk):
     assert gk.dense_reduction_workspace_bytes(0, 1) == 0
     assert gk.dense_reduction_workspace_bytes(10, 1) == 8
     big = gk.dense_reduction_workspace_bytes(1 << 24, 3)
-    assert big == 8 * 1024 * 3
+    assert big == 8 * 2048 * 3
 
 
 def test_product_never_references_oracle():

@@ -21,7 +21,7 @@ STRATEGIES = {"auto": 0, "stream": STREAM, "stream_v1": STREAM | (1 << 8),
               "stream_v4": STREAM | (4 << 8), "stream_noswz": STREAM | (1 << 16),
               "stream_v5": STREAM | (5 << 8), "stream_v8": STREAM | (8 << 8), "stream_v9": STREAM | (9 << 8),
               "stream_v13": STREAM | (13 << 8), "stream_v11_noswz": STREAM | (11 << 8) | (1 << 16),
-              "vector": VECTOR, "vector64": VECTOR | (64 << 8), "vector2": VECTOR | (2 << 8)}
+              "vector": VECTOR, "vector64": VECTOR | (64 << 8), "vector2": VECTOR | (2 << 8), "balanced": 3}
 BITEXACT = {k for k in STRATEGIES if k.startswith("stream") or k == "auto"}
 
 
@@ -75,7 +75,7 @@ def test_random_532x231(gk, oracle, strategy, advanced, nrhs, sort):
         assert matgen.rel_err(got, expect) <= 1e-14
 
 
-@pytest.mark.parametrize("strategy", ["stream", "stream_v1", "stream_v3", "stream_v5", "stream_v8", "stream_v11_noswz", "vector", "auto"])
+@pytest.mark.parametrize("strategy", ["stream", "stream_v1", "stream_v3", "stream_v5", "stream_v8", "stream_v11_noswz", "vector", "balanced", "auto"])
 def test_ragged_and_empty_rows(gk, oracle, strategy):
     # empty rows, rows longer than one LDS tile (8192), an empty last row
     rng = np.random.default_rng(7)
@@ -168,3 +168,33 @@ def test_full_size_poisson_p2_bitexact_and_linear(gk, oracle):
     assert matgen.rel_err(y, 2 * expect + y1.reshape(n, 1)) <= 1e-14
     got_v = host(csr_apply(gk, A, xd, strategy=STRATEGIES["vector"]))
     assert matgen.rel_err(got_v, expect) <= 1e-14
+
+
+@pytest.mark.parametrize("advanced", [False, True], ids=["simple", "advanced"])
+@pytest.mark.parametrize("nrhs", [1, 2])
+def test_load_balanced_on_skewed_matrices(gk, oracle, advanced, nrhs):
+    """A few rows hold most of the nonzeros (power-law like): the automatic
+    strategy must pick the nonzero-split kernel and agree with the oracle."""
+    rng = np.random.default_rng(21)
+    n, ncols = 20000, 30000
+    counts = rng.integers(0, 6, size=n)
+    counts[rng.choice(n, size=12, replace=False)] = rng.integers(8000, 25000, size=12)
+    counts[0] = 0
+    counts[-1] = 17000
+    rp = np.zeros(n + 1, np.int32)
+    np.cumsum(counts, out=rp[1:])
+    ci = np.concatenate([np.sort(rng.choice(ncols, size=k, replace=False)) for k in counts]).astype(np.int32)
+    v = rng.standard_normal(int(rp[-1]))
+    b = rng.standard_normal((ncols, nrhs))
+    c0 = rng.standard_normal((n, nrhs))
+    A = DevCsr(n, ncols, rp, ci, v)
+    assert A.max_row_nnz > 64 * (A.nnz // n + 1)
+    for strat in ("balanced", "auto"):
+        if advanced:
+            expect = _oracle_apply(oracle, n, rp, ci, v, b, c0, -0.5, 2.0)
+            got = host(csr_apply(gk, A, dev(b), dev(c0), -0.5, 2.0, STRATEGIES[strat]))
+        else:
+            expect = _oracle_apply(oracle, n, rp, ci, v, b)
+            got = host(csr_apply(gk, A, dev(b), strategy=STRATEGIES[strat]))
+        assert matgen.rel_err(got, expect) <= 1e-14, strat
+        assert got[0, 0] == (2.0 * c0[0, 0] if advanced else 0.0)  # empty row: just beta*c / 0
