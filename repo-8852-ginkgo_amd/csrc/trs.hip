@@ -179,9 +179,17 @@ __global__ __launch_bounds__(block) void trs_syncfree_kernel(
             }
             pe = -1;
         }
+        // nothing moved last round: wait a little BEFORE asking again, so that
+        // the answer is fresh when it is looked at
+        if (idle > 1 && !__any(progressed)) {
+            for (int i = 1; i < idle; ++i) __builtin_amdgcn_s_sleep(4);
+        }
         // (2) next out-of-chunk dependency of the window: ask memory now, look
-        // next round
-        if (far_mask != 0) {
+        // next round.  (Letting only the wave's earliest waiting row ask while
+        // the wave is stuck was tried and is 40x slower: at a grid-line boundary
+        // the later rows of a wave are needed long before its earlier ones.)
+        const bool ask = far_mask != 0;
+        if (ask) {
             pe = __ffs(far_mask) - 1;
             const int ppos = pe == wj ? cur_pos : s_pos[pe][tid];
             const int col = Lower ? ppos : n - 1 - ppos;
@@ -223,12 +231,7 @@ __global__ __launch_bounds__(block) void trs_syncfree_kernel(
         // back off while nothing moves: thousands of resident waves far behind
         // the dependency front would otherwise flood the memory system with
         // polls (MI355X_MICROARCH.md "polling-cost")
-        if (__any(progressed)) {
-            idle = 1;
-        } else {
-            for (int i = 0; i < idle; ++i) __builtin_amdgcn_s_sleep(4);
-            idle = min(idle * 2, max_idle);
-        }
+        idle = __any(progressed) ? 1 : min(idle * 2, max_idle);
     }
     if ((tid & 63) == 0) atomicExch(&ws->overrun, 1u);
 }

@@ -49,6 +49,17 @@ def chain(m, group=None):
 
 for m, g in ((64, None), (4096, None)) if quick else ((64, None), (256, None), (256, 64), (1024, None), (4096, None), (100000, None), (1 << 20, 64), (1 << 20, 256)):
     run(f"chain, groups of {g}", m, *chain(m, g))
+if os.environ.get("TRS_PLANES"):  # slope = per-plane hand-off, intercept = in-plane time
+    for nx in (1, 4, 16, 48, 108, 216):
+        nn, rp, ci, v = matgen.poisson_3d_7pt(nx, 108, 108)
+        run(f"3-D 7-pt lower, {nx}x108x108", nn, *lower_of(nn, rp, ci, v))
+    for ny in (1, 4, 16, 108, 432):
+        nn, rp, ci, v = matgen.poisson_3d_7pt(1, ny, 108)
+        run(f"2-D lines of 108, {ny} lines", nn, *lower_of(nn, rp, ci, v))
+    for ny in (1, 4, 16, 108):
+        nn, rp, ci, v = matgen.poisson_3d_7pt(1, ny, 1000)
+        run(f"2-D lines of 1000, {ny} lines", nn, *lower_of(nn, rp, ci, v))
+    sys.exit(0)
 for g in (200, 1000):
     nn, rp, ci, v = matgen.poisson_2d_5pt(g)
     run(f"2-D 5-pt lower, {g}^2", nn, *lower_of(nn, rp, ci, v))
