@@ -425,6 +425,35 @@ int gkomi_par_ilu_compute_l_u_factors_f64_i32(
     const double* coo_vals, const int32_t* l_row_ptrs,
     const int32_t* l_col_idxs, double* l_vals, const int32_t* ut_row_ptrs,
     const int32_t* ut_col_idxs, double* ut_vals);
+/* ---- matrix assembly: device_matrix_data ---------- */
+/* components::{sort_row_major, sum_duplicates, remove_zeros}
+ * (core/base/device_matrix_data_kernels.hpp;
+ * reference/base/device_matrix_data_kernels.cpp:84-190) on SoA triplets in
+ * device memory.  sort_row_major is in place and STABLE (the reference's
+ * std::sort leaves the order of duplicate (row, col) entries unspecified).
+ * remove_zeros / sum_duplicates write into caller arrays of capacity nnz and
+ * return the new count through host_nnz (blocking), the decision the
+ * reference takes with array::resize_and_reset; sum_duplicates expects
+ * sorted input and adds each run left to right starting from 0 (bit-exact).
+ * Csr::read is then gkomi_convert_idxs_to_ptrs_i32 on the sorted row indices
+ * (core/matrix/csr.cpp:453-470).  nnz < 2^31 - 1. */
+size_t gkomi_matrix_data_workspace_bytes(int64_t nnz);
+int gkomi_matrix_data_sort_row_major_f64_i32(gkomi_stream_t s, int64_t nnz,
+                                             int32_t* row_idxs,
+                                             int32_t* col_idxs, double* values,
+                                             void* workspace,
+                                             size_t workspace_bytes);
+int gkomi_matrix_data_remove_zeros_f64_i32(
+    gkomi_stream_t s, int64_t nnz, const int32_t* row_idxs,
+    const int32_t* col_idxs, const double* values, int32_t* out_row_idxs,
+    int32_t* out_col_idxs, double* out_values, void* workspace,
+    size_t workspace_bytes, int64_t* host_nnz);
+int gkomi_matrix_data_sum_duplicates_f64_i32(
+    gkomi_stream_t s, int64_t nnz, const int32_t* row_idxs,
+    const int32_t* col_idxs, const double* values, int32_t* out_row_idxs,
+    int32_t* out_col_idxs, double* out_values, void* workspace,
+    size_t workspace_bytes, int64_t* host_nnz);
+
 /* csr::transpose (reference/matrix/csr_kernels.cpp:551-586) */
 size_t gkomi_csr_transpose_workspace_bytes(int64_t ncols);
 int gkomi_csr_transpose_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols,

@@ -49,6 +49,18 @@ int main()
     bool solver_not_compiled = false;
     try { solver->apply(b.get(), x.get()); } catch (const gko::NotCompiled&) { solver_not_compiled = true; }
     CHECK(solver_not_compiled);
+    // matrix_data helpers and device_matrix_data on a host memory space
+    gko::matrix_data<double, int> md;
+    md.size = gko::dim<2>(3, 3);
+    md.nonzeros = {{2, 1, 1.0}, {0, 0, 2.0}, {2, 1, 3.0}, {1, 1, 0.0}};
+    auto dd = gko::device_matrix_data<double, int>::create_from_host(ref, md);
+    CHECK(dd.get_num_elems() == 4 && dd.get_const_row_idxs()[0] == 2 && dd.copy_to_host().nonzeros[2].value == 3.0);
+    bool sort_not_compiled = false;
+    try { dd.sort_row_major(); } catch (const gko::NotCompiled&) { sort_not_compiled = true; }
+    CHECK(sort_not_compiled);
+    md.remove_zeros();
+    md.sum_duplicates();
+    CHECK(md.nonzeros.size() == 2 && md.nonzeros[0].row == 0 && md.nonzeros[1].value == 4.0);
     std::cout << "host api ok\n";
     return 0;
 }

@@ -107,6 +107,28 @@ int main()
         std::cout << "gmres_ilu_iters " << gm->get_last_iteration_count() << " converged " << gm->has_converged()
                   << " true_residual " << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
 
+        // assembly on the device: shuffled triplets with duplicates and zeros ->
+        // device_matrix_data::sum_duplicates / remove_zeros -> Csr::read
+        {
+            auto data = stencil(g, 0.0);
+            gko::matrix_data<double, int> messy;
+            messy.size = data.size;
+            for (std::size_t i = 0; i < data.nonzeros.size(); ++i) {
+                const auto& e = data.nonzeros[(i * 7919) % data.nonzeros.size()];  // 7919 is coprime to nnz
+                messy.nonzeros.push_back({e.row, e.column, 0.25 * e.value});
+                messy.nonzeros.push_back({e.row, e.column, 0.75 * e.value});
+                if (i % 3 == 0) messy.nonzeros.push_back({e.row, (e.column + 5) % n, 0.0});
+            }
+            auto dev_data = gko::device_matrix_data<double, int>::create_from_host(exec, messy);
+            dev_data.remove_zeros();
+            dev_data.sum_duplicates();
+            auto C = csr::create(exec);
+            C->read(std::move(dev_data));
+            C->apply(x.get(), y2.get());
+            std::cout << "assembly_nnz " << C->get_num_stored_elements() << " of " << A->get_num_stored_elements() << " diff "
+                      << diff_norm(exec, y.get(), y2.get()) << "\n";
+        }
+
         // error behaviour: dimension mismatch is caught before the boundary
         try {
             auto bad = vec::create(exec, gko::dim<2>(n + 1, 1));

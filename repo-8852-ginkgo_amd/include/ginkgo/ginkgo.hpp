@@ -392,6 +392,121 @@ struct matrix_data {
             return std::tie(a.row, a.column) < std::tie(b.row, b.column);
         });
     }
+    // include/ginkgo/core/base/matrix_data.hpp: remove_zeros / sum_duplicates
+    void remove_zeros()
+    {
+        nonzeros.erase(std::remove_if(nonzeros.begin(), nonzeros.end(), [](const nonzero_type& e) { return e.value == V{}; }), nonzeros.end());
+    }
+    void sum_duplicates()
+    {
+        ensure_row_major_order();
+        std::vector<nonzero_type> out;
+        for (const auto& e : nonzeros) {
+            if (out.empty() || out.back().row != e.row || out.back().column != e.column) out.push_back({e.row, e.column, V{}});
+            out.back().value += e.value;
+        }
+        nonzeros = std::move(out);
+    }
+};
+
+// ---- device_matrix_data (include/ginkgo/core/base/device_matrix_data.hpp:63-270) -------
+// SoA triplets in the executor's memory; sort / de-duplicate / drop zeros run on
+// the device (core/base/device_matrix_data.cpp:115-141 -> csrc/assembly.hip).
+template <typename V = double, typename I = int32>
+class device_matrix_data {
+public:
+    using value_type = V;
+    using index_type = I;
+    using host_type = matrix_data<V, I>;
+    struct arrays { array<I> row_idxs; array<I> col_idxs; array<V> values; };
+    explicit device_matrix_data(std::shared_ptr<const Executor> exec, dim<2> size = {}, size_type num_entries = 0)
+        : size_(size), row_idxs_(exec, num_entries), col_idxs_(exec, num_entries), values_(exec, num_entries) {}
+    device_matrix_data(std::shared_ptr<const Executor> exec, const device_matrix_data& data)
+        : size_(data.size_), row_idxs_(exec, data.row_idxs_), col_idxs_(exec, data.col_idxs_), values_(exec, data.values_) {}
+    device_matrix_data(dim<2> size, array<I> row_idxs, array<I> col_idxs, array<V> values)
+        : size_(size), row_idxs_(std::move(row_idxs)), col_idxs_(std::move(col_idxs)), values_(std::move(values))
+    {
+        if (values_.get_num_elems() != row_idxs_.get_num_elems() || values_.get_num_elems() != col_idxs_.get_num_elems())
+            throw BadDimension(__FILE__, __LINE__, "device_matrix_data: array sizes differ");
+    }
+    host_type copy_to_host() const
+    {
+        host_type result;
+        result.size = size_;
+        auto r = row_idxs_.to_host(); auto c = col_idxs_.to_host(); auto v = values_.to_host();
+        result.nonzeros.resize(v.size());
+        for (size_type i = 0; i < v.size(); ++i) result.nonzeros[i] = {r[i], c[i], v[i]};
+        return result;
+    }
+    static device_matrix_data create_from_host(std::shared_ptr<const Executor> exec, const host_type& data)
+    {
+        std::vector<I> r(data.nonzeros.size()), c(data.nonzeros.size());
+        std::vector<V> v(data.nonzeros.size());
+        for (size_type i = 0; i < v.size(); ++i) { r[i] = data.nonzeros[i].row; c[i] = data.nonzeros[i].column; v[i] = data.nonzeros[i].value; }
+        return device_matrix_data(data.size, array<I>(exec, r.begin(), r.end()), array<I>(exec, c.begin(), c.end()), array<V>(exec, v.begin(), v.end()));
+    }
+    void sort_row_major()
+    {
+        auto exec = device("components::sort_row_major");
+        array<char> ws(exec, gkomi_matrix_data_workspace_bytes(get_num_elems()));
+        GKOMI_CALL(gkomi_matrix_data_sort_row_major_f64_i32(nullptr, get_num_elems(), row_idxs_.get_data(), col_idxs_.get_data(), values_.get_data(),
+                                                            ws.get_data(), ws.get_num_elems()));
+    }
+    void remove_zeros() { compact("components::remove_zeros", gkomi_matrix_data_remove_zeros_f64_i32); }
+    void sum_duplicates()
+    {
+        sort_row_major();
+        compact("components::sum_duplicates", gkomi_matrix_data_sum_duplicates_f64_i32);
+    }
+    std::shared_ptr<const Executor> get_executor() const { return values_.get_executor(); }
+    dim<2> get_size() const { return size_; }
+    size_type get_num_elems() const { return values_.get_num_elems(); }
+    I* get_row_idxs() { return row_idxs_.get_data(); }
+    const I* get_const_row_idxs() const { return row_idxs_.get_const_data(); }
+    I* get_col_idxs() { return col_idxs_.get_data(); }
+    const I* get_const_col_idxs() const { return col_idxs_.get_const_data(); }
+    V* get_values() { return values_.get_data(); }
+    const V* get_const_values() const { return values_.get_const_data(); }
+    void resize_and_reset(size_type n) { row_idxs_.resize_and_reset(n); col_idxs_.resize_and_reset(n); values_.resize_and_reset(n); }
+    void resize_and_reset(dim<2> new_size, size_type n) { size_ = new_size; resize_and_reset(n); }
+    arrays empty_out()
+    {
+        arrays result{std::move(row_idxs_), std::move(col_idxs_), std::move(values_)};
+        size_ = {};
+        return result;
+    }
+private:
+    std::shared_ptr<const Executor> device(const char* what) const
+    {
+        auto exec = get_executor();
+        detail::require_device(exec, what);
+        return exec;
+    }
+    template <typename Fn>
+    void compact(const char* what, Fn kernel)
+    {
+        auto exec = device(what);
+        const size_type n = get_num_elems();
+        array<I> r(exec, n), c(exec, n);
+        array<V> v(exec, n);
+        array<char> ws(exec, gkomi_matrix_data_workspace_bytes(n));
+        int64_t kept = 0;
+        GKOMI_CALL(kernel(nullptr, n, row_idxs_.get_const_data(), col_idxs_.get_const_data(), values_.get_const_data(), r.get_data(), c.get_data(),
+                          v.get_data(), ws.get_data(), ws.get_num_elems(), &kept));
+        if (static_cast<size_type>(kept) == n) return;  // nothing removed: keep the arrays (no reallocation, as the reference)
+        array<I> r2(exec, kept), c2(exec, kept);
+        array<V> v2(exec, kept);
+        if (kept) {
+            exec->copy_from(exec.get(), kept, r.get_const_data(), r2.get_data());
+            exec->copy_from(exec.get(), kept, c.get_const_data(), c2.get_data());
+            exec->copy_from(exec.get(), kept, v.get_const_data(), v2.get_data());
+        }
+        row_idxs_ = std::move(r2); col_idxs_ = std::move(c2); values_ = std::move(v2);
+    }
+    dim<2> size_;
+    array<I> row_idxs_;
+    array<I> col_idxs_;
+    array<V> values_;
 };
 
 template <typename V = double, typename I = int32>
@@ -680,6 +795,26 @@ public:
         col_idxs_ = array<I>(exec_, ci.begin(), ci.end());
         values_ = array<V>(exec_, v.begin(), v.end());
         set_size(data.size);
+    }
+    // Csr::read(device_matrix_data) (core/matrix/csr.cpp:445-470): takes the
+    // arrays over as they are (row-major order is the caller's job) and builds
+    // row_ptrs with convert_idxs_to_ptrs on the device
+    using device_mat_data = device_matrix_data<V, I>;
+    void read(const device_mat_data& data) { this->read(device_mat_data{exec_, data}); }
+    void read(device_mat_data&& data)
+    {
+        detail::require_device(exec_, "csr::convert_idxs_to_ptrs");
+        const auto size = data.get_size();
+        auto arrays = data.empty_out();
+        arrays.row_idxs.set_executor(exec_); arrays.col_idxs.set_executor(exec_); arrays.values.set_executor(exec_);
+        row_ptrs_.resize_and_reset(size[0] + 1);
+        set_size(size);
+        values_ = std::move(arrays.values);
+        col_idxs_ = std::move(arrays.col_idxs);
+        array<char> ws(exec_, gkomi_prefix_sum_workspace_bytes(size[0] + 1));
+        GKOMI_CALL(gkomi_convert_idxs_to_ptrs_i32(nullptr, arrays.row_idxs.get_const_data(), arrays.row_idxs.get_num_elems(), size[0], row_ptrs_.get_data(),
+                                                  ws.get_data(), ws.get_num_elems()));
+        max_row_nnz_ = -1;
     }
     void write(mat_data& data) const
     {

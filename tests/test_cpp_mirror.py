@@ -85,4 +85,6 @@ def test_hot_path_tour(bins):
     assert kv["cg_jacobi_iters"][2] == "1" and float(kv["cg_jacobi_iters"][4]) < 1e-9
     assert kv["gmres_ilu_iters"][2] == "1" and float(kv["gmres_ilu_iters"][4]) < 1e-9
     assert int(kv["gmres_ilu_iters"][0]) < 200
+    # device assembly: duplicates summed, explicit zeros dropped, Csr::read on the device
+    assert kv["assembly_nnz"][0] == kv["assembly_nnz"][2] and float(kv["assembly_nnz"][4]) == 0.0
     assert kv["dimension_check"] == ["ok"]
