@@ -315,7 +315,8 @@ int gkomi_hybrid_ell_width_i32(gkomi_stream_t s, const int32_t* row_ptrs,
                                int64_t* host_result);
 
 /* ---- block-Jacobi preconditioner (core/preconditioner/jacobi_kernels.hpp:50-190)
- * fp64 block storage (precision_reduction(0,0)); blocks use the reference's
+ * fp64 block storage (precision_reduction(0,0)) or adaptive precision (the
+ * *_adaptive entry points); blocks use the reference's
  * block_interleaved_storage_scheme with max_block_stride = 64, the HIP
  * wavefront size (include/ginkgo/core/preconditioner/jacobi.hpp:62-167,
  * 578-609).  1 <= max_block_size <= 32. ---------------------------------- */
@@ -350,6 +351,28 @@ int gkomi_jacobi_apply_f64_i32(gkomi_stream_t s, int64_t num_blocks,
                                const double* alpha, const double* b,
                                int64_t b_stride, const double* beta, double* x,
                                int64_t x_stride);
+/* The same two kernels with the reference's ADAPTIVE block storage precision
+ * (storage_optimization, include/ginkgo/core/preconditioner/jacobi.hpp:262-330;
+ * core/preconditioner/jacobi_utils.hpp:46-201).  block_precisions[num_blocks]
+ * holds gko::precision_reduction bytes ((preserving << 4) | nonpreserving;
+ * 0xff = autodetect): on input the request per block, on output the precision
+ * used, common to all blocks of a storage group.  Autodetection picks per
+ * group the smallest of {double (0,0), float (0,1), half (0,2),
+ * truncated<double,2> (1,0), truncated<float,2> (1,1), truncated<double,4>
+ * (2,0)} with cond * eps < accuracy that passes the reference's feasibility
+ * checks (jacobi_kernels.cpp:311-336).  conditioning is required.  half uses
+ * the reference executor's conversion (extended_float.hpp:357-399:
+ * truncation, flush below 2^-14). */
+int gkomi_jacobi_generate_adaptive_f64_i32(
+    gkomi_stream_t s, int64_t nrows, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, int64_t num_blocks,
+    int max_block_size, const int32_t* block_ptrs, double accuracy,
+    double* conditioning, uint8_t* block_precisions, double* blocks);
+int gkomi_jacobi_apply_adaptive_f64_i32(
+    gkomi_stream_t s, int64_t num_blocks, int max_block_size,
+    const int32_t* block_ptrs, const uint8_t* block_precisions,
+    const double* blocks, int64_t nrhs, const double* alpha, const double* b,
+    int64_t b_stride, const double* beta, double* x, int64_t x_stride);
 /* scalar Jacobi (max_block_size == 1): csr::extract_diagonal
  * (reference/matrix/csr_kernels.cpp:1016-1034), jacobi::invert_diagonal
  * (:608-620), simple_scalar_apply / scalar_apply (:565-594) */
@@ -560,6 +583,7 @@ typedef struct gkomi_jacobi_ctx {
     int32_t pad_;
     const int32_t* block_ptrs;
     const double* blocks;
+    const uint8_t* block_precisions; /* NULL: fp64 storage; else adaptive (see above) */
 } gkomi_jacobi_ctx;
 typedef struct gkomi_ilu_ctx {
     int64_t n;

@@ -46,8 +46,11 @@ __device__ __forceinline__ int xcd_chunked_block(int bid, int per)
 // Dot = true adds the CG epilogue: partial[logical block] = sum over the
 // block's rows of b[row] * c[row] (fixed-order tree, no atomics), and the whole
 // launch is skipped when stop_status[0] says the solver has stopped.
+typedef double nt_double2 __attribute__((ext_vector_type(2)));
+typedef int nt_int2 __attribute__((ext_vector_type(2)));
+
 template <int Block, int RowsPerThread, int Tile, bool Advanced, bool Swizzle,
-          bool Dot = false>
+          bool Dot = false, bool NT = false>
 __global__ __launch_bounds__(Block) void csr_stream_kernel(
     int nrows, const int32_t* __restrict__ row_ptrs,
     const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
@@ -110,8 +113,17 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
             ci[u] = make_int2(0, 0);
             if (k < p1) {
                 if (k + 1 < nnz_total) {
-                    v[u] = *reinterpret_cast<const double2*>(vals + k);
-                    ci[u] = *reinterpret_cast<const int2*>(col_idxs + k);
+                    if (NT) {  // read-once streams: do not keep them in the caches b lives in
+                        const nt_double2 tv = __builtin_nontemporal_load(
+                            reinterpret_cast<const nt_double2*>(vals + k));
+                        const nt_int2 tc = __builtin_nontemporal_load(
+                            reinterpret_cast<const nt_int2*>(col_idxs + k));
+                        v[u] = make_double2(tv.x, tv.y);
+                        ci[u] = make_int2(tc.x, tc.y);
+                    } else {
+                        v[u] = *reinterpret_cast<const double2*>(vals + k);
+                        ci[u] = *reinterpret_cast<const int2*>(col_idxs + k);
+                    }
                 } else {
                     v[u].x = vals[k];
                     ci[u].x = col_idxs[k];
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(256) void csr_max_row_nnz_kernel(
     }
 }
 
-template <int Block, int RowsPerThread, int Tile>
+template <int Block, int RowsPerThread, int Tile, bool NT = false>
 int launch_stream(hipStream_t stream, bool swizzle, int chunk, int nrows, int nrhs,
                   const int32_t* row_ptrs, const int32_t* col_idxs,
                   const double* vals, const double* b, int64_t b_stride,
@@ -357,7 +369,8 @@ int launch_stream(hipStream_t stream, bool swizzle, int chunk, int nrows, int nr
     dim3 grid(swz ? groups * per * num_xcd : nblocks, nrhs);
 #define GKOMI_LAUNCH(ADV, SWZ)                                                 \
     hipLaunchKernelGGL(                                                        \
-        (csr_stream_kernel<Block, RowsPerThread, Tile, ADV, SWZ>), grid,       \
+        (csr_stream_kernel<Block, RowsPerThread, Tile, ADV, SWZ, false, NT>),  \
+        grid,                                                                  \
         dim3(Block), 0, stream, nrows, row_ptrs, col_idxs, vals, b, b_stride,  \
         c, c_stride, alpha, beta, nblocks, per)
     if (advanced) {
@@ -415,7 +428,9 @@ int csr_spmv_dot_launch(hipStream_t stream, int nrows, int64_t nnz,
                            col_idxs, vals, p, int64_t{1}, q, int64_t{1},
                            nullptr, nullptr, nblocks, per, partial, stop_status);
     } else {
-        hipLaunchKernelGGL((csr_stream_kernel<Block, 1, Tile, false, false, true>),
+        // not Infinity-Cache resident: the matrix streams from HBM every
+        // iteration, read it with nontemporal loads (see csr_auto_swizzle)
+        hipLaunchKernelGGL((csr_stream_kernel<Block, 1, Tile, false, false, true, true>),
                            grid, dim3(Block), 0, stream, nrows, row_ptrs,
                            col_idxs, vals, p, int64_t{1}, q, int64_t{1},
                            nullptr, nullptr, nblocks, per, partial, stop_status);
@@ -431,7 +446,9 @@ int csr_spmv_dot_num_partials(int nrows)
 // swizzle heuristic shared by the automatic strategy: XCD-chunked row blocks
 // pay while the matrix is Infinity-Cache resident (measured 13.7 vs 15.1 us
 // warm at 1M rows) and cost ~4 % once it streams from HBM (57.3 vs 59.6 us at
-// 4M rows) -- profiles/README.md.
+// 4M rows) -- profiles/README.md.  The same threshold selects nontemporal
+// loads of vals / col_idxs: 54.6 vs 59.0 us at 4M rows (5.86 TB/s), but 15.6 vs
+// 13.8 us on a resident 1M-row matrix (profiles/r01_tune_nt.log).
 bool csr_auto_swizzle(int64_t nrows, int64_t nnz)
 {
     if (nnz < 0) return true;
@@ -485,8 +502,8 @@ extern "C" int gkomi_csr_spmv_f64_i32(
     if (kind == GKOMI_CSR_STREAM && !aligned) kind = GKOMI_CSR_VECTOR;
     if (automatic) {
         // 256 threads, 256 rows, 1536-nonzero tile: fastest measured
-        variant = kind == GKOMI_CSR_STREAM ? 5 : 0;
         no_swizzle = !csr_auto_swizzle(nrows, nnz);
+        variant = kind == GKOMI_CSR_STREAM ? (no_swizzle ? 14 : 5) : 0;
     }
 
 #define GKOMI_ARGS                                                            \
@@ -506,6 +523,7 @@ extern "C" int gkomi_csr_spmv_f64_i32(
         case 11: return launch_stream<128, 1, 768>(stream, !no_swizzle, chunk, GKOMI_ARGS);
         case 12: return launch_stream<256, 1, 1024>(stream, !no_swizzle, chunk, GKOMI_ARGS);
         case 13: return launch_stream<384, 1, 2304>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 14: return launch_stream<256, 1, 1536, true>(stream, !no_swizzle, chunk, GKOMI_ARGS);
         default: return launch_stream<256, 1, 2048>(stream, !no_swizzle, chunk, GKOMI_ARGS);
         }
     }

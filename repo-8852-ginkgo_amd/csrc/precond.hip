@@ -13,6 +13,12 @@ extern "C" int gkomi_jacobi_apply_cb(void* ctx_, gkomi_stream_t s, const double*
         return gkomi_jacobi_scalar_apply_f64(s, c->n, c->nrhs, c->blocks, nullptr, in, c->nrhs,
                                              nullptr, out, c->nrhs);
     }
+    if (c->block_precisions != nullptr) {
+        return gkomi_jacobi_apply_adaptive_f64_i32(s, c->num_blocks, c->max_block_size,
+                                                   c->block_ptrs, c->block_precisions, c->blocks,
+                                                   c->nrhs, nullptr, in, c->nrhs, nullptr, out,
+                                                   c->nrhs);
+    }
     return gkomi_jacobi_apply_f64_i32(s, c->num_blocks, c->max_block_size, c->block_ptrs,
                                       c->blocks, c->nrhs, nullptr, in, c->nrhs, nullptr, out,
                                       c->nrhs);

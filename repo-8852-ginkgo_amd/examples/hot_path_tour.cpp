@@ -89,6 +89,28 @@ int main()
         std::cout << "cg_jacobi_iters " << cg->get_last_iteration_count() << " converged " << cg->has_converged()
                   << " true_residual " << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
 
+        // the same solve with adaptive-precision block storage (storage_optimization = autodetect)
+        {
+            sol->fill(0.0);
+            auto bj = gko::share(gko::preconditioner::Jacobi<double, int>::build()
+                                     .with_max_block_size(8u)
+                                     .with_storage_optimization(gko::precision_reduction::autodetect())
+                                     .with_accuracy(1e-1)
+                                     .on(exec)
+                                     ->generate(A));
+            int reduced = 0;
+            for (auto p : bj->get_block_precisions()) reduced += p != gko::precision_reduction(0, 0);
+            auto cg2 = gko::solver::Cg<double>::build()
+                           .with_criteria(gko::stop::Iteration::build().with_max_iters(2000u).on(exec),
+                                          gko::stop::ResidualNorm<double>::build().with_reduction_factor(1e-10).on(exec))
+                           .with_generated_preconditioner(bj)
+                           .on(exec)
+                           ->generate(A);
+            cg2->apply(b.get(), sol.get());
+            std::cout << "cg_adaptive_jacobi_iters " << cg2->get_last_iteration_count() << " converged " << cg2->has_converged() << " reduced_blocks "
+                      << reduced << " of " << bj->get_num_blocks() << "\n";
+        }
+
         // GMRES(30) + ParILU on the nonsymmetric variant
         auto B = gko::share(csr::create(exec));
         B->read(stencil(g, 0.5));

@@ -50,7 +50,8 @@ class JacobiCtx(ctypes.Structure):
     """gkomi_jacobi_ctx (include/gkomi.h)."""
     _fields_ = [("n", ctypes.c_int64), ("nrhs", ctypes.c_int64), ("num_blocks", ctypes.c_int64),
                 ("max_block_size", ctypes.c_int32), ("pad_", ctypes.c_int32),
-                ("block_ptrs", ctypes.c_void_p), ("blocks", ctypes.c_void_p)]
+                ("block_ptrs", ctypes.c_void_p), ("blocks", ctypes.c_void_p),
+                ("block_precisions", ctypes.c_void_p)]
 
 
 class IluCtx(ctypes.Structure):
@@ -72,9 +73,16 @@ class Preconditioner:
         self.keep = keep
 
 
-def jacobi_generate(gk, n, row_ptrs, col_idxs, vals, max_block_size=32, nrhs=1):
+AUTODETECT = 0xff  # gko::precision_reduction::autodetect()
+
+
+def jacobi_generate(gk, n, row_ptrs, col_idxs, vals, max_block_size=32, nrhs=1, storage_optimization=None,
+                    accuracy=1e-1):
     """preconditioner::Jacobi::generate (core/preconditioner/jacobi.cpp:300-370):
-    detect_blocks + generate, or extract/invert the diagonal for max_block_size 1."""
+    detect_blocks + generate, or extract/invert the diagonal for max_block_size 1.
+    storage_optimization: None (fp64 blocks), a precision_reduction byte for all
+    blocks (AUTODETECT = adaptive) or a sequence repeated over the blocks
+    (jacobi::initialize_precisions, jacobi_kernels.cpp:485-493)."""
     dv = vals.device
     s = torch.cuda.current_stream().cuda_stream
     if max_block_size == 1:
@@ -82,7 +90,7 @@ def jacobi_generate(gk, n, row_ptrs, col_idxs, vals, max_block_size=32, nrhs=1):
         gk.csr_extract_diagonal_f64_i32(s, n, row_ptrs, col_idxs, vals, diag)
         inv = torch.zeros_like(diag)
         gk.jacobi_invert_diagonal_f64(s, n, diag, inv)
-        ctx = JacobiCtx(n, nrhs, n, 1, 0, 0, inv.data_ptr())
+        ctx = JacobiCtx(n, nrhs, n, 1, 0, 0, inv.data_ptr(), 0)
         return Preconditioner(gk, "gkomi_jacobi_apply_cb", ctx, (inv,))
     ptrs = torch.zeros(n + 1, dtype=torch.int32, device=dv)
     nbd = torch.zeros(1, dtype=torch.int64, device=dv)
@@ -91,10 +99,19 @@ def jacobi_generate(gk, n, row_ptrs, col_idxs, vals, max_block_size=32, nrhs=1):
     gk.jacobi_find_blocks_i32(s, n, row_ptrs, col_idxs, max_block_size, ptrs, nbd, ws, n + 8, ctypes.addressof(hn))
     nb = int(hn.value)
     blocks = torch.zeros(max(gk.jacobi_storage_elements(max_block_size, nb), 1), dtype=torch.float64, device=dv)
-    gk.jacobi_generate_f64_i32(s, n, row_ptrs, col_idxs, vals, nb, max_block_size, ptrs, None, blocks)
-    ctx = JacobiCtx(n, nrhs, nb, max_block_size, 0, ptrs.data_ptr(), blocks.data_ptr())
-    p = Preconditioner(gk, "gkomi_jacobi_apply_cb", ctx, (ptrs, blocks))
-    p.num_blocks, p.block_ptrs, p.blocks = nb, ptrs, blocks
+    prec = cond = None
+    if storage_optimization is None:
+        gk.jacobi_generate_f64_i32(s, n, row_ptrs, col_idxs, vals, nb, max_block_size, ptrs, None, blocks)
+    else:
+        src = np.atleast_1d(np.asarray(storage_optimization, np.uint8))
+        prec = torch.from_numpy(np.resize(src, max(nb, 1))).to(dv)
+        cond = torch.zeros(max(nb, 1), dtype=torch.float64, device=dv)
+        gk.jacobi_generate_adaptive_f64_i32(s, n, row_ptrs, col_idxs, vals, nb, max_block_size, ptrs, accuracy,
+                                            cond, prec, blocks)
+    ctx = JacobiCtx(n, nrhs, nb, max_block_size, 0, ptrs.data_ptr(), blocks.data_ptr(),
+                    prec.data_ptr() if prec is not None else 0)
+    p = Preconditioner(gk, "gkomi_jacobi_apply_cb", ctx, (ptrs, blocks, prec, cond))
+    p.num_blocks, p.block_ptrs, p.blocks, p.block_precisions, p.conditioning = nb, ptrs, blocks, prec, cond
     return p
 
 

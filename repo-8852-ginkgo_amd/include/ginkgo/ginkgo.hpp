@@ -1178,6 +1178,22 @@ struct linop_callback {
 };
 }  // namespace detail
 
+// include/ginkgo/core/base/types.hpp:257-400
+class precision_reduction {
+public:
+    using storage_type = uint8;
+    constexpr precision_reduction() noexcept : data_{0} {}
+    constexpr precision_reduction(storage_type preserving, storage_type nonpreserving) noexcept
+        : data_(static_cast<storage_type>((preserving << 4) | nonpreserving)) {}
+    constexpr operator storage_type() const noexcept { return data_; }
+    constexpr storage_type get_preserving() const noexcept { return data_ >> 4; }
+    constexpr storage_type get_nonpreserving() const noexcept { return data_ & 0xf; }
+    constexpr static precision_reduction autodetect() noexcept { return from_bits(0xff); }
+    constexpr static precision_reduction from_bits(storage_type b) noexcept { precision_reduction p; p.data_ = b; return p; }
+private:
+    storage_type data_;
+};
+
 namespace preconditioner {
 template <typename V = double, typename I = int32>
 class Jacobi : public LinOp {
@@ -1185,18 +1201,38 @@ public:
     class Factory : public LinOpFactory {
     public:
         Factory& with_max_block_size(uint32 n) { max_block_size_ = n; return *this; }
+        // storage_optimization (jacobi.hpp:262-330): one precision for all blocks
+        // (autodetect() = adaptive) or a list repeated over the blocks
+        Factory& with_storage_optimization(precision_reduction p) { storage_.assign(1, p); adaptive_ = true; return *this; }
+        Factory& with_storage_optimization(const std::vector<precision_reduction>& p) { storage_ = p; adaptive_ = !p.empty(); return *this; }
+        Factory& with_accuracy(double a) { accuracy_ = a; return *this; }
         std::shared_ptr<Factory> on(std::shared_ptr<const Executor> exec) const { auto f = std::make_shared<Factory>(*this); f->exec_ = std::move(exec); return f; }
-        std::unique_ptr<Jacobi> generate(std::shared_ptr<const LinOp> A) const { return std::unique_ptr<Jacobi>(new Jacobi(this->exec_, max_block_size_, std::move(A))); }
+        std::unique_ptr<Jacobi> generate(std::shared_ptr<const LinOp> A) const
+        {
+            return std::unique_ptr<Jacobi>(new Jacobi(this->exec_, max_block_size_, adaptive_ ? &storage_ : nullptr, accuracy_, std::move(A)));
+        }
         std::unique_ptr<LinOp> generate_impl(std::shared_ptr<const LinOp> A) const override { return generate(std::move(A)); }
         Factory() : LinOpFactory(nullptr) {}
     private:
         uint32 max_block_size_{32};  // jacobi.hpp:338-349
+        std::vector<precision_reduction> storage_;
+        bool adaptive_{false};
+        double accuracy_{1e-1};      // jacobi.hpp:332-336
     };
     static Factory build() { return Factory{}; }
     size_type get_num_blocks() const noexcept { return num_blocks_; }
     uint32 get_max_block_size() const noexcept { return max_block_size_; }
+    // per-block storage precisions actually used / condition numbers (adaptive storage only)
+    std::vector<precision_reduction> get_block_precisions() const
+    {
+        std::vector<precision_reduction> out;
+        for (auto b : precisions_.to_host()) out.push_back(precision_reduction::from_bits(b));
+        return out;
+    }
+    std::vector<double> get_conditioning() const { return conditioning_.to_host(); }
 protected:
-    Jacobi(std::shared_ptr<const Executor> exec, uint32 max_bs, std::shared_ptr<const LinOp> A) : LinOp(exec, A->get_size()), max_block_size_(max_bs), block_ptrs_(exec), blocks_(exec)
+    Jacobi(std::shared_ptr<const Executor> exec, uint32 max_bs, const std::vector<precision_reduction>* storage, double accuracy, std::shared_ptr<const LinOp> A)
+        : LinOp(exec, A->get_size()), max_block_size_(max_bs), block_ptrs_(exec), blocks_(exec), precisions_(exec), conditioning_(exec)
     {
         ::gko::detail::require_device(exec_, "jacobi::generate");
         if (max_bs < 1 || max_bs > 32) GKO_NOT_SUPPORTED("max_block_size must be in [1, 32]");
@@ -1217,7 +1253,17 @@ protected:
         GKOMI_CALL(gkomi_jacobi_find_blocks_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), max_bs, block_ptrs_.get_data(), nb.get_data(), ws.get_data(), ws.get_num_elems(), &host_nb));
         num_blocks_ = static_cast<size_type>(host_nb);
         blocks_.resize_and_reset(gkomi_jacobi_storage_elements(max_bs, host_nb));
-        GKOMI_CALL(gkomi_jacobi_generate_f64_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(), host_nb, max_bs, block_ptrs_.get_const_data(), nullptr, blocks_.get_data()));
+        if (storage == nullptr) {
+            GKOMI_CALL(gkomi_jacobi_generate_f64_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(), host_nb, max_bs, block_ptrs_.get_const_data(), nullptr, blocks_.get_data()));
+            return;
+        }
+        // jacobi::initialize_precisions (jacobi_kernels.cpp:485-493): the list repeats over the blocks
+        std::vector<uint8> req(num_blocks_);
+        for (size_type i = 0; i < num_blocks_; ++i) req[i] = (*storage)[i % storage->size()];
+        precisions_ = array<uint8>(exec_, req.begin(), req.end());
+        conditioning_.resize_and_reset(num_blocks_);
+        GKOMI_CALL(gkomi_jacobi_generate_adaptive_f64_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(), host_nb, max_bs,
+                                                          block_ptrs_.get_const_data(), accuracy, conditioning_.get_data(), precisions_.get_data(), blocks_.get_data()));
     }
     void run(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const
     {
@@ -1226,6 +1272,9 @@ protected:
         const double* be = beta ? matrix::detail_fmt::dense(beta)->get_const_values() : nullptr;
         if (max_block_size_ == 1) {
             GKOMI_CALL(gkomi_jacobi_scalar_apply_f64(nullptr, size_[0], db->cols(), blocks_.get_const_data(), a, db->get_const_values(), db->get_stride(), be, dx->get_values(), dx->get_stride()));
+        } else if (precisions_.get_num_elems() > 0) {
+            GKOMI_CALL(gkomi_jacobi_apply_adaptive_f64_i32(nullptr, num_blocks_, max_block_size_, block_ptrs_.get_const_data(), precisions_.get_const_data(), blocks_.get_const_data(),
+                                                           db->cols(), a, db->get_const_values(), db->get_stride(), be, dx->get_values(), dx->get_stride()));
         } else {
             GKOMI_CALL(gkomi_jacobi_apply_f64_i32(nullptr, num_blocks_, max_block_size_, block_ptrs_.get_const_data(), blocks_.get_const_data(), db->cols(), a, db->get_const_values(), db->get_stride(), be, dx->get_values(), dx->get_stride()));
         }
@@ -1236,6 +1285,8 @@ protected:
     size_type num_blocks_{0};
     array<I> block_ptrs_;
     array<V> blocks_;
+    array<uint8> precisions_;
+    array<double> conditioning_;
 };
 }  // namespace preconditioner
 

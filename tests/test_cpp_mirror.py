@@ -83,6 +83,9 @@ def test_hot_path_tour(bins):
     assert float(kv["coo_diff"][0]) < 1e-12 and float(kv["hybrid_diff"][0]) < 1e-12
     assert int(kv["hybrid_diff"][2]) > 0
     assert kv["cg_jacobi_iters"][2] == "1" and float(kv["cg_jacobi_iters"][4]) < 1e-9
+    # adaptive block storage: some blocks reduced, same convergence within a few iterations
+    assert kv["cg_adaptive_jacobi_iters"][2] == "1" and int(kv["cg_adaptive_jacobi_iters"][4]) > 0
+    assert abs(int(kv["cg_adaptive_jacobi_iters"][0]) - int(kv["cg_jacobi_iters"][0])) <= 5
     assert kv["gmres_ilu_iters"][2] == "1" and float(kv["gmres_ilu_iters"][4]) < 1e-9
     assert int(kv["gmres_ilu_iters"][0]) < 200
     # device assembly: duplicates summed, explicit zeros dropped, Csr::read on the device

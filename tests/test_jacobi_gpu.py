@@ -202,3 +202,145 @@ def test_find_blocks_large_poisson_and_identity_patterns(gk, oracle):
     x = torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")
     gk.jacobi_apply_f64_i32(stream_ptr(), nb, 32, ptrs, blocks, 1, None, dev(b), 1, None, x, 1)
     assert np.array_equal(host(x), ex)
+
+
+# ---- adaptive precision block storage --------------------------------------------------
+A = G["adaptive"]
+
+
+def gpu_generate_adaptive(gk, n, rpd, cid, vd, ptrs_d, nb, max_bs, precisions, accuracy=1e-1):
+    nel = gk.jacobi_storage_elements(max_bs, nb)
+    blocks = torch.full((max(nel, 1),), float("nan"), dtype=torch.float64, device="cuda:0")
+    cond = torch.zeros(max(nb, 1), dtype=torch.float64, device="cuda:0")
+    prec = dev(np.resize(np.asarray(precisions, np.uint8), max(nb, 1)))
+    gk.jacobi_generate_adaptive_f64_i32(stream_ptr(), n, rpd, cid, vd, nb, max_bs, ptrs_d, accuracy, cond, prec, blocks)
+    return blocks, cond, prec
+
+
+def oracle_generate_adaptive(oracle, n, rp, ci, v, ptrs, nb, max_bs, precisions, accuracy=1e-1):
+    es = np.zeros(3, np.int64)
+    oracle.ref_jacobi_storage_scheme(max_bs, 64, es)
+    blocks = np.zeros(int(oracle.ref_jacobi_storage_space(es, nb)))
+    cond = np.zeros(max(nb, 1))
+    prec = np.resize(np.asarray(precisions, np.uint8), max(nb, 1)).copy()
+    oracle.ref_jacobi_generate_adaptive(n, rp, ci, v, nb, es, np.asarray(ptrs, np.int32), accuracy, cond, prec, blocks)
+    return es, blocks, cond, prec
+
+
+def test_adaptive_known_answers(gk, oracle):
+    n, rp, ci, v = mtx()
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    ptrs = np.array(G["block_pointers"], np.int32)
+    # requested {(0,1), (0,0)}: with the HIP stride of 64 both blocks share a
+    # group at every max_block_size <= 32 -> common precision (0,0), :450-470
+    for max_bs in (17, 3):
+        blocks, cond, prec = gpu_generate_adaptive(gk, n, rpd, cid, vd, dev(ptrs), 2, max_bs, A["block_precisions"])
+        es, eb, ec, ep = oracle_generate_adaptive(oracle, n, rp, ci, v, ptrs, 2, max_bs, A["block_precisions"])
+        assert list(host(prec)) == list(ep) == [0, 0]
+        assert np.array_equal(host(blocks), eb) and np.array_equal(host(cond), ec)
+        assert np.allclose(host(cond), G["conditioning"]["expect"], rtol=0, atol=G["conditioning"]["tol"])
+    # SelectsCorrectBlockPrecisions (:582-602): alone in their groups the
+    # blocks pick half and float; sharing one group they settle on float
+    c = A["selects"]
+    for b, expect in ((0, 2), (1, 1)):
+        one = ptrs[b:b + 2]
+        lo, hi = int(one[0]), int(one[1])
+        sub_rows = range(lo, hi)
+        srp, sci, sv = [0], [], []
+        for r in sub_rows:
+            for k in range(rp[r], rp[r + 1]):
+                if lo <= ci[k] < hi:
+                    sci.append(ci[k] - lo); sv.append(v[k])
+            srp.append(len(sci))
+        srp, sci, sv = np.array(srp, np.int32), np.array(sci, np.int32), np.array(sv)
+        p1 = np.array([0, hi - lo], np.int32)
+        _, _, prec = gpu_generate_adaptive(gk, hi - lo, dev(srp), dev(sci), dev(sv), dev(p1), 1, c["max_block_size"],
+                                           [255], c["accuracy"])
+        assert list(host(prec)) == [expect]
+    _, _, prec = gpu_generate_adaptive(gk, n, rpd, cid, vd, dev(ptrs), 2, c["max_block_size"], [255], c["accuracy"])
+    _, _, _, ep = oracle_generate_adaptive(oracle, n, rp, ci, v, ptrs, 2, c["max_block_size"], [255], c["accuracy"])
+    assert list(host(prec)) == list(ep) == [1, 1]
+    # AvoidsPrecisionsThatOverflow (:605-645)
+    c = A["overflow"]
+    rows, cols, vals = [], [], []
+    for k, blk in enumerate(c["diag_blocks"]):
+        for i in range(2):
+            for j in range(2):
+                rows.append(2 * k + i); cols.append(2 * k + j); vals.append(blk[i][j])
+    orp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=4))]).astype(np.int32)
+    _, _, prec = gpu_generate_adaptive(gk, 4, dev(orp), dev(np.array(cols, np.int32)), dev(np.array(vals)),
+                                       dev(np.array(c["block_pointers"], np.int32)), 2, c["max_block_size"], [255],
+                                       c["accuracy"])
+    assert list(host(prec)) == c["expect"]
+
+
+@pytest.mark.parametrize("case", A["applies"], ids=lambda c: c["name"])
+def test_adaptive_applies_known_answers(gk, case):
+    # at stride 64 both blocks share a group; here BOTH are stored as float (the
+    # reference's fixture keeps the second in fp64), hence 2 x its half_tol
+    n, rp, ci, v = mtx()
+    ptrs = dev(np.array(G["block_pointers"], np.int32))
+    blocks, _, prec = gpu_generate_adaptive(gk, n, dev(rp), dev(ci), dev(v), ptrs, 2, case["max_block_size"], [1])
+    assert list(host(prec)) == [1, 1]   # float storage for the whole group
+    st = case.get("stride")
+    x, b = dev(_strided(case["x"], st)), dev(_strided(case["b"], st))
+    nrhs = np.array(case["x"]).shape[1]
+    al = dev(np.array([case["alpha"]])) if "alpha" in case else None
+    be = dev(np.array([case["beta"]])) if "alpha" in case else None
+    gk.jacobi_apply_adaptive_f64_i32(stream_ptr(), 2, case["max_block_size"], ptrs, prec, blocks, nrhs, al, b,
+                                     b.shape[1], be, x, x.shape[1])
+    assert matgen.rel_err(host(x)[:, :nrhs], case["expect"]) <= 2 * A["half_tol"]
+    assert np.all(host(x)[:, nrhs:] == -9.0)
+
+
+@pytest.mark.parametrize("max_bs", [2, 4, 7, 13, 16, 32])
+@pytest.mark.parametrize("storage", [0x00, 0x01, 0x02, 0x10, 0x11, 0x20, "mixed", "auto"])
+def test_adaptive_generate_apply_bitexact_vs_oracle(gk, oracle, max_bs, storage):
+    n, rp, ci, v, _ = block_structured_matrix(203, max_bs, seed=100 + max_bs)
+    if storage == "auto":   # spread the condition numbers so that several precisions get chosen
+        scale = np.repeat(10.0 ** np.random.default_rng(3).integers(-3, 4, n), np.diff(rp))
+        v = v * scale
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    eptrs = np.zeros(n + 1, np.int32)
+    nb = oracle.ref_jacobi_find_blocks(n, rp, ci, max_bs, eptrs)
+    ptrs = dev(eptrs)
+    req = {"mixed": [0x01, 0x00, 0x02, 0x10, 0x11, 0x20, 0xff], "auto": [0xff]}.get(storage, [storage])
+    for accuracy in ((1e-1, 1e-3, 1e-6) if storage in ("auto", "mixed") else (1e-1,)):
+        blocks, cond, prec = gpu_generate_adaptive(gk, n, rpd, cid, vd, ptrs, nb, max_bs, req, accuracy)
+        es, eb, ec, ep = oracle_generate_adaptive(oracle, n, rp, ci, v, eptrs[:nb + 1], nb, max_bs, req, accuracy)
+        assert np.array_equal(host(prec)[:nb], ep[:nb])
+        assert np.array_equal(host(cond)[:nb], ec[:nb])
+        assert host(blocks).tobytes() == eb.tobytes()
+        if storage == "auto" and accuracy == 1e-1:
+            assert len(set(ep[:nb].tolist())) >= 2   # the test data exercises more than one storage type
+        rng = np.random.default_rng(7)
+        for nrhs in (1, 3):
+            b = rng.standard_normal((n, nrhs))
+            x0 = rng.standard_normal((n, nrhs))
+            for alpha, beta in ((None, None), (2.0, -1.0), (0.5, 0.0)):
+                ex = x0.copy()
+                oracle.ref_jacobi_apply_adaptive(nb, es, eptrs, ep, eb, nrhs, 1.0 if alpha is None else alpha, b, nrhs,
+                                                 0.0 if beta is None else beta, ex, nrhs)
+                x = dev(x0)
+                gk.jacobi_apply_adaptive_f64_i32(stream_ptr(), nb, max_bs, ptrs, prec, blocks, nrhs,
+                                                 None if alpha is None else dev(np.array([alpha])), dev(b), nrhs,
+                                                 None if beta is None else dev(np.array([beta])), x, nrhs)
+                assert np.array_equal(host(x), ex)
+
+
+def test_adaptive_storage_speeds_up_block_jacobi_cg(gk, oracle):
+    """Adaptive storage is a preconditioner-quality trade: CG with the reduced
+    blocks still converges to the same tolerance (benchmark/solver use)."""
+    from gkomi import solvers
+    n, rp, ci, v = matgen.poisson_2d_5pt(64)
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    b = torch.ones(n, dtype=torch.float64, device="cuda:0")
+    its = {}
+    for name, storage in (("fp64", None), ("adaptive", solvers.AUTODETECT)):
+        pc = solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=8, storage_optimization=storage)
+        res = solvers.cg_solve(gk, n, rpd, cid, vd, b, max_iters=2000, reduction=1e-10, precond=pc)
+        assert res["converged"] and res["rel_residual"] < 1e-10
+        its[name] = res["iterations"]
+        if storage is not None:
+            assert set(host(pc.block_precisions).tolist()) - {0}   # something was actually reduced
+    assert abs(its["adaptive"] - its["fp64"]) <= max(3, its["fp64"] // 10)

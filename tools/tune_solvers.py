@@ -27,6 +27,8 @@ def ev_time(fn, reps=20):
 
 
 # ---- AT-like: 3-D 7-pt convection-diffusion, GMRES(30) + ParILU ----
+if os.environ.get("JACOBI_ONLY"):
+    g3 = 8
 n, rp, ci, v = matgen.poisson_3d_7pt(g3)
 v = v.copy(); rows = np.repeat(np.arange(n), np.diff(rp))
 v[ci == rows - 1] -= 0.5; v[ci == rows] += 0.5
@@ -68,7 +70,18 @@ tsp = ev_time(lambda: gk.csr_spmv_f64_i32(s, n, n, 1, nnz, rpd, cid, vd, x, 1, y
 print(f"T2-like {g2}^2 permuted: n={n} nnz={nnz}  csr spmv {tsp:.1f} us ({(12*nnz+20*n)/tsp/1e3:.0f} GB/s algorithmic)")
 t0 = time.perf_counter(); pre = solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=32); torch.cuda.synchronize()
 print(f"  block-Jacobi(32) generate {1e3*(time.perf_counter()-t0):.1f} ms, {pre.num_blocks} blocks")
-for prec, name in ((None, "none"), (pre, "Jacobi32")):
+t0 = time.perf_counter(); pre_ad = solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=32, storage_optimization=solvers.AUTODETECT); torch.cuda.synchronize()
+hist = np.bincount(pre_ad.block_precisions.cpu().numpy(), minlength=256)
+print(f"  block-Jacobi(32, adaptive) generate {1e3*(time.perf_counter()-t0):.1f} ms, precisions " + ", ".join(f"0x{k:02x}: {c}" for k, c in enumerate(hist) if c))
+yb = torch.zeros_like(b)
+forced = [(f"0x{st:02x}", solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=32, storage_optimization=st))
+          for st in (0x01, 0x10, 0x02, 0x11, 0x20)]
+for name, pcd in [("fp64", pre), ("adaptive", pre_ad)] + forced:
+    t = ev_time(lambda: gk.jacobi_apply_cb(pcd.ctx_ptr, s, b, yb), 50)
+    print(f"  block-Jacobi(32) apply, {name:8s} storage: {t:7.1f} us")
+if os.environ.get("JACOBI_ONLY"):
+    sys.exit(0)
+for prec, name in ((None, "none"), (pre, "Jacobi32"), (pre_ad, "Jac32-ad")):
     solvers.cg_solve(gk, n, rpd, cid, vd, b, max_iters=20000, reduction=1e-10, mode=1, check_every=32, precond=prec)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     r = solvers.cg_solve(gk, n, rpd, cid, vd, b, max_iters=20000, reduction=1e-10, mode=1, check_every=32, precond=prec)

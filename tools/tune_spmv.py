@@ -32,7 +32,10 @@ variants = {"stream_v0(256,1,2048)": STREAM, "v1(256,2,4096)": STREAM | (1 << 8)
             "vector4": VECTOR | (4 << 8),
             "v8(64,1,384)": STREAM | (8 << 8), "v9(192,1,1152)": STREAM | (9 << 8), "v10(320,1,1920)": STREAM | (10 << 8),
             "v11(128,1,768)": STREAM | (11 << 8), "v12(256,1,1024)": STREAM | (12 << 8), "v13(384,1,2304)": STREAM | (13 << 8),
-            "v9_noswz": STREAM | (9 << 8) | (1 << 16), "v11_noswz": STREAM | (11 << 8) | (1 << 16)}
+            "v9_noswz": STREAM | (9 << 8) | (1 << 16), "v11_noswz": STREAM | (11 << 8) | (1 << 16),
+            "v14(256,1,1536,nt)": STREAM | (14 << 8), "v14_noswz": STREAM | (14 << 8) | (1 << 16)}
+if os.environ.get("TUNE_ONLY"):
+    variants = {k: v for k, v in variants.items() if any(t in k for t in os.environ["TUNE_ONLY"].split(","))}
 extra = [a for a in sys.argv[2:]]
 for e in extra:
     variants[f"custom_{e}"] = int(e, 0)
