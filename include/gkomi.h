@@ -327,7 +327,8 @@ size_t gkomi_jacobi_storage_elements(int max_block_size, int64_t num_blocks);
 /* jacobi::find_blocks (reference/preconditioner/jacobi_kernels.cpp:66-151):
  * block_ptrs has nrows + 1 entries; the count goes to num_blocks_device
  * (device int64) and, if host_num_blocks != NULL, to the host (blocking).
- * workspace: nrows + 8 bytes. */
+ * workspace: gkomi_jacobi_find_blocks_workspace_bytes(nrows). */
+size_t gkomi_jacobi_find_blocks_workspace_bytes(int64_t nrows);
 int gkomi_jacobi_find_blocks_i32(gkomi_stream_t s, int64_t nrows,
                                  const int32_t* row_ptrs,
                                  const int32_t* col_idxs, int max_block_size,

@@ -24,7 +24,12 @@
 // generate: Gauss-Jordan with the reference's implicit row pivoting, each
 // block in LDS, one lane per row; every element sees the same operations in
 // the same order as reference invert_block -> bit-identical inverse.
+#include <cstring>
+
 #include "common.hpp"
+
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
 
 namespace gkomi {
 namespace {
@@ -68,61 +73,132 @@ __global__ __launch_bounds__(block) void compare_rows_kernel(
     }
 }
 
-// The greedy natural-block + agglomeration recurrences are sequential; one wave
-// streams the flags (ballot -> 64-bit mask per 64 rows) and walks the bits
-// with wave-uniform state, fusing both passes of the reference: when natural
-// block k closes it is handed to the agglomerator at once.
-__global__ __launch_bounds__(64) void find_blocks_serial_kernel(
-    int64_t nrows, const uint8_t* __restrict__ same, int max_block_size,
-    int32_t* __restrict__ block_ptrs, int64_t* __restrict__ num_blocks_out)
+// The reference's two greedy passes (find_natural_blocks, then
+// agglomerate_supervariables, jacobi_kernels.cpp:66-137 -- single-thread kernels
+// in its GPU backends too) restated as data-parallel steps:
+//  1. run starts: rows whose pattern differs from the previous row; a max-scan
+//     gives every row the start rs(i) of its run of identical rows.  A natural
+//     block starts at i  <=>  (i - rs(i)) % max_block_size == 0.
+//  2. a second max-scan gives L(x) = last natural start <= x.  The agglomerated
+//     block that starts at natural start r ends at the largest natural
+//     boundary within r + max_block_size:  next(r) = L(r + max_bs), or n.
+//  3. the block starts are the chain 0, next(0), next(next(0)), ...  A hop
+//     covers at most max_bs rows, so the chain enters every chunk of 2048 rows
+//     within its first max_bs rows: every chunk walks (in LDS) from each of
+//     those <= 32 candidate entries to its exit, one thread composes the
+//     exits of consecutive chunks, and every chunk re-walks from its real
+//     entry marking the chain; flags -> scan -> block_ptrs.
+// 120 ms -> well under 1 ms for 1.2M rows (profiles/r01_jacobi.log).
+constexpr int fb_chunk = 2048;
+
+__global__ __launch_bounds__(block) void fb_run_start_values_kernel(int n,
+                                                                    const uint8_t* __restrict__ same,
+                                                                    int* __restrict__ v)
 {
-    const int lane = threadIdx.x;
-    if (nrows == 0) {
-        if (lane == 0) {
-            block_ptrs[0] = 0;
-            *num_blocks_out = 0;
-        }
-        return;
+    const int i = blockIdx.x * block + threadIdx.x;
+    if (i < n) v[i] = same[i] ? -1 : i;
+}
+
+// in place: v holds rs(i) on entry, the natural-start value on exit
+__global__ __launch_bounds__(block) void fb_natural_values_kernel(int n, int max_bs,
+                                                                  int* __restrict__ v)
+{
+    const int i = blockIdx.x * block + threadIdx.x;
+    if (i < n) v[i] = (i - v[i]) % max_bs == 0 ? i : -1;
+}
+
+// Mark = false: exits[chunk * 32 + e] = first chain row >= chunk end when the
+// chain enters the chunk at its row e.  Mark = true: walk from the real entry
+// and flag the chain rows.
+template <bool Mark>
+__global__ __launch_bounds__(block) void fb_walk_kernel(int n, int max_bs,
+                                                        const int* __restrict__ last_natural,
+                                                        int* __restrict__ exits,
+                                                        const int* __restrict__ entry,
+                                                        int* __restrict__ flags)
+{
+    __shared__ int s_next[fb_chunk];
+    const int cs = blockIdx.x * fb_chunk;
+    const int ce = min(cs + fb_chunk, n);
+    for (int t = threadIdx.x; t < ce - cs; t += block) {
+        const int r = cs + t;
+        s_next[t] = r + max_bs >= n ? n : last_natural[r + max_bs];
     }
-    int64_t nout = 1;          // entries written to block_ptrs so far (ptrs[0] = 0)
-    int cur = 1;               // size of the open natural block (row 0 opened it)
-    int64_t nat_start = 0;     // first row of the open natural block
-    int acc = -1;              // size of the open agglomerated block, -1 = none yet
-    if (lane == 0) block_ptrs[0] = 0;
-    for (int64_t base = 0; base < nrows; base += 64) {
-        const int64_t i = base + lane;
-        const bool flag = i < nrows && i > 0 && same[i] != 0;
-        const unsigned long long mask = __ballot(flag);
-        const int count = static_cast<int>(min(int64_t{64}, nrows - base));
-        for (int j = (base == 0 ? 1 : 0); j < count; ++j) {
-            const bool s = (mask >> j) & 1ull;
-            if (cur < max_block_size && s) {
-                ++cur;
+    __syncthreads();
+    if (!Mark) {
+        if (threadIdx.x < 32) {
+            int r = cs + threadIdx.x;
+            if (static_cast<int>(threadIdx.x) < max_bs && r < ce) {
+                while (r < ce) r = s_next[r - cs];
             } else {
-                // natural block [nat_start, nat_start + cur) closes
-                if (acc < 0) {
-                    acc = cur;
-                } else if (acc + cur <= max_block_size) {
-                    acc += cur;
-                } else {
-                    if (lane == 0) block_ptrs[nout] = static_cast<int32_t>(nat_start);
-                    ++nout;
-                    acc = cur;
-                }
-                nat_start = base + j;
-                cur = 1;
+                r = n;
             }
+            exits[blockIdx.x * 32 + threadIdx.x] = r;
+        }
+    } else if (threadIdx.x == 0) {
+        int r = entry[blockIdx.x];
+        while (r < ce) {
+            flags[r] = 1;
+            r = s_next[r - cs];
         }
     }
-    // the last natural block closes at the end
-    if (acc >= 0 && acc + cur > max_block_size) {
-        if (lane == 0) block_ptrs[nout] = static_cast<int32_t>(nat_start);
-        ++nout;
+}
+
+// entry[c] = first chain row >= c * fb_chunk (n once the chain has ended)
+__global__ void fb_compose_kernel(int n, int nchunks, const int* __restrict__ exits,
+                                  int* __restrict__ entry)
+{
+    int e = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        entry[c] = e;
+        const int ce = min((c + 1) * fb_chunk, n);
+        if (e < ce) e = exits[c * 32 + (e - c * fb_chunk)];
     }
-    if (lane == 0) {
-        block_ptrs[nout] = static_cast<int32_t>(nrows);
-        *num_blocks_out = nout;
+}
+
+// offsets = exclusive scan of flags over n + 1 entries
+__global__ __launch_bounds__(block) void fb_scatter_kernel(int n, const int* __restrict__ offsets,
+                                                           int32_t* __restrict__ block_ptrs,
+                                                           int64_t* __restrict__ num_blocks_out)
+{
+    const int i = blockIdx.x * block + threadIdx.x;
+    if (i < n && offsets[i + 1] != offsets[i]) block_ptrs[offsets[i]] = i;
+    if (i == n) {
+        block_ptrs[offsets[n]] = n;
+        *num_blocks_out = offsets[n];
     }
+}
+
+struct fb_layout {
+    size_t same, a, flags, exits, entry, scan_tmp, psum_ws, total;
+    size_t scan_tmp_bytes, psum_bytes;
+};
+
+fb_layout make_fb_layout(int64_t nrows)
+{
+    fb_layout l{};
+    const size_t n = static_cast<size_t>(nrows > 0 ? nrows : 1);
+    const size_t nchunks = (n + fb_chunk - 1) / fb_chunk;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) / 256 * 256;
+        return at;
+    };
+    l.same = take(n);
+    l.a = take(4 * (n + 1));
+    l.flags = take(4 * (n + 1));
+    l.exits = take(4 * 32 * nchunks);
+    l.entry = take(4 * (nchunks + 1));
+    size_t tmp = 0;
+    (void)rocprim::inclusive_scan(nullptr, tmp, static_cast<int*>(nullptr), static_cast<int*>(nullptr), n,
+                                  rocprim::maximum<int>(), hipStream_t{nullptr});
+    l.scan_tmp_bytes = tmp;
+    l.scan_tmp = take(tmp);
+    l.psum_bytes = gkomi_prefix_sum_workspace_bytes(static_cast<int64_t>(n) + 1);
+    l.psum_ws = take(l.psum_bytes);
+    l.total = off;
+    return l;
 }
 
 // ---- generate ---------------------------------------------------------------
@@ -610,6 +686,11 @@ extern "C" size_t gkomi_jacobi_storage_elements(int max_block_size, int64_t num_
     return static_cast<size_t>(ceildiv(num_blocks, gs) * sc.group_offset);
 }
 
+extern "C" size_t gkomi_jacobi_find_blocks_workspace_bytes(int64_t nrows)
+{
+    return make_fb_layout(nrows).total;
+}
+
 extern "C" int gkomi_jacobi_find_blocks_i32(gkomi_stream_t s, int64_t nrows,
                                             const int32_t* row_ptrs, const int32_t* col_idxs,
                                             int max_block_size, int32_t* block_ptrs,
@@ -617,18 +698,53 @@ extern "C" int gkomi_jacobi_find_blocks_i32(gkomi_stream_t s, int64_t nrows,
                                             size_t workspace_bytes, int64_t* host_num_blocks)
 {
     if (nrows < 0 || max_block_size < 1 || max_block_size > 32) return GKOMI_EINVAL;
-    if (workspace_bytes < static_cast<size_t>(nrows) + 8 || (workspace == nullptr && nrows > 0)) {
-        return GKOMI_EWORKSPACE;
-    }
+    if (nrows > INT32_MAX - fb_chunk - 64) return GKOMI_ENOTSUPPORTED;
+    const fb_layout l = make_fb_layout(nrows);
+    if (workspace_bytes < l.total || workspace == nullptr) return GKOMI_EWORKSPACE;
     hipStream_t stream = to_stream(s);
-    uint8_t* same = static_cast<uint8_t*>(workspace);
-    if (nrows > 0) {
+    const int n = static_cast<int>(nrows);
+    int err = 0;
+    if (n == 0) {
+        err = static_cast<int>(hipMemsetAsync(block_ptrs, 0, sizeof(int32_t), stream));
+        if (!err) err = static_cast<int>(hipMemsetAsync(num_blocks_device, 0, sizeof(int64_t), stream));
+    } else {
+        char* ws = static_cast<char*>(workspace);
+        uint8_t* same = reinterpret_cast<uint8_t*>(ws + l.same);
+        int* a = reinterpret_cast<int*>(ws + l.a);
+        int* flags = reinterpret_cast<int*>(ws + l.flags);
+        int* exits = reinterpret_cast<int*>(ws + l.exits);
+        int* entry = reinterpret_cast<int*>(ws + l.entry);
+        const int nchunks = static_cast<int>(ceildiv(nrows, fb_chunk));
+        const dim3 grid_n(static_cast<unsigned>(ceildiv(nrows, block)));
+        const dim3 grid_n1(static_cast<unsigned>(ceildiv(nrows + 1, block)));
         hipLaunchKernelGGL(compare_rows_kernel, dim3(grid_for(nrows, block, 1 << 16)), dim3(block),
                            0, stream, nrows, row_ptrs, col_idxs, same);
+        hipLaunchKernelGGL(fb_run_start_values_kernel, grid_n, dim3(block), 0, stream, n, same, a);
+        size_t tmp_bytes = l.scan_tmp_bytes;
+        err = static_cast<int>(rocprim::inclusive_scan(ws + l.scan_tmp, tmp_bytes, a, a,
+                                                       static_cast<size_t>(n),
+                                                       rocprim::maximum<int>(), stream));
+        if (err) return err;
+        hipLaunchKernelGGL(fb_natural_values_kernel, grid_n, dim3(block), 0, stream, n,
+                           max_block_size, a);
+        tmp_bytes = l.scan_tmp_bytes;
+        err = static_cast<int>(rocprim::inclusive_scan(ws + l.scan_tmp, tmp_bytes, a, a,
+                                                       static_cast<size_t>(n),
+                                                       rocprim::maximum<int>(), stream));
+        if (err) return err;
+        err = static_cast<int>(hipMemsetAsync(flags, 0, sizeof(int) * (static_cast<size_t>(n) + 1), stream));
+        if (err) return err;
+        hipLaunchKernelGGL(fb_walk_kernel<false>, dim3(nchunks), dim3(block), 0, stream, n,
+                           max_block_size, a, exits, entry, flags);
+        hipLaunchKernelGGL(fb_compose_kernel, dim3(1), dim3(1), 0, stream, n, nchunks, exits, entry);
+        hipLaunchKernelGGL(fb_walk_kernel<true>, dim3(nchunks), dim3(block), 0, stream, n,
+                           max_block_size, a, exits, entry, flags);
+        err = gkomi_prefix_sum_i32(s, flags, nrows + 1, ws + l.psum_ws, l.psum_bytes);
+        if (err) return err;
+        hipLaunchKernelGGL(fb_scatter_kernel, grid_n1, dim3(block), 0, stream, n, flags, block_ptrs,
+                           num_blocks_device);
+        err = check_launch();
     }
-    hipLaunchKernelGGL(find_blocks_serial_kernel, dim3(1), dim3(64), 0, stream, nrows, same,
-                       max_block_size, block_ptrs, num_blocks_device);
-    int err = check_launch();
     if (err) return err;
     if (host_num_blocks != nullptr) {
         err = static_cast<int>(hipMemcpyAsync(host_num_blocks, num_blocks_device, sizeof(int64_t),

@@ -94,9 +94,10 @@ def jacobi_generate(gk, n, row_ptrs, col_idxs, vals, max_block_size=32, nrhs=1, 
         return Preconditioner(gk, "gkomi_jacobi_apply_cb", ctx, (inv,))
     ptrs = torch.zeros(n + 1, dtype=torch.int32, device=dv)
     nbd = torch.zeros(1, dtype=torch.int64, device=dv)
-    ws = torch.empty(n + 8, dtype=torch.uint8, device=dv)
+    nws = gk.jacobi_find_blocks_workspace_bytes(n)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dv)
     hn = ctypes.c_int64(0)
-    gk.jacobi_find_blocks_i32(s, n, row_ptrs, col_idxs, max_block_size, ptrs, nbd, ws, n + 8, ctypes.addressof(hn))
+    gk.jacobi_find_blocks_i32(s, n, row_ptrs, col_idxs, max_block_size, ptrs, nbd, ws, nws, ctypes.addressof(hn))
     nb = int(hn.value)
     blocks = torch.zeros(max(gk.jacobi_storage_elements(max_block_size, nb), 1), dtype=torch.float64, device=dv)
     prec = cond = None

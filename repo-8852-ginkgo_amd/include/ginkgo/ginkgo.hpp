@@ -1248,7 +1248,7 @@ protected:
         }
         block_ptrs_.resize_and_reset(n + 1);
         array<int64> nb(exec_, 1);
-        array<char> ws(exec_, n + 8);
+        array<char> ws(exec_, gkomi_jacobi_find_blocks_workspace_bytes(n));
         int64_t host_nb = 0;
         GKOMI_CALL(gkomi_jacobi_find_blocks_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), max_bs, block_ptrs_.get_data(), nb.get_data(), ws.get_data(), ws.get_num_elems(), &host_nb));
         num_blocks_ = static_cast<size_type>(host_nb);

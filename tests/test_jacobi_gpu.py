@@ -35,9 +35,10 @@ def gpu_find_blocks(gk, n, rpd, cid, max_bs):
     import ctypes
     ptrs = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda:0")
     nbd = torch.zeros(1, dtype=torch.int64, device="cuda:0")
-    ws = torch.empty(n + 8, dtype=torch.uint8, device="cuda:0")
+    nws = gk.jacobi_find_blocks_workspace_bytes(n)
+    ws = torch.empty(nws, dtype=torch.uint8, device="cuda:0")
     hn = ctypes.c_int64(-1)
-    gk.jacobi_find_blocks_i32(stream_ptr(), n, rpd, cid, max_bs, ptrs, nbd, ws, n + 8, ctypes.addressof(hn))
+    gk.jacobi_find_blocks_i32(stream_ptr(), n, rpd, cid, max_bs, ptrs, nbd, ws, nws, ctypes.addressof(hn))
     return int(hn.value), ptrs
 
 
@@ -344,3 +345,66 @@ def test_adaptive_storage_speeds_up_block_jacobi_cg(gk, oracle):
         if storage is not None:
             assert set(host(pc.block_precisions).tolist()) - {0}   # something was actually reduced
     assert abs(its["adaptive"] - its["fp64"]) <= max(3, its["fp64"] // 10)
+
+
+def _rows_with_runs(run_lengths, seed):
+    """CSR pattern whose consecutive rows are identical inside each run and differ across runs"""
+    rng = np.random.default_rng(seed)
+    n = int(np.sum(run_lengths))
+    rp, ci = [0], []
+    prev = None
+    for L in run_lengths:
+        while True:
+            cols = sorted(set(int(c) for c in rng.integers(0, n, size=int(rng.integers(1, 4)))))
+            if cols != prev:
+                break
+        prev = cols
+        for _ in range(int(L)):
+            ci.extend(cols)
+            rp.append(len(ci))
+    return n, np.array(rp, np.int32), np.array(ci, np.int32)
+
+
+@pytest.mark.parametrize("max_bs", [1, 2, 3, 5, 8, 13, 32])
+@pytest.mark.parametrize("shape", ["short", "long", "mixed", "chunk_edges"])
+def test_find_blocks_parallel_chain_vs_oracle(gk, oracle, max_bs, shape):
+    """the data-parallel restatement of the two greedy passes: runs of identical
+    rows of every length, crossing the 2048-row chunks of the chain walk"""
+    rng = np.random.default_rng(17 + max_bs)
+    if shape == "short":
+        runs = rng.integers(1, 4, size=4000)
+    elif shape == "long":
+        runs = rng.integers(20, 400, size=60)
+    elif shape == "mixed":
+        runs = np.where(rng.random(1500) < 0.9, rng.integers(1, 6, size=1500), rng.integers(30, 120, size=1500))
+    else:  # boundaries placed around multiples of 2048
+        runs = []
+        total = 0
+        for k in range(1, 6):
+            target = 2048 * k + int(rng.integers(-3, 4))
+            while total < target - 40:
+                r = int(rng.integers(1, 40))
+                runs.append(r); total += r
+            runs.append(target - total); total = target
+        runs = np.array([r for r in runs if r > 0])
+    n, rp, ci = _rows_with_runs(runs, 5)
+    eptrs = np.zeros(n + 1, np.int32)
+    enb = oracle.ref_jacobi_find_blocks(n, rp, ci, max_bs, eptrs)
+    nb, ptrs = gpu_find_blocks(gk, n, dev(rp), dev(ci), max_bs)
+    assert nb == enb and np.array_equal(host(ptrs)[:nb + 1], eptrs[:nb + 1])
+
+
+def test_find_blocks_degenerate_sizes(gk, oracle):
+    for n in (1, 2, 31, 32, 33, 2047, 2048, 2049):
+        rp = np.arange(n + 1, dtype=np.int32)          # diagonal: no two rows alike
+        ci = np.arange(n, dtype=np.int32)
+        for max_bs in (1, 4, 32):
+            eptrs = np.zeros(n + 1, np.int32)
+            enb = oracle.ref_jacobi_find_blocks(n, rp, ci, max_bs, eptrs)
+            nb, ptrs = gpu_find_blocks(gk, n, dev(rp), dev(ci), max_bs)
+            assert nb == enb and np.array_equal(host(ptrs)[:nb + 1], eptrs[:nb + 1])
+        ci2 = np.zeros(n, dtype=np.int32)               # every row = {0}: one run of n rows
+        eptrs = np.zeros(n + 1, np.int32)
+        enb = oracle.ref_jacobi_find_blocks(n, rp, ci2, 5, eptrs)
+        nb, ptrs = gpu_find_blocks(gk, n, dev(rp), dev(ci2), 5)
+        assert nb == enb and np.array_equal(host(ptrs)[:nb + 1], eptrs[:nb + 1])
