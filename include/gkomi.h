@@ -523,6 +523,94 @@ int gkomi_cg_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
                            size_t workspace_bytes, double* host_info);
 
 /* ---- row-partitioned distributed matrix (core/distributed/{partition,matrix}_kernels.hpp) */
+/* ---- BiCGSTAB / FCG / CGS ---------------------------
+ * Step kernels of core/solver/{bicgstab,fcg,cgs}_kernels.hpp with the
+ * semantics of reference/solver/{bicgstab_kernels.cpp:57-232,
+ * fcg_kernels.cpp:55-145, cgs_kernels.cpp:55-185}: vectors n x nrhs row-major
+ * with a stride, the per-column scalars (1 x nrhs) in device memory,
+ * stop_status one byte per column.  Elementwise bit-exact.  The drivers are
+ * {Bicgstab,Fcg,Cgs}::apply_dense_impl (core/solver/bicgstab.cpp:107-234,
+ * fcg.cpp:104-196, cgs.cpp:107-205) for a CSR matrix, an optional
+ * preconditioner and Combined(Iteration(max_iters), ResidualNorm(reduction,
+ * baseline)), checked on the host where the reference checks it; arguments and
+ * host_info as for gkomi_gmres_solve_f64_i32, workspace
+ * gkomi_krylov_workspace_bytes(n, nrhs). */
+int gkomi_bicgstab_initialize_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+    const double* b, int64_t b_stride, double* r, int64_t r_stride, double*
+    rr, int64_t rr_stride, double* y, int64_t y_stride, double* s_vec, int64_t
+    s_stride, double* t, int64_t t_stride, double* z, int64_t z_stride,
+    double* v, int64_t v_stride, double* p, int64_t p_stride, double*
+    prev_rho, double* rho, double* alpha, double* beta, double* gamma, double*
+    omega, uint8_t* stop_status);
+int gkomi_bicgstab_step_1_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const
+    double* r, int64_t r_stride, double* p, int64_t p_stride, const double* v,
+    int64_t v_stride, const double* rho, const double* prev_rho, const double*
+    alpha, const double* omega, const uint8_t* stop_status);
+int gkomi_bicgstab_step_2_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const
+    double* r, int64_t r_stride, double* s_vec, int64_t s_stride, const
+    double* v, int64_t v_stride, const double* rho, double* alpha, const
+    double* beta, const uint8_t* stop_status);
+int gkomi_bicgstab_step_3_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+    double* x, int64_t x_stride, double* r, int64_t r_stride, const double*
+    s_vec, int64_t s_stride, const double* t, int64_t t_stride, const double*
+    y, int64_t y_stride, const double* z, int64_t z_stride, const double*
+    alpha, const double* beta, const double* gamma, double* omega, const
+    uint8_t* stop_status);
+int gkomi_bicgstab_finalize_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+    double* x, int64_t x_stride, const double* y, int64_t y_stride, const
+    double* alpha, uint8_t* stop_status);
+int gkomi_fcg_initialize_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const
+    double* b, int64_t b_stride, double* r, int64_t r_stride, double* z,
+    int64_t z_stride, double* p, int64_t p_stride, double* q, int64_t
+    q_stride, double* t, int64_t t_stride, double* prev_rho, double* rho,
+    double* rho_t, uint8_t* stop_status);
+int gkomi_fcg_step_1_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, double* p,
+    int64_t p_stride, const double* z, int64_t z_stride, const double* rho_t,
+    const double* prev_rho, const uint8_t* stop_status);
+int gkomi_fcg_step_2_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, double* x,
+    int64_t x_stride, double* r, int64_t r_stride, double* t, int64_t
+    t_stride, const double* p, int64_t p_stride, const double* q, int64_t
+    q_stride, const double* beta, const double* rho, const uint8_t*
+    stop_status);
+int gkomi_cgs_initialize_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const
+    double* b, int64_t b_stride, double* r, int64_t r_stride, double* r_tld,
+    int64_t r_tld_stride, double* p, int64_t p_stride, double* q, int64_t
+    q_stride, double* u, int64_t u_stride, double* u_hat, int64_t
+    u_hat_stride, double* v_hat, int64_t v_hat_stride, double* t, int64_t
+    t_stride, double* alpha, double* beta, double* gamma, double* prev_rho,
+    double* rho, uint8_t* stop_status);
+int gkomi_cgs_step_1_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const
+    double* r, int64_t r_stride, double* u, int64_t u_stride, double* p,
+    int64_t p_stride, const double* q, int64_t q_stride, double* beta, const
+    double* rho, const double* prev_rho, const uint8_t* stop_status);
+int gkomi_cgs_step_2_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const
+    double* u, int64_t u_stride, const double* v_hat, int64_t v_hat_stride,
+    double* q, int64_t q_stride, double* t, int64_t t_stride, double* alpha,
+    const double* rho, const double* gamma, const uint8_t* stop_status);
+int gkomi_cgs_step_3_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const
+    double* t, int64_t t_stride, const double* u_hat, int64_t u_hat_stride,
+    double* r, int64_t r_stride, double* x, int64_t x_stride, const double*
+    alpha, const uint8_t* stop_status);
+size_t gkomi_krylov_workspace_bytes(int64_t n, int64_t nrhs);
+int gkomi_bicgstab_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
+    int64_t nnz, const int32_t* row_ptrs, const int32_t* col_idxs, const
+    double* vals, int spmv_strategy, int64_t max_row_nnz_hint, gkomi_apply_fn
+    precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
+    double reduction_factor, int baseline, void* workspace, size_t
+    workspace_bytes, double* host_info);
+int gkomi_fcg_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t
+    nnz, const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
+    int spmv_strategy, int64_t max_row_nnz_hint, gkomi_apply_fn precond, void*
+    precond_ctx, const double* b, double* x, int64_t max_iters, double
+    reduction_factor, int baseline, void* workspace, size_t workspace_bytes,
+    double* host_info);
+int gkomi_cgs_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t
+    nnz, const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
+    int spmv_strategy, int64_t max_row_nnz_hint, gkomi_apply_fn precond, void*
+    precond_ctx, const double* b, double* x, int64_t max_iters, double
+    reduction_factor, int baseline, void* workspace, size_t workspace_bytes,
+    double* host_info);
+
 /* Partition metadata on HOST arrays (O(#ranges); core/distributed/matrix.cpp
  * consumes it on the host for the communication plan):
  * reference/distributed/partition_kernels.cpp:42-135.

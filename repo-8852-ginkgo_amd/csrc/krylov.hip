@@ -1,0 +1,751 @@
+// BiCGSTAB, FCG and CGS for gfx950 (the Krylov solvers that
+// share CG's BLAS-1).  Replaces gko::kernels::hip::{bicgstab, fcg, cgs}::
+// {initialize, step_1, step_2, step_3, finalize}
+// (core/solver/{bicgstab,fcg,cgs}_kernels.hpp; the reference's GPU versions
+// are the unified kernels common/unified/solver/*_kernels.cpp) and provides
+// native drivers for {Bicgstab,Fcg,Cgs}::apply_dense_impl
+// (core/solver/bicgstab.cpp:107-234, fcg.cpp:104-196, cgs.cpp:107-205).
+// Semantics = reference/solver/{bicgstab,fcg,cgs}_kernels.cpp.
+//
+// The step kernels are pure streaming (3n..7n values, HBM-bound): one thread
+// per element, the per-column scalars read from device memory, every
+// expression written exactly as the reference's (-ffp-contract=off) ->
+// bit-identical.  Scalars a step defines (alpha, omega, beta) are recomputed by
+// every thread from their inputs and stored once by row 0.
+#include <algorithm>
+#include <utility>
+
+#include "common.hpp"
+
+namespace gkomi {
+namespace {
+
+constexpr int block = 256;
+constexpr uint8_t finalized_mask = 0x40;  // stopping_status::is_finalized (stopping_status.hpp)
+
+#define GKOMI_ELEMENTWISE(i, j)                                                         \
+    const int64_t idx_ = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;        \
+    if (idx_ >= n * nrhs) return;                                                       \
+    const int64_t i = idx_ / nrhs;                                                      \
+    const int64_t j = idx_ - i * nrhs
+
+// ---- BiCGSTAB ---------------------------------------------------------------
+__global__ __launch_bounds__(block) void bicgstab_initialize_kernel(
+    int64_t n, int64_t nrhs, const double* __restrict__ b, int64_t b_stride,
+    double* __restrict__ r, int64_t r_stride, double* __restrict__ rr, int64_t rr_stride,
+    double* __restrict__ y, int64_t y_stride, double* __restrict__ s, int64_t s_stride,
+    double* __restrict__ t, int64_t t_stride, double* __restrict__ z, int64_t z_stride,
+    double* __restrict__ v, int64_t v_stride, double* __restrict__ p, int64_t p_stride,
+    double* __restrict__ prev_rho, double* __restrict__ rho, double* __restrict__ alpha,
+    double* __restrict__ beta, double* __restrict__ gamma, double* __restrict__ omega,
+    uint8_t* __restrict__ stop_status)
+{
+    const int64_t idx = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
+    if (idx < nrhs) {
+        rho[idx] = prev_rho[idx] = alpha[idx] = beta[idx] = gamma[idx] = omega[idx] = 1.0;
+        stop_status[idx] = 0;
+    }
+    if (idx >= n * nrhs) return;
+    const int64_t i = idx / nrhs, j = idx - i * nrhs;
+    r[i * r_stride + j] = b[i * b_stride + j];
+    rr[i * rr_stride + j] = z[i * z_stride + j] = v[i * v_stride + j] = s[i * s_stride + j] =
+        t[i * t_stride + j] = y[i * y_stride + j] = p[i * p_stride + j] = 0.0;
+}
+
+__global__ __launch_bounds__(block) void bicgstab_step_1_kernel(
+    int64_t n, int64_t nrhs, const double* __restrict__ r, int64_t r_stride,
+    double* __restrict__ p, int64_t p_stride, const double* __restrict__ v, int64_t v_stride,
+    const double* __restrict__ rho, const double* __restrict__ prev_rho,
+    const double* __restrict__ alpha, const double* __restrict__ omega,
+    const uint8_t* __restrict__ stop_status)
+{
+    GKOMI_ELEMENTWISE(i, j);
+    if (status_has_stopped(stop_status[j])) return;
+    if (prev_rho[j] * omega[j] != 0.0) {
+        const double tmp = rho[j] / prev_rho[j] * alpha[j] / omega[j];
+        p[i * p_stride + j] =
+            r[i * r_stride + j] + tmp * (p[i * p_stride + j] - omega[j] * v[i * v_stride + j]);
+    } else {
+        p[i * p_stride + j] = r[i * r_stride + j];
+    }
+}
+
+__global__ __launch_bounds__(block) void bicgstab_step_2_kernel(
+    int64_t n, int64_t nrhs, const double* __restrict__ r, int64_t r_stride,
+    double* __restrict__ s, int64_t s_stride, const double* __restrict__ v, int64_t v_stride,
+    const double* __restrict__ rho, double* __restrict__ alpha, const double* __restrict__ beta,
+    const uint8_t* __restrict__ stop_status)
+{
+    GKOMI_ELEMENTWISE(i, j);
+    if (status_has_stopped(stop_status[j])) return;
+    double a = 0.0;
+    if (beta[j] != 0.0) {
+        a = rho[j] / beta[j];
+        s[i * s_stride + j] = r[i * r_stride + j] - a * v[i * v_stride + j];
+    } else {
+        s[i * s_stride + j] = r[i * r_stride + j];
+    }
+    if (i == 0) alpha[j] = a;  // nobody reads alpha in this kernel
+}
+
+__global__ __launch_bounds__(block) void bicgstab_step_3_kernel(
+    int64_t n, int64_t nrhs, double* __restrict__ x, int64_t x_stride, double* __restrict__ r,
+    int64_t r_stride, const double* __restrict__ s, int64_t s_stride,
+    const double* __restrict__ t, int64_t t_stride, const double* __restrict__ y,
+    int64_t y_stride, const double* __restrict__ z, int64_t z_stride,
+    const double* __restrict__ alpha, const double* __restrict__ beta,
+    const double* __restrict__ gamma, double* __restrict__ omega,
+    const uint8_t* __restrict__ stop_status)
+{
+    GKOMI_ELEMENTWISE(i, j);
+    if (status_has_stopped(stop_status[j])) return;
+    const double om = beta[j] != 0.0 ? gamma[j] / beta[j] : 0.0;
+    x[i * x_stride + j] += alpha[j] * y[i * y_stride + j] + om * z[i * z_stride + j];
+    r[i * r_stride + j] = s[i * s_stride + j] - om * t[i * t_stride + j];
+    if (i == 0) omega[j] = om;
+}
+
+// x += alpha * y for the columns that stopped but are not finalized yet ...
+__global__ __launch_bounds__(block) void bicgstab_finalize_kernel(
+    int64_t n, int64_t nrhs, double* __restrict__ x, int64_t x_stride,
+    const double* __restrict__ y, int64_t y_stride, const double* __restrict__ alpha,
+    const uint8_t* __restrict__ stop_status)
+{
+    GKOMI_ELEMENTWISE(i, j);
+    const uint8_t st = stop_status[j];
+    if (status_has_stopped(st) && !(st & finalized_mask)) {
+        x[i * x_stride + j] += alpha[j] * y[i * y_stride + j];
+    }
+}
+
+// ... which then become finalized (separate launch: every row reads the status)
+__global__ __launch_bounds__(block) void finalize_status_kernel(int64_t nrhs, bool have_rows,
+                                                                uint8_t* __restrict__ stop_status)
+{
+    const int64_t j = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
+    if (j < nrhs && have_rows && status_has_stopped(stop_status[j])) stop_status[j] |= finalized_mask;
+}
+
+// ---- FCG ----------------------------------------------------------------------
+__global__ __launch_bounds__(block) void fcg_initialize_kernel(
+    int64_t n, int64_t nrhs, const double* __restrict__ b, int64_t b_stride,
+    double* __restrict__ r, int64_t r_stride, double* __restrict__ z, int64_t z_stride,
+    double* __restrict__ p, int64_t p_stride, double* __restrict__ q, int64_t q_stride,
+    double* __restrict__ t, int64_t t_stride, double* __restrict__ prev_rho,
+    double* __restrict__ rho, double* __restrict__ rho_t, uint8_t* __restrict__ stop_status)
+{
+    const int64_t idx = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
+    if (idx < nrhs) {
+        rho[idx] = 0.0;
+        prev_rho[idx] = rho_t[idx] = 1.0;
+        stop_status[idx] = 0;
+    }
+    if (idx >= n * nrhs) return;
+    const int64_t i = idx / nrhs, j = idx - i * nrhs;
+    t[i * t_stride + j] = r[i * r_stride + j] = b[i * b_stride + j];
+    z[i * z_stride + j] = p[i * p_stride + j] = q[i * q_stride + j] = 0.0;
+}
+
+__global__ __launch_bounds__(block) void fcg_step_1_kernel(
+    int64_t n, int64_t nrhs, double* __restrict__ p, int64_t p_stride,
+    const double* __restrict__ z, int64_t z_stride, const double* __restrict__ rho_t,
+    const double* __restrict__ prev_rho, const uint8_t* __restrict__ stop_status)
+{
+    GKOMI_ELEMENTWISE(i, j);
+    if (status_has_stopped(stop_status[j])) return;
+    if (prev_rho[j] == 0.0) {
+        p[i * p_stride + j] = z[i * z_stride + j];
+    } else {
+        const double tmp = rho_t[j] / prev_rho[j];
+        p[i * p_stride + j] = z[i * z_stride + j] + tmp * p[i * p_stride + j];
+    }
+}
+
+__global__ __launch_bounds__(block) void fcg_step_2_kernel(
+    int64_t n, int64_t nrhs, double* __restrict__ x, int64_t x_stride, double* __restrict__ r,
+    int64_t r_stride, double* __restrict__ t, int64_t t_stride, const double* __restrict__ p,
+    int64_t p_stride, const double* __restrict__ q, int64_t q_stride,
+    const double* __restrict__ beta, const double* __restrict__ rho,
+    const uint8_t* __restrict__ stop_status)
+{
+    GKOMI_ELEMENTWISE(i, j);
+    if (status_has_stopped(stop_status[j])) return;
+    if (beta[j] != 0.0) {
+        const double tmp = rho[j] / beta[j];
+        const double prev_r = r[i * r_stride + j];
+        x[i * x_stride + j] += tmp * p[i * p_stride + j];
+        const double new_r = prev_r - tmp * q[i * q_stride + j];
+        r[i * r_stride + j] = new_r;
+        t[i * t_stride + j] = new_r - prev_r;
+    }
+}
+
+// ---- CGS ----------------------------------------------------------------------
+__global__ __launch_bounds__(block) void cgs_initialize_kernel(
+    int64_t n, int64_t nrhs, const double* __restrict__ b, int64_t b_stride,
+    double* __restrict__ r, int64_t r_stride, double* __restrict__ r_tld, int64_t r_tld_stride,
+    double* __restrict__ p, int64_t p_stride, double* __restrict__ q, int64_t q_stride,
+    double* __restrict__ u, int64_t u_stride, double* __restrict__ u_hat, int64_t u_hat_stride,
+    double* __restrict__ v_hat, int64_t v_hat_stride, double* __restrict__ t, int64_t t_stride,
+    double* __restrict__ alpha, double* __restrict__ beta, double* __restrict__ gamma,
+    double* __restrict__ prev_rho, double* __restrict__ rho, uint8_t* __restrict__ stop_status)
+{
+    const int64_t idx = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
+    if (idx < nrhs) {
+        rho[idx] = 0.0;
+        prev_rho[idx] = alpha[idx] = beta[idx] = gamma[idx] = 1.0;
+        stop_status[idx] = 0;
+    }
+    if (idx >= n * nrhs) return;
+    const int64_t i = idx / nrhs, j = idx - i * nrhs;
+    r[i * r_stride + j] = r_tld[i * r_tld_stride + j] = b[i * b_stride + j];
+    u[i * u_stride + j] = u_hat[i * u_hat_stride + j] = p[i * p_stride + j] = q[i * q_stride + j] =
+        v_hat[i * v_hat_stride + j] = t[i * t_stride + j] = 0.0;
+}
+
+// beta is rewritten only when prev_rho != 0, and then nobody reads the old value
+__global__ __launch_bounds__(block) void cgs_step_1_kernel(
+    int64_t n, int64_t nrhs, const double* __restrict__ r, int64_t r_stride,
+    double* __restrict__ u, int64_t u_stride, double* __restrict__ p, int64_t p_stride,
+    const double* __restrict__ q, int64_t q_stride, double* beta, const double* __restrict__ rho,
+    const double* __restrict__ prev_rho, const uint8_t* __restrict__ stop_status)
+{
+    GKOMI_ELEMENTWISE(i, j);
+    if (status_has_stopped(stop_status[j])) return;
+    const bool update = prev_rho[j] != 0.0;
+    const double bt = update ? rho[j] / prev_rho[j] : beta[j];
+    const double uu = r[i * r_stride + j] + bt * q[i * q_stride + j];
+    u[i * u_stride + j] = uu;
+    p[i * p_stride + j] = uu + bt * (q[i * q_stride + j] + bt * p[i * p_stride + j]);
+    if (i == 0 && update) beta[j] = bt;
+}
+
+__global__ __launch_bounds__(block) void cgs_step_2_kernel(
+    int64_t n, int64_t nrhs, const double* __restrict__ u, int64_t u_stride,
+    const double* __restrict__ v_hat, int64_t v_hat_stride, double* __restrict__ q,
+    int64_t q_stride, double* __restrict__ t, int64_t t_stride, double* alpha,
+    const double* __restrict__ rho, const double* __restrict__ gamma,
+    const uint8_t* __restrict__ stop_status)
+{
+    GKOMI_ELEMENTWISE(i, j);
+    if (status_has_stopped(stop_status[j])) return;
+    const bool update = gamma[j] != 0.0;
+    const double a = update ? rho[j] / gamma[j] : alpha[j];
+    const double qq = u[i * u_stride + j] - a * v_hat[i * v_hat_stride + j];
+    q[i * q_stride + j] = qq;
+    t[i * t_stride + j] = u[i * u_stride + j] + qq;
+    if (i == 0 && update) alpha[j] = a;
+}
+
+__global__ __launch_bounds__(block) void cgs_step_3_kernel(
+    int64_t n, int64_t nrhs, const double* __restrict__ t, int64_t t_stride,
+    const double* __restrict__ u_hat, int64_t u_hat_stride, double* __restrict__ r,
+    int64_t r_stride, double* __restrict__ x, int64_t x_stride, const double* __restrict__ alpha,
+    const uint8_t* __restrict__ stop_status)
+{
+    GKOMI_ELEMENTWISE(i, j);
+    if (status_has_stopped(stop_status[j])) return;
+    x[i * x_stride + j] += alpha[j] * u_hat[i * u_hat_stride + j];
+    r[i * r_stride + j] -= alpha[j] * t[i * t_stride + j];
+}
+
+// the scalar updates of steps that define a scalar must also happen for n == 0
+// (the reference loops over the columns first): tiny single-block kernels
+__global__ void cgs_scalar_kernel(int64_t nrhs, double* out, const double* num, const double* den,
+                                  const uint8_t* stop_status)
+{
+    for (int64_t j = threadIdx.x; j < nrhs; j += blockDim.x) {
+        if (!status_has_stopped(stop_status[j]) && den[j] != 0.0) out[j] = num[j] / den[j];
+    }
+}
+__global__ void bicgstab_omega_kernel(int64_t nrhs, double* omega, const double* gamma,
+                                      const double* beta, const uint8_t* stop_status)
+{
+    for (int64_t j = threadIdx.x; j < nrhs; j += blockDim.x) {
+        if (!status_has_stopped(stop_status[j])) omega[j] = beta[j] != 0.0 ? gamma[j] / beta[j] : 0.0;
+    }
+}
+
+bool bad_dims(int64_t n, int64_t nrhs) { return n < 0 || nrhs < 0; }
+dim3 grid_of(int64_t n, int64_t nrhs) { return dim3(static_cast<unsigned>(ceildiv(std::max<int64_t>(n * nrhs, nrhs), block))); }
+
+#define GKOMI_TRY(expr)        \
+    do {                       \
+        const int e_ = (expr); \
+        if (e_) return e_;     \
+    } while (0)
+
+// ---- drivers ------------------------------------------------------------------
+struct solver_layout {
+    size_t vec[8], small, red, total;
+};
+
+solver_layout make_solver_layout(int64_t n, int64_t nrhs, int nvec)
+{
+    solver_layout l{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) / 256 * 256;
+        return at;
+    };
+    for (int k = 0; k < nvec; ++k) l.vec[k] = take(sizeof(double) * static_cast<size_t>(n) * nrhs + 8);
+    // 10 scalar rows + statuses + flags
+    l.small = take(sizeof(double) * 10 * nrhs + 2 * static_cast<size_t>(nrhs) + 64);
+    l.red = take(gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8);
+    l.total = off;
+    return l;
+}
+
+// what the three drivers share: r = b - A x, the baseline norm, the criterion
+struct driver_common {
+    gkomi_stream_t s;
+    hipStream_t stream;
+    int64_t n, nrhs, nnz;
+    const int32_t* row_ptrs;
+    const int32_t* col_idxs;
+    const double* vals;
+    int strategy;
+    int64_t hint;
+    gkomi_apply_fn precond;
+    void* precond_ctx;
+    int64_t max_iters;
+    double reduction;
+    double *tau, *orig_tau, *one, *neg_one;
+    uint8_t *stop_status, *dev_flags;
+    void* red;
+    size_t red_bytes;
+    int converged = 0;
+    uint8_t host_flags[2] = {0, 0};
+
+    int spmv(const double* in, double* out) const
+    {
+        return gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, in, nrhs, out,
+                                      nrhs, nullptr, nullptr, strategy, hint);
+    }
+    int apply_precond(const double* in, double* out) const
+    {
+        if (precond == nullptr) return gkomi_dense_copy_f64(s, n, nrhs, in, nrhs, out, nrhs);
+        return precond(precond_ctx, s, in, out);
+    }
+    int dot(const double* a, const double* b2, double* result) const
+    {
+        return gkomi_dense_compute_dot_f64(s, n, nrhs, a, nrhs, b2, nrhs, result, red, red_bytes);
+    }
+    int start(const double* b, const double* x, double* r, int baseline)
+    {
+        GKOMI_TRY(gkomi_dense_fill_f64(s, 1, nrhs, one, nrhs, 1.0));
+        GKOMI_TRY(gkomi_dense_fill_f64(s, 1, nrhs, neg_one, nrhs, -1.0));
+        // r = b - A x (r already holds b)
+        GKOMI_TRY(gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, x, nrhs, r,
+                                         nrhs, neg_one, one, strategy, hint));
+        if (baseline == 0) {
+            return gkomi_dense_compute_norm2_f64(s, n, nrhs, b, nrhs, orig_tau, red, red_bytes);
+        }
+        if (baseline == 1) {
+            return gkomi_dense_compute_norm2_f64(s, n, nrhs, r, nrhs, orig_tau, red, red_bytes);
+        }
+        return gkomi_dense_fill_f64(s, 1, nrhs, orig_tau, nrhs, 1.0);
+    }
+    // Combined(Iteration [id 1], ResidualNorm [id 1]) on `residual`; stop = all stopped
+    int check(int64_t iter, const double* residual, bool set_finalized, bool* stop, bool* one_changed)
+    {
+        if (iter >= max_iters) {
+            GKOMI_TRY(gkomi_set_all_statuses(s, nrhs, 1, set_finalized ? 1 : 0, stop_status));
+            *stop = true;
+            *one_changed = true;
+            converged = 0;
+            return 0;
+        }
+        GKOMI_TRY(gkomi_dense_compute_norm2_f64(s, n, nrhs, residual, nrhs, tau, red, red_bytes));
+        GKOMI_TRY(gkomi_residual_norm_f64(s, nrhs, tau, orig_tau, reduction, 1,
+                                          set_finalized ? 1 : 0, stop_status, dev_flags,
+                                          host_flags));
+        *stop = host_flags[0] != 0;
+        *one_changed = host_flags[1] != 0;
+        converged = *stop ? 1 : 0;
+        return 0;
+    }
+    int finish(int64_t iter, const double* residual, double* host_info)
+    {
+        if (host_info != nullptr) {
+            // report the norm of the final residual
+            GKOMI_TRY(gkomi_dense_compute_norm2_f64(s, n, nrhs, residual, nrhs, tau, red, red_bytes));
+            for (int64_t j = 0; j < nrhs; ++j) {
+                GKOMI_TRY(static_cast<int>(hipMemcpyAsync(host_info + 2 + 2 * j, tau + j,
+                                                          sizeof(double), hipMemcpyDeviceToHost, stream)));
+                GKOMI_TRY(static_cast<int>(hipMemcpyAsync(host_info + 3 + 2 * j, orig_tau + j,
+                                                          sizeof(double), hipMemcpyDeviceToHost, stream)));
+            }
+            host_info[0] = static_cast<double>(iter);
+            host_info[1] = static_cast<double>(converged);
+        }
+        return static_cast<int>(hipStreamSynchronize(stream));
+    }
+};
+
+int make_common(driver_common& c, gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz,
+                const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
+                int strategy, int64_t hint, gkomi_apply_fn precond, void* precond_ctx,
+                int64_t max_iters, double reduction, int baseline, char* ws,
+                const solver_layout& l, double** scalars)
+{
+    if (n < 0 || nrhs <= 0 || max_iters < 0 || baseline < 0 || baseline > 2) return GKOMI_EINVAL;
+    c.s = s;
+    c.stream = to_stream(s);
+    c.n = n; c.nrhs = nrhs; c.nnz = nnz;
+    c.row_ptrs = row_ptrs; c.col_idxs = col_idxs; c.vals = vals;
+    c.strategy = strategy; c.hint = hint;
+    c.precond = precond; c.precond_ctx = precond_ctx;
+    c.max_iters = max_iters; c.reduction = reduction;
+    double* small = reinterpret_cast<double*>(ws + l.small);
+    c.tau = small;
+    c.orig_tau = small + nrhs;
+    c.one = small + 2 * nrhs;
+    c.neg_one = small + 3 * nrhs;
+    *scalars = small + 4 * nrhs;  // 6 rows for the solver's own scalars
+    c.stop_status = reinterpret_cast<uint8_t*>(small + 10 * nrhs);
+    c.dev_flags = c.stop_status + nrhs + (8 - nrhs % 8) % 8;
+    c.red = ws + l.red;
+    c.red_bytes = gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8;
+    return 0;
+}
+
+}  // namespace
+}  // namespace gkomi
+
+using namespace gkomi;
+
+// ---- kernel entry points ---------------------------------------------------------
+extern "C" int gkomi_bicgstab_initialize_f64(
+    gkomi_stream_t s, int64_t n, int64_t nrhs, const double* b, int64_t b_stride, double* r,
+    int64_t r_stride, double* rr, int64_t rr_stride, double* y, int64_t y_stride, double* sv,
+    int64_t s_stride, double* t, int64_t t_stride, double* z, int64_t z_stride, double* v,
+    int64_t v_stride, double* p, int64_t p_stride, double* prev_rho, double* rho, double* alpha,
+    double* beta, double* gamma, double* omega, uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(bicgstab_initialize_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n,
+                       nrhs, b, b_stride, r, r_stride, rr, rr_stride, y, y_stride, sv, s_stride, t,
+                       t_stride, z, z_stride, v, v_stride, p, p_stride, prev_rho, rho, alpha, beta,
+                       gamma, omega, stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_bicgstab_step_1_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const double* r,
+                                         int64_t r_stride, double* p, int64_t p_stride,
+                                         const double* v, int64_t v_stride, const double* rho,
+                                         const double* prev_rho, const double* alpha,
+                                         const double* omega, const uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (n == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(bicgstab_step_1_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n,
+                       nrhs, r, r_stride, p, p_stride, v, v_stride, rho, prev_rho, alpha, omega,
+                       stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_bicgstab_step_2_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const double* r,
+                                         int64_t r_stride, double* sv, int64_t s_stride,
+                                         const double* v, int64_t v_stride, const double* rho,
+                                         double* alpha, const double* beta,
+                                         const uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (n == 0 || nrhs == 0) return GKOMI_SUCCESS;  // the reference sets alpha inside the row loop
+    hipLaunchKernelGGL(bicgstab_step_2_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n,
+                       nrhs, r, r_stride, sv, s_stride, v, v_stride, rho, alpha, beta, stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_bicgstab_step_3_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, double* x,
+                                         int64_t x_stride, double* r, int64_t r_stride,
+                                         const double* sv, int64_t s_stride, const double* t,
+                                         int64_t t_stride, const double* y, int64_t y_stride,
+                                         const double* z, int64_t z_stride, const double* alpha,
+                                         const double* beta, const double* gamma, double* omega,
+                                         const uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    if (n == 0) {
+        hipLaunchKernelGGL(bicgstab_omega_kernel, dim3(1), dim3(block), 0, to_stream(s), nrhs, omega,
+                           gamma, beta, stop_status);
+        return check_launch();
+    }
+    hipLaunchKernelGGL(bicgstab_step_3_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n,
+                       nrhs, x, x_stride, r, r_stride, sv, s_stride, t, t_stride, y, y_stride, z,
+                       z_stride, alpha, beta, gamma, omega, stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_bicgstab_finalize_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, double* x,
+                                           int64_t x_stride, const double* y, int64_t y_stride,
+                                           const double* alpha, uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    hipStream_t stream = to_stream(s);
+    if (n > 0) {
+        hipLaunchKernelGGL(bicgstab_finalize_kernel, grid_of(n, nrhs), dim3(block), 0, stream, n,
+                           nrhs, x, x_stride, y, y_stride, alpha, stop_status);
+    }
+    // the reference finalizes inside the row loop: nothing happens for n == 0
+    hipLaunchKernelGGL(finalize_status_kernel, dim3(static_cast<unsigned>(ceildiv(nrhs, block))),
+                       dim3(block), 0, stream, nrhs, n > 0, stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_fcg_initialize_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const double* b,
+                                        int64_t b_stride, double* r, int64_t r_stride, double* z,
+                                        int64_t z_stride, double* p, int64_t p_stride, double* q,
+                                        int64_t q_stride, double* t, int64_t t_stride,
+                                        double* prev_rho, double* rho, double* rho_t,
+                                        uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(fcg_initialize_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n, nrhs,
+                       b, b_stride, r, r_stride, z, z_stride, p, p_stride, q, q_stride, t, t_stride,
+                       prev_rho, rho, rho_t, stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_fcg_step_1_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, double* p,
+                                    int64_t p_stride, const double* z, int64_t z_stride,
+                                    const double* rho_t, const double* prev_rho,
+                                    const uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (n == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(fcg_step_1_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n, nrhs, p,
+                       p_stride, z, z_stride, rho_t, prev_rho, stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_fcg_step_2_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, double* x,
+                                    int64_t x_stride, double* r, int64_t r_stride, double* t,
+                                    int64_t t_stride, const double* p, int64_t p_stride,
+                                    const double* q, int64_t q_stride, const double* beta,
+                                    const double* rho, const uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (n == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(fcg_step_2_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n, nrhs, x,
+                       x_stride, r, r_stride, t, t_stride, p, p_stride, q, q_stride, beta, rho,
+                       stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_cgs_initialize_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const double* b,
+                                        int64_t b_stride, double* r, int64_t r_stride,
+                                        double* r_tld, int64_t r_tld_stride, double* p,
+                                        int64_t p_stride, double* q, int64_t q_stride, double* u,
+                                        int64_t u_stride, double* u_hat, int64_t u_hat_stride,
+                                        double* v_hat, int64_t v_hat_stride, double* t,
+                                        int64_t t_stride, double* alpha, double* beta,
+                                        double* gamma, double* prev_rho, double* rho,
+                                        uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(cgs_initialize_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n, nrhs,
+                       b, b_stride, r, r_stride, r_tld, r_tld_stride, p, p_stride, q, q_stride, u,
+                       u_stride, u_hat, u_hat_stride, v_hat, v_hat_stride, t, t_stride, alpha, beta,
+                       gamma, prev_rho, rho, stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_cgs_step_1_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const double* r,
+                                    int64_t r_stride, double* u, int64_t u_stride, double* p,
+                                    int64_t p_stride, const double* q, int64_t q_stride,
+                                    double* beta, const double* rho, const double* prev_rho,
+                                    const uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    if (n == 0) {
+        hipLaunchKernelGGL(cgs_scalar_kernel, dim3(1), dim3(block), 0, to_stream(s), nrhs, beta, rho,
+                           prev_rho, stop_status);
+        return check_launch();
+    }
+    hipLaunchKernelGGL(cgs_step_1_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n, nrhs, r,
+                       r_stride, u, u_stride, p, p_stride, q, q_stride, beta, rho, prev_rho,
+                       stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_cgs_step_2_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const double* u,
+                                    int64_t u_stride, const double* v_hat, int64_t v_hat_stride,
+                                    double* q, int64_t q_stride, double* t, int64_t t_stride,
+                                    double* alpha, const double* rho, const double* gamma,
+                                    const uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    if (n == 0) {
+        hipLaunchKernelGGL(cgs_scalar_kernel, dim3(1), dim3(block), 0, to_stream(s), nrhs, alpha, rho,
+                           gamma, stop_status);
+        return check_launch();
+    }
+    hipLaunchKernelGGL(cgs_step_2_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n, nrhs, u,
+                       u_stride, v_hat, v_hat_stride, q, q_stride, t, t_stride, alpha, rho, gamma,
+                       stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_cgs_step_3_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const double* t,
+                                    int64_t t_stride, const double* u_hat, int64_t u_hat_stride,
+                                    double* r, int64_t r_stride, double* x, int64_t x_stride,
+                                    const double* alpha, const uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (n == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(cgs_step_3_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n, nrhs, t,
+                       t_stride, u_hat, u_hat_stride, r, r_stride, x, x_stride, alpha, stop_status);
+    return check_launch();
+}
+
+// ---- drivers ------------------------------------------------------------------------
+extern "C" size_t gkomi_krylov_workspace_bytes(int64_t n, int64_t nrhs)
+{
+    if (n < 0 || nrhs <= 0) return 0;
+    return make_solver_layout(n, nrhs, 8).total;
+}
+
+#define GKOMI_DRIVER_PROLOGUE(NVEC)                                                              \
+    if (n < 0 || nrhs <= 0) return GKOMI_EINVAL;                                                 \
+    const solver_layout l = make_solver_layout(n, nrhs, 8);                                      \
+    if (workspace == nullptr || workspace_bytes < l.total) return GKOMI_EWORKSPACE;              \
+    char* ws = static_cast<char*>(workspace);                                                    \
+    driver_common c;                                                                             \
+    double* sc = nullptr;                                                                        \
+    GKOMI_TRY(make_common(c, s, n, nrhs, nnz, row_ptrs, col_idxs, vals, spmv_strategy,           \
+                          max_row_nnz_hint, precond, precond_ctx, max_iters, reduction_factor,   \
+                          baseline, ws, l, &sc));                                                \
+    auto V = [&](int k) { return reinterpret_cast<double*>(ws + l.vec[k]); }
+
+extern "C" int gkomi_bicgstab_solve_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
+    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
+    double reduction_factor, int baseline, void* workspace, size_t workspace_bytes,
+    double* host_info)
+{
+    GKOMI_DRIVER_PROLOGUE(8);
+    double *r = V(0), *z = V(1), *y = V(2), *v = V(3), *sv = V(4), *t = V(5), *p = V(6), *rr = V(7);
+    double *alpha = sc, *beta = sc + nrhs, *gamma = sc + 2 * nrhs, *prev_rho = sc + 3 * nrhs,
+           *rho = sc + 4 * nrhs, *omega = sc + 5 * nrhs;
+    GKOMI_TRY(gkomi_bicgstab_initialize_f64(s, n, nrhs, b, nrhs, r, nrhs, rr, nrhs, y, nrhs, sv, nrhs,
+                                            t, nrhs, z, nrhs, v, nrhs, p, nrhs, prev_rho, rho, alpha,
+                                            beta, gamma, omega, c.stop_status));
+    GKOMI_TRY(c.start(b, x, r, baseline));
+    GKOMI_TRY(gkomi_dense_copy_f64(s, n, nrhs, r, nrhs, rr, nrhs));
+    int64_t iter = -1;
+    const double* last_residual = r;
+    while (true) {
+        ++iter;
+        GKOMI_TRY(c.dot(rr, r, rho));
+        bool stop = false, changed = false;
+        GKOMI_TRY(c.check(iter, r, true, &stop, &changed));
+        last_residual = r;
+        if (stop) break;
+        GKOMI_TRY(gkomi_bicgstab_step_1_f64(s, n, nrhs, r, nrhs, p, nrhs, v, nrhs, rho, prev_rho,
+                                            alpha, omega, c.stop_status));
+        GKOMI_TRY(c.apply_precond(p, y));
+        GKOMI_TRY(c.spmv(y, v));
+        GKOMI_TRY(c.dot(rr, v, beta));
+        GKOMI_TRY(gkomi_bicgstab_step_2_f64(s, n, nrhs, r, nrhs, sv, nrhs, v, nrhs, rho, alpha, beta,
+                                            c.stop_status));
+        GKOMI_TRY(c.check(iter, sv, false, &stop, &changed));
+        if (changed) {
+            GKOMI_TRY(gkomi_bicgstab_finalize_f64(s, n, nrhs, x, nrhs, y, nrhs, alpha, c.stop_status));
+        }
+        if (stop) {
+            last_residual = sv;
+            break;
+        }
+        GKOMI_TRY(c.apply_precond(sv, z));
+        GKOMI_TRY(c.spmv(z, t));
+        GKOMI_TRY(c.dot(sv, t, gamma));
+        GKOMI_TRY(c.dot(t, t, beta));
+        GKOMI_TRY(gkomi_bicgstab_step_3_f64(s, n, nrhs, x, nrhs, r, nrhs, sv, nrhs, t, nrhs, y, nrhs,
+                                            z, nrhs, alpha, beta, gamma, omega, c.stop_status));
+        std::swap(prev_rho, rho);
+    }
+    return c.finish(iter, last_residual, host_info);
+}
+
+extern "C" int gkomi_fcg_solve_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
+    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
+    double reduction_factor, int baseline, void* workspace, size_t workspace_bytes,
+    double* host_info)
+{
+    GKOMI_DRIVER_PROLOGUE(5);
+    double *r = V(0), *z = V(1), *p = V(2), *q = V(3), *t = V(4);
+    double *beta = sc, *prev_rho = sc + nrhs, *rho = sc + 2 * nrhs, *rho_t = sc + 3 * nrhs;
+    GKOMI_TRY(gkomi_fcg_initialize_f64(s, n, nrhs, b, nrhs, r, nrhs, z, nrhs, p, nrhs, q, nrhs, t,
+                                       nrhs, prev_rho, rho, rho_t, c.stop_status));
+    GKOMI_TRY(c.start(b, x, r, baseline));
+    int64_t iter = -1;
+    while (true) {
+        GKOMI_TRY(c.apply_precond(r, z));
+        GKOMI_TRY(c.dot(r, z, rho));
+        GKOMI_TRY(c.dot(t, z, rho_t));
+        ++iter;
+        bool stop = false, changed = false;
+        GKOMI_TRY(c.check(iter, r, true, &stop, &changed));
+        if (stop) break;
+        GKOMI_TRY(gkomi_fcg_step_1_f64(s, n, nrhs, p, nrhs, z, nrhs, rho_t, prev_rho, c.stop_status));
+        GKOMI_TRY(c.spmv(p, q));
+        GKOMI_TRY(c.dot(p, q, beta));
+        GKOMI_TRY(gkomi_fcg_step_2_f64(s, n, nrhs, x, nrhs, r, nrhs, t, nrhs, p, nrhs, q, nrhs, beta,
+                                       rho, c.stop_status));
+        std::swap(prev_rho, rho);
+    }
+    return c.finish(iter, r, host_info);
+}
+
+extern "C" int gkomi_cgs_solve_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
+    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
+    double reduction_factor, int baseline, void* workspace, size_t workspace_bytes,
+    double* host_info)
+{
+    GKOMI_DRIVER_PROLOGUE(8);
+    double *r = V(0), *r_tld = V(1), *p = V(2), *q = V(3), *u = V(4), *u_hat = V(5), *v_hat = V(6),
+           *t = V(7);
+    double *alpha = sc, *beta = sc + nrhs, *gamma = sc + 2 * nrhs, *prev_rho = sc + 3 * nrhs,
+           *rho = sc + 4 * nrhs;
+    GKOMI_TRY(gkomi_cgs_initialize_f64(s, n, nrhs, b, nrhs, r, nrhs, r_tld, nrhs, p, nrhs, q, nrhs, u,
+                                       nrhs, u_hat, nrhs, v_hat, nrhs, t, nrhs, alpha, beta, gamma,
+                                       prev_rho, rho, c.stop_status));
+    GKOMI_TRY(c.start(b, x, r, baseline));
+    GKOMI_TRY(gkomi_dense_copy_f64(s, n, nrhs, r, nrhs, r_tld, nrhs));
+    int64_t iter = -1;
+    while (true) {
+        GKOMI_TRY(c.dot(r, r_tld, rho));
+        ++iter;
+        bool stop = false, changed = false;
+        GKOMI_TRY(c.check(iter, r, true, &stop, &changed));
+        if (stop) break;
+        GKOMI_TRY(gkomi_cgs_step_1_f64(s, n, nrhs, r, nrhs, u, nrhs, p, nrhs, q, nrhs, beta, rho,
+                                       prev_rho, c.stop_status));
+        GKOMI_TRY(c.apply_precond(p, t));
+        GKOMI_TRY(c.spmv(t, v_hat));
+        GKOMI_TRY(c.dot(r_tld, v_hat, gamma));
+        GKOMI_TRY(gkomi_cgs_step_2_f64(s, n, nrhs, u, nrhs, v_hat, nrhs, q, nrhs, t, nrhs, alpha, rho,
+                                       gamma, c.stop_status));
+        GKOMI_TRY(c.apply_precond(t, u_hat));
+        GKOMI_TRY(c.spmv(u_hat, t));
+        GKOMI_TRY(gkomi_cgs_step_3_f64(s, n, nrhs, t, nrhs, u_hat, nrhs, r, nrhs, x, nrhs, alpha,
+                                       c.stop_status));
+        std::swap(prev_rho, rho);
+    }
+    return c.finish(iter, r, host_info);
+}

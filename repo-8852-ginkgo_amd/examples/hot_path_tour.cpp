@@ -129,6 +129,40 @@ int main()
         std::cout << "gmres_ilu_iters " << gm->get_last_iteration_count() << " converged " << gm->has_converged()
                   << " true_residual " << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
 
+        // the other Krylov solvers on the same systems: FCG (SPD), BiCGSTAB and CGS (nonsymmetric)
+        {
+            auto crit = [&]() {
+                return std::make_pair(gko::stop::Iteration::build().with_max_iters(2000u).on(exec),
+                                      gko::stop::ResidualNorm<double>::build().with_reduction_factor(1e-10).on(exec));
+            };
+            auto report = [&](const char* name, const csr* M, int64_t iters, bool conv) {
+                r->copy_from(b.get());
+                M->apply(neg.get(), sol.get(), one.get(), r.get());
+                r->compute_norm2(rn.get());
+                std::cout << name << " " << iters << " converged " << conv << " true_residual "
+                          << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
+            };
+            sol->fill(0.0);
+            auto c1 = crit();
+            auto fcg = gko::solver::Fcg<double>::build().with_criteria(c1.first, c1.second)
+                           .with_preconditioner(gko::preconditioner::Jacobi<double, int>::build().with_max_block_size(8u).on(exec)).on(exec)->generate(A);
+            fcg->apply(b.get(), sol.get());
+            report("fcg_jacobi_iters", A.get(), fcg->get_last_iteration_count(), fcg->has_converged());
+            sol->fill(0.0);
+            auto c2 = crit();
+            auto bicg = gko::solver::Bicgstab<double>::build().with_criteria(c2.first, c2.second)
+                            .with_preconditioner(gko::preconditioner::Ilu<double, int>::build().with_factorization_iterations(20u).on(exec)).on(exec)->generate(B);
+            bicg->apply(b.get(), sol.get());
+            report("bicgstab_ilu_iters", B.get(), bicg->get_last_iteration_count(), bicg->has_converged());
+            sol->fill(0.0);
+            auto c3 = crit();
+            // (unpreconditioned CGS loses its recurrence residual on this matrix -- in the reference too)
+            auto cgs = gko::solver::Cgs<double>::build().with_criteria(c3.first, c3.second)
+                           .with_preconditioner(gko::preconditioner::Ilu<double, int>::build().with_factorization_iterations(20u).on(exec)).on(exec)->generate(B);
+            cgs->apply(b.get(), sol.get());
+            report("cgs_ilu_iters", B.get(), cgs->get_last_iteration_count(), cgs->has_converged());
+        }
+
         // assembly on the device: shuffled triplets with duplicates and zeros ->
         // device_matrix_data::sum_duplicates / remove_zeros -> Csr::read
         {

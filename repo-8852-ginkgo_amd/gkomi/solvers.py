@@ -46,6 +46,32 @@ def cg_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reducti
             "rel_residual": float(np.max(res / np.where(base == 0, 1.0, base)))}
 
 
+def krylov_solve(gk, solver, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reduction=1e-10,
+                 baseline="rhs_norm", strategy=0, max_row_nnz=-1, precond=None):
+    """solver in {"bicgstab", "fcg", "cgs"}: {Bicgstab,Fcg,Cgs}::apply with
+    Combined(Iteration(max_iters), ResidualNorm(reduction, baseline)); precond: None or a Preconditioner."""
+    assert solver in ("bicgstab", "fcg", "cgs")
+    b2 = b.reshape(n, -1)
+    nrhs = b2.shape[1]
+    if x is None:
+        x = torch.zeros_like(b2)
+    x2 = x.reshape(n, nrhs)
+    assert b2.is_contiguous() and x2.is_contiguous()
+    nnz = int(vals.numel())
+    nbytes = gk.krylov_workspace_bytes(n, nrhs)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+    info = np.zeros(2 + 2 * nrhs, dtype=np.float64)
+    stream = torch.cuda.current_stream().cuda_stream
+    fn = precond.fn if precond is not None else None
+    ctx = precond.ctx_ptr if precond is not None else None
+    getattr(gk, solver + "_solve_f64_i32")(stream, n, nrhs, nnz, row_ptrs, col_idxs, vals, strategy, max_row_nnz, fn, ctx,
+                                           b2, x2, max_iters, reduction, BASELINES[baseline], ws, nbytes, info)
+    res, base = info[2::2].copy(), info[3::2].copy()
+    return {"x": x2 if b.dim() > 1 else x2.reshape(n), "iterations": int(info[0]), "converged": bool(info[1]),
+            "residual_norm": res, "baseline_norm": base,
+            "rel_residual": float(np.max(res / np.where(base == 0, 1.0, base)))}
+
+
 class JacobiCtx(ctypes.Structure):
     """gkomi_jacobi_ctx (include/gkomi.h)."""
     _fields_ = [("n", ctypes.c_int64), ("nrhs", ctypes.c_int64), ("num_blocks", ctypes.c_int64),

@@ -1378,6 +1378,71 @@ protected:
     mutable bool last_converged_{false};
 };
 
+// Bicgstab / Fcg / Cgs (include/ginkgo/core/solver/{bicgstab,fcg,cgs}.hpp): same
+// factory parameters as Cg, native drivers of csrc/krylov.hip
+namespace detail {
+using krylov_driver = int (*)(gkomi_stream_t, int64_t, int64_t, int64_t, const int32_t*, const int32_t*, const double*, int, int64_t, gkomi_apply_fn, void*,
+                              const double*, double*, int64_t, double, int, void*, size_t, double*);
+template <typename Derived, krylov_driver Driver>
+class krylov_solver : public LinOp {
+public:
+    class Factory : public factory_base<Derived> {};
+    static Factory build() { return Factory{}; }
+    std::shared_ptr<const LinOp> get_system_matrix() const { return A_; }
+    std::shared_ptr<const LinOp> get_preconditioner() const { return precond_; }
+    int64_t get_last_iteration_count() const noexcept { return last_iters_; }
+    bool has_converged() const noexcept { return last_converged_; }
+protected:
+    krylov_solver(const Factory* f, std::shared_ptr<const LinOp> A) : LinOp(f->get_executor(), gko::transpose(A->get_size())), A_(std::move(A)), settings_(f->settings())
+    {
+        if (size_[0] != size_[1]) throw DimensionMismatch(__FILE__, __LINE__, "the solver needs a square system matrix");
+        precond_ = f->precond_ ? f->precond_ : (f->precond_factory_ ? std::shared_ptr<const LinOp>(f->precond_factory_->generate_impl(A_)) : nullptr);
+    }
+    void apply_impl(const LinOp* b, LinOp* x) const override
+    {
+        ::gko::detail::require_device(exec_, "solver::apply");
+        auto csr = as<const matrix::Csr<double, int32>>(A_.get());
+        auto db = matrix::detail_fmt::dense(b); auto dx = matrix::detail_fmt::dense(x);
+        const int64_t n = size_[0], nrhs = db->cols();
+        if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
+        array<char> ws(exec_, gkomi_krylov_workspace_bytes(n, nrhs));
+        std::vector<double> info(2 + 2 * nrhs, 0.0);
+        ::gko::detail::linop_callback cb{precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
+        GKOMI_CALL(Driver(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
+                          csr->get_strategy()->get_code(), csr->get_max_row_nnz(), precond_ ? &::gko::detail::linop_callback::call : nullptr, precond_ ? &cb : nullptr,
+                          db->get_const_values(), dx->get_values(), settings_.max_iters, settings_.reduction_factor, baseline_code(settings_.baseline), ws.get_data(),
+                          ws.get_num_elems(), info.data()));
+        last_iters_ = static_cast<int64_t>(info[0]);
+        last_converged_ = info[1] != 0.0;
+    }
+    void apply_impl(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const override
+    {
+        auto dx = matrix::detail_fmt::dense(x);
+        auto x_clone = dx->clone();
+        this->apply_impl(b, x_clone.get());
+        dx->scale(matrix::detail_fmt::dense(beta));
+        dx->add_scaled(matrix::detail_fmt::dense(alpha), x_clone.get());
+    }
+    std::shared_ptr<const LinOp> A_;
+    std::shared_ptr<const LinOp> precond_;
+    stop::criterion_settings settings_;
+    mutable int64_t last_iters_{-1};
+    mutable bool last_converged_{false};
+};
+}  // namespace detail
+
+#define GKOMI_KRYLOV_SOLVER(Name, driver)                                                          \
+    template <typename V = double>                                                                 \
+    class Name : public detail::krylov_solver<Name<V>, driver> {                                   \
+        using base = detail::krylov_solver<Name<V>, driver>;                                       \
+        friend class detail::factory_base<Name>;                                                   \
+        Name(const typename base::Factory* f, std::shared_ptr<const LinOp> A) : base(f, std::move(A)) {} \
+    }
+GKOMI_KRYLOV_SOLVER(Bicgstab, gkomi_bicgstab_solve_f64_i32);
+GKOMI_KRYLOV_SOLVER(Fcg, gkomi_fcg_solve_f64_i32);
+GKOMI_KRYLOV_SOLVER(Cgs, gkomi_cgs_solve_f64_i32);
+#undef GKOMI_KRYLOV_SOLVER
+
 template <typename V = double>
 class Gmres : public LinOp {
 public:

@@ -1,0 +1,162 @@
+"""GPU parity (through the C ABI) of BiCGSTAB / FCG / CGS: the step kernels
+bit-exact against the oracle (known answers of the reference's tests, then
+random data with stopped columns and zero denominators), the drivers against
+the reference's solve answers and the oracle's iteration counts."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import matgen
+from gkomi import solvers
+from gpu_util import dev, host, stream_ptr
+from krylov_util import KERNEL_ARGS, dense_to_csr
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "krylov.json")))
+
+
+def run_kernel(gk, oracle, solver, op, n, nrhs, data, stop, strides=None):
+    """runs ref_<solver>_<op> on copies and gkomi_<solver>_<op>_f64 on the device; returns both result dicts"""
+    vecs, scalars = KERNEL_ARGS[(solver, op)]
+    strides = strides or {k: nrhs for k in vecs}
+    e = {k: v.copy() for k, v in data.items()}
+    es = stop.copy()
+    args = [n, nrhs]
+    for k in vecs:
+        args += [e[k], strides[k]]
+    args += [e[k] for k in scalars] + [es]
+    getattr(oracle, f"ref_{solver}_{op}")(*args)
+    d = {k: dev(v) for k, v in data.items()}
+    ds = dev(stop)
+    args = [stream_ptr(), n, nrhs]
+    for k in vecs:
+        args += [d[k], strides[k]]
+    args += [d[k] for k in scalars] + [ds]
+    getattr(gk, f"{solver}_{op}_f64")(*args)
+    got = {k: host(v) for k, v in d.items()}
+    got["stop"], e["stop"] = host(ds), es
+    return got, e
+
+
+@pytest.mark.parametrize("case", G["kernels"], ids=lambda c: c["solver"] + "_" + c["name"])
+def test_kernel_known_answers(gk, oracle, case):
+    vecs, scalars = KERNEL_ARGS[(case["solver"], case["op"])]
+    data = {k: np.array(case[k], np.float64) for k in vecs + scalars}
+    got, _ = run_kernel(gk, oracle, case["solver"], case["op"], 2, 2, data, np.array(case["stop"], np.uint8))
+    for k, exp in case["expect"].items():
+        assert np.array_equal(got[k], np.array(exp, got[k].dtype)), (case["name"], k)
+
+
+@pytest.mark.parametrize("key", sorted(KERNEL_ARGS), ids=lambda k: "_".join(k))
+@pytest.mark.parametrize("n,nrhs,pad", [(1, 1, 0), (1000, 1, 0), (777, 3, 2), (100003, 2, 0)])
+def test_kernels_bitexact_random(gk, oracle, key, n, nrhs, pad):
+    solver, op = key
+    vecs, scalars = KERNEL_ARGS[key]
+    rng = np.random.default_rng(hash(key) % 1000 + n)
+    stride = nrhs + pad
+    data = {k: rng.standard_normal((n, stride)) for k in vecs}
+    for k in scalars:
+        data[k] = rng.standard_normal(nrhs)
+        if nrhs > 1:
+            data[k][rng.integers(0, nrhs)] = 0.0      # a zero denominator somewhere
+    stop = np.zeros(nrhs, np.uint8)
+    if nrhs > 2:
+        stop[1] = 1                                    # a stopped column
+    if op == "finalize":
+        stop = np.array(([1, 65, 0] * nrhs)[:nrhs], np.uint8)
+    got, exp = run_kernel(gk, oracle, solver, op, n, nrhs, data, stop, {k: stride for k in vecs})
+    for k in exp:
+        assert got[k].tobytes() == exp[k].tobytes(), (key, k)
+
+
+def test_initialize_kernels(gk):
+    n, nrhs = 1000, 3
+    b = dev(np.random.default_rng(0).standard_normal((n, nrhs)))
+    mk = lambda: torch.full((n, nrhs), 7.0, dtype=torch.float64, device="cuda:0")
+    sc = lambda: torch.full((nrhs,), 5.0, dtype=torch.float64, device="cuda:0")
+    st = torch.ones(nrhs, dtype=torch.uint8, device="cuda:0")
+    r, rr, y, s, t, z, v, p = (mk() for _ in range(8))
+    sca = [sc() for _ in range(6)]
+    gk.bicgstab_initialize_f64(stream_ptr(), n, nrhs, b, nrhs, r, nrhs, rr, nrhs, y, nrhs, s, nrhs, t, nrhs, z, nrhs, v,
+                               nrhs, p, nrhs, *sca, st)
+    assert torch.equal(r, b) and not any(bool(a.any()) for a in (rr, y, s, t, z, v, p))
+    assert all(bool((a == 1).all()) for a in sca) and not bool(st.any())
+    st.fill_(1)
+    r, z, p, q, t = (mk() for _ in range(5))
+    prev_rho, rho, rho_t = sc(), sc(), sc()
+    gk.fcg_initialize_f64(stream_ptr(), n, nrhs, b, nrhs, r, nrhs, z, nrhs, p, nrhs, q, nrhs, t, nrhs, prev_rho, rho,
+                          rho_t, st)
+    assert torch.equal(r, b) and torch.equal(t, b) and not any(bool(a.any()) for a in (z, p, q))
+    assert bool((prev_rho == 1).all()) and bool((rho_t == 1).all()) and not bool(rho.any()) and not bool(st.any())
+    st.fill_(1)
+    r, r_tld, p, q, u, u_hat, v_hat, t = (mk() for _ in range(8))
+    alpha, beta, gamma, prev_rho, rho = (sc() for _ in range(5))
+    gk.cgs_initialize_f64(stream_ptr(), n, nrhs, b, nrhs, r, nrhs, r_tld, nrhs, p, nrhs, q, nrhs, u, nrhs, u_hat, nrhs,
+                          v_hat, nrhs, t, nrhs, alpha, beta, gamma, prev_rho, rho, st)
+    assert torch.equal(r, b) and torch.equal(r_tld, b) and not any(bool(a.any()) for a in (p, q, u, u_hat, v_hat, t))
+    assert all(bool((a == 1).all()) for a in (alpha, beta, gamma, prev_rho)) and not bool(rho.any())
+
+
+@pytest.mark.parametrize("case", G["solves"], ids=lambda c: c["solver"] + "_" + c["name"])
+def test_solve_known_answers(gk, oracle, case):
+    n, rp, ci, v = dense_to_csr(case["A"])
+    res = solvers.krylov_solve(gk, case["solver"], n, dev(rp), dev(ci), dev(v), dev(np.array(case["b"])),
+                               max_iters=case["max_iters"], reduction=case["reduction"])
+    # the reference's tolerance holds for its sequential dots; the device sums in
+    # a two-stage order (deterministic, but different): allow 4x
+    assert matgen.rel_err(host(res["x"]), case["expect_x"]) <= 4 * case["tol"], res
+    xe = np.zeros(n)
+    ite = getattr(oracle, f"ref_{case['solver']}_solve")(n, rp, ci, v, np.array(case["b"]), xe, case["max_iters"],
+                                                        case["reduction"], 0)
+    # near machine precision the last iterations are rounding noise (the
+    # "DivergenceCheck" systems are badly conditioned on purpose)
+    assert abs(res["iterations"] - ite) <= max(2, ite // 4)
+
+
+@pytest.mark.parametrize("solver", ["bicgstab", "fcg", "cgs"])
+@pytest.mark.parametrize("problem", ["poisson", "convection"])
+def test_solves_like_the_oracle(gk, oracle, solver, problem):
+    if problem == "poisson":
+        n, rp, ci, v = matgen.poisson_2d_5pt(40)
+    else:
+        if solver == "fcg":
+            pytest.skip("FCG needs a symmetric matrix")
+        n, rp, ci, v = matgen.poisson_3d_7pt(12)
+        v = v.copy()
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        v[ci == rows - 1] -= 0.5
+        v[ci == rows] += 0.5
+    xs = np.sin(0.3 * np.arange(n))
+    b = np.zeros((n, 1))
+    oracle.ref_csr_spmv(n, 1, rp, ci, v, xs.reshape(n, 1), 1, b, 1)
+    xe = np.zeros(n)
+    ite = getattr(oracle, f"ref_{solver}_solve")(n, rp, ci, v, b[:, 0].copy(), xe, 2000, 1e-10, 0)
+    res = solvers.krylov_solve(gk, solver, n, dev(rp), dev(ci), dev(v), dev(b[:, 0].copy()), max_iters=2000,
+                               reduction=1e-10)
+    assert res["converged"] and res["rel_residual"] <= 1e-10
+    # reductions are summed in a different order: the iterates drift by rounding
+    assert abs(res["iterations"] - ite) <= max(2, ite // 10), (res["iterations"], ite)
+    assert matgen.rel_err(host(res["x"]), xs) < 1e-7
+    # the reported residual is the true norm of the final residual vector
+    r = b[:, 0] - (np.add.reduceat(v * host(res["x"])[ci], rp[:-1]))
+    assert abs(np.linalg.norm(r) - res["residual_norm"][0]) <= 1e-6 * np.linalg.norm(b) + 1e-3 * res["residual_norm"][0]
+
+
+def test_multiple_rhs_preconditioner_and_iteration_limit(gk, oracle):
+    n, rp, ci, v = matgen.poisson_2d_5pt(32)
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    rng = np.random.default_rng(4)
+    xs = rng.standard_normal((n, 3))
+    b = np.zeros((n, 3))
+    oracle.ref_csr_spmv(n, 3, rp, ci, v, xs, 3, b, 3)
+    pc = solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=4, nrhs=3)
+    for solver in ("bicgstab", "fcg", "cgs"):
+        plain = solvers.krylov_solve(gk, solver, n, rpd, cid, vd, dev(b), max_iters=2000, reduction=1e-11)
+        assert plain["converged"] and matgen.rel_err(host(plain["x"]), xs) < 1e-8
+        pre = solvers.krylov_solve(gk, solver, n, rpd, cid, vd, dev(b), max_iters=2000, reduction=1e-11, precond=pc)
+        assert pre["converged"] and matgen.rel_err(host(pre["x"]), xs) < 1e-8
+        capped = solvers.krylov_solve(gk, solver, n, rpd, cid, vd, dev(b), max_iters=3, reduction=1e-11)
+        assert capped["iterations"] == 3 and not capped["converged"]
