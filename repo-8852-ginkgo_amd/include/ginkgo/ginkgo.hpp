@@ -759,6 +759,9 @@ public:
     struct load_balance : strategy_type { load_balance(int64_t = 0) : strategy_type("load_balance", GKOMI_CSR_BALANCED) {} };
     struct merge_path : strategy_type { merge_path() : strategy_type("merge_path", GKOMI_CSR_STREAM) {} };
     struct automatical : strategy_type { automatical(int64_t = 0) : strategy_type("automatical", GKOMI_CSR_AUTO) {} };
+    // the vendor-library strategy (csr.hpp:299-330): no hipSPARSE behind this backend, the automatic choice serves it
+    struct sparselib : strategy_type { sparselib() : strategy_type("sparselib", GKOMI_CSR_AUTO) {} };
+    struct cusparse : strategy_type { cusparse() : strategy_type("cusparse", GKOMI_CSR_AUTO) {} };
 
     static std::unique_ptr<Csr> create(std::shared_ptr<const Executor> exec, const dim<2>& size = dim<2>{}, size_type nnz = 0,
                                        std::shared_ptr<strategy_type> strategy = std::make_shared<automatical>())
