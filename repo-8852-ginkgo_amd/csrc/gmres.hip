@@ -151,8 +151,84 @@ __global__ __launch_bounds__(block) void gmres_finalize_status_kernel(
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- fused modified Gram-Schmidt (single right-hand side) ---------------------
+// The reference's Arnoldi step (core/solver/gmres.cpp:300-319) is, per basis
+// vector i, hessenberg(i) = dot(next, basis_i) followed by next -= hessenberg(i)
+// * basis_i: 5n values of traffic and two launches + a reduction finish each.
+// Fused: launch i subtracts h_{i-1} * basis_{i-1} from next AND accumulates the
+// partial sums of dot(next, basis_i) in the same pass (4n values, one launch);
+// every workgroup re-adds the previous launch's partials (fixed order) to get
+// h_{i-1}, so no separate finishing kernel and no host round trip.  The last
+// launch produces the partials of ||next||^2; the scaling kernel re-adds them,
+// writes hessenberg(k+1) = ||next|| and scales next.  Same operations in the
+// same order as the reference (MGS), only the summation order of the dots
+// differs (two-stage, deterministic).
+constexpr int arnoldi_block = 256;
+constexpr int arnoldi_max_blocks = 2048;
+
+// deterministic sum of `count` partials by the whole workgroup
+__device__ double sum_partials(const double* __restrict__ partials, int count, double* smem)
+{
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += arnoldi_block) acc += partials[i];
+    return block_reduce_sum<arnoldi_block>(acc, smem);
+}
+
+// next -= h_prev * prev (if prev), partial_out[block] = sum next * (with ? with : next)
+__global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_step_kernel(
+    int64_t n, double* __restrict__ next, const double* __restrict__ prev,
+    const double* __restrict__ with, const double* __restrict__ partial_in, int count_in,
+    double* __restrict__ h_prev_out, double* __restrict__ partial_out)
+{
+    __shared__ double smem[arnoldi_block / wave_size];
+    __shared__ double h_s;
+    double h = 0.0;
+    if (prev != nullptr) {
+        const double total = sum_partials(partial_in, count_in, smem);
+        if (threadIdx.x == 0) {
+            h_s = total;
+            if (blockIdx.x == 0) *h_prev_out = total;
+        }
+        __syncthreads();
+        h = h_s;
+    }
+    double acc = 0.0;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(arnoldi_block) + threadIdx.x; e < n;
+         e += static_cast<int64_t>(gridDim.x) * arnoldi_block) {
+        double v = next[e];
+        if (prev != nullptr) {
+            v -= h * prev[e];
+            next[e] = v;
+        }
+        acc += v * (with != nullptr ? with[e] : v);
+    }
+    __syncthreads();
+    const double total = block_reduce_sum<arnoldi_block>(acc, smem);
+    if (threadIdx.x == 0) partial_out[blockIdx.x] = total;
+}
+
+// hn = sqrt(sum partials) -> *hn_out; next /= hn
+__global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_scale_kernel(
+    int64_t n, double* __restrict__ next, const double* __restrict__ partial_in, int count_in,
+    double* __restrict__ hn_out)
+{
+    __shared__ double smem[arnoldi_block / wave_size];
+    __shared__ double h_s;
+    const double total = sum_partials(partial_in, count_in, smem);
+    if (threadIdx.x == 0) {
+        h_s = sqrt(total);
+        if (blockIdx.x == 0) *hn_out = h_s;
+    }
+    __syncthreads();
+    const double hn = h_s;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(arnoldi_block) + threadIdx.x; e < n;
+         e += static_cast<int64_t>(gridDim.x) * arnoldi_block) {
+        next[e] /= hn;
+    }
+}
+
 struct gmres_layout {
-    size_t residual, pv, before, after, kb, hess, gsin, gcos, rnc, y, small, fin, red, total;
+    size_t residual, pv, before, after, kb, hess, gsin, gcos, rnc, y, small, fin, red, partials, total;
 };
 
 gmres_layout make_layout(int64_t n, int64_t nrhs, int64_t d)
@@ -174,6 +250,7 @@ gmres_layout make_layout(int64_t n, int64_t nrhs, int64_t d)
     l.small = off; off += align_up(sizeof(double) * 4 * static_cast<size_t>(nrhs) + nrhs + 16, 256);
     l.fin = off; off += align_up(sizeof(uint64_t) * static_cast<size_t>(nrhs), 256);
     l.red = off; off += align_up(gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8, 256);
+    l.partials = off; off += align_up(sizeof(double) * 2 * arnoldi_max_blocks, 256);
     l.total = off;
     return l;
 }
@@ -369,16 +446,35 @@ extern "C" int gkomi_gmres_solve_f64_i32(
         GKOMI_TRY(gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, pv, nrhs,
                                          next_k, nrhs, nullptr, nullptr, spmv_strategy,
                                          max_row_nnz_hint));
-        for (int64_t i = 0; i <= restart_iter; ++i) {
-            double* h = hess_iter + i * h_stride;
-            const double* basis = kb + n * nrhs * i;
-            GKOMI_TRY(gkomi_dense_compute_dot_f64(s, n, nrhs, next_k, nrhs, basis, nrhs, h, red,
-                                                  red_bytes));
-            GKOMI_TRY(gkomi_dense_sub_scaled_f64(s, n, nrhs, h, nrhs, basis, nrhs, next_k, nrhs));
+        if (nrhs == 1 && n > 0) {
+            // fused modified Gram-Schmidt: one pass over next_k per basis vector
+            const int blocks = static_cast<int>(
+                std::min<int64_t>(arnoldi_max_blocks, ceildiv(n, arnoldi_block)));
+            double* partial[2] = {D(l.partials), D(l.partials) + arnoldi_max_blocks};
+            for (int64_t i = 0; i <= restart_iter + 1; ++i) {
+                const double* prev = i > 0 ? kb + n * (i - 1) : nullptr;
+                const double* with = i <= restart_iter ? kb + n * i : nullptr;
+                double* h_prev = i > 0 ? hess_iter + (i - 1) * h_stride : nullptr;
+                hipLaunchKernelGGL(gmres_arnoldi_step_kernel, dim3(blocks), dim3(arnoldi_block), 0,
+                                   stream, n, next_k, prev, with, partial[(i + 1) & 1], blocks,
+                                   h_prev, partial[i & 1]);
+            }
+            double* hn = hess_iter + (restart_iter + 1) * h_stride;
+            hipLaunchKernelGGL(gmres_arnoldi_scale_kernel, dim3(blocks), dim3(arnoldi_block), 0,
+                               stream, n, next_k, partial[(restart_iter + 1) & 1], blocks, hn);
+            GKOMI_TRY(check_launch());
+        } else {
+            for (int64_t i = 0; i <= restart_iter; ++i) {
+                double* h = hess_iter + i * h_stride;
+                const double* basis = kb + n * nrhs * i;
+                GKOMI_TRY(gkomi_dense_compute_dot_f64(s, n, nrhs, next_k, nrhs, basis, nrhs, h, red,
+                                                      red_bytes));
+                GKOMI_TRY(gkomi_dense_sub_scaled_f64(s, n, nrhs, h, nrhs, basis, nrhs, next_k, nrhs));
+            }
+            double* hn = hess_iter + (restart_iter + 1) * h_stride;
+            GKOMI_TRY(gkomi_dense_compute_norm2_f64(s, n, nrhs, next_k, nrhs, hn, red, red_bytes));
+            GKOMI_TRY(gkomi_dense_inv_scale_f64(s, n, nrhs, hn, nrhs, next_k, nrhs));
         }
-        double* hn = hess_iter + (restart_iter + 1) * h_stride;
-        GKOMI_TRY(gkomi_dense_compute_norm2_f64(s, n, nrhs, next_k, nrhs, hn, red, red_bytes));
-        GKOMI_TRY(gkomi_dense_inv_scale_f64(s, n, nrhs, hn, nrhs, next_k, nrhs));
         GKOMI_TRY(gkomi_gmres_hessenberg_qr_f64(s, nrhs, gsin, gcos, residual_norm, rnc, hess_iter,
                                                 h_stride, restart_iter, final_iter_nums,
                                                 stop_status));
