@@ -449,6 +449,34 @@ int gkomi_par_ilu_compute_l_u_factors_f64_i32(
     const double* coo_vals, const int32_t* l_row_ptrs,
     const int32_t* l_col_idxs, double* l_vals, const int32_t* ut_row_ptrs,
     const int32_t* ut_col_idxs, double* ut_vals);
+/* ParIC: factorization::initialize_row_ptrs_l /
+ * initialize_l (reference/factorization/factorization_kernels.cpp:251-318;
+ * diag_sqrt != 0 stores sqrt of the diagonal, 1 if not finite) and
+ * par_ic_factorization::{init_factor, compute_factor}
+ * (reference/factorization/par_ic_kernels.cpp:55-124).  compute_factor gets the
+ * row index of every stored entry of L (convert_ptrs_to_idxs of l_row_ptrs) and
+ * a copy of the lower-triangle values of A in L's pattern (the COO copy of
+ * core/factorization/par_ic.cpp:121-131); `iterations` asynchronous sweeps,
+ * 0 = 10.  The Ic preconditioner is gkomi_ilu_apply_cb with U = L^T
+ * (gkomi_csr_transpose_f64_i32). */
+int gkomi_factorization_initialize_row_ptrs_l_i32(
+    gkomi_stream_t s, int64_t n, const int32_t* row_ptrs,
+    const int32_t* col_idxs, int32_t* l_row_ptrs, void* workspace,
+    size_t workspace_bytes);
+int gkomi_factorization_initialize_l_f64_i32(
+    gkomi_stream_t s, int64_t n, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, const int32_t* l_row_ptrs,
+    int32_t* l_col_idxs, double* l_vals, int diag_sqrt);
+int gkomi_par_ic_init_factor_f64_i32(gkomi_stream_t s, int64_t n,
+                                     const int32_t* l_row_ptrs,
+                                     const int32_t* l_col_idxs, double* l_vals);
+int gkomi_par_ic_compute_factor_f64_i32(gkomi_stream_t s, int64_t iterations,
+                                        int64_t l_nnz,
+                                        const int32_t* l_row_idxs,
+                                        const double* a_lower_vals,
+                                        const int32_t* l_row_ptrs,
+                                        const int32_t* l_col_idxs,
+                                        double* l_vals);
 /* ---- matrix assembly: device_matrix_data ---------- */
 /* components::{sort_row_major, sum_duplicates, remove_zeros}
  * (core/base/device_matrix_data_kernels.hpp;

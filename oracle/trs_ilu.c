@@ -195,3 +195,85 @@ ORACLE_API void ref_par_ilu_compute_l_u_factors(
         }
     }
 }
+
+/* ---- ParIC ------------------------------------------------
+ * reference/factorization/factorization_kernels.cpp:251-318 (initialize_row_ptrs_l,
+ * initialize_l) and reference/factorization/par_ic_kernels.cpp:55-124
+ * (init_factor, compute_factor: ONE sequential sweep = exact IC(0) in row-major
+ * order, whatever `iterations` says). */
+ORACLE_API void ref_initialize_row_ptrs_l(i64 n, const i32* row_ptrs, const i32* col_idxs,
+                                          i32* l_row_ptrs)
+{
+    i64 l_nnz = 0;
+    l_row_ptrs[0] = 0;
+    for (i64 row = 0; row < n; ++row) {
+        for (i32 el = row_ptrs[row]; el < row_ptrs[row + 1]; ++el) l_nnz += col_idxs[el] < row;
+        l_nnz++; /* the diagonal */
+        l_row_ptrs[row + 1] = (i32)l_nnz;
+    }
+}
+
+ORACLE_API void ref_initialize_l(i64 n, const i32* row_ptrs, const i32* col_idxs,
+                                 const double* vals, const i32* l_row_ptrs, i32* l_col_idxs,
+                                 double* l_vals, int diag_sqrt)
+{
+    for (i64 row = 0; row < n; ++row) {
+        i64 cur = l_row_ptrs[row];
+        double diag = 1.0;
+        for (i32 el = row_ptrs[row]; el < row_ptrs[row + 1]; ++el) {
+            const i32 col = col_idxs[el];
+            if (col < row) {
+                l_col_idxs[cur] = col;
+                l_vals[cur] = vals[el];
+                ++cur;
+            } else if (col == row) {
+                diag = vals[el];
+            }
+        }
+        const i64 d = l_row_ptrs[row + 1] - 1;
+        l_col_idxs[d] = (i32)row;
+        if (diag_sqrt) {
+            diag = sqrt(diag);
+            if (!isfinite(diag)) diag = 1.0;
+        }
+        l_vals[d] = diag;
+    }
+}
+
+ORACLE_API void ref_par_ic_init_factor(i64 n, const i32* l_row_ptrs, const i32* l_col_idxs,
+                                       double* l_vals)
+{
+    for (i64 row = 0; row < n; ++row)
+        for (i32 nz = l_row_ptrs[row]; nz < l_row_ptrs[row + 1]; ++nz)
+            if (l_col_idxs[nz] == row) {
+                const double d = sqrt(l_vals[nz]);
+                l_vals[nz] = isfinite(d) ? d : 1.0;
+            }
+}
+
+/* a_vals: the values of the lower triangle of A in L's pattern (the COO copy) */
+ORACLE_API void ref_par_ic_compute_factor(i64 n, const double* a_vals, const i32* l_row_ptrs,
+                                          const i32* l_col_idxs, double* l_vals)
+{
+    for (i64 row = 0; row < n; ++row) {
+        for (i32 nz = l_row_ptrs[row]; nz < l_row_ptrs[row + 1]; ++nz) {
+            const i32 col = l_col_idxs[nz];
+            double sum = 0.0;
+            i32 lb = l_row_ptrs[row], le = l_row_ptrs[row + 1];
+            i32 hb = l_row_ptrs[col], he = l_row_ptrs[col + 1];
+            while (lb < le && hb < he) {
+                const i32 l_col = l_col_idxs[lb], lh_row = l_col_idxs[hb];
+                if (l_col == lh_row && l_col < col) sum += l_vals[lb] * l_vals[hb];
+                lb += (l_col <= lh_row);
+                hb += (lh_row <= l_col);
+            }
+            double nv = a_vals[nz] - sum;
+            if (row == col) {
+                nv = sqrt(nv);
+            } else {
+                nv = nv / l_vals[l_row_ptrs[col + 1] - 1];
+            }
+            if (isfinite(nv)) l_vals[nz] = nv;
+        }
+    }
+}

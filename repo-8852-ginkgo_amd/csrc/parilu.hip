@@ -177,6 +177,101 @@ __global__ __launch_bounds__(block) void par_ilu_sweep_kernel(
     }
 }
 
+// ---- ParIC: L-only setup + fixed-point sweeps ------------
+// factorization::initialize_row_ptrs_l / initialize_l
+// (reference/factorization/factorization_kernels.cpp:251-318) and
+// par_ic_factorization::{init_factor, compute_factor}
+// (reference/factorization/par_ic_kernels.cpp:55-124).
+
+__global__ __launch_bounds__(block) void count_l_kernel(int64_t n,
+                                                       const int32_t* __restrict__ row_ptrs,
+                                                       const int32_t* __restrict__ col_idxs,
+                                                       int32_t* __restrict__ l_counts)
+{
+    for (int64_t row = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; row <= n;
+         row += static_cast<int64_t>(gridDim.x) * block) {
+        int32_t l = 0;
+        if (row < n) {
+            const int32_t end = row_ptrs[row + 1];
+            for (int32_t k = row_ptrs[row]; k < end; ++k) l += col_idxs[k] < row;
+            ++l;  // the diagonal is always stored
+        }
+        l_counts[row] = l;
+    }
+}
+
+__global__ __launch_bounds__(block) void initialize_l_kernel(
+    int64_t n, const int32_t* __restrict__ row_ptrs, const int32_t* __restrict__ col_idxs,
+    const double* __restrict__ vals, const int32_t* __restrict__ l_row_ptrs,
+    int32_t* __restrict__ l_cols, double* __restrict__ l_vals, bool diag_sqrt)
+{
+    for (int64_t row = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; row < n;
+         row += static_cast<int64_t>(gridDim.x) * block) {
+        int64_t il = l_row_ptrs[row];
+        double diag = 1.0;
+        const int32_t end = row_ptrs[row + 1];
+        for (int32_t k = row_ptrs[row]; k < end; ++k) {
+            const int32_t col = col_idxs[k];
+            if (col < row) {
+                l_cols[il] = col;
+                l_vals[il] = vals[k];
+                ++il;
+            } else if (col == row) {
+                diag = vals[k];
+            }
+        }
+        if (diag_sqrt) {
+            diag = sqrt(diag);
+            if (!isfinite(diag)) diag = 1.0;
+        }
+        l_cols[l_row_ptrs[row + 1] - 1] = static_cast<int32_t>(row);
+        l_vals[l_row_ptrs[row + 1] - 1] = diag;
+    }
+}
+
+__global__ __launch_bounds__(block) void par_ic_init_factor_kernel(
+    int64_t n, const int32_t* __restrict__ l_row_ptrs, const int32_t* __restrict__ l_cols,
+    double* __restrict__ l_vals)
+{
+    for (int64_t row = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; row < n;
+         row += static_cast<int64_t>(gridDim.x) * block) {
+        for (int32_t nz = l_row_ptrs[row]; nz < l_row_ptrs[row + 1]; ++nz) {
+            if (l_cols[nz] == row) {
+                const double d = sqrt(l_vals[nz]);
+                l_vals[nz] = isfinite(d) ? d : 1.0;
+            }
+        }
+    }
+}
+
+// one thread per stored entry of L; asynchronous (entries read whatever the
+// other threads have written so far), like the reference's GPU sweeps
+__global__ __launch_bounds__(block) void par_ic_sweep_kernel(
+    int64_t l_nnz, const int32_t* __restrict__ l_row_idxs, const double* __restrict__ a_vals,
+    const int32_t* __restrict__ l_row_ptrs, const int32_t* __restrict__ l_cols, double* l_vals)
+{
+    for (int64_t nz = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; nz < l_nnz;
+         nz += static_cast<int64_t>(gridDim.x) * block) {
+        const int32_t row = l_row_idxs[nz], col = l_cols[nz];
+        int32_t lb = l_row_ptrs[row], hb = l_row_ptrs[col];
+        const int32_t le = l_row_ptrs[row + 1], he = l_row_ptrs[col + 1];
+        double sum = 0.0;
+        while (lb < le && hb < he) {
+            const int32_t l_col = l_cols[lb], lh_row = l_cols[hb];
+            if (l_col == lh_row && l_col < col) sum += l_vals[lb] * l_vals[hb];
+            lb += (l_col <= lh_row);
+            hb += (lh_row <= l_col);
+        }
+        double nv = a_vals[nz] - sum;
+        if (row == col) {
+            nv = sqrt(nv);
+        } else {
+            nv = nv / l_vals[he - 1];
+        }
+        if (isfinite(nv)) l_vals[nz] = nv;
+    }
+}
+
 // ---- transpose ------------------------------------------------------------------
 
 __global__ __launch_bounds__(block) void count_cols_kernel(int64_t nnz,
@@ -334,6 +429,59 @@ extern "C" int gkomi_par_ilu_compute_l_u_factors_f64_i32(
         hipLaunchKernelGGL(par_ilu_sweep_kernel, dim3(grid_for(nnz, block, 1 << 16)), dim3(block), 0,
                            to_stream(s), nnz, coo_row_idxs, coo_col_idxs, coo_vals, l_row_ptrs,
                            l_col_idxs, l_vals, ut_row_ptrs, ut_col_idxs, ut_vals);
+    }
+    return check_launch();
+}
+
+extern "C" int gkomi_factorization_initialize_row_ptrs_l_i32(
+    gkomi_stream_t s, int64_t n, const int32_t* row_ptrs, const int32_t* col_idxs,
+    int32_t* l_row_ptrs, void* workspace, size_t workspace_bytes)
+{
+    if (n < 0) return GKOMI_EINVAL;
+    hipLaunchKernelGGL(count_l_kernel, dim3(grid_for(n + 1, block, 1 << 16)), dim3(block), 0,
+                       to_stream(s), n, row_ptrs, col_idxs, l_row_ptrs);
+    int err = check_launch();
+    if (err) return err;
+    return gkomi_prefix_sum_i32(s, l_row_ptrs, n + 1, workspace, workspace_bytes);
+}
+
+extern "C" int gkomi_factorization_initialize_l_f64_i32(
+    gkomi_stream_t s, int64_t n, const int32_t* row_ptrs, const int32_t* col_idxs,
+    const double* vals, const int32_t* l_row_ptrs, int32_t* l_col_idxs, double* l_vals,
+    int diag_sqrt)
+{
+    if (n < 0) return GKOMI_EINVAL;
+    if (n == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(initialize_l_kernel, dim3(grid_for(n, block, 1 << 16)), dim3(block), 0,
+                       to_stream(s), n, row_ptrs, col_idxs, vals, l_row_ptrs, l_col_idxs, l_vals,
+                       diag_sqrt != 0);
+    return check_launch();
+}
+
+extern "C" int gkomi_par_ic_init_factor_f64_i32(gkomi_stream_t s, int64_t n,
+                                                const int32_t* l_row_ptrs,
+                                                const int32_t* l_col_idxs, double* l_vals)
+{
+    if (n < 0) return GKOMI_EINVAL;
+    if (n == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(par_ic_init_factor_kernel, dim3(grid_for(n, block, 1 << 16)), dim3(block), 0,
+                       to_stream(s), n, l_row_ptrs, l_col_idxs, l_vals);
+    return check_launch();
+}
+
+extern "C" int gkomi_par_ic_compute_factor_f64_i32(gkomi_stream_t s, int64_t iterations,
+                                                   int64_t l_nnz, const int32_t* l_row_idxs,
+                                                   const double* a_lower_vals,
+                                                   const int32_t* l_row_ptrs,
+                                                   const int32_t* l_col_idxs, double* l_vals)
+{
+    if (iterations < 0 || l_nnz < 0) return GKOMI_EINVAL;
+    if (l_nnz == 0) return GKOMI_SUCCESS;
+    if (iterations == 0) iterations = 10;  // "Auto", as for ParILU
+    for (int64_t it = 0; it < iterations; ++it) {
+        hipLaunchKernelGGL(par_ic_sweep_kernel, dim3(grid_for(l_nnz, block, 1 << 16)), dim3(block), 0,
+                           to_stream(s), l_nnz, l_row_idxs, a_lower_vals, l_row_ptrs, l_col_idxs,
+                           l_vals);
     }
     return check_launch();
 }

@@ -149,6 +149,12 @@ int main()
             fcg->apply(b.get(), sol.get());
             report("fcg_jacobi_iters", A.get(), fcg->get_last_iteration_count(), fcg->has_converged());
             sol->fill(0.0);
+            auto c4 = crit();
+            auto iccg = gko::solver::Cg<double>::build().with_criteria(c4.first, c4.second)
+                            .with_preconditioner(gko::preconditioner::Ic<double, int>::build().with_factorization_iterations(10u).on(exec)).on(exec)->generate(A);
+            iccg->apply(b.get(), sol.get());
+            report("cg_ic_iters", A.get(), iccg->get_last_iteration_count(), iccg->has_converged());
+            sol->fill(0.0);
             auto c2 = crit();
             auto bicg = gko::solver::Bicgstab<double>::build().with_criteria(c2.first, c2.second)
                             .with_preconditioner(gko::preconditioner::Ilu<double, int>::build().with_factorization_iterations(20u).on(exec)).on(exec)->generate(B);

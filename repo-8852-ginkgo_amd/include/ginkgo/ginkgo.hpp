@@ -1649,6 +1649,109 @@ protected:
 };
 }  // namespace preconditioner
 
+// ---- ParIc + Ic (core/factorization/par_ic.cpp:70-145, include/ginkgo/core/preconditioner/ic.hpp) ------
+namespace factorization {
+template <typename V = double, typename I = int32>
+class ParIc {
+public:
+    using matrix_type = matrix::Csr<V, I>;
+    class Factory {
+    public:
+        Factory& with_iterations(size_type n) { iterations_ = n; return *this; }
+        Factory& with_skip_sorting(bool) { return *this; }
+        Factory& with_both_factors(bool) { return *this; }
+        std::shared_ptr<Factory> on(std::shared_ptr<const Executor> exec) const { auto f = std::make_shared<Factory>(*this); f->exec_ = std::move(exec); return f; }
+        std::unique_ptr<ParIc> generate(std::shared_ptr<const LinOp> A) const { return std::unique_ptr<ParIc>(new ParIc(exec_, iterations_, std::move(A))); }
+        std::shared_ptr<const Executor> exec_;
+        size_type iterations_{0};
+    };
+    static Factory build() { return Factory{}; }
+    std::shared_ptr<const matrix_type> get_l_factor() const { return l_; }
+    std::shared_ptr<const matrix_type> get_lt_factor() const { return lt_; }
+protected:
+    ParIc(std::shared_ptr<const Executor> exec, size_type iterations, std::shared_ptr<const LinOp> A)
+    {
+        detail::require_device(exec, "par_ic_factorization");
+        auto src = as<const matrix_type>(A.get());
+        const size_type n = src->get_size()[0];
+        if (n != src->get_size()[1]) throw DimensionMismatch(__FILE__, __LINE__, "ParIc needs a square matrix");
+        array<I> rp(exec, n + 1);
+        exec->copy(n + 1, src->get_const_row_ptrs(), rp.get_data());
+        size_type nnz = src->get_num_stored_elements();
+        array<char> fws(exec, gkomi_factorization_workspace_bytes(n));
+        int64_t missing = 0;
+        GKOMI_CALL(gkomi_factorization_count_missing_diagonal_i32(nullptr, n, n, rp.get_const_data(), src->get_const_col_idxs(), fws.get_data(), fws.get_num_elems(), &missing));
+        array<I> ci(exec, nnz + missing);
+        array<V> v(exec, nnz + missing);
+        if (missing) {
+            GKOMI_CALL(gkomi_factorization_add_diagonal_elements_f64_i32(nullptr, n, n, rp.get_data(), src->get_const_col_idxs(), src->get_const_values(), ci.get_data(), v.get_data(), fws.get_const_data()));
+        } else {
+            exec->copy(nnz, src->get_const_col_idxs(), ci.get_data());
+            exec->copy(nnz, src->get_const_values(), v.get_data());
+        }
+        array<I> lrp(exec, n + 1);
+        array<char> sws(exec, gkomi_prefix_sum_workspace_bytes(n + 1) + 8);
+        GKOMI_CALL(gkomi_factorization_initialize_row_ptrs_l_i32(nullptr, n, rp.get_const_data(), ci.get_const_data(), lrp.get_data(), sws.get_data(), sws.get_num_elems()));
+        const size_type lnnz = exec->copy_val_to_host(lrp.get_const_data() + n);
+        array<I> lc(exec, lnnz), rows(exec, lnnz);
+        array<V> lv(exec, lnnz);
+        GKOMI_CALL(gkomi_factorization_initialize_l_f64_i32(nullptr, n, rp.get_const_data(), ci.get_const_data(), v.get_const_data(), lrp.get_const_data(), lc.get_data(), lv.get_data(), 0));
+        array<V> a_vals(exec, lv);  // the COO copy of the lower triangle (par_ic.cpp:121-131)
+        GKOMI_CALL(gkomi_convert_ptrs_to_idxs_i32(nullptr, lrp.get_const_data(), n, rows.get_data()));
+        GKOMI_CALL(gkomi_par_ic_init_factor_f64_i32(nullptr, n, lrp.get_const_data(), lc.get_const_data(), lv.get_data()));
+        GKOMI_CALL(gkomi_par_ic_compute_factor_f64_i32(nullptr, iterations, lnnz, rows.get_const_data(), a_vals.get_const_data(), lrp.get_const_data(), lc.get_const_data(), lv.get_data()));
+        auto l = matrix_type::create(exec);
+        l->adopt(dim<2>(n, n), std::move(lrp), std::move(lc), std::move(lv));
+        lt_ = l->transpose();
+        l_ = std::move(l);
+    }
+    std::shared_ptr<matrix_type> l_, lt_;
+};
+}  // namespace factorization
+
+namespace preconditioner {
+// Ic::apply = L^-1 then L^-H (ic.hpp: two triangular solves, like Ilu)
+template <typename V = double, typename I = int32>
+class Ic : public LinOp {
+public:
+    class Factory : public LinOpFactory {
+    public:
+        Factory() : LinOpFactory(nullptr) {}
+        Factory& with_factorization_iterations(size_type n) { iterations_ = n; return *this; }
+        std::shared_ptr<Factory> on(std::shared_ptr<const Executor> exec) const { auto f = std::make_shared<Factory>(*this); f->exec_ = std::move(exec); return f; }
+        std::unique_ptr<Ic> generate(std::shared_ptr<const LinOp> A) const { return std::unique_ptr<Ic>(new Ic(this->exec_, iterations_, std::move(A))); }
+        std::unique_ptr<LinOp> generate_impl(std::shared_ptr<const LinOp> A) const override { return generate(std::move(A)); }
+        size_type iterations_{0};
+    };
+    static Factory build() { return Factory{}; }
+    std::shared_ptr<const LinOp> get_l_solver() const { return l_solver_; }
+    std::shared_ptr<const LinOp> get_lh_solver() const { return lh_solver_; }
+protected:
+    Ic(std::shared_ptr<const Executor> exec, size_type iterations, std::shared_ptr<const LinOp> A) : LinOp(exec, A->get_size())
+    {
+        auto fact = factorization::ParIc<V, I>::build().with_iterations(iterations).on(exec)->generate(std::move(A));
+        l_solver_ = solver::LowerTrs<V, I>::build().on(exec)->generate(fact->get_l_factor());
+        lh_solver_ = solver::UpperTrs<V, I>::build().on(exec)->generate(fact->get_lt_factor());
+    }
+    void apply_impl(const LinOp* b, LinOp* x) const override
+    {
+        auto db = matrix::detail_fmt::dense(b);
+        auto mid = matrix::Dense<V>::create(exec_, db->get_size());
+        l_solver_->apply(b, mid.get());
+        lh_solver_->apply(mid.get(), x);
+    }
+    void apply_impl(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const override
+    {
+        auto dx = matrix::detail_fmt::dense(x);
+        auto x_clone = dx->clone();
+        this->apply_impl(b, x_clone.get());
+        dx->scale(matrix::detail_fmt::dense(beta));
+        dx->add_scaled(matrix::detail_fmt::dense(alpha), x_clone.get());
+    }
+    std::shared_ptr<const LinOp> l_solver_, lh_solver_;
+};
+}  // namespace preconditioner
+
 }  // namespace gko
 
 #endif  // GKOMI_GINKGO_HPP_

@@ -75,3 +75,61 @@ def gpu_par_ilu(gk, torch, n, rpd, cid, vd, iterations=0):
     uc2, uv2 = torch.zeros_like(uc), torch.zeros_like(uv)
     gk.csr_transpose_f64_i32(s, n, n, unnz, utrp, utc, utv, urp2, uc2, uv2, tws, tb)
     return dict(A=(rpd, cid, vd), L=(lrp, lc, lv), U=(urp2, uc2, uv2), Ut=(utrp, utc, utv))
+
+
+def oracle_par_ic(oracle, n, rp, ci, v):
+    """ParIc::generate (core/factorization/par_ic.cpp:70-145) through the oracle:
+    add_diagonal_elements, initialize_row_ptrs_l, initialize_l, init_factor,
+    compute_factor, conj_transpose."""
+    rp = rp.copy()
+    nnz = int(rp[-1])
+    ncols = np.zeros(nnz + n, np.int32)
+    nvals = np.zeros(nnz + n)
+    new_nnz = int(oracle.ref_add_diagonal_elements(n, n, rp, ci if nnz else np.zeros(1, np.int32),
+                                                   v if nnz else np.zeros(1), ncols, nvals))
+    ci, v = ncols[:new_nnz].copy(), nvals[:new_nnz].copy()
+    lrp = np.zeros(n + 1, np.int32)
+    oracle.ref_initialize_row_ptrs_l(n, rp, ci, lrp)
+    lc, lv = np.zeros(lrp[-1], np.int32), np.zeros(lrp[-1])
+    oracle.ref_initialize_l(n, rp, ci, v, lrp, lc, lv, 0)
+    a_vals = lv.copy()
+    oracle.ref_par_ic_init_factor(n, lrp, lc, lv)
+    oracle.ref_par_ic_compute_factor(n, a_vals, lrp, lc, lv)
+    ltrp, ltc, ltv = np.zeros(n + 1, np.int32), np.zeros(lrp[-1], np.int32), np.zeros(lrp[-1])
+    oracle.ref_csr_transpose(n, n, lrp, lc, lv, ltrp, ltc, ltv)
+    return dict(L=(lrp, lc, lv), Lt=(ltrp, ltc, ltv))
+
+
+def gpu_par_ic(gk, torch, n, rpd, cid, vd, iterations=0):
+    """The same chain on the device (rpd modified in place: pass a clone)."""
+    s = torch.cuda.current_stream().cuda_stream
+    dv = rpd.device
+    nbytes = gk.factorization_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dv)
+    missing = ctypes.c_int64(0)
+    gk.factorization_count_missing_diagonal_i32(s, n, n, rpd, cid, ws, nbytes, ctypes.addressof(missing))
+    nnz = int(vd.numel())
+    if missing.value:
+        nc = torch.zeros(nnz + missing.value, dtype=torch.int32, device=dv)
+        nv = torch.zeros(nnz + missing.value, dtype=torch.float64, device=dv)
+        gk.factorization_add_diagonal_elements_f64_i32(s, n, n, rpd, cid, vd, nc, nv, ws)
+        cid, vd, nnz = nc, nv, nnz + missing.value
+    lrp = torch.zeros(n + 1, dtype=torch.int32, device=dv)
+    sb = gk.prefix_sum_workspace_bytes(n + 1)
+    sws = torch.empty(max(sb, 8), dtype=torch.uint8, device=dv)
+    gk.factorization_initialize_row_ptrs_l_i32(s, n, rpd, cid, lrp, sws, sb)
+    lnnz = int(lrp[n].item())
+    lc = torch.zeros(lnnz, dtype=torch.int32, device=dv)
+    lv = torch.zeros(lnnz, dtype=torch.float64, device=dv)
+    gk.factorization_initialize_l_f64_i32(s, n, rpd, cid, vd, lrp, lc, lv, 0)
+    a_vals = lv.clone()
+    rows = torch.zeros(max(lnnz, 1), dtype=torch.int32, device=dv)
+    gk.convert_ptrs_to_idxs_i32(s, lrp, n, rows)
+    gk.par_ic_init_factor_f64_i32(s, n, lrp, lc, lv)
+    gk.par_ic_compute_factor_f64_i32(s, iterations, lnnz, rows, a_vals, lrp, lc, lv)
+    tb = gk.csr_transpose_workspace_bytes(n)
+    tws = torch.empty(tb, dtype=torch.uint8, device=dv)
+    ltrp = torch.zeros(n + 1, dtype=torch.int32, device=dv)
+    ltc, ltv = torch.zeros_like(lc), torch.zeros_like(lv)
+    gk.csr_transpose_f64_i32(s, n, n, lnnz, lrp, lc, lv, ltrp, ltc, ltv, tws, tb)
+    return dict(L=(lrp, lc, lv), Lt=(ltrp, ltc, ltv))

@@ -91,6 +91,9 @@ def test_hot_path_tour(bins):
     for name in ("fcg_jacobi_iters", "bicgstab_ilu_iters", "cgs_ilu_iters"):
         assert kv[name][2] == "1" and float(kv[name][4]) < 1e-8, (name, kv[name])
     assert kv["fcg_jacobi_iters"][0] == kv["cg_jacobi_iters"][0]   # FCG = CG in exact arithmetic on an SPD matrix
+    assert kv["cg_ic_iters"][2] == "1" and float(kv["cg_ic_iters"][4]) < 1e-8
+    # (asynchronous sweeps: the factor, hence the count, varies a little from run to run)
+    assert int(kv["cg_ic_iters"][0]) < 0.7 * int(kv["cg_jacobi_iters"][0])
     # device assembly: duplicates summed, explicit zeros dropped, Csr::read on the device
     assert kv["assembly_nnz"][0] == kv["assembly_nnz"][2] and float(kv["assembly_nnz"][4]) == 0.0
     assert kv["dimension_check"] == ["ok"]
