@@ -506,6 +506,19 @@ int gkomi_matrix_data_sum_duplicates_f64_i32(
     int32_t* out_col_idxs, double* out_values, void* workspace,
     size_t workspace_bytes, int64_t* host_nnz);
 
+/* csr::sort_by_column_index / is_sorted_by_column_index
+ * (reference/matrix/csr_kernels.cpp:969-1009), the first step of the
+ * factorizations unless skip_sorting is set.  The sort is stable.
+ * is_sorted needs 4 bytes of workspace and blocks. */
+int gkomi_csr_sort_by_column_index_f64_i32(gkomi_stream_t s, int64_t nrows,
+                                           const int32_t* row_ptrs,
+                                           int32_t* col_idxs, double* vals);
+int gkomi_csr_is_sorted_by_column_index_i32(gkomi_stream_t s, int64_t nrows,
+                                            const int32_t* row_ptrs,
+                                            const int32_t* col_idxs,
+                                            void* workspace,
+                                            size_t workspace_bytes,
+                                            int* host_is_sorted);
 /* csr::transpose (reference/matrix/csr_kernels.cpp:551-586) */
 size_t gkomi_csr_transpose_workspace_bytes(int64_t ncols);
 int gkomi_csr_transpose_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols,

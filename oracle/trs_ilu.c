@@ -277,3 +277,34 @@ ORACLE_API void ref_par_ic_compute_factor(i64 n, const double* a_vals, const i32
         }
     }
 }
+
+/* csr::sort_by_column_index / is_sorted_by_column_index
+ * (reference/matrix/csr_kernels.cpp:969-1009); stable insertion sort (the
+ * reference's std::sort leaves duplicate columns in unspecified order) */
+ORACLE_API void ref_csr_sort_by_column_index(i64 nrows, const i32* row_ptrs, i32* col_idxs,
+                                             double* vals)
+{
+    for (i64 row = 0; row < nrows; ++row) {
+        for (i32 i = row_ptrs[row] + 1; i < row_ptrs[row + 1]; ++i) {
+            const i32 c = col_idxs[i];
+            const double v = vals[i];
+            i32 j = i - 1;
+            while (j >= row_ptrs[row] && col_idxs[j] > c) {
+                col_idxs[j + 1] = col_idxs[j];
+                vals[j + 1] = vals[j];
+                --j;
+            }
+            col_idxs[j + 1] = c;
+            vals[j + 1] = v;
+        }
+    }
+}
+
+ORACLE_API int ref_csr_is_sorted_by_column_index(i64 nrows, const i32* row_ptrs,
+                                                 const i32* col_idxs)
+{
+    for (i64 row = 0; row < nrows; ++row)
+        for (i32 k = row_ptrs[row] + 1; k < row_ptrs[row + 1]; ++k)
+            if (col_idxs[k - 1] > col_idxs[k]) return 0;
+    return 1;
+}

@@ -325,10 +325,66 @@ __global__ __launch_bounds__(block) void sort_rows_kernel(int64_t nrows,
     }
 }
 
+__global__ __launch_bounds__(block) void is_sorted_kernel(int64_t nrows,
+                                                         const int32_t* __restrict__ row_ptrs,
+                                                         const int32_t* __restrict__ cols,
+                                                         int* __restrict__ unsorted)
+{
+    for (int64_t row = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; row < nrows;
+         row += static_cast<int64_t>(gridDim.x) * block) {
+        for (int32_t k = row_ptrs[row] + 1; k < row_ptrs[row + 1]; ++k) {
+            if (cols[k - 1] > cols[k]) {
+                *unsorted = 1;  // benign race: everybody writes the same value
+                break;
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace gkomi
 
 using namespace gkomi;
+
+// csr::sort_by_column_index / is_sorted_by_column_index
+// (reference/matrix/csr_kernels.cpp:969-1009): one thread per row, stable
+// insertion sort (rows on this path are short; the reference's std::sort leaves
+// the order of duplicate columns unspecified)
+extern "C" int gkomi_csr_sort_by_column_index_f64_i32(gkomi_stream_t s, int64_t nrows,
+                                                      const int32_t* row_ptrs, int32_t* col_idxs,
+                                                      double* vals)
+{
+    if (nrows < 0) return GKOMI_EINVAL;
+    if (nrows == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(sort_rows_kernel, dim3(grid_for(nrows, block, 1 << 16)), dim3(block), 0,
+                       to_stream(s), nrows, row_ptrs, col_idxs, vals);
+    return check_launch();
+}
+
+extern "C" int gkomi_csr_is_sorted_by_column_index_i32(gkomi_stream_t s, int64_t nrows,
+                                                       const int32_t* row_ptrs,
+                                                       const int32_t* col_idxs, void* workspace,
+                                                       size_t workspace_bytes, int* host_is_sorted)
+{
+    if (nrows < 0 || host_is_sorted == nullptr) return GKOMI_EINVAL;
+    *host_is_sorted = 1;
+    if (nrows == 0) return GKOMI_SUCCESS;
+    if (workspace == nullptr || workspace_bytes < sizeof(int)) return GKOMI_EWORKSPACE;
+    hipStream_t stream = to_stream(s);
+    int* flag = static_cast<int*>(workspace);
+    int err = static_cast<int>(hipMemsetAsync(flag, 0, sizeof(int), stream));
+    if (err) return err;
+    hipLaunchKernelGGL(is_sorted_kernel, dim3(grid_for(nrows, block, 1 << 16)), dim3(block), 0, stream,
+                       nrows, row_ptrs, col_idxs, flag);
+    err = check_launch();
+    if (err) return err;
+    int unsorted = 0;
+    err = static_cast<int>(hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (err) return err;
+    err = static_cast<int>(hipStreamSynchronize(stream));
+    *host_is_sorted = unsorted ? 0 : 1;
+    return err;
+}
 
 extern "C" size_t gkomi_factorization_workspace_bytes(int64_t nrows)
 {

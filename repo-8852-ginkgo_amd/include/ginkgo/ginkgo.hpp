@@ -840,6 +840,20 @@ public:
         t->max_row_nnz_ = -1;
         return t;
     }
+    // csr::sort_by_column_index / is_sorted_by_column_index (core/matrix/csr.cpp)
+    void sort_by_column_index()
+    {
+        detail::require_device(exec_, "csr::sort_by_column_index");
+        GKOMI_CALL(gkomi_csr_sort_by_column_index_f64_i32(nullptr, size_[0], get_const_row_ptrs(), get_col_idxs(), get_values()));
+    }
+    bool is_sorted_by_column_index() const
+    {
+        detail::require_device(exec_, "csr::is_sorted_by_column_index");
+        array<char> ws(exec_, 8);
+        int sorted = 1;
+        GKOMI_CALL(gkomi_csr_is_sorted_by_column_index_i32(nullptr, size_[0], get_const_row_ptrs(), get_const_col_idxs(), ws.get_data(), ws.get_num_elems(), &sorted));
+        return sorted != 0;
+    }
     // arrays handed over by kernels that size their own outputs
     void adopt(const dim<2>& size, array<I> rp, array<I> ci, array<V> v)
     {

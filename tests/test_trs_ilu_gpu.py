@@ -198,3 +198,23 @@ def test_transpose_bitexact_vs_oracle(gk, oracle):
         tv = torch.zeros(nnz, dtype=torch.float64, device="cuda:0")
         gk.csr_transpose_f64_i32(stream_ptr(), nr, nc, nnz, dev(rp), dev(ci), dev(v), trp, tc, tv, ws, nb)
         assert np.array_equal(host(trp), etrp) and np.array_equal(host(tc), etc_) and np.array_equal(host(tv), etv)
+
+
+def test_sort_by_column_index_and_is_sorted(gk, oracle):
+    """csr::sort_by_column_index / is_sorted_by_column_index (csr_kernels.cpp:969-1009)"""
+    import ctypes
+    n = 2000
+    rp, ci, v = matgen.random_csr(n, 1500, 0, 40, seed=9, sort=False)
+    ws = torch.zeros(8, dtype=torch.uint8, device="cuda:0")
+    flag = ctypes.c_int(-1)
+    gk.csr_is_sorted_by_column_index_i32(stream_ptr(), n, dev(rp), dev(ci), ws, 8, ctypes.addressof(flag))
+    assert flag.value == 0 == oracle.ref_csr_is_sorted_by_column_index(n, rp, ci)
+    ec, ev = ci.copy(), v.copy()
+    oracle.ref_csr_sort_by_column_index(n, rp, ec, ev)
+    cd, vd = dev(ci), dev(v)
+    gk.csr_sort_by_column_index_f64_i32(stream_ptr(), n, dev(rp), cd, vd)
+    assert np.array_equal(host(cd), ec) and host(vd).tobytes() == ev.tobytes()
+    gk.csr_is_sorted_by_column_index_i32(stream_ptr(), n, dev(rp), cd, ws, 8, ctypes.addressof(flag))
+    assert flag.value == 1 == oracle.ref_csr_is_sorted_by_column_index(n, rp, ec)
+    gk.csr_is_sorted_by_column_index_i32(stream_ptr(), 0, dev(rp[:1]), cd, ws, 8, ctypes.addressof(flag))
+    assert flag.value == 1
