@@ -1,0 +1,239 @@
+"""gko::matrix::{Csr, Coo, Ell, Sellp, Hybrid} over the C ABI for Python callers
+(tests, bench, tools/benchmark_*.py): device arrays are torch tensors, every
+conversion and apply is a gkomi_* kernel -- no CPU fallback.  Conversions
+follow core/matrix/csr.cpp:257-405 (the sizes the reference reads back with
+exec->copy_val_to_host are read back here too)."""
+import ctypes
+
+import numpy as np
+import torch
+
+I32, I64, F64, U8 = torch.int32, torch.int64, torch.float64, torch.uint8
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _scalar(dev, x):
+    return None if x is None else torch.tensor([float(x)], dtype=F64, device=dev)
+
+
+class Csr:
+    name = "csr"
+
+    def __init__(self, gk, nrows, ncols, row_ptrs, col_idxs, vals, strategy=0):
+        self.gk, self.nrows, self.ncols = gk, int(nrows), int(ncols)
+        self.row_ptrs, self.col_idxs, self.vals = row_ptrs, col_idxs, vals
+        self.nnz = int(vals.numel())
+        self.strategy = strategy
+        self._max_row_nnz = None
+
+    @classmethod
+    def from_host(cls, gk, nrows, ncols, row_ptrs, col_idxs, vals, device="cuda:0", strategy=0):
+        d = lambda a, t: torch.from_numpy(np.ascontiguousarray(a, dtype=t)).to(device)
+        return cls(gk, nrows, ncols, d(row_ptrs, np.int32), d(col_idxs, np.int32), d(vals, np.float64), strategy)
+
+    @classmethod
+    def from_triplets(cls, gk, nrows, ncols, rows, cols, vals, sum_duplicates=True, strategy=0):
+        """Csr::read(device_matrix_data): sort (+ sum duplicates) on the device, then idxs -> ptrs"""
+        s = _stream(vals)
+        rows, cols, vals = rows.clone(), cols.clone(), vals.clone()
+        nnz = int(vals.numel())
+        nb = gk.matrix_data_workspace_bytes(nnz)
+        ws = torch.empty(max(nb, 8), dtype=U8, device=vals.device)
+        gk.matrix_data_sort_row_major_f64_i32(s, nnz, rows, cols, vals, ws, nb)
+        if sum_duplicates and nnz:
+            orr, oc, ov = torch.empty_like(rows), torch.empty_like(cols), torch.empty_like(vals)
+            kept = ctypes.c_int64(0)
+            gk.matrix_data_sum_duplicates_f64_i32(s, nnz, rows, cols, vals, orr, oc, ov, ws, nb, ctypes.addressof(kept))
+            rows, cols, vals = orr[:kept.value], oc[:kept.value], ov[:kept.value]
+            nnz = kept.value
+        ptrs = torch.zeros(nrows + 1, dtype=I32, device=vals.device)
+        pb = gk.prefix_sum_workspace_bytes(nrows + 1)
+        pws = torch.empty(max(pb, 8), dtype=U8, device=vals.device)
+        gk.convert_idxs_to_ptrs_i32(s, rows, nnz, nrows, ptrs, pws, pb)
+        return cls(gk, nrows, ncols, ptrs, cols.contiguous(), vals.contiguous(), strategy)
+
+    def storage_bytes(self):
+        return 4 * (self.nrows + 1) + 12 * self.nnz
+
+    def max_row_nnz(self):
+        if self._max_row_nnz is None:
+            mx = torch.zeros(1, dtype=I32, device=self.vals.device)
+            self.gk.csr_max_row_nnz_i32(_stream(self.vals), self.nrows, self.row_ptrs, mx)
+            self._max_row_nnz = int(mx.item())
+        return self._max_row_nnz
+
+    def apply(self, b, x, alpha=None, beta=None):
+        dv = self.vals.device
+        self.gk.csr_spmv_f64_i32(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.nnz, self.row_ptrs,
+                                 self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0), _scalar(dv, alpha),
+                                 _scalar(dv, beta), self.strategy, self.max_row_nnz())
+        return x
+
+    def row_idxs(self):
+        rows = torch.zeros(max(self.nnz, 1), dtype=I32, device=self.vals.device)
+        self.gk.convert_ptrs_to_idxs_i32(_stream(self.vals), self.row_ptrs, self.nrows, rows)
+        return rows
+
+    def to(self, fmt, **kw):
+        if fmt == "csr":
+            return self
+        return {"coo": Coo, "ell": Ell, "sellp": Sellp, "hybrid": Hybrid}[fmt].from_csr(self, **kw)
+
+
+class Coo:
+    name = "coo"
+
+    def __init__(self, csr, row_idxs):
+        self.gk, self.nrows, self.ncols, self.nnz = csr.gk, csr.nrows, csr.ncols, csr.nnz
+        self.row_idxs, self.col_idxs, self.vals = row_idxs, csr.col_idxs, csr.vals
+
+    @classmethod
+    def from_csr(cls, csr):
+        return cls(csr, csr.row_idxs())
+
+    def storage_bytes(self):
+        return 16 * self.nnz
+
+    def apply(self, b, x, alpha=None, beta=None):
+        dv = self.vals.device
+        self.gk.coo_spmv_f64_i32(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.nnz, self.row_idxs,
+                                 self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0), _scalar(dv, alpha),
+                                 _scalar(dv, beta))
+        return x
+
+
+class Ell:
+    name = "ell"
+
+    def __init__(self, gk, nrows, ncols, k, stride, col_idxs, vals):
+        self.gk, self.nrows, self.ncols, self.k, self.stride = gk, nrows, ncols, k, stride
+        self.col_idxs, self.vals = col_idxs, vals
+
+    @classmethod
+    def from_csr(cls, csr, stride=None):
+        k = csr.max_row_nnz()
+        stride = csr.nrows if stride is None else stride
+        dv = csr.vals.device
+        cols = torch.full((max(stride * k, 1),), -1, dtype=I32, device=dv)
+        vals = torch.zeros(max(stride * k, 1), dtype=F64, device=dv)
+        csr.gk.csr_convert_to_ell_f64_i32(_stream(vals), csr.nrows, csr.row_ptrs, csr.col_idxs, csr.vals, k, stride,
+                                          cols, vals)
+        return cls(csr.gk, csr.nrows, csr.ncols, k, stride, cols, vals)
+
+    def storage_bytes(self):
+        return 12 * self.stride * self.k
+
+    def apply(self, b, x, alpha=None, beta=None):
+        dv = self.vals.device
+        self.gk.ell_spmv_f64_i32(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.k, self.stride,
+                                 self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0), _scalar(dv, alpha),
+                                 _scalar(dv, beta))
+        return x
+
+
+class Sellp:
+    name = "sellp"
+
+    def __init__(self, gk, nrows, ncols, slice_size, sets, lens, col_idxs, vals):
+        self.gk, self.nrows, self.ncols, self.slice_size = gk, nrows, ncols, slice_size
+        self.sets, self.lens, self.col_idxs, self.vals = sets, lens, col_idxs, vals
+
+    @classmethod
+    def from_csr(cls, csr, slice_size=64, stride_factor=1):
+        gk, dv = csr.gk, csr.vals.device
+        s = _stream(csr.vals)
+        nsl = (csr.nrows + slice_size - 1) // slice_size
+        sets = torch.zeros(nsl + 1, dtype=I64, device=dv)
+        lens = torch.zeros(max(nsl, 1), dtype=I64, device=dv)
+        nb = gk.prefix_sum_workspace_bytes(nsl + 1)
+        ws = torch.empty(max(nb, 8), dtype=U8, device=dv)
+        gk.sellp_compute_slice_sets_i32(s, csr.row_ptrs, csr.nrows, slice_size, stride_factor, sets, lens, ws, nb)
+        total = int(sets[nsl].item()) * slice_size
+        cols = torch.full((max(total, 1),), -1, dtype=I32, device=dv)
+        vals = torch.zeros(max(total, 1), dtype=F64, device=dv)
+        gk.csr_convert_to_sellp_f64_i32(s, csr.nrows, csr.row_ptrs, csr.col_idxs, csr.vals, slice_size, sets, lens,
+                                        cols, vals)
+        return cls(gk, csr.nrows, csr.ncols, slice_size, sets, lens, cols, vals)
+
+    def storage_bytes(self):
+        return 12 * int(self.vals.numel()) + 16 * int(self.lens.numel()) + 8
+
+    def apply(self, b, x, alpha=None, beta=None):
+        dv = self.vals.device
+        self.gk.sellp_spmv_f64_i32(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.slice_size, self.sets,
+                                   self.lens, self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0),
+                                   _scalar(dv, alpha), _scalar(dv, beta))
+        return x
+
+
+class Hybrid:
+    """strategy kinds as GKOMI_HYBRID_* (include/gkomi.h); 4 = automatic"""
+    name = "hybrid"
+
+    def __init__(self, gk, nrows, ncols, ell_lim, ell_cols, ell_vals, coo_nnz, coo_rows, coo_cols, coo_vals):
+        self.gk, self.nrows, self.ncols, self.ell_lim = gk, nrows, ncols, ell_lim
+        self.ell_cols, self.ell_vals = ell_cols, ell_vals
+        self.coo_nnz, self.coo_rows, self.coo_cols, self.coo_vals = coo_nnz, coo_rows, coo_cols, coo_vals
+
+    @classmethod
+    def from_csr(cls, csr, kind=4, percent=0.8, ratio=1e-4, num_columns=0):
+        gk, dv = csr.gk, csr.vals.device
+        s = _stream(csr.vals)
+        n = csr.nrows
+        res = ctypes.c_int64(0)
+        gk.hybrid_ell_width_i32(s, csr.row_ptrs, n, kind, percent, ratio, num_columns, ctypes.addressof(res))
+        ell_lim = min(int(res.value), csr.ncols)
+        crp = torch.zeros(n + 1, dtype=I64, device=dv)
+        nb = gk.prefix_sum_workspace_bytes(n + 1)
+        ws = torch.empty(max(nb, 8), dtype=U8, device=dv)
+        gk.hybrid_compute_coo_row_ptrs_i32(s, csr.row_ptrs, n, ell_lim, crp, ws, nb)
+        coo_nnz = int(crp[n].item())
+        ell_cols = torch.full((max(ell_lim * n, 1),), -1, dtype=I32, device=dv)
+        ell_vals = torch.zeros(max(ell_lim * n, 1), dtype=F64, device=dv)
+        cr = torch.zeros(max(coo_nnz, 1), dtype=I32, device=dv)
+        cc = torch.zeros(max(coo_nnz, 1), dtype=I32, device=dv)
+        cv = torch.zeros(max(coo_nnz, 1), dtype=F64, device=dv)
+        gk.csr_convert_to_hybrid_f64_i32(s, n, csr.row_ptrs, csr.col_idxs, csr.vals, crp, ell_lim, n, ell_cols,
+                                         ell_vals, cr, cc, cv)
+        return cls(gk, n, csr.ncols, ell_lim, ell_cols, ell_vals, coo_nnz, cr, cc, cv)
+
+    def storage_bytes(self):
+        return 12 * self.ell_lim * self.nrows + 16 * self.coo_nnz
+
+    def apply(self, b, x, alpha=None, beta=None):
+        dv = self.ell_vals.device
+        self.gk.hybrid_spmv_f64_i32(_stream(self.ell_vals), self.nrows, self.ncols, b.shape[1], self.ell_lim,
+                                    self.nrows, self.ell_cols, self.ell_vals, self.coo_nnz, self.coo_rows,
+                                    self.coo_cols, self.coo_vals, b, b.stride(0), x, x.stride(0), _scalar(dv, alpha),
+                                    _scalar(dv, beta))
+        return x
+
+
+FORMATS = ("csr", "coo", "ell", "sellp", "hybrid")
+
+
+def read_mtx(gk, path, device="cuda:0"):
+    """MatrixMarket coordinate file -> Csr, assembled on the device (symmetric
+    storage expanded, duplicates summed, row-major sorted)."""
+    with open(path) as f:
+        header = f.readline().lower().split()
+        assert header[:3] == ["%%matrixmarket", "matrix", "coordinate"], "coordinate MatrixMarket files only"
+        field, symmetry = header[3], header[4]
+        line = f.readline()
+        while line.startswith("%"):
+            line = f.readline()
+        nrows, ncols, nnz = (int(t) for t in line.split())
+        data = np.loadtxt(f, ndmin=2) if nnz else np.zeros((0, 3))
+    rows = data[:, 0].astype(np.int32) - 1
+    cols = data[:, 1].astype(np.int32) - 1
+    vals = data[:, 2].astype(np.float64) if field != "pattern" else np.ones(len(rows))
+    if symmetry in ("symmetric", "skew-symmetric"):
+        off = rows != cols
+        sign = -1.0 if symmetry == "skew-symmetric" else 1.0
+        rows, cols, vals = (np.concatenate([rows, cols[off]]), np.concatenate([cols, rows[off]]),
+                            np.concatenate([vals, sign * vals[off]]))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return Csr.from_triplets(gk, nrows, ncols, t(rows), t(cols), t(vals))

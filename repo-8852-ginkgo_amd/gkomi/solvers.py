@@ -175,3 +175,81 @@ def gmres_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, krylov_dim=100, max_
     return {"x": x2 if b.dim() > 1 else x2.reshape(n), "iterations": int(info[0]), "converged": bool(info[1]),
             "residual_norm": res, "baseline_norm": base,
             "rel_residual": float(np.max(res / np.where(base == 0, 1.0, base)))}
+
+
+def _with_diagonal(gk, n, row_ptrs, col_idxs, vals):
+    """factorization::add_diagonal_elements on a working copy (par_ilu.cpp:93-95)"""
+    s = torch.cuda.current_stream().cuda_stream
+    dv = vals.device
+    rp = row_ptrs.clone()
+    nb = gk.factorization_workspace_bytes(n)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dv)
+    missing = ctypes.c_int64(0)
+    gk.factorization_count_missing_diagonal_i32(s, n, n, rp, col_idxs, ws, nb, ctypes.addressof(missing))
+    if not missing.value:
+        return rp, col_idxs, vals
+    nnz = int(vals.numel()) + missing.value
+    nc = torch.zeros(nnz, dtype=torch.int32, device=dv)
+    nv = torch.zeros(nnz, dtype=torch.float64, device=dv)
+    gk.factorization_add_diagonal_elements_f64_i32(s, n, n, rp, col_idxs, vals, nc, nv, ws)
+    return rp, nc, nv
+
+
+def _transpose(gk, n, rp, ci, v):
+    s = torch.cuda.current_stream().cuda_stream
+    tb = gk.csr_transpose_workspace_bytes(n)
+    tws = torch.empty(tb, dtype=torch.uint8, device=v.device)
+    trp = torch.zeros(n + 1, dtype=torch.int32, device=v.device)
+    tc, tv = torch.zeros_like(ci), torch.zeros_like(v)
+    gk.csr_transpose_f64_i32(s, n, n, int(v.numel()), rp, ci, v, trp, tc, tv, tws, tb)
+    return trp, tc, tv
+
+
+def par_ilu_generate(gk, n, row_ptrs, col_idxs, vals, iterations=0, nrhs=1):
+    """preconditioner::Ilu over factorization::ParIlu (core/factorization/par_ilu.cpp:74-163):
+    returns the Preconditioner (L^-1 then U^-1); .L / .U hold the factors."""
+    s = torch.cuda.current_stream().cuda_stream
+    dv = vals.device
+    rp, ci, v = _with_diagonal(gk, n, row_ptrs, col_idxs, vals)
+    nnz = int(v.numel())
+    lrp = torch.zeros(n + 1, dtype=torch.int32, device=dv)
+    urp = torch.zeros(n + 1, dtype=torch.int32, device=dv)
+    sb = gk.prefix_sum_workspace_bytes(n + 1)
+    sws = torch.empty(max(sb, 8), dtype=torch.uint8, device=dv)
+    gk.factorization_initialize_row_ptrs_l_u_i32(s, n, rp, ci, lrp, urp, sws, sb)
+    lnnz, unnz = int(lrp[n].item()), int(urp[n].item())
+    lc, lv = torch.zeros(lnnz, dtype=torch.int32, device=dv), torch.zeros(lnnz, dtype=torch.float64, device=dv)
+    uc, uv = torch.zeros(unnz, dtype=torch.int32, device=dv), torch.zeros(unnz, dtype=torch.float64, device=dv)
+    gk.factorization_initialize_l_u_f64_i32(s, n, rp, ci, v, lrp, lc, lv, urp, uc, uv)
+    utrp, utc, utv = _transpose(gk, n, urp, uc, uv)
+    rows = torch.zeros(max(nnz, 1), dtype=torch.int32, device=dv)
+    gk.convert_ptrs_to_idxs_i32(s, rp, n, rows)
+    gk.par_ilu_compute_l_u_factors_f64_i32(s, iterations, nnz, rows, ci, v, lrp, lc, lv, utrp, utc, utv)
+    U = _transpose(gk, n, utrp, utc, utv)
+    p = ilu_from_factors(gk, n, (lrp, lc, lv), U, nrhs=nrhs)
+    p.L, p.U = (lrp, lc, lv), U
+    return p
+
+
+def par_ic_generate(gk, n, row_ptrs, col_idxs, vals, iterations=0, nrhs=1):
+    """preconditioner::Ic over factorization::ParIc (core/factorization/par_ic.cpp:70-145):
+    L^-1 then L^-T through the triangular solves; .L / .Lt hold the factors."""
+    s = torch.cuda.current_stream().cuda_stream
+    dv = vals.device
+    rp, ci, v = _with_diagonal(gk, n, row_ptrs, col_idxs, vals)
+    lrp = torch.zeros(n + 1, dtype=torch.int32, device=dv)
+    sb = gk.prefix_sum_workspace_bytes(n + 1)
+    sws = torch.empty(max(sb, 8), dtype=torch.uint8, device=dv)
+    gk.factorization_initialize_row_ptrs_l_i32(s, n, rp, ci, lrp, sws, sb)
+    lnnz = int(lrp[n].item())
+    lc, lv = torch.zeros(lnnz, dtype=torch.int32, device=dv), torch.zeros(lnnz, dtype=torch.float64, device=dv)
+    gk.factorization_initialize_l_f64_i32(s, n, rp, ci, v, lrp, lc, lv, 0)
+    a_vals = lv.clone()
+    rows = torch.zeros(max(lnnz, 1), dtype=torch.int32, device=dv)
+    gk.convert_ptrs_to_idxs_i32(s, lrp, n, rows)
+    gk.par_ic_init_factor_f64_i32(s, n, lrp, lc, lv)
+    gk.par_ic_compute_factor_f64_i32(s, iterations, lnnz, rows, a_vals, lrp, lc, lv)
+    Lt = _transpose(gk, n, lrp, lc, lv)
+    p = ilu_from_factors(gk, n, (lrp, lc, lv), Lt, nrhs=nrhs)
+    p.L, p.Lt = (lrp, lc, lv), Lt
+    return p
