@@ -573,9 +573,12 @@ int gkomi_cg_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
  * {Bicgstab,Fcg,Cgs}::apply_dense_impl (core/solver/bicgstab.cpp:107-234,
  * fcg.cpp:104-196, cgs.cpp:107-205) for a CSR matrix, an optional
  * preconditioner and Combined(Iteration(max_iters), ResidualNorm(reduction,
- * baseline)), checked on the host where the reference checks it; arguments and
- * host_info as for gkomi_gmres_solve_f64_i32, workspace
- * gkomi_krylov_workspace_bytes(n, nrhs). */
+ * baseline)), evaluated on the device at every point where the reference
+ * evaluates it (the statuses stop the columns at once); the host looks at the
+ * outcome every `check_every` evaluations (>= 1), the iterations launched
+ * meanwhile change nothing, and the reported iteration count is the one the
+ * device recorded.  Other arguments and host_info as for
+ * gkomi_gmres_solve_f64_i32, workspace gkomi_krylov_workspace_bytes(n, nrhs). */
 int gkomi_bicgstab_initialize_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
     const double* b, int64_t b_stride, double* r, int64_t r_stride, double*
     rr, int64_t rr_stride, double* y, int64_t y_stride, double* s_vec, int64_t
@@ -637,19 +640,19 @@ int gkomi_bicgstab_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
     int64_t nnz, const int32_t* row_ptrs, const int32_t* col_idxs, const
     double* vals, int spmv_strategy, int64_t max_row_nnz_hint, gkomi_apply_fn
     precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
-    double reduction_factor, int baseline, void* workspace, size_t
+    double reduction_factor, int baseline, int64_t check_every, void* workspace, size_t
     workspace_bytes, double* host_info);
 int gkomi_fcg_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t
     nnz, const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
     int spmv_strategy, int64_t max_row_nnz_hint, gkomi_apply_fn precond, void*
     precond_ctx, const double* b, double* x, int64_t max_iters, double
-    reduction_factor, int baseline, void* workspace, size_t workspace_bytes,
+    reduction_factor, int baseline, int64_t check_every, void* workspace, size_t workspace_bytes,
     double* host_info);
 int gkomi_cgs_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t
     nnz, const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
     int spmv_strategy, int64_t max_row_nnz_hint, gkomi_apply_fn precond, void*
     precond_ctx, const double* b, double* x, int64_t max_iters, double
-    reduction_factor, int baseline, void* workspace, size_t workspace_bytes,
+    reduction_factor, int baseline, int64_t check_every, void* workspace, size_t workspace_bytes,
     double* host_info);
 
 /* Partition metadata on HOST arrays (O(#ranges); core/distributed/matrix.cpp

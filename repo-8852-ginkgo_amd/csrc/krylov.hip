@@ -266,6 +266,24 @@ __global__ void bicgstab_omega_kernel(int64_t nrhs, double* omega, const double*
     }
 }
 
+// deferred criterion: the device remembers where every column had stopped; the
+// host looks only every few iterations (the step kernels skip stopped columns,
+// so the extra iterations launched meanwhile change nothing)
+struct stop_record {
+    long long iter;
+    int phase;
+    int pad_;
+};
+
+__global__ void record_stop_kernel(const uint8_t* __restrict__ flags, long long iter, int phase,
+                                   stop_record* __restrict__ rec)
+{
+    if (flags[0] != 0 && rec->iter < 0) {
+        rec->iter = iter;
+        rec->phase = phase;
+    }
+}
+
 bool bad_dims(int64_t n, int64_t nrhs) { return n < 0 || nrhs < 0; }
 dim3 grid_of(int64_t n, int64_t nrhs) { return dim3(static_cast<unsigned>(ceildiv(std::max<int64_t>(n * nrhs, nrhs), block))); }
 
@@ -291,7 +309,7 @@ solver_layout make_solver_layout(int64_t n, int64_t nrhs, int nvec)
     };
     for (int k = 0; k < nvec; ++k) l.vec[k] = take(sizeof(double) * static_cast<size_t>(n) * nrhs + 8);
     // 10 scalar rows + statuses + flags
-    l.small = take(sizeof(double) * 10 * nrhs + 2 * static_cast<size_t>(nrhs) + 64);
+    l.small = take(sizeof(double) * 10 * nrhs + 2 * static_cast<size_t>(nrhs) + 128);
     l.red = take(gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8);
     l.total = off;
     return l;
@@ -347,25 +365,54 @@ struct driver_common {
         }
         return gkomi_dense_fill_f64(s, 1, nrhs, orig_tau, nrhs, 1.0);
     }
-    // Combined(Iteration [id 1], ResidualNorm [id 1]) on `residual`; stop = all stopped
-    int check(int64_t iter, const double* residual, bool set_finalized, bool* stop, bool* one_changed)
+    stop_record* record = nullptr;  // device
+    int64_t check_every = 1;
+    int64_t unpolled = 0;
+    stop_record host_record{-1, 0, 0};
+
+    int poll()
     {
+        unpolled = 0;
+        GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&host_record, record, sizeof(stop_record),
+                                                  hipMemcpyDeviceToHost, stream)));
+        return static_cast<int>(hipStreamSynchronize(stream));
+    }
+    // Combined(Iteration [id 1], ResidualNorm [id 1]) on `residual`; *stop = every
+    // column has stopped.  The criterion itself is evaluated on the device at
+    // every call, exactly where the reference evaluates it; the host learns the
+    // outcome every `check_every` calls (stop_iter() is then the iteration the
+    // device recorded, not the current one).
+    int check(int64_t iter, const double* residual, bool set_finalized, int phase, bool* stop)
+    {
+        *stop = false;
         if (iter >= max_iters) {
-            GKOMI_TRY(gkomi_set_all_statuses(s, nrhs, 1, set_finalized ? 1 : 0, stop_status));
+            GKOMI_TRY(poll());  // converged during the iterations not looked at yet?
+            if (host_record.iter < 0) {
+                GKOMI_TRY(gkomi_set_all_statuses(s, nrhs, 1, set_finalized ? 1 : 0, stop_status));
+                converged = 0;
+                host_record.iter = iter;
+                host_record.phase = phase;
+            } else {
+                converged = 1;
+            }
             *stop = true;
-            *one_changed = true;
-            converged = 0;
             return 0;
         }
         GKOMI_TRY(gkomi_dense_compute_norm2_f64(s, n, nrhs, residual, nrhs, tau, red, red_bytes));
         GKOMI_TRY(gkomi_residual_norm_f64(s, nrhs, tau, orig_tau, reduction, 1,
-                                          set_finalized ? 1 : 0, stop_status, dev_flags,
-                                          host_flags));
-        *stop = host_flags[0] != 0;
-        *one_changed = host_flags[1] != 0;
-        converged = *stop ? 1 : 0;
+                                          set_finalized ? 1 : 0, stop_status, dev_flags, nullptr));
+        hipLaunchKernelGGL(record_stop_kernel, dim3(1), dim3(1), 0, stream, dev_flags,
+                           static_cast<long long>(iter), phase, record);
+        if (++unpolled >= check_every) {
+            GKOMI_TRY(poll());
+            if (host_record.iter >= 0) {
+                converged = 1;
+                *stop = true;
+            }
+        }
         return 0;
     }
+    int64_t stop_iter() const { return static_cast<int64_t>(host_record.iter); }
     int finish(int64_t iter, const double* residual, double* host_info)
     {
         if (host_info != nullptr) {
@@ -387,7 +434,7 @@ struct driver_common {
 int make_common(driver_common& c, gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz,
                 const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
                 int strategy, int64_t hint, gkomi_apply_fn precond, void* precond_ctx,
-                int64_t max_iters, double reduction, int baseline, char* ws,
+                int64_t max_iters, double reduction, int baseline, int64_t check_every, char* ws,
                 const solver_layout& l, double** scalars)
 {
     if (n < 0 || nrhs <= 0 || max_iters < 0 || baseline < 0 || baseline > 2) return GKOMI_EINVAL;
@@ -406,6 +453,11 @@ int make_common(driver_common& c, gkomi_stream_t s, int64_t n, int64_t nrhs, int
     *scalars = small + 4 * nrhs;  // 6 rows for the solver's own scalars
     c.stop_status = reinterpret_cast<uint8_t*>(small + 10 * nrhs);
     c.dev_flags = c.stop_status + nrhs + (8 - nrhs % 8) % 8;
+    c.record = reinterpret_cast<stop_record*>(c.dev_flags + 16);
+    c.check_every = check_every < 1 ? 1 : check_every;
+    const stop_record init{-1, 0, 0};
+    if (int err = static_cast<int>(hipMemcpyAsync(c.record, &init, sizeof(init), hipMemcpyHostToDevice, c.stream))) return err;
+    if (int err = static_cast<int>(hipStreamSynchronize(c.stream))) return err;  // `init` is a stack object
     c.red = ws + l.red;
     c.red_bytes = gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8;
     return 0;
@@ -624,15 +676,15 @@ extern "C" size_t gkomi_krylov_workspace_bytes(int64_t n, int64_t nrhs)
     double* sc = nullptr;                                                                        \
     GKOMI_TRY(make_common(c, s, n, nrhs, nnz, row_ptrs, col_idxs, vals, spmv_strategy,           \
                           max_row_nnz_hint, precond, precond_ctx, max_iters, reduction_factor,   \
-                          baseline, ws, l, &sc));                                                \
+                          baseline, check_every, ws, l, &sc));                                   \
     auto V = [&](int k) { return reinterpret_cast<double*>(ws + l.vec[k]); }
 
 extern "C" int gkomi_bicgstab_solve_f64_i32(
     gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
     const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
     gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
-    double reduction_factor, int baseline, void* workspace, size_t workspace_bytes,
-    double* host_info)
+    double reduction_factor, int baseline, int64_t check_every, void* workspace,
+    size_t workspace_bytes, double* host_info)
 {
     GKOMI_DRIVER_PROLOGUE(8);
     double *r = V(0), *z = V(1), *y = V(2), *v = V(3), *sv = V(4), *t = V(5), *p = V(6), *rr = V(7);
@@ -644,13 +696,11 @@ extern "C" int gkomi_bicgstab_solve_f64_i32(
     GKOMI_TRY(c.start(b, x, r, baseline));
     GKOMI_TRY(gkomi_dense_copy_f64(s, n, nrhs, r, nrhs, rr, nrhs));
     int64_t iter = -1;
-    const double* last_residual = r;
     while (true) {
         ++iter;
         GKOMI_TRY(c.dot(rr, r, rho));
-        bool stop = false, changed = false;
-        GKOMI_TRY(c.check(iter, r, true, &stop, &changed));
-        last_residual = r;
+        bool stop = false;
+        GKOMI_TRY(c.check(iter, r, true, 1, &stop));
         if (stop) break;
         GKOMI_TRY(gkomi_bicgstab_step_1_f64(s, n, nrhs, r, nrhs, p, nrhs, v, nrhs, rho, prev_rho,
                                             alpha, omega, c.stop_status));
@@ -659,14 +709,12 @@ extern "C" int gkomi_bicgstab_solve_f64_i32(
         GKOMI_TRY(c.dot(rr, v, beta));
         GKOMI_TRY(gkomi_bicgstab_step_2_f64(s, n, nrhs, r, nrhs, sv, nrhs, v, nrhs, rho, alpha, beta,
                                             c.stop_status));
-        GKOMI_TRY(c.check(iter, sv, false, &stop, &changed));
-        if (changed) {
-            GKOMI_TRY(gkomi_bicgstab_finalize_f64(s, n, nrhs, x, nrhs, y, nrhs, alpha, c.stop_status));
-        }
-        if (stop) {
-            last_residual = sv;
-            break;
-        }
+        GKOMI_TRY(c.check(iter, sv, false, 2, &stop));
+        // the reference finalizes "if (one_changed)"; the kernel only touches
+        // columns that stopped without being finalized, so calling it always
+        // is the same thing without asking the host
+        GKOMI_TRY(gkomi_bicgstab_finalize_f64(s, n, nrhs, x, nrhs, y, nrhs, alpha, c.stop_status));
+        if (stop) break;
         GKOMI_TRY(c.apply_precond(sv, z));
         GKOMI_TRY(c.spmv(z, t));
         GKOMI_TRY(c.dot(sv, t, gamma));
@@ -675,15 +723,15 @@ extern "C" int gkomi_bicgstab_solve_f64_i32(
                                             z, nrhs, alpha, beta, gamma, omega, c.stop_status));
         std::swap(prev_rho, rho);
     }
-    return c.finish(iter, last_residual, host_info);
+    return c.finish(c.stop_iter(), c.host_record.phase == 2 ? sv : r, host_info);
 }
 
 extern "C" int gkomi_fcg_solve_f64_i32(
     gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
     const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
     gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
-    double reduction_factor, int baseline, void* workspace, size_t workspace_bytes,
-    double* host_info)
+    double reduction_factor, int baseline, int64_t check_every, void* workspace,
+    size_t workspace_bytes, double* host_info)
 {
     GKOMI_DRIVER_PROLOGUE(5);
     double *r = V(0), *z = V(1), *p = V(2), *q = V(3), *t = V(4);
@@ -697,8 +745,8 @@ extern "C" int gkomi_fcg_solve_f64_i32(
         GKOMI_TRY(c.dot(r, z, rho));
         GKOMI_TRY(c.dot(t, z, rho_t));
         ++iter;
-        bool stop = false, changed = false;
-        GKOMI_TRY(c.check(iter, r, true, &stop, &changed));
+        bool stop = false;
+        GKOMI_TRY(c.check(iter, r, true, 1, &stop));
         if (stop) break;
         GKOMI_TRY(gkomi_fcg_step_1_f64(s, n, nrhs, p, nrhs, z, nrhs, rho_t, prev_rho, c.stop_status));
         GKOMI_TRY(c.spmv(p, q));
@@ -707,15 +755,15 @@ extern "C" int gkomi_fcg_solve_f64_i32(
                                        rho, c.stop_status));
         std::swap(prev_rho, rho);
     }
-    return c.finish(iter, r, host_info);
+    return c.finish(c.stop_iter(), r, host_info);
 }
 
 extern "C" int gkomi_cgs_solve_f64_i32(
     gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
     const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
     gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
-    double reduction_factor, int baseline, void* workspace, size_t workspace_bytes,
-    double* host_info)
+    double reduction_factor, int baseline, int64_t check_every, void* workspace,
+    size_t workspace_bytes, double* host_info)
 {
     GKOMI_DRIVER_PROLOGUE(8);
     double *r = V(0), *r_tld = V(1), *p = V(2), *q = V(3), *u = V(4), *u_hat = V(5), *v_hat = V(6),
@@ -731,8 +779,8 @@ extern "C" int gkomi_cgs_solve_f64_i32(
     while (true) {
         GKOMI_TRY(c.dot(r, r_tld, rho));
         ++iter;
-        bool stop = false, changed = false;
-        GKOMI_TRY(c.check(iter, r, true, &stop, &changed));
+        bool stop = false;
+        GKOMI_TRY(c.check(iter, r, true, 1, &stop));
         if (stop) break;
         GKOMI_TRY(gkomi_cgs_step_1_f64(s, n, nrhs, r, nrhs, u, nrhs, p, nrhs, q, nrhs, beta, rho,
                                        prev_rho, c.stop_status));
@@ -747,5 +795,5 @@ extern "C" int gkomi_cgs_solve_f64_i32(
                                        c.stop_status));
         std::swap(prev_rho, rho);
     }
-    return c.finish(iter, r, host_info);
+    return c.finish(c.stop_iter(), r, host_info);
 }

@@ -47,7 +47,7 @@ def cg_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reducti
 
 
 def krylov_solve(gk, solver, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reduction=1e-10,
-                 baseline="rhs_norm", strategy=0, max_row_nnz=-1, precond=None):
+                 baseline="rhs_norm", strategy=0, max_row_nnz=-1, precond=None, check_every=8):
     """solver in {"bicgstab", "fcg", "cgs"}: {Bicgstab,Fcg,Cgs}::apply with
     Combined(Iteration(max_iters), ResidualNorm(reduction, baseline)); precond: None or a Preconditioner."""
     assert solver in ("bicgstab", "fcg", "cgs")
@@ -65,7 +65,8 @@ def krylov_solve(gk, solver, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1
     fn = precond.fn if precond is not None else None
     ctx = precond.ctx_ptr if precond is not None else None
     getattr(gk, solver + "_solve_f64_i32")(stream, n, nrhs, nnz, row_ptrs, col_idxs, vals, strategy, max_row_nnz, fn, ctx,
-                                           b2, x2, max_iters, reduction, BASELINES[baseline], ws, nbytes, info)
+                                           b2, x2, max_iters, reduction, BASELINES[baseline], check_every, ws, nbytes,
+                                           info)
     res, base = info[2::2].copy(), info[3::2].copy()
     return {"x": x2 if b.dim() > 1 else x2.reshape(n), "iterations": int(info[0]), "converged": bool(info[1]),
             "residual_norm": res, "baseline_norm": base,

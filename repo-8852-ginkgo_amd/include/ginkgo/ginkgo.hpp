@@ -1399,7 +1399,7 @@ protected:
 // factory parameters as Cg, native drivers of csrc/krylov.hip
 namespace detail {
 using krylov_driver = int (*)(gkomi_stream_t, int64_t, int64_t, int64_t, const int32_t*, const int32_t*, const double*, int, int64_t, gkomi_apply_fn, void*,
-                              const double*, double*, int64_t, double, int, void*, size_t, double*);
+                              const double*, double*, int64_t, double, int, int64_t, void*, size_t, double*);
 template <typename Derived, krylov_driver Driver>
 class krylov_solver : public LinOp {
 public:
@@ -1427,7 +1427,7 @@ protected:
         ::gko::detail::linop_callback cb{precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
         GKOMI_CALL(Driver(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
                           csr->get_strategy()->get_code(), csr->get_max_row_nnz(), precond_ ? &::gko::detail::linop_callback::call : nullptr, precond_ ? &cb : nullptr,
-                          db->get_const_values(), dx->get_values(), settings_.max_iters, settings_.reduction_factor, baseline_code(settings_.baseline), ws.get_data(),
+                          db->get_const_values(), dx->get_values(), settings_.max_iters, settings_.reduction_factor, baseline_code(settings_.baseline), 8, ws.get_data(),
                           ws.get_num_elems(), info.data()));
         last_iters_ = static_cast<int64_t>(info[0]);
         last_converged_ = info[1] != 0.0;

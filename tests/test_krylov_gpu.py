@@ -137,6 +137,13 @@ def test_solves_like_the_oracle(gk, oracle, solver, problem):
     res = solvers.krylov_solve(gk, solver, n, dev(rp), dev(ci), dev(v), dev(b[:, 0].copy()), max_iters=2000,
                                reduction=1e-10)
     assert res["converged"] and res["rel_residual"] <= 1e-10
+    # the criterion lives on the device: how often the host looks changes nothing
+    for every in (1, 3, 50):
+        again = solvers.krylov_solve(gk, solver, n, dev(rp), dev(ci), dev(v), dev(b[:, 0].copy()), max_iters=2000,
+                                     reduction=1e-10, check_every=every)
+        assert again["iterations"] == res["iterations"] and again["converged"]
+        assert host(again["x"]).tobytes() == host(res["x"]).tobytes()
+        assert again["residual_norm"][0] == res["residual_norm"][0]
     # reductions are summed in a different order: the iterates drift by rounding
     assert abs(res["iterations"] - ite) <= max(2, ite // 10), (res["iterations"], ite)
     assert matgen.rel_err(host(res["x"]), xs) < 1e-7
