@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cg", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dist-cg-iters", type=int, default=300, help="iteration cap of the N > 1 CG leg")
     return ap.parse_args()
 
 
@@ -115,15 +116,28 @@ def cpu_baseline(n, rp, ci, v, x, seconds):
 
 def main():
     args = parse()
+    # stdout carries exactly one JSON line: whatever libraries print on fd 1
+    # (RCCL's version banner, ...) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # GKOMI_BENCH_FORCE_DIST=1 rehearses the N > 1 code path (Partition,
+    # halo plan, RCCL all-to-all-v, distributed CG) with a world of one rank
+    distributed = world > 1 or os.environ.get("GKOMI_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if not dist.is_initialized():
+            if world == 1:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29533")
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+            dist.init_process_group("nccl", device_id=device)
         barrier = lambda: dist.barrier(device_ids=[local_rank])
     else:
         barrier = lambda: None
@@ -253,6 +267,28 @@ def main():
                               "achieved_gbs": round(cg_bytes * res["iterations"] / el / 1e9, 1),
                               "final_residual_norm_rel": res["rel_residual"], "converged": bool(res["converged"])}
 
+    if distributed and not args.no_cg:
+        # config 5 in small: row-partitioned CG (core/solver/cg.cpp on distributed
+        # vectors: local kernels + all-reduced dots, criterion on every iteration)
+        nloc = dmat.num_local_rows
+        bd = torch.ones((nloc, 1), dtype=torch.float64, device=device)
+        xd = torch.zeros((nloc, 1), dtype=torch.float64, device=device)
+        gd.cg(dmat, bd, xd, max_iters=50, reduction=1e-10)  # warm-up
+        xd.zero_()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        its, conv = gd.cg(dmat, bd, xd, max_iters=args.dist_cg_iters, reduction=1e-10)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        out["cg"] = {"metric": "row-partitioned CG iterations/sec (reference kernel sequence, criterion evaluated "
+                               "on the device every iteration, b = 1)", "iterations": int(its), "converged": bool(conv),
+                     "seconds": round(el, 5), "iters_per_sec": round(its / el, 1),
+                     "global_rows": int(n) * world}
+
     if rank == 0 and not distributed and not args.no_cpu_baseline:
         base, y_cpu = cpu_baseline(n, rp, ci, v, x_host, args.cpu_seconds)
         out["cpu_baseline"] = base
@@ -262,7 +298,8 @@ def main():
             f"rel err {matgen.rel_err(got, y_cpu):.3e}"
 
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 

@@ -163,8 +163,9 @@ class GpuOps:
         self.gk.residual_norm_f64(self.stream(), tau.numel(), tau, orig_tau, reduction, 2, 1, stop, flags, host)
         return bool(host[0])
 
-    def side_stream(self):
-        return torch.cuda.Stream(self.device)
+    def residual_check_device(self, tau, orig_tau, reduction, stop, flags):
+        """the same kernel without the host copy: flags = {all_converged, one_changed} on the device"""
+        self.gk.residual_norm_f64(self.stream(), tau.numel(), tau, orig_tau, reduction, 2, 1, stop, flags, None)
 
 
 class Matrix:
@@ -206,7 +207,6 @@ class Matrix:
         self.send_count, self.recv_count = sum(self.send_sizes), sum(self.recv_sizes)
         self._bufs = {}
         self._one = ops.tensor(np.array([1.0]))
-        self._comm_stream = ops.side_stream() if hasattr(ops, "side_stream") else None
         return self
 
     def _buffers(self, nrhs):
@@ -221,19 +221,14 @@ class Matrix:
         nrhs = b.shape[1]
         send, recv = self._buffers(nrhs)
         ops.row_gather(self.gather_idxs, self.send_count, b, send)
-        split = lambda sizes: [s * 1 for s in sizes]
-        if self._comm_stream is not None:
-            # halo exchange on a side stream, overlapped with the local SpMV
-            self._comm_stream.wait_stream(torch.cuda.current_stream(ops.device))
-            with torch.cuda.stream(self._comm_stream):
-                work = dist.all_to_all_single(recv[:self.recv_count], send[:self.send_count], split(self.recv_sizes),
-                                              split(self.send_sizes), group=self.group, async_op=True)
-            ops.spmv(self.local, b, x)
-            work.wait()
-            torch.cuda.current_stream(ops.device).wait_stream(self._comm_stream)
+        if self.send_count == 0 and self.recv_count == 0:
+            ops.spmv(self.local, b, x)  # no neighbours: nothing to exchange
         else:
-            work = dist.all_to_all_single(recv[:self.recv_count], send[:self.send_count], split(self.recv_sizes),
-                                          split(self.send_sizes), group=self.group, async_op=True)
+            # the collective runs on the backend's own stream (RCCL) behind the
+            # pack kernel; the local SpMV is launched meanwhile and the wait only
+            # fences the non-local part: halo exchange overlapped with compute
+            work = dist.all_to_all_single(recv[:self.recv_count], send[:self.send_count], self.recv_sizes,
+                                          self.send_sizes, group=self.group, async_op=True)
             ops.spmv(self.local, b, x)
             work.wait()
         if self.non_local[2] > 0:
@@ -260,10 +255,16 @@ class VectorOps:
         return result
 
 
-def cg(matrix, b, x, max_iters=1000, reduction=1e-10):
+def cg(matrix, b, x, max_iters=1000, reduction=1e-10, check_every=8):
     """Cg::apply_dense_impl on distributed vectors (core/solver/cg.cpp:107-193
     with detail::get_local for the step kernels), Identity preconditioner,
-    Combined(Iteration, ResidualNorm(rhs_norm)).  Returns (iterations, converged)."""
+    Combined(Iteration, ResidualNorm(rhs_norm)).  Returns (iterations, converged).
+
+    The criterion is evaluated on the device every iteration, where the
+    reference evaluates it (the statuses stop the step kernels at once); the
+    host reads the outcome every `check_every` iterations only -- the iterates
+    and the returned count (= the checks that did not end the solve, counted on
+    the device) do not depend on check_every."""
     ops = matrix.ops
     n, k = b.shape
     r, z, p, q = (ops.empty((n, k), torch.float64) for _ in range(4))
@@ -272,22 +273,27 @@ def cg(matrix, b, x, max_iters=1000, reduction=1e-10):
     stop = ops.empty((k,), torch.uint8)
     vec = VectorOps(ops, n, k, matrix.group)
     flags = ops.empty((2,), torch.uint8)
+    running = ops.tensor(np.zeros(1, np.int64))   # checks that found unconverged columns
     one = ops.tensor(np.ones(1))
     ops.cg_initialize(b, r, z, p, q, prev_rho, rho, stop)
     matrix.apply(x, q)                       # r = b - A x
     ops.sub_scaled(one, q, r)
     ops.fill(q, 0.0)
     vec.norm2(b, orig)
+    check_every = max(1, int(check_every))
     it = -1
     while True:
         ops.copy(r, z)
         vec.dot(r, z, rho)
         it += 1
         if it >= max_iters:
-            return it, False
+            done = int(running.item())
+            return (done, True) if done < it else (it, False)
         vec.norm2(r, tau)
-        if ops.residual_check(tau, orig, reduction, stop, flags):
-            return it, True
+        ops.residual_check_device(tau, orig, reduction, stop, flags)
+        running += (flags[0:1] == 0)
+        if (it + 1) % check_every == 0 and int(flags[0].item()):
+            return int(running.item()), True
         ops.cg_step_1(p, z, rho, prev_rho, stop)
         matrix.apply(p, q)
         vec.dot(p, q, beta)

@@ -83,6 +83,13 @@ def _worker(rank, world, port, grid, out_dir):
         ite = oracle.ref_cg_solve(n_global, rp, ci, v, bg[:, 0].copy(), xe, 2000, 1e-10, 0, None, 0)
         assert conv and abs(it - ite) <= 1, (it, ite)
         assert matgen.rel_err(xs.numpy()[:, 0], xe[lo:lo + n_local]) <= 1e-6
+        # the host may look at the criterion as rarely as it likes: same iterates, same count
+        for every in (1, 5):
+            xs2 = torch.zeros((n_local, 1), dtype=torch.float64)
+            it2, conv2 = gd.cg(A, b, xs2, max_iters=2000, reduction=1e-10, check_every=every)
+            assert (it2, conv2) == (it, conv) and torch.equal(xs2, xs)
+        it3, conv3 = gd.cg(A, b, torch.zeros((n_local, 1), dtype=torch.float64), max_iters=3, reduction=1e-10)
+        assert (it3, conv3) == (3, False)
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
