@@ -32,8 +32,9 @@ if st:
               f"{float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |")
 tr = find("trace", "kernel_trace.csv")
 if tr:
-    rows = [r for r in csv.DictReader(open(tr)) if "csr_stream_kernel<256, 1, 1536, false, true, false>" in r["Kernel_Name"]
-            or "csr_stream_kernel<256, 1, 1536, false, false, false>" in r["Kernel_Name"]]
+    # the plain (non-advanced, no dot epilogue) instantiation, swizzled or not
+    rows = [r for r in csv.DictReader(open(tr)) if "csr_stream_kernel<256, 1, 1536, false, true, false" in r["Kernel_Name"]
+            or "csr_stream_kernel<256, 1, 1536, false, false, false" in r["Kernel_Name"]]
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
     if len(d) >= 440:
         print(f"\ncsr_stream_kernel, bench order = 20 warm-up + 200 cold (rotating copies) + 20 + 200 warm: "
