@@ -655,6 +655,43 @@ int gkomi_cgs_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t
     reduction_factor, int baseline, int64_t check_every, void* workspace, size_t workspace_bytes,
     double* host_info);
 
+/* BiCG (reference/solver/bicg_kernels.cpp:55-145; driver core/solver/bicg.cpp:
+ * 117-232: t_* = csr::transpose of the system matrix, precond_t = the
+ * transposed preconditioner, both NULL = Identity) and IR (ir_kernels.cpp:
+ * 48-56; driver core/solver/ir.cpp:186-277 with the caller's x as initial
+ * guess: x += relaxation_factor * inner(b - A x), inner == NULL = Richardson).
+ * Other arguments as for gkomi_bicgstab_solve_f64_i32. */
+int gkomi_bicg_initialize_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const
+    double* b, int64_t b_stride, double* r, int64_t r_stride, double* z,
+    int64_t z_stride, double* p, int64_t p_stride, double* q, int64_t
+    q_stride, double* prev_rho, double* rho, double* r2, int64_t r2_stride,
+    double* z2, int64_t z2_stride, double* p2, int64_t p2_stride, double* q2,
+    int64_t q2_stride, uint8_t* stop_status);
+int gkomi_bicg_step_1_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, double*
+    p, int64_t p_stride, const double* z, int64_t z_stride, double* p2,
+    int64_t p2_stride, const double* z2, int64_t z2_stride, const double* rho,
+    const double* prev_rho, const uint8_t* stop_status);
+int gkomi_bicg_step_2_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, double*
+    x, int64_t x_stride, double* r, int64_t r_stride, double* r2, int64_t
+    r2_stride, const double* p, int64_t p_stride, const double* q, int64_t
+    q_stride, const double* q2, int64_t q2_stride, const double* beta, const
+    double* rho, const uint8_t* stop_status);
+int gkomi_ir_initialize(gkomi_stream_t s, int64_t nrhs, uint8_t* stop_status);
+int gkomi_bicg_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
+    int64_t nnz, const int32_t* row_ptrs, const int32_t* col_idxs, const
+    double* vals, const int32_t* t_row_ptrs, const int32_t* t_col_idxs, const
+    double* t_vals, int spmv_strategy, int64_t max_row_nnz_hint,
+    gkomi_apply_fn precond, void* precond_ctx, gkomi_apply_fn precond_t, void*
+    precond_t_ctx, const double* b, double* x, int64_t max_iters, double
+    reduction_factor, int baseline, int64_t check_every, void* workspace,
+    size_t workspace_bytes, double* host_info);
+int gkomi_ir_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t
+    nnz, const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
+    int spmv_strategy, int64_t max_row_nnz_hint, gkomi_apply_fn inner, void*
+    inner_ctx, double relaxation_factor, const double* b, double* x, int64_t
+    max_iters, double reduction_factor, int baseline, void* workspace, size_t
+    workspace_bytes, double* host_info);
+
 /* Partition metadata on HOST arrays (O(#ranges); core/distributed/matrix.cpp
  * consumes it on the host for the communication plan):
  * reference/distributed/partition_kernels.cpp:42-135.

@@ -362,3 +362,132 @@ ORACLE_API i64 ref_cgs_solve(i64 n, const i32* row_ptrs, const i32* col_idxs, co
     free(r); free(r_tld); free(p); free(q); free(u); free(u_hat); free(v_hat); free(t);
     return iter;
 }
+
+/* ---- BiCG (bicg_kernels.cpp:55-145, core/solver/bicg.cpp:117-232) ------------- */
+ORACLE_API void ref_bicg_initialize(i64 n, i64 nrhs, const double* b, i64 b_stride, double* r,
+                                    i64 r_stride, double* z, i64 z_stride, double* p, i64 p_stride,
+                                    double* q, i64 q_stride, double* prev_rho, double* rho,
+                                    double* r2, i64 r2_stride, double* z2, i64 z2_stride,
+                                    double* p2, i64 p2_stride, double* q2, i64 q2_stride,
+                                    u8* stop_status)
+{
+    for (i64 j = 0; j < nrhs; ++j) {
+        rho[j] = 0.0;
+        prev_rho[j] = 1.0;
+        stop_status[j] = 0;
+    }
+    for (i64 i = 0; i < n; ++i)
+        for (i64 j = 0; j < nrhs; ++j) {
+            AT(r, i, j) = AT(r2, i, j) = AT(b, i, j);
+            AT(z, i, j) = AT(p, i, j) = AT(q, i, j) = 0.0;
+            AT(z2, i, j) = AT(p2, i, j) = AT(q2, i, j) = 0.0;
+        }
+}
+
+ORACLE_API void ref_bicg_step_1(i64 n, i64 nrhs, double* p, i64 p_stride, const double* z,
+                                i64 z_stride, double* p2, i64 p2_stride, const double* z2,
+                                i64 z2_stride, const double* rho, const double* prev_rho,
+                                const u8* stop_status)
+{
+    for (i64 i = 0; i < n; ++i)
+        for (i64 j = 0; j < nrhs; ++j) {
+            if (st_has_stopped(stop_status[j])) continue;
+            if (prev_rho[j] == 0.0) {
+                AT(p, i, j) = AT(z, i, j);
+                AT(p2, i, j) = AT(z2, i, j);
+            } else {
+                const double tmp = rho[j] / prev_rho[j];
+                AT(p, i, j) = AT(z, i, j) + tmp * AT(p, i, j);
+                AT(p2, i, j) = AT(z2, i, j) + tmp * AT(p2, i, j);
+            }
+        }
+}
+
+ORACLE_API void ref_bicg_step_2(i64 n, i64 nrhs, double* x, i64 x_stride, double* r, i64 r_stride,
+                                double* r2, i64 r2_stride, const double* p, i64 p_stride,
+                                const double* q, i64 q_stride, const double* q2, i64 q2_stride,
+                                const double* beta, const double* rho, const u8* stop_status)
+{
+    for (i64 i = 0; i < n; ++i)
+        for (i64 j = 0; j < nrhs; ++j) {
+            if (st_has_stopped(stop_status[j])) continue;
+            if (beta[j] != 0.0) {
+                const double tmp = rho[j] / beta[j];
+                AT(x, i, j) += tmp * AT(p, i, j);
+                AT(r, i, j) -= tmp * AT(q, i, j);
+                AT(r2, i, j) -= tmp * AT(q2, i, j);
+            }
+        }
+}
+
+void ref_csr_transpose(i64, i64, const i32*, const i32*, const double*, i32*, i32*, double*);
+
+ORACLE_API i64 ref_bicg_solve(i64 n, const i32* row_ptrs, const i32* col_idxs, const double* vals,
+                              const double* b, double* x, i64 max_iters, double reduction,
+                              int baseline)
+{
+    const i64 nnz = row_ptrs[n];
+    i32* trp = (i32*)calloc((size_t)n + 1, sizeof(i32));
+    i32* tci = (i32*)calloc((size_t)(nnz > 0 ? nnz : 1), sizeof(i32));
+    double* tv = vec(nnz);
+    ref_csr_transpose(n, n, row_ptrs, col_idxs, vals, trp, tci, tv);
+    double *r = vec(n), *z = vec(n), *p = vec(n), *q = vec(n), *r2 = vec(n), *z2 = vec(n),
+           *p2 = vec(n), *q2 = vec(n);
+    double beta, prev_rho, rho;
+    u8 status, one_changed;
+    ref_bicg_initialize(n, 1, b, 1, r, 1, z, 1, p, 1, q, 1, &prev_rho, &rho, r2, 1, z2, 1, p2, 1, q2,
+                        1, &status);
+    ref_csr_advanced_spmv(n, 1, -1.0, row_ptrs, col_idxs, vals, x, 1, 1.0, r, 1);
+    memcpy(r2, r, sizeof(double) * (size_t)n);
+    const double orig_tau = baseline_norm(baseline, n, b, r);
+    i64 iter = -1;
+    while (1) {
+        memcpy(z, r, sizeof(double) * (size_t)n);
+        memcpy(z2, r2, sizeof(double) * (size_t)n);
+        ref_dense_compute_dot(n, 1, z, 1, r2, 1, &rho);
+        ++iter;
+        if (check(iter, max_iters, n, r, orig_tau, reduction, 1, &status, &one_changed)) break;
+        ref_bicg_step_1(n, 1, p, 1, z, 1, p2, 1, z2, 1, &rho, &prev_rho, &status);
+        ref_csr_spmv(n, 1, row_ptrs, col_idxs, vals, p, 1, q, 1);
+        ref_csr_spmv(n, 1, trp, tci, tv, p2, 1, q2, 1);
+        ref_dense_compute_dot(n, 1, p2, 1, q, 1, &beta);
+        ref_bicg_step_2(n, 1, x, 1, r, 1, r2, 1, p, 1, q, 1, q2, 1, &beta, &rho, &status);
+        double sw = prev_rho;
+        prev_rho = rho;
+        rho = sw;
+    }
+    free(r); free(z); free(p); free(q); free(r2); free(z2); free(p2); free(q2);
+    free(trp); free(tci); free(tv);
+    return iter;
+}
+
+/* ---- IR (core/solver/ir.cpp:186-277; ir_kernels.cpp:48-56) with the Identity as
+ * inner solver = Richardson: x += relaxation_factor * (b - A x) -------------------- */
+ORACLE_API void ref_ir_initialize(i64 nrhs, u8* stop_status)
+{
+    for (i64 j = 0; j < nrhs; ++j) stop_status[j] = 0;
+}
+
+ORACLE_API i64 ref_ir_solve(i64 n, const i32* row_ptrs, const i32* col_idxs, const double* vals,
+                            double relaxation_factor, const double* b, double* x, i64 max_iters,
+                            double reduction, int baseline)
+{
+    double* residual = vec(n);
+    u8 status, one_changed;
+    ref_ir_initialize(1, &status);
+    memcpy(residual, b, sizeof(double) * (size_t)n);
+    ref_csr_advanced_spmv(n, 1, -1.0, row_ptrs, col_idxs, vals, x, 1, 1.0, residual, 1);
+    const double orig_tau = baseline_norm(baseline, n, b, residual);
+    i64 iter = -1;
+    while (1) {
+        ++iter;
+        if (iter > 0) { /* residual = b - A x (the reference's two checks see the same vector) */
+            memcpy(residual, b, sizeof(double) * (size_t)n);
+            ref_csr_advanced_spmv(n, 1, -1.0, row_ptrs, col_idxs, vals, x, 1, 1.0, residual, 1);
+        }
+        if (check(iter, max_iters, n, residual, orig_tau, reduction, 1, &status, &one_changed)) break;
+        for (i64 i = 0; i < n; ++i) x[i] += relaxation_factor * residual[i];
+    }
+    free(residual);
+    return iter;
+}

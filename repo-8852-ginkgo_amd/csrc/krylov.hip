@@ -249,6 +249,71 @@ __global__ __launch_bounds__(block) void cgs_step_3_kernel(
     r[i * r_stride + j] -= alpha[j] * t[i * t_stride + j];
 }
 
+// ---- BiCG ---------------------------------------------------------------------
+__global__ __launch_bounds__(block) void bicg_initialize_kernel(
+    int64_t n, int64_t nrhs, const double* __restrict__ b, int64_t b_stride,
+    double* __restrict__ r, int64_t r_stride, double* __restrict__ z, int64_t z_stride,
+    double* __restrict__ p, int64_t p_stride, double* __restrict__ q, int64_t q_stride,
+    double* __restrict__ prev_rho, double* __restrict__ rho, double* __restrict__ r2,
+    int64_t r2_stride, double* __restrict__ z2, int64_t z2_stride, double* __restrict__ p2,
+    int64_t p2_stride, double* __restrict__ q2, int64_t q2_stride,
+    uint8_t* __restrict__ stop_status)
+{
+    const int64_t idx = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
+    if (idx < nrhs) {
+        rho[idx] = 0.0;
+        prev_rho[idx] = 1.0;
+        stop_status[idx] = 0;
+    }
+    if (idx >= n * nrhs) return;
+    const int64_t i = idx / nrhs, j = idx - i * nrhs;
+    r[i * r_stride + j] = r2[i * r2_stride + j] = b[i * b_stride + j];
+    z[i * z_stride + j] = p[i * p_stride + j] = q[i * q_stride + j] = 0.0;
+    z2[i * z2_stride + j] = p2[i * p2_stride + j] = q2[i * q2_stride + j] = 0.0;
+}
+
+__global__ __launch_bounds__(block) void bicg_step_1_kernel(
+    int64_t n, int64_t nrhs, double* __restrict__ p, int64_t p_stride,
+    const double* __restrict__ z, int64_t z_stride, double* __restrict__ p2, int64_t p2_stride,
+    const double* __restrict__ z2, int64_t z2_stride, const double* __restrict__ rho,
+    const double* __restrict__ prev_rho, const uint8_t* __restrict__ stop_status)
+{
+    GKOMI_ELEMENTWISE(i, j);
+    if (status_has_stopped(stop_status[j])) return;
+    if (prev_rho[j] == 0.0) {
+        p[i * p_stride + j] = z[i * z_stride + j];
+        p2[i * p2_stride + j] = z2[i * z2_stride + j];
+    } else {
+        const double tmp = rho[j] / prev_rho[j];
+        p[i * p_stride + j] = z[i * z_stride + j] + tmp * p[i * p_stride + j];
+        p2[i * p2_stride + j] = z2[i * z2_stride + j] + tmp * p2[i * p2_stride + j];
+    }
+}
+
+__global__ __launch_bounds__(block) void bicg_step_2_kernel(
+    int64_t n, int64_t nrhs, double* __restrict__ x, int64_t x_stride, double* __restrict__ r,
+    int64_t r_stride, double* __restrict__ r2, int64_t r2_stride, const double* __restrict__ p,
+    int64_t p_stride, const double* __restrict__ q, int64_t q_stride,
+    const double* __restrict__ q2, int64_t q2_stride, const double* __restrict__ beta,
+    const double* __restrict__ rho, const uint8_t* __restrict__ stop_status)
+{
+    GKOMI_ELEMENTWISE(i, j);
+    if (status_has_stopped(stop_status[j])) return;
+    if (beta[j] != 0.0) {
+        const double tmp = rho[j] / beta[j];
+        x[i * x_stride + j] += tmp * p[i * p_stride + j];
+        r[i * r_stride + j] -= tmp * q[i * q_stride + j];
+        r2[i * r2_stride + j] -= tmp * q2[i * q2_stride + j];
+    }
+}
+
+__global__ __launch_bounds__(block) void ir_initialize_kernel(int64_t nrhs,
+                                                              uint8_t* __restrict__ stop_status)
+{
+    const int64_t j = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
+    if (j < nrhs) stop_status[j] = 0;
+}
+
 // the scalar updates of steps that define a scalar must also happen for n == 0
 // (the reference loops over the columns first): tiny single-block kernels
 __global__ void cgs_scalar_kernel(int64_t nrhs, double* out, const double* num, const double* den,
@@ -796,4 +861,148 @@ extern "C" int gkomi_cgs_solve_f64_i32(
         std::swap(prev_rho, rho);
     }
     return c.finish(c.stop_iter(), r, host_info);
+}
+
+// ---- BiCG / IR ---------------------------------------------------------------------------
+extern "C" int gkomi_bicg_initialize_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, const double* b,
+                                         int64_t b_stride, double* r, int64_t r_stride, double* z,
+                                         int64_t z_stride, double* p, int64_t p_stride, double* q,
+                                         int64_t q_stride, double* prev_rho, double* rho,
+                                         double* r2, int64_t r2_stride, double* z2,
+                                         int64_t z2_stride, double* p2, int64_t p2_stride,
+                                         double* q2, int64_t q2_stride, uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(bicg_initialize_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n, nrhs,
+                       b, b_stride, r, r_stride, z, z_stride, p, p_stride, q, q_stride, prev_rho, rho,
+                       r2, r2_stride, z2, z2_stride, p2, p2_stride, q2, q2_stride, stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_bicg_step_1_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, double* p,
+                                     int64_t p_stride, const double* z, int64_t z_stride,
+                                     double* p2, int64_t p2_stride, const double* z2,
+                                     int64_t z2_stride, const double* rho, const double* prev_rho,
+                                     const uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (n == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(bicg_step_1_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n, nrhs, p,
+                       p_stride, z, z_stride, p2, p2_stride, z2, z2_stride, rho, prev_rho,
+                       stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_bicg_step_2_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, double* x,
+                                     int64_t x_stride, double* r, int64_t r_stride, double* r2,
+                                     int64_t r2_stride, const double* p, int64_t p_stride,
+                                     const double* q, int64_t q_stride, const double* q2,
+                                     int64_t q2_stride, const double* beta, const double* rho,
+                                     const uint8_t* stop_status)
+{
+    if (bad_dims(n, nrhs)) return GKOMI_EINVAL;
+    if (n == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(bicg_step_2_kernel, grid_of(n, nrhs), dim3(block), 0, to_stream(s), n, nrhs, x,
+                       x_stride, r, r_stride, r2, r2_stride, p, p_stride, q, q_stride, q2, q2_stride,
+                       beta, rho, stop_status);
+    return check_launch();
+}
+
+extern "C" int gkomi_ir_initialize(gkomi_stream_t s, int64_t nrhs, uint8_t* stop_status)
+{
+    if (nrhs < 0) return GKOMI_EINVAL;
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(ir_initialize_kernel, dim3(static_cast<unsigned>(ceildiv(nrhs, block))),
+                       dim3(block), 0, to_stream(s), nrhs, stop_status);
+    return check_launch();
+}
+
+// Bicg::apply_dense_impl (core/solver/bicg.cpp:117-232).  The conjugate-transposed
+// system matrix is passed in (t_*: csr::transpose of A, what the reference
+// builds at the top of every apply); precond_t applies the transposed
+// preconditioner (NULL with precond == NULL: Identity; a symmetric
+// preconditioner passes the same callback twice).
+extern "C" int gkomi_bicg_solve_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, const int32_t* t_row_ptrs,
+    const int32_t* t_col_idxs, const double* t_vals, int spmv_strategy, int64_t max_row_nnz_hint,
+    gkomi_apply_fn precond, void* precond_ctx, gkomi_apply_fn precond_t, void* precond_t_ctx,
+    const double* b, double* x, int64_t max_iters, double reduction_factor, int baseline,
+    int64_t check_every, void* workspace, size_t workspace_bytes, double* host_info)
+{
+    if ((precond == nullptr) != (precond_t == nullptr)) return GKOMI_EINVAL;
+    GKOMI_DRIVER_PROLOGUE(8);
+    double *r = V(0), *z = V(1), *p = V(2), *q = V(3), *r2 = V(4), *z2 = V(5), *p2 = V(6),
+           *q2 = V(7);
+    double *beta = sc, *prev_rho = sc + nrhs, *rho = sc + 2 * nrhs;
+    GKOMI_TRY(gkomi_bicg_initialize_f64(s, n, nrhs, b, nrhs, r, nrhs, z, nrhs, p, nrhs, q, nrhs,
+                                        prev_rho, rho, r2, nrhs, z2, nrhs, p2, nrhs, q2, nrhs,
+                                        c.stop_status));
+    GKOMI_TRY(c.start(b, x, r, baseline));
+    GKOMI_TRY(gkomi_dense_copy_f64(s, n, nrhs, r, nrhs, r2, nrhs));
+    int64_t iter = -1;
+    while (true) {
+        GKOMI_TRY(c.apply_precond(r, z));
+        if (precond_t == nullptr) {
+            GKOMI_TRY(gkomi_dense_copy_f64(s, n, nrhs, r2, nrhs, z2, nrhs));
+        } else {
+            GKOMI_TRY(precond_t(precond_t_ctx, s, r2, z2));
+        }
+        GKOMI_TRY(c.dot(z, r2, rho));
+        ++iter;
+        bool stop = false;
+        GKOMI_TRY(c.check(iter, r, true, 1, &stop));
+        if (stop) break;
+        GKOMI_TRY(gkomi_bicg_step_1_f64(s, n, nrhs, p, nrhs, z, nrhs, p2, nrhs, z2, nrhs, rho, prev_rho,
+                                        c.stop_status));
+        GKOMI_TRY(c.spmv(p, q));
+        GKOMI_TRY(gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, t_row_ptrs, t_col_idxs, t_vals, p2, nrhs,
+                                         q2, nrhs, nullptr, nullptr, spmv_strategy, -1));
+        GKOMI_TRY(c.dot(p2, q, beta));
+        GKOMI_TRY(gkomi_bicg_step_2_f64(s, n, nrhs, x, nrhs, r, nrhs, r2, nrhs, p, nrhs, q, nrhs, q2,
+                                        nrhs, beta, rho, c.stop_status));
+        std::swap(prev_rho, rho);
+    }
+    return c.finish(c.stop_iter(), r, host_info);
+}
+
+// Ir::apply_dense_impl (core/solver/ir.cpp:186-277) with the caller's x as the
+// initial guess: residual = b - A x, criterion, x += relaxation_factor *
+// inner(residual); inner == NULL is the Identity (Richardson).  The criterion
+// is looked at on the host every iteration (the update is not status-aware in
+// the reference either: a stopped column keeps being relaxed until all stop).
+extern "C" int gkomi_ir_solve_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
+    gkomi_apply_fn inner, void* inner_ctx, double relaxation_factor, const double* b, double* x,
+    int64_t max_iters, double reduction_factor, int baseline, void* workspace,
+    size_t workspace_bytes, double* host_info)
+{
+    gkomi_apply_fn precond = inner;
+    void* precond_ctx = inner_ctx;
+    const int64_t check_every = 1;
+    GKOMI_DRIVER_PROLOGUE(2);
+    double *residual = V(0), *inner_solution = V(1);
+    double* relax = sc;
+    GKOMI_TRY(gkomi_dense_fill_f64(s, 1, nrhs, relax, nrhs, relaxation_factor));
+    GKOMI_TRY(gkomi_ir_initialize(s, nrhs, c.stop_status));
+    GKOMI_TRY(gkomi_dense_copy_f64(s, n, nrhs, b, nrhs, residual, nrhs));
+    GKOMI_TRY(c.start(b, x, residual, baseline));
+    int64_t iter = -1;
+    while (true) {
+        ++iter;
+        if (iter > 0) {
+            GKOMI_TRY(gkomi_dense_copy_f64(s, n, nrhs, b, nrhs, residual, nrhs));
+            GKOMI_TRY(gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, x, nrhs,
+                                             residual, nrhs, c.neg_one, c.one, spmv_strategy,
+                                             max_row_nnz_hint));
+        }
+        bool stop = false;
+        GKOMI_TRY(c.check(iter, residual, true, 1, &stop));
+        if (stop) break;
+        GKOMI_TRY(c.apply_precond(residual, inner_solution));
+        GKOMI_TRY(gkomi_dense_add_scaled_f64(s, n, nrhs, relax, nrhs, inner_solution, nrhs, x, nrhs));
+    }
+    return c.finish(c.stop_iter(), residual, host_info);
 }

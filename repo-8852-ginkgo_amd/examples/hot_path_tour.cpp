@@ -169,6 +169,36 @@ int main()
             report("cgs_ilu_iters", B.get(), cgs->get_last_iteration_count(), cgs->has_converged());
         }
 
+        // BiCG on the nonsymmetric system; Richardson / IR with block-Jacobi as the inner "solver"
+        {
+            sol->fill(0.0);
+            auto bicg = gko::solver::Bicg<double>::build()
+                            .with_criteria(gko::stop::Iteration::build().with_max_iters(2000u).on(exec),
+                                           gko::stop::ResidualNorm<double>::build().with_reduction_factor(1e-10).on(exec))
+                            .on(exec)->generate(B);
+            bicg->apply(b.get(), sol.get());
+            r->copy_from(b.get());
+            B->apply(neg.get(), sol.get(), one.get(), r.get());
+            r->compute_norm2(rn.get());
+            std::cout << "bicg_iters " << bicg->get_last_iteration_count() << " converged " << bicg->has_converged() << " true_residual "
+                      << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
+            sol->fill(0.0);
+            auto ir = gko::solver::Ir<double>::build()
+                          .with_criteria(gko::stop::Iteration::build().with_max_iters(200u).on(exec),
+                                         gko::stop::ResidualNorm<double>::build().with_reduction_factor(1e-2).on(exec))
+                          .with_solver(gko::preconditioner::Jacobi<double, int>::build().with_max_block_size(8u).on(exec))
+                          .with_relaxation_factor(0.9)
+                          .on(exec)->generate(A);
+            ir->apply(b.get(), sol.get());
+            r->copy_from(b.get());
+            A->apply(neg.get(), sol.get(), one.get(), r.get());
+            r->compute_norm2(rn.get());
+            auto bn = vec::create(exec, gko::dim<2>(1, 1));
+            b->compute_norm2(bn.get());
+            std::cout << "ir_jacobi_iters " << ir->get_last_iteration_count() << " converged " << ir->has_converged() << " rel_residual "
+                      << exec->copy_val_to_host(rn->get_const_values()) / exec->copy_val_to_host(bn->get_const_values()) << "\n";
+        }
+
         // assembly on the device: shuffled triplets with duplicates and zeros ->
         // device_matrix_data::sum_duplicates / remove_zeros -> Csr::read
         {

@@ -73,6 +73,56 @@ def krylov_solve(gk, solver, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1
             "rel_residual": float(np.max(res / np.where(base == 0, 1.0, base)))}
 
 
+def bicg_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reduction=1e-10, baseline="rhs_norm",
+               strategy=0, max_row_nnz=-1, precond=None, precond_t=None, check_every=8, transposed=None):
+    """Bicg::apply: the transposed system matrix is built once here (csr::transpose)
+    unless `transposed` = (row_ptrs, col_idxs, vals) is given; precond_t is the
+    transposed preconditioner (pass the same object for a symmetric one)."""
+    b2 = b.reshape(n, -1)
+    nrhs = b2.shape[1]
+    if x is None:
+        x = torch.zeros_like(b2)
+    x2 = x.reshape(n, nrhs)
+    nnz = int(vals.numel())
+    trp, tci, tv = transposed if transposed is not None else _transpose(gk, n, row_ptrs, col_idxs, vals)
+    nbytes = gk.krylov_workspace_bytes(n, nrhs)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+    info = np.zeros(2 + 2 * nrhs, dtype=np.float64)
+    stream = torch.cuda.current_stream().cuda_stream
+    args = [p.fn if p is not None else None for p in (precond, precond_t)]
+    ctxs = [p.ctx_ptr if p is not None else None for p in (precond, precond_t)]
+    gk.bicg_solve_f64_i32(stream, n, nrhs, nnz, row_ptrs, col_idxs, vals, trp, tci, tv, strategy, max_row_nnz, args[0],
+                          ctxs[0], args[1], ctxs[1], b2, x2, max_iters, reduction, BASELINES[baseline], check_every, ws,
+                          nbytes, info)
+    res, base = info[2::2].copy(), info[3::2].copy()
+    return {"x": x2 if b.dim() > 1 else x2.reshape(n), "iterations": int(info[0]), "converged": bool(info[1]),
+            "residual_norm": res, "baseline_norm": base,
+            "rel_residual": float(np.max(res / np.where(base == 0, 1.0, base)))}
+
+
+def ir_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, relaxation_factor=1.0, inner=None, max_iters=1000,
+             reduction=1e-10, baseline="rhs_norm", strategy=0, max_row_nnz=-1):
+    """Ir::apply with x as the initial guess; inner: None (Richardson) or a
+    Preconditioner-like object whose apply approximates A^-1."""
+    b2 = b.reshape(n, -1)
+    nrhs = b2.shape[1]
+    if x is None:
+        x = torch.zeros_like(b2)
+    x2 = x.reshape(n, nrhs)
+    nnz = int(vals.numel())
+    nbytes = gk.krylov_workspace_bytes(n, nrhs)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+    info = np.zeros(2 + 2 * nrhs, dtype=np.float64)
+    stream = torch.cuda.current_stream().cuda_stream
+    gk.ir_solve_f64_i32(stream, n, nrhs, nnz, row_ptrs, col_idxs, vals, strategy, max_row_nnz,
+                        inner.fn if inner is not None else None, inner.ctx_ptr if inner is not None else None,
+                        relaxation_factor, b2, x2, max_iters, reduction, BASELINES[baseline], ws, nbytes, info)
+    res, base = info[2::2].copy(), info[3::2].copy()
+    return {"x": x2 if b.dim() > 1 else x2.reshape(n), "iterations": int(info[0]), "converged": bool(info[1]),
+            "residual_norm": res, "baseline_norm": base,
+            "rel_residual": float(np.max(res / np.where(base == 0, 1.0, base)))}
+
+
 class JacobiCtx(ctypes.Structure):
     """gkomi_jacobi_ctx (include/gkomi.h)."""
     _fields_ = [("n", ctypes.c_int64), ("nrhs", ctypes.c_int64), ("num_blocks", ctypes.c_int64),

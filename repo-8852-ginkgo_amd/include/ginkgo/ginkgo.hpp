@@ -1460,6 +1460,115 @@ GKOMI_KRYLOV_SOLVER(Fcg, gkomi_fcg_solve_f64_i32);
 GKOMI_KRYLOV_SOLVER(Cgs, gkomi_cgs_solve_f64_i32);
 #undef GKOMI_KRYLOV_SOLVER
 
+// Bicg (include/ginkgo/core/solver/bicg.hpp): the transposed system matrix is
+// built once at generate (the reference rebuilds it in every apply); only the
+// Identity preconditioner here -- the mirror has no Transposable preconditioners.
+template <typename V = double>
+class Bicg : public LinOp {
+public:
+    class Factory : public detail::factory_base<Bicg> {};
+    static Factory build() { return Factory{}; }
+    std::shared_ptr<const LinOp> get_system_matrix() const { return A_; }
+    int64_t get_last_iteration_count() const noexcept { return last_iters_; }
+    bool has_converged() const noexcept { return last_converged_; }
+protected:
+    friend class detail::factory_base<Bicg>;
+    Bicg(const Factory* f, std::shared_ptr<const LinOp> A) : LinOp(f->get_executor(), gko::transpose(A->get_size())), A_(std::move(A)), settings_(f->settings())
+    {
+        if (size_[0] != size_[1]) throw DimensionMismatch(__FILE__, __LINE__, "Bicg needs a square system matrix");
+        if (f->precond_ || f->precond_factory_) GKO_NOT_SUPPORTED("Bicg: preconditioners need a transpose, which this mirror does not provide");
+        At_ = as<const matrix::Csr<V, int32>>(A_.get())->transpose();
+    }
+    void apply_impl(const LinOp* b, LinOp* x) const override
+    {
+        ::gko::detail::require_device(exec_, "bicg::apply");
+        auto csr = as<const matrix::Csr<V, int32>>(A_.get());
+        auto db = matrix::detail_fmt::dense(b); auto dx = matrix::detail_fmt::dense(x);
+        const int64_t n = size_[0], nrhs = db->cols();
+        if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
+        array<char> ws(exec_, gkomi_krylov_workspace_bytes(n, nrhs));
+        std::vector<double> info(2 + 2 * nrhs, 0.0);
+        GKOMI_CALL(gkomi_bicg_solve_f64_i32(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
+                                            At_->get_const_row_ptrs(), At_->get_const_col_idxs(), At_->get_const_values(), csr->get_strategy()->get_code(), csr->get_max_row_nnz(),
+                                            nullptr, nullptr, nullptr, nullptr, db->get_const_values(), dx->get_values(), settings_.max_iters, settings_.reduction_factor,
+                                            detail::baseline_code(settings_.baseline), 8, ws.get_data(), ws.get_num_elems(), info.data()));
+        last_iters_ = static_cast<int64_t>(info[0]);
+        last_converged_ = info[1] != 0.0;
+    }
+    void apply_impl(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const override
+    {
+        auto dx = matrix::detail_fmt::dense(x);
+        auto x_clone = dx->clone();
+        this->apply_impl(b, x_clone.get());
+        dx->scale(matrix::detail_fmt::dense(beta));
+        dx->add_scaled(matrix::detail_fmt::dense(alpha), x_clone.get());
+    }
+    std::shared_ptr<const LinOp> A_;
+    std::unique_ptr<matrix::Csr<V, int32>> At_;
+    stop::criterion_settings settings_;
+    mutable int64_t last_iters_{-1};
+    mutable bool last_converged_{false};
+};
+
+// Ir (include/ginkgo/core/solver/ir.hpp): x += relaxation_factor * solver(b - A x);
+// without an inner solver it is the Richardson iteration.  with_preconditioner /
+// with_generated_preconditioner of the common factory play with_solver /
+// with_generated_solver.
+template <typename V = double>
+class Ir : public LinOp {
+public:
+    class Factory : public detail::factory_base<Ir> {
+    public:
+        Factory& with_relaxation_factor(V r) { relaxation_factor_ = r; return *this; }
+        Factory& with_solver(std::shared_ptr<const LinOpFactory> f) { this->precond_factory_ = std::move(f); return *this; }
+        Factory& with_generated_solver(std::shared_ptr<const LinOp> p) { this->precond_ = std::move(p); return *this; }
+        V relaxation_factor_{1.0};
+    };
+    static Factory build() { return Factory{}; }
+    std::shared_ptr<const LinOp> get_system_matrix() const { return A_; }
+    std::shared_ptr<const LinOp> get_solver() const { return inner_; }
+    int64_t get_last_iteration_count() const noexcept { return last_iters_; }
+    bool has_converged() const noexcept { return last_converged_; }
+protected:
+    friend class detail::factory_base<Ir>;
+    Ir(const Factory* f, std::shared_ptr<const LinOp> A) : LinOp(f->get_executor(), gko::transpose(A->get_size())), A_(std::move(A)), settings_(f->settings()), relaxation_factor_(f->relaxation_factor_)
+    {
+        if (size_[0] != size_[1]) throw DimensionMismatch(__FILE__, __LINE__, "Ir needs a square system matrix");
+        inner_ = f->precond_ ? f->precond_ : (f->precond_factory_ ? std::shared_ptr<const LinOp>(f->precond_factory_->generate_impl(A_)) : nullptr);
+    }
+    void apply_impl(const LinOp* b, LinOp* x) const override
+    {
+        ::gko::detail::require_device(exec_, "ir::apply");
+        auto csr = as<const matrix::Csr<V, int32>>(A_.get());
+        auto db = matrix::detail_fmt::dense(b); auto dx = matrix::detail_fmt::dense(x);
+        const int64_t n = size_[0], nrhs = db->cols();
+        if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
+        array<char> ws(exec_, gkomi_krylov_workspace_bytes(n, nrhs));
+        std::vector<double> info(2 + 2 * nrhs, 0.0);
+        ::gko::detail::linop_callback cb{inner_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
+        GKOMI_CALL(gkomi_ir_solve_f64_i32(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
+                                          csr->get_strategy()->get_code(), csr->get_max_row_nnz(), inner_ ? &::gko::detail::linop_callback::call : nullptr, inner_ ? &cb : nullptr,
+                                          relaxation_factor_, db->get_const_values(), dx->get_values(), settings_.max_iters, settings_.reduction_factor,
+                                          detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
+        last_iters_ = static_cast<int64_t>(info[0]);
+        last_converged_ = info[1] != 0.0;
+    }
+    void apply_impl(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const override
+    {
+        auto dx = matrix::detail_fmt::dense(x);
+        auto x_clone = dx->clone();
+        this->apply_impl(b, x_clone.get());
+        dx->scale(matrix::detail_fmt::dense(beta));
+        dx->add_scaled(matrix::detail_fmt::dense(alpha), x_clone.get());
+    }
+    std::shared_ptr<const LinOp> A_;
+    std::shared_ptr<const LinOp> inner_;
+    stop::criterion_settings settings_;
+    V relaxation_factor_;
+    mutable int64_t last_iters_{-1};
+    mutable bool last_converged_{false};
+};
+
 template <typename V = double>
 class Gmres : public LinOp {
 public:

@@ -15,6 +15,8 @@ KERNEL_ARGS = {
     ("cgs", "step_1"): (["r", "u", "p", "q"], ["beta", "rho", "prev_rho"]),
     ("cgs", "step_2"): (["u", "v_hat", "q", "t"], ["alpha", "rho", "gamma"]),
     ("cgs", "step_3"): (["t", "u_hat", "r", "x"], ["alpha"]),
+    ("bicg", "step_1"): (["p", "z", "p2", "z2"], ["rho", "prev_rho"]),
+    ("bicg", "step_2"): (["x", "r", "r2", "p", "q", "q2"], ["beta", "rho"]),
 }
 
 

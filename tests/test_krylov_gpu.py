@@ -103,8 +103,20 @@ def test_initialize_kernels(gk):
 @pytest.mark.parametrize("case", G["solves"], ids=lambda c: c["solver"] + "_" + c["name"])
 def test_solve_known_answers(gk, oracle, case):
     n, rp, ci, v = dense_to_csr(case["A"])
-    res = solvers.krylov_solve(gk, case["solver"], n, dev(rp), dev(ci), dev(v), dev(np.array(case["b"])),
-                               max_iters=case["max_iters"], reduction=case["reduction"])
+    if case["solver"] == "ir":
+        res = solvers.ir_solve(gk, n, dev(rp), dev(ci), dev(v), dev(np.array(case["b"])),
+                               relaxation_factor=case["relaxation_factor"], max_iters=case["max_iters"],
+                               reduction=case["reduction"])
+        assert matgen.rel_err(host(res["x"]), case["expect_x"]) <= 4 * case["tol"], res
+        xe = np.zeros(n)
+        ite = oracle.ref_ir_solve(n, rp, ci, v, case["relaxation_factor"], np.array(case["b"]), xe, case["max_iters"],
+                                  case["reduction"], 0)
+        assert abs(res["iterations"] - ite) <= 1
+        return
+    solve = (lambda *a, **k: solvers.bicg_solve(gk, *a[1:], **k)) if case["solver"] == "bicg" else \
+        (lambda *a, **k: solvers.krylov_solve(gk, *a, **k))
+    res = solve(case["solver"], n, dev(rp), dev(ci), dev(v), dev(np.array(case["b"])),
+                max_iters=case["max_iters"], reduction=case["reduction"])
     # the reference's tolerance holds for its sequential dots; the device sums in
     # a two-stage order (deterministic, but different): allow 4x
     assert matgen.rel_err(host(res["x"]), case["expect_x"]) <= 4 * case["tol"], res
@@ -167,3 +179,46 @@ def test_multiple_rhs_preconditioner_and_iteration_limit(gk, oracle):
         assert pre["converged"] and matgen.rel_err(host(pre["x"]), xs) < 1e-8
         capped = solvers.krylov_solve(gk, solver, n, rpd, cid, vd, dev(b), max_iters=3, reduction=1e-11)
         assert capped["iterations"] == 3 and not capped["converged"]
+
+
+def test_bicg_like_the_oracle_and_with_jacobi(gk, oracle):
+    n, rp, ci, v = matgen.poisson_3d_7pt(12)
+    v = v.copy()
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    v[ci == rows - 1] -= 0.5
+    v[ci == rows] += 0.5
+    xs = np.sin(0.3 * np.arange(n))
+    b = np.zeros((n, 1))
+    oracle.ref_csr_spmv(n, 1, rp, ci, v, xs.reshape(n, 1), 1, b, 1)
+    xe = np.zeros(n)
+    ite = oracle.ref_bicg_solve(n, rp, ci, v, b[:, 0].copy(), xe, 2000, 1e-10, 0)
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    res = solvers.bicg_solve(gk, n, rpd, cid, vd, dev(b[:, 0].copy()), max_iters=2000, reduction=1e-10)
+    assert res["converged"] and abs(res["iterations"] - ite) <= max(2, ite // 10)
+    assert matgen.rel_err(host(res["x"]), xs) < 1e-7
+    again = solvers.bicg_solve(gk, n, rpd, cid, vd, dev(b[:, 0].copy()), max_iters=2000, reduction=1e-10, check_every=1)
+    assert again["iterations"] == res["iterations"] and host(again["x"]).tobytes() == host(res["x"]).tobytes()
+    pc = solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=1)     # scalar Jacobi = its own transpose
+    pre = solvers.bicg_solve(gk, n, rpd, cid, vd, dev(b[:, 0].copy()), max_iters=2000, reduction=1e-10, precond=pc,
+                             precond_t=pc)
+    assert pre["converged"] and matgen.rel_err(host(pre["x"]), xs) < 1e-7
+
+
+def test_ir_with_inner_preconditioner_and_richardson(gk, oracle):
+    n, rp, ci, v = matgen.poisson_2d_5pt(24)
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    xs = np.cos(0.2 * np.arange(n))
+    b = np.zeros((n, 1))
+    oracle.ref_csr_spmv(n, 1, rp, ci, v, xs.reshape(n, 1), 1, b, 1)
+    # Richardson with relaxation 1/4 (< 2 / lambda_max = 1/4 for the 5-point stencil) vs the oracle
+    xe = np.zeros(n)
+    ite = oracle.ref_ir_solve(n, rp, ci, v, 0.24, b[:, 0].copy(), xe, 300, 1e-3, 0)
+    res = solvers.ir_solve(gk, n, rpd, cid, vd, dev(b[:, 0].copy()), relaxation_factor=0.24, max_iters=300, reduction=1e-3)
+    assert res["iterations"] == ite and matgen.rel_err(host(res["x"]), xe) < 1e-12
+    # block-Jacobi as inner "solver": converges in fewer sweeps than scalar Richardson
+    pc = solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=8)
+    inner = solvers.ir_solve(gk, n, rpd, cid, vd, dev(b[:, 0].copy()), relaxation_factor=0.9, inner=pc, max_iters=300,
+                             reduction=1e-3)
+    assert inner["converged"] and inner["iterations"] < res["iterations"] or not res["converged"]
+    r = b[:, 0] - np.add.reduceat(v * host(inner["x"])[ci], rp[:-1])
+    assert np.linalg.norm(r) <= 1.01e-3 * np.linalg.norm(b)

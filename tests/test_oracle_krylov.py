@@ -60,13 +60,17 @@ def test_initialize_kernels(oracle):
 def test_solve_known_answers(oracle, case):
     n, rp, ci, v = dense_to_csr(case["A"])
     x = np.zeros(n)
-    it = getattr(oracle, f"ref_{case['solver']}_solve")(n, rp, ci, v, np.array(case["b"]), x, case["max_iters"],
-                                                       case["reduction"], 0)
+    if case["solver"] == "ir":
+        it = oracle.ref_ir_solve(n, rp, ci, v, case["relaxation_factor"], np.array(case["b"]), x, case["max_iters"],
+                                 case["reduction"], 0)
+    else:
+        it = getattr(oracle, f"ref_{case['solver']}_solve")(n, rp, ci, v, np.array(case["b"]), x, case["max_iters"],
+                                                           case["reduction"], 0)
     assert it <= case["max_iters"]
     assert matgen.rel_err(x, case["expect_x"]) <= case["tol"], (it, x)
 
 
-@pytest.mark.parametrize("solver", ["bicgstab", "fcg", "cgs"])
+@pytest.mark.parametrize("solver", ["bicgstab", "fcg", "cgs", "bicg"])
 def test_solves_poisson(oracle, solver):
     n, rp, ci, v = matgen.poisson_2d_5pt(24)
     xs = np.sin(0.3 * np.arange(n))
