@@ -215,6 +215,35 @@ class Hybrid:
 FORMATS = ("csr", "coo", "ell", "sellp", "hybrid")
 
 
+_BINARY_TYPES = {b"D": np.float64, b"S": np.float32, b"I": np.int32, b"L": np.int64}
+
+
+def read_binary(gk, path, device="cuda:0"):
+    """the reference's binary format (core/base/mtx_io.cpp:768-960): header
+    "GINKGO" + value type + index type, rows, cols, entries, then (row, col,
+    value) records -> Csr, assembled on the device"""
+    with open(path, "rb") as f:
+        header = f.read(32)
+        assert len(header) == 32 and header[:6] == b"GINKGO", "not a Ginkgo binary matrix file"
+        vt, it = header[6:7], header[7:8]
+        if vt in (b"Z", b"C"):
+            raise ValueError("cannot read into this format, would assign complex to real")
+        rows_n, cols_n, entries = (int(x) for x in np.frombuffer(header[8:], dtype=np.uint64))
+        rec = np.dtype([("row", _BINARY_TYPES[it]), ("col", _BINARY_TYPES[it]), ("val", _BINARY_TYPES[vt])])
+        data = np.frombuffer(f.read(rec.itemsize * entries), dtype=rec)
+        assert len(data) == entries, "truncated file"
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(device)
+    return Csr.from_triplets(gk, rows_n, cols_n, t(data["row"], np.int32), t(data["col"], np.int32),
+                             t(data["val"], np.float64), sum_duplicates=False)
+
+
+def read_matrix(gk, path, device="cuda:0"):
+    """read_generic: MatrixMarket text if the file starts with '%', binary otherwise"""
+    with open(path, "rb") as f:
+        first = f.read(1)
+    return read_mtx(gk, path, device) if first == b"%" else read_binary(gk, path, device)
+
+
 def read_mtx(gk, path, device="cuda:0"):
     """MatrixMarket coordinate file -> Csr, assembled on the device (symmetric
     storage expanded, duplicates summed, row-major sorted)."""

@@ -52,6 +52,7 @@ using size_type = std::size_t;
 using int32 = std::int32_t;
 using int64 = std::int64_t;
 using uint8 = std::uint8_t;
+using uint64 = std::uint64_t;
 using uint32 = std::uint32_t;
 template <typename T>
 using remove_complex = T;
@@ -1085,7 +1086,99 @@ void Csr<V, I>::convert_to(Hybrid<V, I>* result) const
 
 }  // namespace matrix
 
+// ---- binary matrix I/O (core/base/mtx_io.cpp:768-960): 32-byte header = magic
+// "GINKGO" + value type (D/S) + index type (I/L), rows, cols, entries as uint64,
+// then (row, column, value) records; complex files are refused ----------------------
+namespace detail {
+inline uint64 binary_magic(char value_bit, char index_bit)
+{
+    const char m[8] = {'G', 'I', 'N', 'K', 'G', 'O', value_bit, index_bit};
+    uint64 v;
+    std::memcpy(&v, m, 8);
+    return v;
+}
+template <typename FV, typename FI, typename V, typename I>
+matrix_data<V, I> read_binary_entries(std::istream& is, uint64 rows, uint64 cols, uint64 entries)
+{
+    if (rows > static_cast<uint64>(std::numeric_limits<I>::max()) || cols > static_cast<uint64>(std::numeric_limits<I>::max()))
+        throw StreamError(__FILE__, __LINE__, "cannot read into this format, its index type would overflow");
+    matrix_data<V, I> result;
+    result.size = dim<2>(rows, cols);
+    result.nonzeros.resize(entries);
+    for (uint64 i = 0; i < entries; ++i) {
+        char block[sizeof(FV) + 2 * sizeof(FI)];
+        if (!is.read(block, sizeof(block))) throw StreamError(__FILE__, __LINE__, "failed reading entry " + std::to_string(i));
+        FI row, column; FV value;
+        std::memcpy(&row, block, sizeof(FI));
+        std::memcpy(&column, block + sizeof(FI), sizeof(FI));
+        std::memcpy(&value, block + 2 * sizeof(FI), sizeof(FV));
+        result.nonzeros[i] = {static_cast<I>(row), static_cast<I>(column), static_cast<V>(value)};
+    }
+    result.ensure_row_major_order();
+    return result;
+}
+}  // namespace detail
+
+template <typename V = double, typename I = int32>
+matrix_data<V, I> read_binary_raw(std::istream& is)
+{
+    char header[32];
+    if (!is.read(header, 32)) throw StreamError(__FILE__, __LINE__, "failed reading header");
+    uint64 magic, rows, cols, entries;
+    std::memcpy(&magic, header, 8); std::memcpy(&rows, header + 8, 8); std::memcpy(&cols, header + 16, 8); std::memcpy(&entries, header + 24, 8);
+    if (magic == detail::binary_magic('D', 'I')) return detail::read_binary_entries<double, int32, V, I>(is, rows, cols, entries);
+    if (magic == detail::binary_magic('S', 'I')) return detail::read_binary_entries<float, int32, V, I>(is, rows, cols, entries);
+    if (magic == detail::binary_magic('D', 'L')) return detail::read_binary_entries<double, int64, V, I>(is, rows, cols, entries);
+    if (magic == detail::binary_magic('S', 'L')) return detail::read_binary_entries<float, int64, V, I>(is, rows, cols, entries);
+    if (magic == detail::binary_magic('Z', 'I') || magic == detail::binary_magic('C', 'I') || magic == detail::binary_magic('Z', 'L') || magic == detail::binary_magic('C', 'L'))
+        throw StreamError(__FILE__, __LINE__, "cannot read into this format, would assign complex to real");
+    throw StreamError(__FILE__, __LINE__, "invalid header magic number '" + std::string(header, 8) + "'");
+}
+template <typename V = double, typename I = int32>
+matrix_data<V, I> read_generic_raw(std::istream& is)
+{
+    const auto first = is.peek();
+    if (!is) throw StreamError(__FILE__, __LINE__, "failed reading from stream");
+    return first == '%' ? read_raw<V, I>(is) : read_binary_raw<V, I>(is);
+}
+template <typename V, typename I>
+void write_binary_raw(std::ostream& os, const matrix_data<V, I>& data)
+{
+    static_assert(std::is_same<V, double>::value && std::is_same<I, int32>::value, "this mirror stores double / int32");
+    const uint64 hdr[4] = {detail::binary_magic('D', 'I'), data.size[0], data.size[1], data.nonzeros.size()};
+    os.write(reinterpret_cast<const char*>(hdr), 32);
+    for (const auto& e : data.nonzeros) {
+        char block[16];
+        std::memcpy(block, &e.row, 4); std::memcpy(block + 4, &e.column, 4); std::memcpy(block + 8, &e.value, 8);
+        os.write(block, 16);
+    }
+    if (!os) throw StreamError(__FILE__, __LINE__, "failed writing the matrix");
+}
+
 // ---- read / write / initialize ------------------------------------------------------
+template <typename M, typename Stream>
+std::unique_ptr<M> read_binary(Stream&& is, std::shared_ptr<const Executor> exec)
+{
+    auto data = read_binary_raw<double, int32>(is);
+    auto m = M::create(std::move(exec));
+    m->read(data);
+    return m;
+}
+template <typename M, typename Stream>
+std::unique_ptr<M> read_generic(Stream&& is, std::shared_ptr<const Executor> exec)
+{
+    auto data = read_generic_raw<double, int32>(is);
+    auto m = M::create(std::move(exec));
+    m->read(data);
+    return m;
+}
+template <typename M>
+void write_binary(std::ostream& os, const M* m)
+{
+    matrix_data<double, int32> data;
+    m->write(data);
+    write_binary_raw(os, data);
+}
 template <typename M, typename Stream>
 std::unique_ptr<M> read(Stream&& is, std::shared_ptr<const Executor> exec)
 {

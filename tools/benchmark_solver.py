@@ -54,7 +54,7 @@ def main():
     cases = json.load(sys.stdin)
     for case in cases:
         try:
-            A = formats.read_mtx(gk, case["filename"]) if "filename" in case else stencil_matrix(gk, case["stencil"], int(case["size"]))
+            A = formats.read_matrix(gk, case["filename"]) if "filename" in case else stencil_matrix(gk, case["stencil"], int(case["size"]))
         except Exception as e:
             case["error"] = str(e)
             continue

@@ -62,7 +62,7 @@ def main():
     rng = np.random.default_rng(args.seed)
     for case in cases:
         try:
-            A = formats.read_mtx(gk, case["filename"]) if "filename" in case else stencil_matrix(gk, case["stencil"], int(case["size"]))
+            A = formats.read_matrix(gk, case["filename"]) if "filename" in case else stencil_matrix(gk, case["stencil"], int(case["size"]))
         except Exception as e:  # keep going like the reference (--keep_errors)
             case["error"] = str(e)
             continue
