@@ -745,6 +745,108 @@ int gkomi_dist_build_local_nonlocal_fill(
  * Ready-made gkomi_apply_fn implementations and their context records, the
  * generated state of preconditioner::Jacobi / preconditioner::Ilu.  All
  * pointers are device pointers; the records themselves live on the host. */
+/* A system matrix in any format as a callback for the *_solve_op_f64 drivers:
+ * c = A b (alpha == beta == NULL) or c = alpha A b + beta c, vectors n x nrhs
+ * row-major.  The records below + gkomi_*_matrix_apply_cb wrap the SpMV entry
+ * points of this header; the C++ mirror passes any gko::LinOp this way. */
+typedef int (*gkomi_matrix_apply_fn)(void* ctx, gkomi_stream_t s, int64_t nrhs,
+                                     const double* alpha, const double* b,
+                                     int64_t b_stride, const double* beta,
+                                     double* c, int64_t c_stride);
+typedef struct gkomi_csr_ctx {
+    int64_t nrows, ncols, nnz;
+    const int32_t* row_ptrs;
+    const int32_t* col_idxs;
+    const double* vals;
+    int64_t strategy;          /* strategy word of gkomi_csr_spmv_f64_i32 */
+    int64_t max_row_nnz_hint;
+} gkomi_csr_ctx;
+typedef struct gkomi_ell_ctx {
+    int64_t nrows, ncols, num_stored_per_row, stride;
+    const int32_t* col_idxs;
+    const double* vals;
+} gkomi_ell_ctx;
+typedef struct gkomi_sellp_ctx {
+    int64_t nrows, ncols, slice_size;
+    const uint64_t* slice_sets;
+    const uint64_t* slice_lengths;
+    const int32_t* col_idxs;
+    const double* vals;
+} gkomi_sellp_ctx;
+typedef struct gkomi_coo_ctx {
+    int64_t nrows, ncols, nnz;
+    const int32_t* row_idxs;
+    const int32_t* col_idxs;
+    const double* vals;
+} gkomi_coo_ctx;
+typedef struct gkomi_hybrid_ctx {
+    int64_t nrows, ncols, ell_num_stored_per_row, ell_stride;
+    const int32_t* ell_col_idxs;
+    const double* ell_vals;
+    int64_t coo_nnz;
+    const int32_t* coo_row_idxs;
+    const int32_t* coo_col_idxs;
+    const double* coo_vals;
+} gkomi_hybrid_ctx;
+int gkomi_csr_matrix_apply_cb(void* ctx, gkomi_stream_t s, int64_t nrhs,
+                              const double* alpha, const double* b,
+                              int64_t b_stride, const double* beta, double* c,
+                              int64_t c_stride);
+int gkomi_ell_matrix_apply_cb(void* ctx, gkomi_stream_t s, int64_t nrhs,
+                              const double* alpha, const double* b,
+                              int64_t b_stride, const double* beta, double* c,
+                              int64_t c_stride);
+int gkomi_sellp_matrix_apply_cb(void* ctx, gkomi_stream_t s, int64_t nrhs,
+                                const double* alpha, const double* b,
+                                int64_t b_stride, const double* beta,
+                                double* c, int64_t c_stride);
+int gkomi_coo_matrix_apply_cb(void* ctx, gkomi_stream_t s, int64_t nrhs,
+                              const double* alpha, const double* b,
+                              int64_t b_stride, const double* beta, double* c,
+                              int64_t c_stride);
+int gkomi_hybrid_matrix_apply_cb(void* ctx, gkomi_stream_t s, int64_t nrhs,
+                                 const double* alpha, const double* b,
+                                 int64_t b_stride, const double* beta,
+                                 double* c, int64_t c_stride);
+/* The solver drivers with the system matrix behind a callback (config 4 of
+ * BASELINE.json runs GMRES on ELL / SELL-P).  Same loops, same arguments as the
+ * CSR entry points; CG runs the reference kernel sequence (the fused path is
+ * CSR-only). */
+int gkomi_cg_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                          gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+                          gkomi_apply_fn precond, void* precond_ctx,
+                          const double* b, double* x, int64_t max_iters,
+                          double reduction_factor, int baseline,
+                          void* workspace, size_t workspace_bytes,
+                          double* host_info);
+int gkomi_gmres_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                             gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+                             gkomi_apply_fn precond, void* precond_ctx,
+                             const double* b, double* x, int64_t krylov_dim,
+                             int64_t max_iters, double reduction_factor,
+                             int baseline, void* workspace,
+                             size_t workspace_bytes, double* host_info);
+int gkomi_bicgstab_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                                gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+                                gkomi_apply_fn precond, void* precond_ctx,
+                                const double* b, double* x, int64_t max_iters,
+                                double reduction_factor, int baseline,
+                                int64_t check_every, void* workspace,
+                                size_t workspace_bytes, double* host_info);
+int gkomi_fcg_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                           gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+                           gkomi_apply_fn precond, void* precond_ctx,
+                           const double* b, double* x, int64_t max_iters,
+                           double reduction_factor, int baseline,
+                           int64_t check_every, void* workspace,
+                           size_t workspace_bytes, double* host_info);
+int gkomi_cgs_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                           gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+                           gkomi_apply_fn precond, void* precond_ctx,
+                           const double* b, double* x, int64_t max_iters,
+                           double reduction_factor, int baseline,
+                           int64_t check_every, void* workspace,
+                           size_t workspace_bytes, double* host_info);
 typedef struct gkomi_jacobi_ctx {
     int64_t n;               /* rows */
     int64_t nrhs;            /* columns of the vectors (stride == nrhs) */

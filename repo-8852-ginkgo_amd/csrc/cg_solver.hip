@@ -312,14 +312,17 @@ extern "C" size_t gkomi_cg_workspace_bytes(int64_t n, int64_t nrhs)
     return make_layout(n, nrhs).total;
 }
 
-extern "C" int gkomi_cg_solve_f64_i32(
-    gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz,
-    const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
-    int spmv_strategy, int64_t max_row_nnz_hint, gkomi_apply_fn precond,
-    void* precond_ctx, const double* b, double* x, int64_t max_iters,
-    double reduction_factor, int baseline, int mode, int check_every,
-    void* workspace, size_t workspace_bytes, double* host_info)
+namespace {
+int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
+                  void* precond_ctx, const double* b, double* x, int64_t max_iters,
+                  double reduction_factor, int baseline, int mode, int check_every, void* workspace,
+                  size_t workspace_bytes, double* host_info)
 {
+    const int64_t nnz = A.nnz;
+    const int32_t* row_ptrs = A.row_ptrs;
+    const int32_t* col_idxs = A.col_idxs;
+    const double* vals = A.vals;
+    if (mode == 1 && !A.is_csr()) mode = 0;  // the fused path needs the CSR arrays
     if (n < 0 || nrhs <= 0 || max_iters < 0) return GKOMI_EINVAL;
     if (baseline < 0 || baseline > 2 || (mode != 0 && mode != 1)) return GKOMI_EINVAL;
     if (mode == 1 && nrhs != 1) return GKOMI_ENOTSUPPORTED;
@@ -350,9 +353,7 @@ extern "C" int gkomi_cg_solve_f64_i32(
                                       nrhs, q, nrhs, prev_rho, rho, stop_status));
     GKOMI_TRY(gkomi_dense_fill_f64(s, 1, nrhs, one, nrhs, 1.0));
     GKOMI_TRY(gkomi_dense_fill_f64(s, 1, nrhs, neg_one, nrhs, -1.0));
-    GKOMI_TRY(gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals,
-                                     x, nrhs, r, nrhs, neg_one, one,
-                                     spmv_strategy, max_row_nnz_hint));
+    GKOMI_TRY(A.apply(s, nrhs, neg_one, x, one, r));
     // criterion generate: baseline norm (residual_norm.cpp:119-189)
     if (baseline == 0) {
         GKOMI_TRY(gkomi_dense_compute_norm2_f64(s, n, nrhs, b, nrhs, orig_tau, red, red_bytes));
@@ -386,9 +387,7 @@ extern "C" int gkomi_cg_solve_f64_i32(
             }
             if (stop) break;
             GKOMI_TRY(gkomi_cg_step_1_f64(s, n, nrhs, p, nrhs, z, nrhs, rho, prev_rho, stop_status));
-            GKOMI_TRY(gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, p, nrhs,
-                                             q, nrhs, nullptr, nullptr, spmv_strategy,
-                                             max_row_nnz_hint));
+            GKOMI_TRY(A.apply(s, nrhs, nullptr, p, nullptr, q));
             GKOMI_TRY(gkomi_dense_compute_dot_f64(s, n, nrhs, p, nrhs, q, nrhs, beta, red, red_bytes));
             GKOMI_TRY(gkomi_cg_step_2_f64(s, n, nrhs, x, nrhs, r, nrhs, p, nrhs, q, nrhs, beta, rho,
                                           stop_status));
@@ -475,4 +474,33 @@ extern "C" int gkomi_cg_solve_f64_i32(
         host_info[1] = static_cast<double>(converged);
     }
     return GKOMI_SUCCESS;
+}
+}  // namespace
+
+extern "C" int gkomi_cg_solve_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz,
+    const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
+    int spmv_strategy, int64_t max_row_nnz_hint, gkomi_apply_fn precond,
+    void* precond_ctx, const double* b, double* x, int64_t max_iters,
+    double reduction_factor, int baseline, int mode, int check_every,
+    void* workspace, size_t workspace_bytes, double* host_info)
+{
+    return cg_solve_impl(s, n, nrhs,
+                         make_csr_sysmat(n, nnz, row_ptrs, col_idxs, vals, spmv_strategy, max_row_nnz_hint),
+                         precond, precond_ctx, b, x, max_iters, reduction_factor, baseline, mode,
+                         check_every, workspace, workspace_bytes, host_info);
+}
+
+// the system matrix behind a callback: the reference kernel sequence (mode 0)
+extern "C" int gkomi_cg_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                                     gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+                                     gkomi_apply_fn precond, void* precond_ctx, const double* b,
+                                     double* x, int64_t max_iters, double reduction_factor,
+                                     int baseline, void* workspace, size_t workspace_bytes,
+                                     double* host_info)
+{
+    if (matrix == nullptr) return GKOMI_EINVAL;
+    return cg_solve_impl(s, n, nrhs, make_op_sysmat(n, matrix, matrix_ctx), precond, precond_ctx, b, x,
+                         max_iters, reduction_factor, baseline, 0, 1, workspace, workspace_bytes,
+                         host_info);
 }

@@ -350,12 +350,11 @@ extern "C" size_t gkomi_gmres_workspace_bytes(int64_t n, int64_t nrhs, int64_t k
     return make_layout(n, nrhs, krylov_dim).total;
 }
 
-extern "C" int gkomi_gmres_solve_f64_i32(
-    gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
-    const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
-    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t krylov_dim,
-    int64_t max_iters, double reduction_factor, int baseline, void* workspace,
-    size_t workspace_bytes, double* host_info)
+namespace {
+int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
+                     void* precond_ctx, const double* b, double* x, int64_t krylov_dim,
+                     int64_t max_iters, double reduction_factor, int baseline, void* workspace,
+                     size_t workspace_bytes, double* host_info)
 {
     if (n < 0 || nrhs <= 0 || krylov_dim <= 0 || max_iters < 0) return GKOMI_EINVAL;
     if (baseline < 0 || baseline > 2) return GKOMI_EINVAL;
@@ -385,9 +384,7 @@ extern "C" int gkomi_gmres_solve_f64_i32(
     auto residual_and_restart = [&]() -> int {
         // residual = b - A x; residual_norm; restart (gmres.cpp:184-195 / 260-275)
         GKOMI_TRY(gkomi_dense_copy_f64(s, n, nrhs, b, nrhs, residual, nrhs));
-        GKOMI_TRY(gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, x, nrhs,
-                                         residual, nrhs, neg_one, one, spmv_strategy,
-                                         max_row_nnz_hint));
+        GKOMI_TRY(A.apply(s, nrhs, neg_one, x, one, residual));
         GKOMI_TRY(gkomi_dense_compute_norm2_f64(s, n, nrhs, residual, nrhs, residual_norm, red,
                                                 red_bytes));
         return gkomi_gmres_restart_f64(s, n, nrhs, residual, nrhs, residual_norm, rnc, kb, nrhs,
@@ -443,9 +440,7 @@ extern "C" int gkomi_gmres_solve_f64_i32(
         double* next_k = kb + n * nrhs * (restart_iter + 1);
         GKOMI_TRY(apply_precond(this_k, pv));
         double* hess_iter = hess + nrhs * restart_iter;
-        GKOMI_TRY(gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, pv, nrhs,
-                                         next_k, nrhs, nullptr, nullptr, spmv_strategy,
-                                         max_row_nnz_hint));
+        GKOMI_TRY(A.apply(s, nrhs, nullptr, pv, nullptr, next_k));
         if (nrhs == 1 && n > 0) {
             // fused modified Gram-Schmidt: one pass over next_k per basis vector
             const int blocks = static_cast<int>(
@@ -492,4 +487,31 @@ extern "C" int gkomi_gmres_solve_f64_i32(
         host_info[1] = static_cast<double>(converged);
     }
     return static_cast<int>(hipStreamSynchronize(stream));
+}
+}  // namespace
+
+extern "C" int gkomi_gmres_solve_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
+    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t krylov_dim,
+    int64_t max_iters, double reduction_factor, int baseline, void* workspace,
+    size_t workspace_bytes, double* host_info)
+{
+    return gmres_solve_impl(s, n, nrhs,
+                            make_csr_sysmat(n, nnz, row_ptrs, col_idxs, vals, spmv_strategy, max_row_nnz_hint),
+                            precond, precond_ctx, b, x, krylov_dim, max_iters, reduction_factor, baseline,
+                            workspace, workspace_bytes, host_info);
+}
+
+extern "C" int gkomi_gmres_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                                        gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+                                        gkomi_apply_fn precond, void* precond_ctx, const double* b,
+                                        double* x, int64_t krylov_dim, int64_t max_iters,
+                                        double reduction_factor, int baseline, void* workspace,
+                                        size_t workspace_bytes, double* host_info)
+{
+    if (matrix == nullptr) return GKOMI_EINVAL;
+    return gmres_solve_impl(s, n, nrhs, make_op_sysmat(n, matrix, matrix_ctx), precond, precond_ctx, b, x,
+                            krylov_dim, max_iters, reduction_factor, baseline, workspace, workspace_bytes,
+                            host_info);
 }

@@ -16,6 +16,7 @@
 #include <utility>
 
 #include "common.hpp"
+#include "internal.hpp"
 
 namespace gkomi {
 namespace {
@@ -384,12 +385,8 @@ solver_layout make_solver_layout(int64_t n, int64_t nrhs, int nvec)
 struct driver_common {
     gkomi_stream_t s;
     hipStream_t stream;
-    int64_t n, nrhs, nnz;
-    const int32_t* row_ptrs;
-    const int32_t* col_idxs;
-    const double* vals;
-    int strategy;
-    int64_t hint;
+    int64_t n, nrhs;
+    sysmat A;
     gkomi_apply_fn precond;
     void* precond_ctx;
     int64_t max_iters;
@@ -403,8 +400,7 @@ struct driver_common {
 
     int spmv(const double* in, double* out) const
     {
-        return gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, in, nrhs, out,
-                                      nrhs, nullptr, nullptr, strategy, hint);
+        return A.apply(s, nrhs, nullptr, in, nullptr, out);
     }
     int apply_precond(const double* in, double* out) const
     {
@@ -420,8 +416,7 @@ struct driver_common {
         GKOMI_TRY(gkomi_dense_fill_f64(s, 1, nrhs, one, nrhs, 1.0));
         GKOMI_TRY(gkomi_dense_fill_f64(s, 1, nrhs, neg_one, nrhs, -1.0));
         // r = b - A x (r already holds b)
-        GKOMI_TRY(gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, x, nrhs, r,
-                                         nrhs, neg_one, one, strategy, hint));
+        GKOMI_TRY(A.apply(s, nrhs, neg_one, x, one, r));
         if (baseline == 0) {
             return gkomi_dense_compute_norm2_f64(s, n, nrhs, b, nrhs, orig_tau, red, red_bytes);
         }
@@ -496,18 +491,16 @@ struct driver_common {
     }
 };
 
-int make_common(driver_common& c, gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz,
-                const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
-                int strategy, int64_t hint, gkomi_apply_fn precond, void* precond_ctx,
+int make_common(driver_common& c, gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A,
+                gkomi_apply_fn precond, void* precond_ctx,
                 int64_t max_iters, double reduction, int baseline, int64_t check_every, char* ws,
                 const solver_layout& l, double** scalars)
 {
     if (n < 0 || nrhs <= 0 || max_iters < 0 || baseline < 0 || baseline > 2) return GKOMI_EINVAL;
     c.s = s;
     c.stream = to_stream(s);
-    c.n = n; c.nrhs = nrhs; c.nnz = nnz;
-    c.row_ptrs = row_ptrs; c.col_idxs = col_idxs; c.vals = vals;
-    c.strategy = strategy; c.hint = hint;
+    c.n = n; c.nrhs = nrhs;
+    c.A = A;
     c.precond = precond; c.precond_ctx = precond_ctx;
     c.max_iters = max_iters; c.reduction = reduction;
     double* small = reinterpret_cast<double*>(ws + l.small);
@@ -739,17 +732,14 @@ extern "C" size_t gkomi_krylov_workspace_bytes(int64_t n, int64_t nrhs)
     char* ws = static_cast<char*>(workspace);                                                    \
     driver_common c;                                                                             \
     double* sc = nullptr;                                                                        \
-    GKOMI_TRY(make_common(c, s, n, nrhs, nnz, row_ptrs, col_idxs, vals, spmv_strategy,           \
-                          max_row_nnz_hint, precond, precond_ctx, max_iters, reduction_factor,   \
+    GKOMI_TRY(make_common(c, s, n, nrhs, A, precond, precond_ctx, max_iters, reduction_factor,   \
                           baseline, check_every, ws, l, &sc));                                   \
     auto V = [&](int k) { return reinterpret_cast<double*>(ws + l.vec[k]); }
 
-extern "C" int gkomi_bicgstab_solve_f64_i32(
-    gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
-    const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
-    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
-    double reduction_factor, int baseline, int64_t check_every, void* workspace,
-    size_t workspace_bytes, double* host_info)
+namespace {
+int bicgstab_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
+    void* precond_ctx, const double* b, double* x, int64_t max_iters, double reduction_factor,
+    int baseline, int64_t check_every, void* workspace, size_t workspace_bytes, double* host_info)
 {
     GKOMI_DRIVER_PROLOGUE(8);
     double *r = V(0), *z = V(1), *y = V(2), *v = V(3), *sv = V(4), *t = V(5), *p = V(6), *rr = V(7);
@@ -791,12 +781,38 @@ extern "C" int gkomi_bicgstab_solve_f64_i32(
     return c.finish(c.stop_iter(), c.host_record.phase == 2 ? sv : r, host_info);
 }
 
-extern "C" int gkomi_fcg_solve_f64_i32(
+}  // namespace
+
+extern "C" int gkomi_bicgstab_solve_f64_i32(
     gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
     const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
     gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
     double reduction_factor, int baseline, int64_t check_every, void* workspace,
     size_t workspace_bytes, double* host_info)
+{
+    return bicgstab_solve_impl(s, n, nrhs,
+                            make_csr_sysmat(n, nnz, row_ptrs, col_idxs, vals, spmv_strategy, max_row_nnz_hint),
+                            precond, precond_ctx, b, x, max_iters, reduction_factor, baseline, check_every,
+                            workspace, workspace_bytes, host_info);
+}
+
+extern "C" int gkomi_bicgstab_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                                        gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+                                        gkomi_apply_fn precond, void* precond_ctx, const double* b,
+                                        double* x, int64_t max_iters, double reduction_factor,
+                                        int baseline, int64_t check_every, void* workspace,
+                                        size_t workspace_bytes, double* host_info)
+{
+    if (matrix == nullptr) return GKOMI_EINVAL;
+    return bicgstab_solve_impl(s, n, nrhs, make_op_sysmat(n, matrix, matrix_ctx), precond, precond_ctx, b, x,
+                            max_iters, reduction_factor, baseline, check_every, workspace, workspace_bytes,
+                            host_info);
+}
+
+namespace {
+int fcg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
+    void* precond_ctx, const double* b, double* x, int64_t max_iters, double reduction_factor,
+    int baseline, int64_t check_every, void* workspace, size_t workspace_bytes, double* host_info)
 {
     GKOMI_DRIVER_PROLOGUE(5);
     double *r = V(0), *z = V(1), *p = V(2), *q = V(3), *t = V(4);
@@ -823,12 +839,38 @@ extern "C" int gkomi_fcg_solve_f64_i32(
     return c.finish(c.stop_iter(), r, host_info);
 }
 
-extern "C" int gkomi_cgs_solve_f64_i32(
+}  // namespace
+
+extern "C" int gkomi_fcg_solve_f64_i32(
     gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
     const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
     gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
     double reduction_factor, int baseline, int64_t check_every, void* workspace,
     size_t workspace_bytes, double* host_info)
+{
+    return fcg_solve_impl(s, n, nrhs,
+                            make_csr_sysmat(n, nnz, row_ptrs, col_idxs, vals, spmv_strategy, max_row_nnz_hint),
+                            precond, precond_ctx, b, x, max_iters, reduction_factor, baseline, check_every,
+                            workspace, workspace_bytes, host_info);
+}
+
+extern "C" int gkomi_fcg_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                                        gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+                                        gkomi_apply_fn precond, void* precond_ctx, const double* b,
+                                        double* x, int64_t max_iters, double reduction_factor,
+                                        int baseline, int64_t check_every, void* workspace,
+                                        size_t workspace_bytes, double* host_info)
+{
+    if (matrix == nullptr) return GKOMI_EINVAL;
+    return fcg_solve_impl(s, n, nrhs, make_op_sysmat(n, matrix, matrix_ctx), precond, precond_ctx, b, x,
+                            max_iters, reduction_factor, baseline, check_every, workspace, workspace_bytes,
+                            host_info);
+}
+
+namespace {
+int cgs_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
+    void* precond_ctx, const double* b, double* x, int64_t max_iters, double reduction_factor,
+    int baseline, int64_t check_every, void* workspace, size_t workspace_bytes, double* host_info)
 {
     GKOMI_DRIVER_PROLOGUE(8);
     double *r = V(0), *r_tld = V(1), *p = V(2), *q = V(3), *u = V(4), *u_hat = V(5), *v_hat = V(6),
@@ -861,6 +903,34 @@ extern "C" int gkomi_cgs_solve_f64_i32(
         std::swap(prev_rho, rho);
     }
     return c.finish(c.stop_iter(), r, host_info);
+}
+
+}  // namespace
+
+extern "C" int gkomi_cgs_solve_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,
+    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
+    double reduction_factor, int baseline, int64_t check_every, void* workspace,
+    size_t workspace_bytes, double* host_info)
+{
+    return cgs_solve_impl(s, n, nrhs,
+                            make_csr_sysmat(n, nnz, row_ptrs, col_idxs, vals, spmv_strategy, max_row_nnz_hint),
+                            precond, precond_ctx, b, x, max_iters, reduction_factor, baseline, check_every,
+                            workspace, workspace_bytes, host_info);
+}
+
+extern "C" int gkomi_cgs_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                                        gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+                                        gkomi_apply_fn precond, void* precond_ctx, const double* b,
+                                        double* x, int64_t max_iters, double reduction_factor,
+                                        int baseline, int64_t check_every, void* workspace,
+                                        size_t workspace_bytes, double* host_info)
+{
+    if (matrix == nullptr) return GKOMI_EINVAL;
+    return cgs_solve_impl(s, n, nrhs, make_op_sysmat(n, matrix, matrix_ctx), precond, precond_ctx, b, x,
+                            max_iters, reduction_factor, baseline, check_every, workspace, workspace_bytes,
+                            host_info);
 }
 
 // ---- BiCG / IR ---------------------------------------------------------------------------
@@ -932,6 +1002,7 @@ extern "C" int gkomi_bicg_solve_f64_i32(
     int64_t check_every, void* workspace, size_t workspace_bytes, double* host_info)
 {
     if ((precond == nullptr) != (precond_t == nullptr)) return GKOMI_EINVAL;
+    const sysmat A = make_csr_sysmat(n, nnz, row_ptrs, col_idxs, vals, spmv_strategy, max_row_nnz_hint);
     GKOMI_DRIVER_PROLOGUE(8);
     double *r = V(0), *z = V(1), *p = V(2), *q = V(3), *r2 = V(4), *z2 = V(5), *p2 = V(6),
            *q2 = V(7);
@@ -982,6 +1053,7 @@ extern "C" int gkomi_ir_solve_f64_i32(
     gkomi_apply_fn precond = inner;
     void* precond_ctx = inner_ctx;
     const int64_t check_every = 1;
+    const sysmat A = make_csr_sysmat(n, nnz, row_ptrs, col_idxs, vals, spmv_strategy, max_row_nnz_hint);
     GKOMI_DRIVER_PROLOGUE(2);
     double *residual = V(0), *inner_solution = V(1);
     double* relax = sc;
@@ -994,9 +1066,7 @@ extern "C" int gkomi_ir_solve_f64_i32(
         ++iter;
         if (iter > 0) {
             GKOMI_TRY(gkomi_dense_copy_f64(s, n, nrhs, b, nrhs, residual, nrhs));
-            GKOMI_TRY(gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, x, nrhs,
-                                             residual, nrhs, c.neg_one, c.one, spmv_strategy,
-                                             max_row_nnz_hint));
+            GKOMI_TRY(A.apply(s, nrhs, c.neg_one, x, c.one, residual));
         }
         bool stop = false;
         GKOMI_TRY(c.check(iter, residual, true, 1, &stop));

@@ -36,3 +36,58 @@ extern "C" int gkomi_ilu_apply_cb(void* ctx_, gkomi_stream_t s, const double* in
                                          0, c->intermediate, c->nrhs, out, c->nrhs,
                                          c->trs_workspace, c->trs_workspace_bytes);
 }
+
+// ---- system matrices as callbacks (gkomi_matrix_apply_fn) --------------------------------
+extern "C" int gkomi_csr_matrix_apply_cb(void* ctx_, gkomi_stream_t s, int64_t nrhs,
+                                         const double* alpha, const double* b, int64_t b_stride,
+                                         const double* beta, double* c, int64_t c_stride)
+{
+    const gkomi_csr_ctx* m = static_cast<const gkomi_csr_ctx*>(ctx_);
+    if (m == nullptr) return GKOMI_EINVAL;
+    return gkomi_csr_spmv_f64_i32(s, m->nrows, m->ncols, nrhs, m->nnz, m->row_ptrs, m->col_idxs,
+                                  m->vals, b, b_stride, c, c_stride, alpha, beta,
+                                  static_cast<int>(m->strategy), m->max_row_nnz_hint);
+}
+
+extern "C" int gkomi_ell_matrix_apply_cb(void* ctx_, gkomi_stream_t s, int64_t nrhs,
+                                         const double* alpha, const double* b, int64_t b_stride,
+                                         const double* beta, double* c, int64_t c_stride)
+{
+    const gkomi_ell_ctx* m = static_cast<const gkomi_ell_ctx*>(ctx_);
+    if (m == nullptr) return GKOMI_EINVAL;
+    return gkomi_ell_spmv_f64_i32(s, m->nrows, m->ncols, nrhs, m->num_stored_per_row, m->stride,
+                                  m->col_idxs, m->vals, b, b_stride, c, c_stride, alpha, beta);
+}
+
+extern "C" int gkomi_sellp_matrix_apply_cb(void* ctx_, gkomi_stream_t s, int64_t nrhs,
+                                           const double* alpha, const double* b, int64_t b_stride,
+                                           const double* beta, double* c, int64_t c_stride)
+{
+    const gkomi_sellp_ctx* m = static_cast<const gkomi_sellp_ctx*>(ctx_);
+    if (m == nullptr) return GKOMI_EINVAL;
+    return gkomi_sellp_spmv_f64_i32(s, m->nrows, m->ncols, nrhs, m->slice_size, m->slice_sets,
+                                    m->slice_lengths, m->col_idxs, m->vals, b, b_stride, c, c_stride,
+                                    alpha, beta);
+}
+
+extern "C" int gkomi_coo_matrix_apply_cb(void* ctx_, gkomi_stream_t s, int64_t nrhs,
+                                         const double* alpha, const double* b, int64_t b_stride,
+                                         const double* beta, double* c, int64_t c_stride)
+{
+    const gkomi_coo_ctx* m = static_cast<const gkomi_coo_ctx*>(ctx_);
+    if (m == nullptr) return GKOMI_EINVAL;
+    return gkomi_coo_spmv_f64_i32(s, m->nrows, m->ncols, nrhs, m->nnz, m->row_idxs, m->col_idxs,
+                                  m->vals, b, b_stride, c, c_stride, alpha, beta);
+}
+
+extern "C" int gkomi_hybrid_matrix_apply_cb(void* ctx_, gkomi_stream_t s, int64_t nrhs,
+                                            const double* alpha, const double* b, int64_t b_stride,
+                                            const double* beta, double* c, int64_t c_stride)
+{
+    const gkomi_hybrid_ctx* m = static_cast<const gkomi_hybrid_ctx*>(ctx_);
+    if (m == nullptr) return GKOMI_EINVAL;
+    return gkomi_hybrid_spmv_f64_i32(s, m->nrows, m->ncols, nrhs, m->ell_num_stored_per_row,
+                                     m->ell_stride, m->ell_col_idxs, m->ell_vals, m->coo_nnz,
+                                     m->coo_row_idxs, m->coo_col_idxs, m->coo_vals, b, b_stride, c,
+                                     c_stride, alpha, beta);
+}

@@ -129,6 +129,31 @@ int main()
         std::cout << "gmres_ilu_iters " << gm->get_last_iteration_count() << " converged " << gm->has_converged()
                   << " true_residual " << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
 
+        // config 4 of BASELINE.json: GMRES(30) + ILU with the system matrix in SELL-P and ELL
+        {
+            auto Bs = gko::share(gko::matrix::Sellp<double, int>::create(exec));
+            B->convert_to(Bs.get());
+            auto Be = gko::share(gko::matrix::Ell<double, int>::create(exec));
+            B->convert_to(Be.get());
+            auto ilu = gko::share(gko::preconditioner::Ilu<double, int>::build().with_factorization_iterations(20u).on(exec)->generate(B));
+            int k = 0;
+            for (auto M : {std::shared_ptr<const gko::LinOp>(Bs), std::shared_ptr<const gko::LinOp>(Be)}) {
+                sol->fill(0.0);
+                auto g2 = gko::solver::Gmres<double>::build()
+                              .with_krylov_dim(30u)
+                              .with_criteria(gko::stop::Iteration::build().with_max_iters(1000u).on(exec),
+                                             gko::stop::ResidualNorm<double>::build().with_reduction_factor(1e-10).on(exec))
+                              .with_generated_preconditioner(ilu)
+                              .on(exec)->generate(M);
+                g2->apply(b.get(), sol.get());
+                r->copy_from(b.get());
+                B->apply(neg.get(), sol.get(), one.get(), r.get());
+                r->compute_norm2(rn.get());
+                std::cout << (k++ == 0 ? "gmres_ilu_sellp_iters " : "gmres_ilu_ell_iters ") << g2->get_last_iteration_count() << " converged " << g2->has_converged()
+                          << " true_residual " << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
+            }
+        }
+
         // the other Krylov solvers on the same systems: FCG (SPD), BiCGSTAB and CGS (nonsymmetric)
         {
             auto crit = [&]() {

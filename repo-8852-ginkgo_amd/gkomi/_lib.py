@@ -37,6 +37,7 @@ _SCALARS = {
     "float": ctypes.c_float,
     "gkomi_stream_t": ctypes.c_void_p,
     "gkomi_apply_fn": ctypes.c_void_p,
+    "gkomi_matrix_apply_fn": ctypes.c_void_p,
 }
 
 

@@ -11,6 +11,34 @@ import torch
 I32, I64, F64, U8 = torch.int32, torch.int64, torch.float64, torch.uint8
 
 
+def _ctx_type(name, fields):
+    return type(name, (ctypes.Structure,), {"_fields_": fields})
+
+
+_i64, _ptr = ctypes.c_int64, ctypes.c_void_p
+CsrCtx = _ctx_type("CsrCtx", [("nrows", _i64), ("ncols", _i64), ("nnz", _i64), ("row_ptrs", _ptr), ("col_idxs", _ptr),
+                              ("vals", _ptr), ("strategy", _i64), ("max_row_nnz_hint", _i64)])
+EllCtx = _ctx_type("EllCtx", [("nrows", _i64), ("ncols", _i64), ("num_stored_per_row", _i64), ("stride", _i64),
+                              ("col_idxs", _ptr), ("vals", _ptr)])
+SellpCtx = _ctx_type("SellpCtx", [("nrows", _i64), ("ncols", _i64), ("slice_size", _i64), ("slice_sets", _ptr),
+                                  ("slice_lengths", _ptr), ("col_idxs", _ptr), ("vals", _ptr)])
+CooCtx = _ctx_type("CooCtx", [("nrows", _i64), ("ncols", _i64), ("nnz", _i64), ("row_idxs", _ptr), ("col_idxs", _ptr),
+                              ("vals", _ptr)])
+HybridCtx = _ctx_type("HybridCtx", [("nrows", _i64), ("ncols", _i64), ("ell_num_stored_per_row", _i64),
+                                    ("ell_stride", _i64), ("ell_col_idxs", _ptr), ("ell_vals", _ptr), ("coo_nnz", _i64),
+                                    ("coo_row_idxs", _ptr), ("coo_col_idxs", _ptr), ("coo_vals", _ptr)])
+
+
+class MatrixCallback:
+    """(gkomi_matrix_apply_fn, context) of a format object for the *_solve_op_f64 drivers"""
+
+    def __init__(self, gk, symbol, ctx, owner):
+        self.fn = ctypes.cast(getattr(gk._cdll, symbol), ctypes.c_void_p).value
+        self.ctx = ctx
+        self.ctx_ptr = ctypes.addressof(ctx)
+        self.owner = owner  # keeps the device arrays alive
+
+
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -72,6 +100,11 @@ class Csr:
                                  _scalar(dv, beta), self.strategy, self.max_row_nnz())
         return x
 
+    def callback(self):
+        ctx = CsrCtx(self.nrows, self.ncols, self.nnz, self.row_ptrs.data_ptr(), self.col_idxs.data_ptr(),
+                     self.vals.data_ptr(), self.strategy, self.max_row_nnz())
+        return MatrixCallback(self.gk, "gkomi_csr_matrix_apply_cb", ctx, self)
+
     def row_idxs(self):
         rows = torch.zeros(max(self.nnz, 1), dtype=I32, device=self.vals.device)
         self.gk.convert_ptrs_to_idxs_i32(_stream(self.vals), self.row_ptrs, self.nrows, rows)
@@ -96,6 +129,11 @@ class Coo:
 
     def storage_bytes(self):
         return 16 * self.nnz
+
+    def callback(self):
+        ctx = CooCtx(self.nrows, self.ncols, self.nnz, self.row_idxs.data_ptr(), self.col_idxs.data_ptr(),
+                     self.vals.data_ptr())
+        return MatrixCallback(self.gk, "gkomi_coo_matrix_apply_cb", ctx, self)
 
     def apply(self, b, x, alpha=None, beta=None):
         dv = self.vals.device
@@ -125,6 +163,10 @@ class Ell:
 
     def storage_bytes(self):
         return 12 * self.stride * self.k
+
+    def callback(self):
+        ctx = EllCtx(self.nrows, self.ncols, self.k, self.stride, self.col_idxs.data_ptr(), self.vals.data_ptr())
+        return MatrixCallback(self.gk, "gkomi_ell_matrix_apply_cb", ctx, self)
 
     def apply(self, b, x, alpha=None, beta=None):
         dv = self.vals.device
@@ -160,6 +202,11 @@ class Sellp:
 
     def storage_bytes(self):
         return 12 * int(self.vals.numel()) + 16 * int(self.lens.numel()) + 8
+
+    def callback(self):
+        ctx = SellpCtx(self.nrows, self.ncols, self.slice_size, self.sets.data_ptr(), self.lens.data_ptr(),
+                       self.col_idxs.data_ptr(), self.vals.data_ptr())
+        return MatrixCallback(self.gk, "gkomi_sellp_matrix_apply_cb", ctx, self)
 
     def apply(self, b, x, alpha=None, beta=None):
         dv = self.vals.device
@@ -202,6 +249,12 @@ class Hybrid:
 
     def storage_bytes(self):
         return 12 * self.ell_lim * self.nrows + 16 * self.coo_nnz
+
+    def callback(self):
+        ctx = HybridCtx(self.nrows, self.ncols, self.ell_lim, self.nrows, self.ell_cols.data_ptr(),
+                        self.ell_vals.data_ptr(), self.coo_nnz, self.coo_rows.data_ptr(), self.coo_cols.data_ptr(),
+                        self.coo_vals.data_ptr())
+        return MatrixCallback(self.gk, "gkomi_hybrid_matrix_apply_cb", ctx, self)
 
     def apply(self, b, x, alpha=None, beta=None):
         dv = self.ell_vals.device

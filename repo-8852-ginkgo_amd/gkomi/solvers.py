@@ -123,6 +123,42 @@ def ir_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, relaxation_factor=1.0, 
             "rel_residual": float(np.max(res / np.where(base == 0, 1.0, base)))}
 
 
+def solve_op(gk, solver, matrix, b, x=None, max_iters=1000, reduction=1e-10, baseline="rhs_norm", precond=None,
+             krylov_dim=100, check_every=8):
+    """Any solver in {"cg", "gmres", "bicgstab", "fcg", "cgs"} on a system matrix in
+    any format (a gkomi.formats object): the *_solve_op_f64 drivers."""
+    n = matrix.nrows
+    b2 = b.reshape(n, -1)
+    nrhs = b2.shape[1]
+    if x is None:
+        x = torch.zeros_like(b2)
+    x2 = x.reshape(n, nrhs)
+    cb = matrix.callback()
+    info = np.zeros(2 + 2 * nrhs, dtype=np.float64)
+    stream = torch.cuda.current_stream().cuda_stream
+    fn = precond.fn if precond is not None else None
+    ctx = precond.ctx_ptr if precond is not None else None
+    if solver == "cg":
+        nbytes = gk.cg_workspace_bytes(n, nrhs)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+        gk.cg_solve_op_f64(stream, n, nrhs, cb.fn, cb.ctx_ptr, fn, ctx, b2, x2, max_iters, reduction, BASELINES[baseline],
+                           ws, nbytes, info)
+    elif solver == "gmres":
+        nbytes = gk.gmres_workspace_bytes(n, nrhs, krylov_dim)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+        gk.gmres_solve_op_f64(stream, n, nrhs, cb.fn, cb.ctx_ptr, fn, ctx, b2, x2, krylov_dim, max_iters, reduction,
+                              BASELINES[baseline], ws, nbytes, info)
+    else:
+        nbytes = gk.krylov_workspace_bytes(n, nrhs)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+        getattr(gk, solver + "_solve_op_f64")(stream, n, nrhs, cb.fn, cb.ctx_ptr, fn, ctx, b2, x2, max_iters, reduction,
+                                              BASELINES[baseline], check_every, ws, nbytes, info)
+    res, base = info[2::2].copy(), info[3::2].copy()
+    return {"x": x2 if b.dim() > 1 else x2.reshape(n), "iterations": int(info[0]), "converged": bool(info[1]),
+            "residual_norm": res, "baseline_norm": base,
+            "rel_residual": float(np.max(res / np.where(base == 0, 1.0, base)))}
+
+
 class JacobiCtx(ctypes.Structure):
     """gkomi_jacobi_ctx (include/gkomi.h)."""
     _fields_ = [("n", ctypes.c_int64), ("nrhs", ctypes.c_int64), ("num_blocks", ctypes.c_int64),

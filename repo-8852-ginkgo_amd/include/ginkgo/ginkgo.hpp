@@ -1286,6 +1286,32 @@ struct linop_callback {
         return 0;
     }
 };
+// any LinOp as a gkomi_matrix_apply_fn: the system matrix of the *_solve_op_f64
+// drivers (Ell, Sellp, Coo, Hybrid, ... -- config 4 of BASELINE.json)
+struct matrix_callback {
+    const LinOp* op;
+    std::shared_ptr<const Executor> exec;
+    size_type n;
+    static int call(void* ctx, gkomi_stream_t, int64_t nrhs, const double* alpha, const double* b, int64_t b_stride, const double* beta, double* c, int64_t c_stride)
+    {
+        auto* m = static_cast<matrix_callback*>(ctx);
+        try {
+            const size_type k = static_cast<size_type>(nrhs);
+            auto vb = matrix::Dense<double>::create(m->exec, dim<2>(m->n, k), array<double>::view(m->exec, m->n * b_stride, const_cast<double*>(b)), b_stride);
+            auto vc = matrix::Dense<double>::create(m->exec, dim<2>(m->n, k), array<double>::view(m->exec, m->n * c_stride, c), c_stride);
+            if (alpha == nullptr) {
+                m->op->apply(vb.get(), vc.get());
+            } else {
+                auto va = matrix::Dense<double>::create(m->exec, dim<2>(1, 1), array<double>::view(m->exec, 1, const_cast<double*>(alpha)), 1);
+                auto vbeta = matrix::Dense<double>::create(m->exec, dim<2>(1, 1), array<double>::view(m->exec, 1, const_cast<double*>(beta)), 1);
+                m->op->apply(va.get(), vb.get(), vbeta.get(), vc.get());
+            }
+        } catch (const std::exception&) {
+            return GKOMI_EINVAL;
+        }
+        return 0;
+    }
+};
 }  // namespace detail
 
 // include/ginkgo/core/base/types.hpp:257-400
@@ -1458,17 +1484,24 @@ protected:
     void apply_impl(const LinOp* b, LinOp* x) const override
     {
         ::gko::detail::require_device(exec_, "cg::apply");
-        auto csr = as<const matrix::Csr<V, int32>>(A_.get());
+        auto csr = dynamic_cast<const matrix::Csr<V, int32>*>(A_.get());
         auto db = matrix::detail_fmt::dense(b); auto dx = matrix::detail_fmt::dense(x);
         const int64_t n = size_[0], nrhs = db->cols();
         if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
         array<char> ws(exec_, gkomi_cg_workspace_bytes(n, nrhs));
         std::vector<double> info(2 + 2 * nrhs, 0.0);
         ::gko::detail::linop_callback cb{precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
-        GKOMI_CALL(gkomi_cg_solve_f64_i32(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
-                                          csr->get_strategy()->get_code(), csr->get_max_row_nnz(), precond_ ? &::gko::detail::linop_callback::call : nullptr, precond_ ? &cb : nullptr,
-                                          db->get_const_values(), dx->get_values(), settings_.max_iters, settings_.reduction_factor, detail::baseline_code(settings_.baseline),
-                                          nrhs == 1 ? 1 : 0, 8, ws.get_data(), ws.get_num_elems(), info.data()));
+        auto pfn = precond_ ? &::gko::detail::linop_callback::call : nullptr;
+        void* pctx = precond_ ? &cb : nullptr;
+        if (csr) {
+            GKOMI_CALL(gkomi_cg_solve_f64_i32(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
+                                              csr->get_strategy()->get_code(), csr->get_max_row_nnz(), pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
+                                              settings_.reduction_factor, detail::baseline_code(settings_.baseline), nrhs == 1 ? 1 : 0, 8, ws.get_data(), ws.get_num_elems(), info.data()));
+        } else {  // any other format: the system matrix as a callback
+            ::gko::detail::matrix_callback mcb{A_.get(), exec_, static_cast<size_type>(n)};
+            GKOMI_CALL(gkomi_cg_solve_op_f64(nullptr, n, nrhs, &::gko::detail::matrix_callback::call, &mcb, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
+                                             settings_.reduction_factor, detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
+        }
         last_iters_ = static_cast<int64_t>(info[0]);
         last_converged_ = info[1] != 0.0;
     }
@@ -1493,7 +1526,9 @@ protected:
 namespace detail {
 using krylov_driver = int (*)(gkomi_stream_t, int64_t, int64_t, int64_t, const int32_t*, const int32_t*, const double*, int, int64_t, gkomi_apply_fn, void*,
                               const double*, double*, int64_t, double, int, int64_t, void*, size_t, double*);
-template <typename Derived, krylov_driver Driver>
+using krylov_op_driver = int (*)(gkomi_stream_t, int64_t, int64_t, gkomi_matrix_apply_fn, void*, gkomi_apply_fn, void*, const double*, double*, int64_t, double, int, int64_t,
+                                 void*, size_t, double*);
+template <typename Derived, krylov_driver Driver, krylov_op_driver OpDriver>
 class krylov_solver : public LinOp {
 public:
     class Factory : public factory_base<Derived> {};
@@ -1511,17 +1546,24 @@ protected:
     void apply_impl(const LinOp* b, LinOp* x) const override
     {
         ::gko::detail::require_device(exec_, "solver::apply");
-        auto csr = as<const matrix::Csr<double, int32>>(A_.get());
+        auto csr = dynamic_cast<const matrix::Csr<double, int32>*>(A_.get());
         auto db = matrix::detail_fmt::dense(b); auto dx = matrix::detail_fmt::dense(x);
         const int64_t n = size_[0], nrhs = db->cols();
         if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
         array<char> ws(exec_, gkomi_krylov_workspace_bytes(n, nrhs));
         std::vector<double> info(2 + 2 * nrhs, 0.0);
         ::gko::detail::linop_callback cb{precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
-        GKOMI_CALL(Driver(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
-                          csr->get_strategy()->get_code(), csr->get_max_row_nnz(), precond_ ? &::gko::detail::linop_callback::call : nullptr, precond_ ? &cb : nullptr,
-                          db->get_const_values(), dx->get_values(), settings_.max_iters, settings_.reduction_factor, baseline_code(settings_.baseline), 8, ws.get_data(),
-                          ws.get_num_elems(), info.data()));
+        auto pfn = precond_ ? &::gko::detail::linop_callback::call : nullptr;
+        void* pctx = precond_ ? &cb : nullptr;
+        if (csr) {
+            GKOMI_CALL(Driver(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
+                              csr->get_strategy()->get_code(), csr->get_max_row_nnz(), pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
+                              settings_.reduction_factor, baseline_code(settings_.baseline), 8, ws.get_data(), ws.get_num_elems(), info.data()));
+        } else {
+            ::gko::detail::matrix_callback mcb{A_.get(), exec_, static_cast<size_type>(n)};
+            GKOMI_CALL(OpDriver(nullptr, n, nrhs, &::gko::detail::matrix_callback::call, &mcb, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
+                                settings_.reduction_factor, baseline_code(settings_.baseline), 8, ws.get_data(), ws.get_num_elems(), info.data()));
+        }
         last_iters_ = static_cast<int64_t>(info[0]);
         last_converged_ = info[1] != 0.0;
     }
@@ -1541,16 +1583,16 @@ protected:
 };
 }  // namespace detail
 
-#define GKOMI_KRYLOV_SOLVER(Name, driver)                                                          \
+#define GKOMI_KRYLOV_SOLVER(Name, driver, op_driver)                                               \
     template <typename V = double>                                                                 \
-    class Name : public detail::krylov_solver<Name<V>, driver> {                                   \
-        using base = detail::krylov_solver<Name<V>, driver>;                                       \
+    class Name : public detail::krylov_solver<Name<V>, driver, op_driver> {                        \
+        using base = detail::krylov_solver<Name<V>, driver, op_driver>;                            \
         friend class detail::factory_base<Name>;                                                   \
         Name(const typename base::Factory* f, std::shared_ptr<const LinOp> A) : base(f, std::move(A)) {} \
     }
-GKOMI_KRYLOV_SOLVER(Bicgstab, gkomi_bicgstab_solve_f64_i32);
-GKOMI_KRYLOV_SOLVER(Fcg, gkomi_fcg_solve_f64_i32);
-GKOMI_KRYLOV_SOLVER(Cgs, gkomi_cgs_solve_f64_i32);
+GKOMI_KRYLOV_SOLVER(Bicgstab, gkomi_bicgstab_solve_f64_i32, gkomi_bicgstab_solve_op_f64);
+GKOMI_KRYLOV_SOLVER(Fcg, gkomi_fcg_solve_f64_i32, gkomi_fcg_solve_op_f64);
+GKOMI_KRYLOV_SOLVER(Cgs, gkomi_cgs_solve_f64_i32, gkomi_cgs_solve_op_f64);
 #undef GKOMI_KRYLOV_SOLVER
 
 // Bicg (include/ginkgo/core/solver/bicg.hpp): the transposed system matrix is
@@ -1683,17 +1725,24 @@ protected:
     void apply_impl(const LinOp* b, LinOp* x) const override
     {
         ::gko::detail::require_device(exec_, "gmres::apply");
-        auto csr = as<const matrix::Csr<V, int32>>(A_.get());
+        auto csr = dynamic_cast<const matrix::Csr<V, int32>*>(A_.get());
         auto db = matrix::detail_fmt::dense(b); auto dx = matrix::detail_fmt::dense(x);
         const int64_t n = size_[0], nrhs = db->cols();
         if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
         array<char> ws(exec_, gkomi_gmres_workspace_bytes(n, nrhs, krylov_dim_));
         std::vector<double> info(2 + 2 * nrhs, 0.0);
         ::gko::detail::linop_callback cb{precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
-        GKOMI_CALL(gkomi_gmres_solve_f64_i32(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
-                                             csr->get_strategy()->get_code(), csr->get_max_row_nnz(), precond_ ? &::gko::detail::linop_callback::call : nullptr, precond_ ? &cb : nullptr,
-                                             db->get_const_values(), dx->get_values(), krylov_dim_, settings_.max_iters, settings_.reduction_factor, detail::baseline_code(settings_.baseline),
-                                             ws.get_data(), ws.get_num_elems(), info.data()));
+        auto pfn = precond_ ? &::gko::detail::linop_callback::call : nullptr;
+        void* pctx = precond_ ? &cb : nullptr;
+        if (csr) {
+            GKOMI_CALL(gkomi_gmres_solve_f64_i32(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
+                                                 csr->get_strategy()->get_code(), csr->get_max_row_nnz(), pfn, pctx, db->get_const_values(), dx->get_values(), krylov_dim_,
+                                                 settings_.max_iters, settings_.reduction_factor, detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
+        } else {
+            ::gko::detail::matrix_callback mcb{A_.get(), exec_, static_cast<size_type>(n)};
+            GKOMI_CALL(gkomi_gmres_solve_op_f64(nullptr, n, nrhs, &::gko::detail::matrix_callback::call, &mcb, pfn, pctx, db->get_const_values(), dx->get_values(), krylov_dim_,
+                                                settings_.max_iters, settings_.reduction_factor, detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
+        }
         last_iters_ = static_cast<int64_t>(info[0]);
         last_converged_ = info[1] != 0.0;
     }

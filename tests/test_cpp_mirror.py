@@ -88,6 +88,8 @@ def test_hot_path_tour(bins):
     assert abs(int(kv["cg_adaptive_jacobi_iters"][0]) - int(kv["cg_jacobi_iters"][0])) <= 5
     assert kv["gmres_ilu_iters"][2] == "1" and float(kv["gmres_ilu_iters"][4]) < 1e-9
     assert int(kv["gmres_ilu_iters"][0]) < 200
+    for name in ("gmres_ilu_sellp_iters", "gmres_ilu_ell_iters"):   # config 4: other formats as system matrix
+        assert kv[name][2] == "1" and float(kv[name][4]) < 1e-9
     for name in ("fcg_jacobi_iters", "bicgstab_ilu_iters", "cgs_ilu_iters"):
         assert kv[name][2] == "1" and float(kv[name][4]) < 1e-8, (name, kv[name])
     assert kv["fcg_jacobi_iters"][0] == kv["cg_jacobi_iters"][0]   # FCG = CG in exact arithmetic on an SPD matrix

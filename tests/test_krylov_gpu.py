@@ -222,3 +222,40 @@ def test_ir_with_inner_preconditioner_and_richardson(gk, oracle):
     assert inner["converged"] and inner["iterations"] < res["iterations"] or not res["converged"]
     r = b[:, 0] - np.add.reduceat(v * host(inner["x"])[ci], rp[:-1])
     assert np.linalg.norm(r) <= 1.01e-3 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("solver", ["cg", "gmres", "bicgstab", "fcg", "cgs"])
+def test_solvers_on_every_matrix_format(gk, oracle, solver):
+    """config 4 of BASELINE.json solves on ELL / SELL-P: the *_solve_op_f64 drivers
+    take the system matrix in any format.  ELL and SELL-P SpMV are bit-identical to
+    CSR's, so the iterates are too; COO / Hybrid sum with atomics (rounding)."""
+    from gkomi import formats
+    n, rp, ci, v = matgen.poisson_2d_5pt(40)
+    if solver in ("gmres", "bicgstab", "cgs"):
+        v = v.copy()
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        v[ci == rows - 1] -= 0.3
+        v[ci == rows] += 0.3
+    A = formats.Csr.from_host(gk, n, n, rp, ci, v)
+    xs = np.sin(0.3 * np.arange(n))
+    b = A.apply(dev(xs.reshape(n, 1)), torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")).reshape(n)
+    pc = solvers.jacobi_generate(gk, n, A.row_ptrs, A.col_idxs, A.vals, max_block_size=4)
+    kw = dict(max_iters=2000, reduction=1e-10, precond=pc)
+    base = solvers.solve_op(gk, solver, A, b, **kw)
+    assert base["converged"] and matgen.rel_err(host(base["x"]), xs) < 1e-7
+    # the CSR entry point and the operator entry point run the same loop
+    if solver == "cg":
+        direct = solvers.cg_solve(gk, n, A.row_ptrs, A.col_idxs, A.vals, b, mode=0, **kw)
+    elif solver == "gmres":
+        direct = solvers.gmres_solve(gk, n, A.row_ptrs, A.col_idxs, A.vals, b, **kw)
+    else:
+        direct = solvers.krylov_solve(gk, solver, n, A.row_ptrs, A.col_idxs, A.vals, b, **kw)
+    assert direct["iterations"] == base["iterations"] and host(direct["x"]).tobytes() == host(base["x"]).tobytes()
+    for fmt in ("ell", "sellp", "coo", "hybrid"):
+        M = A.to(fmt, kind=0, num_columns=3) if fmt == "hybrid" else A.to(fmt)  # column_limit(3): some COO part
+        res = solvers.solve_op(gk, solver, M, b, **kw)
+        assert res["converged"] and matgen.rel_err(host(res["x"]), xs) < 1e-7, fmt
+        if fmt in ("ell", "sellp"):
+            assert res["iterations"] == base["iterations"] and host(res["x"]).tobytes() == host(base["x"]).tobytes()
+        else:
+            assert abs(res["iterations"] - base["iterations"]) <= max(2, base["iterations"] // 10)
