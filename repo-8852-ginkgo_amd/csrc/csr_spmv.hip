@@ -185,6 +185,125 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
 }
 
 
+// ---- several right-hand sides at once ---------------------------------------
+//
+// The reference's classical kernel (and the stream kernel above with
+// gridDim.y = nrhs) re-reads the matrix for every column of b.  Here a
+// workgroup stages its row block's (val, col) tile in LDS once (12 B per
+// nonzero) and every row thread walks its row, gathering the NR contiguous
+// values b(col, j0 .. j0+NR-1) of the row-major b per nonzero (one 16/32-B
+// load when aligned) into NR register accumulators -- the matrix is read once
+// per NR columns and the per-(row, column) summation order is still the
+// reference's left-to-right one (bit-exact).  The row walk is unrolled by four
+// with clamped indices so that 4*NR gathers are in flight per thread.
+template <int NR, bool Advanced, bool Vec>
+__global__ __launch_bounds__(256) void csr_spmm_kernel(
+    int nrows, const int32_t* __restrict__ row_ptrs,
+    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
+    int64_t c_stride, const double* __restrict__ alpha_p,
+    const double* __restrict__ beta_p)
+{
+    constexpr int Block = 256;
+    constexpr int Tile = 1536;
+    constexpr int pairs = Tile / (2 * Block);
+    constexpr int unroll = NR >= 8 ? 2 : 4;
+    __shared__ __attribute__((aligned(16))) double s_val[Tile];
+    __shared__ __attribute__((aligned(8))) int32_t s_col[Tile];
+
+    b += blockIdx.y * NR;
+    c += blockIdx.y * NR;
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * Block;
+    const int r1 = min(r0 + Block, nrows);
+    const int p0 = row_ptrs[r0];
+    const int p1 = row_ptrs[r1];
+    const int nnz_total = row_ptrs[nrows];
+    double alpha = 1.0, beta = 0.0;
+    if (Advanced) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    const int row = r0 + tid;
+    int ra = p1, rb = p1;
+    double sum[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) sum[j] = 0.0;
+    if (row < r1) {
+        ra = row_ptrs[row];
+        rb = row_ptrs[row + 1];
+        if (Advanced) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) sum[j] = c[row * c_stride + j] * beta;
+        }
+    }
+    for (int t0 = p0 & ~1; t0 < p1; t0 += Tile) {
+#pragma unroll
+        for (int u = 0; u < pairs; ++u) {
+            const int k = t0 + 2 * (tid + u * Block);
+            double2 v = make_double2(0.0, 0.0);
+            int2 ci = make_int2(0, 0);
+            if (k < p1) {
+                if (k + 1 < nnz_total) {
+                    v = *reinterpret_cast<const double2*>(vals + k);
+                    ci = *reinterpret_cast<const int2*>(col_idxs + k);
+                } else {
+                    v.x = vals[k];
+                    ci.x = col_idxs[k];
+                }
+            }
+            *reinterpret_cast<double2*>(s_val + 2 * (tid + u * Block)) = v;
+            *reinterpret_cast<int2*>(s_col + 2 * (tid + u * Block)) = ci;
+        }
+        __syncthreads();
+        const int t1 = t0 + Tile;
+        const int lo = max(ra, t0);
+        const int hi = min(rb, t1);
+        for (int k = lo; k < hi; k += unroll) {
+            double v[unroll];
+            double x[unroll][NR];
+#pragma unroll
+            for (int u = 0; u < unroll; ++u) {
+                const int idx = min(k + u, hi - 1) - t0;
+                v[u] = s_val[idx];
+                const double* src = b + s_col[idx] * b_stride;
+                if (Vec) {
+#pragma unroll
+                    for (int j = 0; j < NR; j += 2) {
+                        const double2 t = *reinterpret_cast<const double2*>(src + j);
+                        x[u][j] = t.x;
+                        x[u][j + 1] = t.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) x[u][j] = src[j];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < unroll; ++u) {
+                if (k + u < hi) {
+                    const double av = Advanced ? alpha * v[u] : v[u];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) sum[j] += av * x[u][j];
+                }
+            }
+        }
+        if (t1 < p1) __syncthreads();
+    }
+    if (row < r1) {
+        if (Vec) {
+#pragma unroll
+            for (int j = 0; j < NR; j += 2) {
+                *reinterpret_cast<double2*>(c + row * c_stride + j) = make_double2(sum[j], sum[j + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) c[row * c_stride + j] = sum[j];
+        }
+    }
+}
+
+
 // ---- load-balanced kernel ("load_balance", csr.hpp:356-524) -------------------
 //
 // For matrices whose row lengths vary wildly the work is split by NONZEROS, not
@@ -382,6 +501,30 @@ int launch_stream(hipStream_t stream, bool swizzle, int chunk, int nrows, int nr
     return check_launch();
 }
 
+template <int NR>
+int launch_spmm(hipStream_t stream, int nrows, int slices,
+                const int32_t* row_ptrs, const int32_t* col_idxs,
+                const double* vals, const double* b, int64_t b_stride,
+                double* c, int64_t c_stride, const double* alpha,
+                const double* beta)
+{
+    dim3 grid(static_cast<unsigned>(ceildiv(nrows, 256)), slices);
+    const bool vec = reinterpret_cast<uintptr_t>(b) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(c) % 16 == 0 &&
+                     b_stride % 2 == 0 && c_stride % 2 == 0;
+#define GKOMI_LAUNCH(ADV, VEC)                                                 \
+    hipLaunchKernelGGL((csr_spmm_kernel<NR, ADV, VEC>), grid, dim3(256), 0,    \
+                       stream, nrows, row_ptrs, col_idxs, vals, b, b_stride,   \
+                       c, c_stride, alpha, beta)
+    if (alpha != nullptr) {
+        if (vec) GKOMI_LAUNCH(true, true); else GKOMI_LAUNCH(true, false);
+    } else {
+        if (vec) GKOMI_LAUNCH(false, true); else GKOMI_LAUNCH(false, false);
+    }
+#undef GKOMI_LAUNCH
+    return check_launch();
+}
+
 template <int SubWave>
 int launch_vector(hipStream_t stream, int nrows, int nrhs,
                   const int32_t* row_ptrs, const int32_t* col_idxs,
@@ -508,6 +651,36 @@ extern "C" int gkomi_csr_spmv_f64_i32(
 
 #define GKOMI_ARGS                                                            \
     n, r, row_ptrs, col_idxs, vals, b, b_stride, c, c_stride, alpha, beta
+    if (kind == GKOMI_CSR_STREAM && r >= 2 && (automatic || variant == 20)) {
+        // several right-hand sides: read the matrix once per 8 (then 4,
+        // then 2) columns; a last odd column goes through the single-column kernel
+        int done = 0;
+        if (r - done >= 8) {
+            const int slices = (r - done) / 8;
+            const int err = launch_spmm<8>(stream, n, slices, row_ptrs, col_idxs, vals, b + done, b_stride,
+                                           c + done, c_stride, alpha, beta);
+            if (err) return err;
+            done += 8 * slices;
+        }
+        if (r - done >= 4) {
+            const int slices = (r - done) / 4;
+            const int err = launch_spmm<4>(stream, n, slices, row_ptrs, col_idxs, vals, b + done, b_stride,
+                                           c + done, c_stride, alpha, beta);
+            if (err) return err;
+            done += 4 * slices;
+        }
+        if (r - done >= 2) {
+            const int err = launch_spmm<2>(stream, n, 1, row_ptrs, col_idxs, vals, b + done, b_stride,
+                                           c + done, c_stride, alpha, beta);
+            if (err) return err;
+            done += 2;
+        }
+        if (r - done == 1) {
+            return launch_stream<256, 1, 1536>(stream, !no_swizzle, chunk, n, 1, row_ptrs, col_idxs, vals,
+                                               b + done, b_stride, c + done, c_stride, alpha, beta);
+        }
+        return GKOMI_SUCCESS;
+    }
     if (kind == GKOMI_CSR_STREAM) {
         switch (variant) {
         case 1: return launch_stream<256, 2, 4096>(stream, !no_swizzle, chunk, GKOMI_ARGS);

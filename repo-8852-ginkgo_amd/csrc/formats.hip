@@ -25,6 +25,7 @@ namespace gkomi {
 namespace {
 
 constexpr int block = 256;
+constexpr int wave_size = 64;
 
 template <bool Advanced>
 __global__ __launch_bounds__(block) void ell_spmv_kernel(
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(block) void coo_spmv2_kernel(
 {
     __shared__ __attribute__((aligned(16))) double prod[coo_tile];
     __shared__ __attribute__((aligned(8))) int32_t rowid[coo_tile];
+    __shared__ int wave_heads[block / wave_size];
     b += blockIdx.y;
     c += blockIdx.y;
     const double alpha = Scaled ? alpha_p[0] : 1.0;
@@ -204,11 +206,17 @@ __global__ __launch_bounds__(block) void coo_spmv2_kernel(
         }
     }
     __syncthreads();
-    // segment heads inside this thread's run of coo_items elements
+    // segment heads inside this thread's run of coo_items elements: the head
+    // adds its segment left to right (the reference's order inside a row)
     const int first = tid * coo_items;
+    double sums[coo_items];
+    int rows[coo_items];
+    int nheads = 0;
 #pragma unroll
     for (int u = 0; u < coo_items; ++u) {
         const int e = first + u;
+        rows[u] = -1;
+        sums[u] = 0.0;
         if (e < count) {
             const int row = rowid[e];
             if (e == 0 || rowid[e - 1] != row) {
@@ -218,9 +226,45 @@ __global__ __launch_bounds__(block) void coo_spmv2_kernel(
                     sum += prod[k];
                     ++k;
                 }
-                unsafeAtomicAdd(c + row * c_stride, sum);
+                rows[u] = row;
+                sums[u] = sum;
+                ++nheads;
             }
         }
+    }
+    // compact (row, sum) into LDS so that consecutive lanes issue the atomics
+    // of consecutive segments: one coalesced atomic instruction per 64
+    // segments instead of scattered ones (43.5 -> 21.4 us on P2,
+    // tools/coo_experiment.hip)
+    const int lane = tid & (wave_size - 1);
+    const int wave = tid / wave_size;
+    int incl = nheads;
+#pragma unroll
+    for (int d = 1; d < wave_size; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == wave_size - 1) wave_heads[wave] = incl;
+    __syncthreads();  // also: every thread is done reading prod / rowid
+    int offset = incl - nheads;
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < block / wave_size; ++w) {
+        const int wc = wave_heads[w];
+        if (w < wave) offset += wc;
+        total += wc;
+    }
+#pragma unroll
+    for (int u = 0; u < coo_items; ++u) {
+        if (rows[u] >= 0) {
+            prod[offset] = sums[u];
+            rowid[offset] = rows[u];
+            ++offset;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < total; i += block) {
+        unsafeAtomicAdd(c + rowid[i] * c_stride, prod[i]);
     }
 }
 

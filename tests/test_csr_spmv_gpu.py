@@ -21,6 +21,7 @@ STRATEGIES = {"auto": 0, "stream": STREAM, "stream_v1": STREAM | (1 << 8),
               "stream_v4": STREAM | (4 << 8), "stream_noswz": STREAM | (1 << 16),
               "stream_v5": STREAM | (5 << 8), "stream_v8": STREAM | (8 << 8), "stream_v9": STREAM | (9 << 8),
               "stream_v13": STREAM | (13 << 8), "stream_v11_noswz": STREAM | (11 << 8) | (1 << 16),
+              "stream_spmm": STREAM | (20 << 8),
               "vector": VECTOR, "vector64": VECTOR | (64 << 8), "vector2": VECTOR | (2 << 8), "balanced": 3}
 BITEXACT = {k for k in STRATEGIES if k.startswith("stream") or k == "auto"}
 
@@ -53,7 +54,7 @@ def _oracle_apply(oracle, n, rp, ci, v, b, c=None, alpha=None, beta=None):
 
 
 @pytest.mark.parametrize("sort", [True, False], ids=["sorted", "unsorted"])
-@pytest.mark.parametrize("nrhs", [1, 3])
+@pytest.mark.parametrize("nrhs", [1, 3, 7])
 @pytest.mark.parametrize("advanced", [False, True], ids=["simple", "advanced"])
 @pytest.mark.parametrize("strategy", sorted(STRATEGIES))
 def test_random_532x231(gk, oracle, strategy, advanced, nrhs, sort):
@@ -123,6 +124,56 @@ def test_strided_rhs_and_output(gk, oracle):
     got = host(cd)
     assert np.array_equal(got[:, :2], expect)
     assert np.all(got[:, 2:] == -7.0)
+
+
+@pytest.mark.parametrize("advanced", [False, True], ids=["simple", "advanced"])
+@pytest.mark.parametrize("nrhs,b_stride,c_stride", [(2, 2, 2), (4, 4, 4), (4, 5, 7), (5, 6, 6), (8, 8, 8), (11, 12, 11), (15, 16, 16), (17, 17, 18)])
+def test_several_right_hand_sides_read_the_matrix_once(gk, oracle, nrhs, b_stride, c_stride, advanced):
+    """The multi-rhs kernel (4 / 2 columns per pass + single-column remainder),
+    aligned (16-B loads of b) and odd strides, rows longer than one LDS tile,
+    empty rows: bit-exact against the oracle per (row, column)."""
+    rng = np.random.default_rng(nrhs * 100 + b_stride)
+    counts = np.concatenate([rng.integers(0, 9, size=700), [0, 4000, 0, 1, 1700], rng.integers(0, 40, size=300)])
+    ncols = 5000
+    rp = np.zeros(len(counts) + 1, np.int32)
+    np.cumsum(counts, out=rp[1:])
+    ci = np.concatenate([np.sort(rng.choice(ncols, size=k, replace=False)) for k in counts]).astype(np.int32)
+    v = rng.standard_normal(int(rp[-1]))
+    n = len(counts)
+    bfull = rng.standard_normal((ncols, b_stride))
+    cfull = rng.standard_normal((n, c_stride))
+    A = DevCsr(n, ncols, rp, ci, v)
+    bd, cd = dev(bfull), dev(cfull)
+    expect = cfull.copy()
+    if advanced:
+        al, be = dev(np.array([0.5])), dev(np.array([-2.0]))
+        oracle.ref_csr_advanced_spmv(n, nrhs, 0.5, rp, ci, v, bfull, b_stride, -2.0, expect, c_stride)
+    else:
+        al = be = None
+        oracle.ref_csr_spmv(n, nrhs, rp, ci, v, bfull, b_stride, expect, c_stride)
+    for strategy in (0, STRATEGIES["stream_spmm"]):
+        cd.copy_(dev(cfull))
+        gk.csr_spmv_f64_i32(torch.cuda.current_stream().cuda_stream, n, ncols, nrhs, A.nnz, A.row_ptrs, A.col_idxs,
+                            A.vals, bd, b_stride, cd, c_stride, al, be, strategy, 0 if strategy else 4000)
+        if strategy == 0:
+            # automatic with a 4000-long row picks the sub-wave kernel: tolerance
+            assert matgen.rel_err(host(cd)[:, :nrhs], expect[:, :nrhs]) <= 1e-14
+        else:
+            assert np.array_equal(host(cd), expect)  # padding columns untouched too
+
+
+def test_full_size_poisson_four_right_hand_sides(gk, oracle):
+    n, rp, ci, v = matgen.poisson_2d_5pt(1000)
+    rng = np.random.default_rng(4)
+    b = rng.standard_normal((n, 4))
+    A = DevCsr(n, n, rp, ci, v)
+    expect = _oracle_apply(oracle, n, rp, ci, v, b)
+    got = host(csr_apply(gk, A, dev(b), strategy=0))
+    assert np.array_equal(got, expect)
+    # each column equals the single-column apply
+    for j in range(4):
+        col = host(csr_apply(gk, A, dev(np.ascontiguousarray(b[:, j:j + 1])), strategy=0))
+        assert np.array_equal(col[:, 0], got[:, j])
 
 
 def test_misaligned_arrays_fall_back(gk, oracle):

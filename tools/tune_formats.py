@@ -82,6 +82,15 @@ report("sellp(64)", lambda: gk.sellp_spmv_f64_i32(s, n, n, 1, 64, sets, lens, sc
 rows = torch.zeros(nnz, dtype=torch.int32, device="cuda")
 gk.convert_ptrs_to_idxs_i32(s, rpd, n, rows)
 report("coo (fill + spmv2)", lambda: gk.coo_spmv_f64_i32(s, n, n, 1, nnz, rows, cid, vd, x, 1, y, 1, None, None), 16 * nnz + 24 * n)
+# several right-hand sides: one pass over the matrix per 4 columns vs one per column
+for k_rhs in (2, 4, 8):
+    xb = d(np.sin(0.01 * np.arange(n * k_rhs)).reshape(n, k_rhs))
+    yb = torch.empty((n, k_rhs), dtype=torch.float64, device="cuda")
+    mb = 12 * nnz + 4 * (n + 1) + 16 * n * k_rhs
+    report(f"csr {k_rhs} rhs, multi-rhs kernel", lambda: gk.csr_spmv_f64_i32(s, n, n, k_rhs, nnz, rpd, cid, vd, xb, k_rhs, yb, k_rhs, None, None, 0, 5), mb)
+    report(f"csr {k_rhs} rhs, one grid row per rhs", lambda: gk.csr_spmv_f64_i32(s, n, n, k_rhs, nnz, rpd, cid, vd, xb, k_rhs, yb, k_rhs, None, None, 1 | (5 << 8), 5), mb)
+if os.environ.get("FORMATS_ONLY"):
+    sys.exit(0)
 # Jacobi apply (max block size 32)
 pre = solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=32)
 jb = 8 * pre.blocks.numel() + 16 * n
