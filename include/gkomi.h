@@ -833,6 +833,26 @@ int gkomi_bicgstab_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
                                 double reduction_factor, int baseline,
                                 int64_t check_every, void* workspace,
                                 size_t workspace_bytes, double* host_info);
+/* Fused single right-hand-side BiCGSTAB: the recurrences and check points of
+ * core/solver/bicgstab.cpp:107-234 in 6 launches per iteration instead of 25
+ * (dot partials in the SpMV / step epilogues, criterion on the device).  Same
+ * arguments and host_info as gkomi_bicgstab_solve_f64_i32 with nrhs = 1;
+ * workspace gkomi_krylov_workspace_bytes(n, 1).  Iterates agree with the
+ * reference sequence to rounding (the dots are summed in a different fixed
+ * order); they do not depend on check_every. */
+int gkomi_bicgstab_solve_fused_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nnz, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, int spmv_strategy,
+    int64_t max_row_nnz_hint, gkomi_apply_fn precond, void* precond_ctx,
+    const double* b, double* x, int64_t max_iters, double reduction_factor,
+    int baseline, int64_t check_every, void* workspace, size_t workspace_bytes,
+    double* host_info);
+int gkomi_bicgstab_solve_fused_op_f64(
+    gkomi_stream_t s, int64_t n, gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x,
+    int64_t max_iters, double reduction_factor, int baseline,
+    int64_t check_every, void* workspace, size_t workspace_bytes,
+    double* host_info);
 int gkomi_fcg_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
                            gkomi_matrix_apply_fn matrix, void* matrix_ctx,
                            gkomi_apply_fn precond, void* precond_ctx,

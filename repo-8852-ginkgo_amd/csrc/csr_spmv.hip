@@ -58,7 +58,9 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
     int64_t c_stride, const double* __restrict__ alpha_p,
     const double* __restrict__ beta_p, int nblocks, int per_xcd,
     double* __restrict__ dot_partial = nullptr,
-    const uint8_t* __restrict__ stop_status = nullptr)
+    const uint8_t* __restrict__ stop_status = nullptr,
+    const double* __restrict__ dot_w = nullptr,
+    double* __restrict__ dot_partial2 = nullptr)
 {
     constexpr int rows_per_block = Block * RowsPerThread;
     constexpr int pairs = Tile / (2 * Block);
@@ -167,13 +169,20 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
         if (t1 < p1) __syncthreads();
     }
 
-    double pq = 0.0;
+    double pq = 0.0, qq = 0.0;
+    // Dot: partials of w . c (w = b unless given: CG's p.q, BiCGSTAB's rr.v and
+    // s.t) and, on request, of c . c (BiCGSTAB's t.t)
+    const double* w = Dot && dot_w != nullptr ? dot_w : b;
+    const int64_t w_stride = Dot && dot_w != nullptr ? 1 : b_stride;
 #pragma unroll
     for (int i = 0; i < RowsPerThread; ++i) {
         const int row = r0 + tid + i * Block;
         if (row < r1) {
             c[row * c_stride] = sum[i];
-            if (Dot) pq += b[row * b_stride] * sum[i];
+            if (Dot) {
+                pq += w[row * w_stride] * sum[i];
+                qq += sum[i] * sum[i];
+            }
         }
     }
     if (Dot) {
@@ -181,6 +190,11 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
         __syncthreads();
         const double total = block_reduce_sum<Block>(pq, red);
         if (tid == 0) dot_partial[logical] = total;
+        if (dot_partial2 != nullptr) {
+            __syncthreads();
+            const double total2 = block_reduce_sum<Block>(qq, red);
+            if (tid == 0) dot_partial2[logical] = total2;
+        }
     }
 }
 
@@ -558,7 +572,7 @@ int csr_spmv_dot_launch(hipStream_t stream, int nrows, int64_t nnz,
                         const int32_t* row_ptrs, const int32_t* col_idxs,
                         const double* vals, const double* p, double* q,
                         double* partial, const uint8_t* stop_status,
-                        bool swizzle)
+                        bool swizzle, const double* dot_w, double* partial2)
 {
     constexpr int Block = 256, Tile = 1536;
     const int nblocks = static_cast<int>(ceildiv(nrows, Block));
@@ -569,14 +583,14 @@ int csr_spmv_dot_launch(hipStream_t stream, int nrows, int64_t nnz,
         hipLaunchKernelGGL((csr_stream_kernel<Block, 1, Tile, false, true, true>),
                            grid, dim3(Block), 0, stream, nrows, row_ptrs,
                            col_idxs, vals, p, int64_t{1}, q, int64_t{1},
-                           nullptr, nullptr, nblocks, per, partial, stop_status);
+                           nullptr, nullptr, nblocks, per, partial, stop_status, dot_w, partial2);
     } else {
         // not Infinity-Cache resident: the matrix streams from HBM every
         // iteration, read it with nontemporal loads (see csr_auto_swizzle)
         hipLaunchKernelGGL((csr_stream_kernel<Block, 1, Tile, false, false, true, true>),
                            grid, dim3(Block), 0, stream, nrows, row_ptrs,
                            col_idxs, vals, p, int64_t{1}, q, int64_t{1},
-                           nullptr, nullptr, nblocks, per, partial, stop_status);
+                           nullptr, nullptr, nblocks, per, partial, stop_status, dot_w, partial2);
     }
     return check_launch();
 }

@@ -361,7 +361,7 @@ dim3 grid_of(int64_t n, int64_t nrhs) { return dim3(static_cast<unsigned>(ceildi
 
 // ---- drivers ------------------------------------------------------------------
 struct solver_layout {
-    size_t vec[8], small, red, total;
+    size_t vec[8], small, red, parts, total;
 };
 
 solver_layout make_solver_layout(int64_t n, int64_t nrhs, int nvec)
@@ -377,6 +377,9 @@ solver_layout make_solver_layout(int64_t n, int64_t nrhs, int nvec)
     // 10 scalar rows + statuses + flags
     l.small = take(sizeof(double) * 10 * nrhs + 2 * static_cast<size_t>(nrhs) + 128);
     l.red = take(gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8);
+    // fused single-rhs drivers: 3 x <=1024 partials of the vector kernels and
+    // 3 x one partial per SpMV row block, plus the device scalars
+    l.parts = take(sizeof(double) * (3 * 1024 + 3 * (static_cast<size_t>(n) / 256 + 2)) + 256);
     l.total = off;
     return l;
 }
@@ -781,7 +784,430 @@ int bicgstab_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat&
     return c.finish(c.stop_iter(), c.host_record.phase == 2 ? sv : r, host_info);
 }
 
+
+// ---- fused BiCGSTAB, one right-hand side --------------------------------------------
+//
+// The reference sequence above costs 25 launches per iteration (two-stage dots,
+// the criterion, the step kernels).  The fused driver keeps the same recurrences
+// and check points in 6 launches (+ the preconditioner's):
+//   KA  re-adds the partials of rho = rr.r and |r|^2 left by KE, evaluates the
+//       criterion on r (phase 1) and -- unless stopped -- updates p (step_1)
+//   KB  v = A y with the partials of rr.v in the SpMV epilogue
+//   KC  re-adds them: alpha, s = r - alpha v (step_2), partials of |s|^2
+//   KD0 re-adds those, evaluates the criterion on s (phase 2); if it fires,
+//       x += alpha y (finalize)
+//   KD  t = A z with the partials of s.t and t.t in the epilogue
+//   KE  re-adds them: omega, x += alpha y + omega z, r = s - omega t (step_3),
+//       partials of rr.r and |r|^2 for the next KA
+// Every workgroup re-adds the partials in the same order, so all agree on the
+// scalars bit for bit; workgroup 0 stores them for the kernels that follow.
+// Once a criterion fires the remaining launches return at once, so x and the
+// iteration count are those of the stopping iteration whatever `check_every`.
+constexpr int fblock = 1024;
+constexpr int fused_max_parts = 1024;
+
+struct bicgstab_scalars {
+    double rho[2];  // rho of iteration `it` lives in rho[it & 1]
+    double alpha, omega, tau, orig_tau;
+    long long stop_iter;
+    long long stop2_iter;   // iteration whose half step converged (KD0 only), -1 before
+    int phase;
+    unsigned char status;   // written by KA only
+    unsigned char status2;  // written by KD0 only
+    unsigned char pad[2];
+};
+
+__device__ __forceinline__ double sum_partials_f(const double* __restrict__ part, int nparts,
+                                                 double* smem)
+{
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += fblock) acc += part[i];
+    acc = wave_reduce_sum(acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wave] = acc;
+    __syncthreads();
+    double total = 0.0;
+#pragma unroll
+    for (int w = 0; w < fblock / wave_size; ++w) total += smem[w];
+    return total;  // identical in every thread of every workgroup
+}
+
+__device__ __forceinline__ bool fused_stopped(const bicgstab_scalars* scal)
+{
+    return status_has_stopped(scal->status) || status_has_stopped(scal->status2);
+}
+
+__global__ void bicgstab_fused_init_kernel(bicgstab_scalars* scal, const double* orig_tau)
+{
+    scal->rho[0] = 1.0;
+    scal->rho[1] = 1.0;  // prev_rho = rho = alpha = omega = 1 (bicgstab::initialize)
+    scal->alpha = 1.0;
+    scal->omega = 1.0;
+    scal->tau = 0.0;
+    scal->orig_tau = orig_tau[0];
+    scal->stop_iter = -1;
+    scal->stop2_iter = -1;
+    scal->phase = 0;
+    scal->status = 0;
+    scal->status2 = 0;
+}
+
+// pa[block] = sum a*b, pb[block] = sum c*c over the workgroup's share (pb optional)
+__global__ __launch_bounds__(fblock) void fused_dot2_partials_kernel(
+    int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+    const double* __restrict__ c, const bicgstab_scalars* scal, double* __restrict__ pa,
+    double* __restrict__ pb)
+{
+    __shared__ double smem[fblock / wave_size];
+    if (scal != nullptr && fused_stopped(scal)) return;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * fblock;
+    double u = 0.0, w = 0.0;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x; i < n; i += step) {
+        u += a[i] * b[i];
+        if (pb != nullptr) {
+            const double cv = c[i];
+            w += cv * cv;
+        }
+    }
+    const double tu = block_reduce_sum<fblock>(u, smem);
+    __syncthreads();
+    const double tw = block_reduce_sum<fblock>(w, smem);
+    if (threadIdx.x == 0) {
+        pa[blockIdx.x] = tu;
+        if (pb != nullptr) pb[blockIdx.x] = tw;
+    }
+}
+
+// The vector kernels move 16 B per lane and issue the loads of their first
+// sweep (which do not depend on the scalars) before re-adding the partials, so
+// the reduction's latency hides behind them (as in cg_solver.hip).
+struct pair_sweep {
+    int64_t n2, step, i0;
+    __device__ pair_sweep(int64_t n)
+        : n2(n / 2), step(static_cast<int64_t>(gridDim.x) * fblock),
+          i0(blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x)
+    {}
+    __device__ bool first() const { return i0 < n2; }
+    __device__ bool tail(int64_t n) const { return (n & 1) && blockIdx.x == 0 && threadIdx.x == 0; }
+};
+
+__device__ __forceinline__ double2 ld2(const double* p, int64_t i)
+{
+    return reinterpret_cast<const double2*>(p)[i];
+}
+__device__ __forceinline__ void st2(double* p, int64_t i, double2 v)
+{
+    reinterpret_cast<double2*>(p)[i] = v;
+}
+
+// KA
+__global__ __launch_bounds__(fblock) void bicgstab_fused_step1_kernel(
+    int64_t n, const double* __restrict__ r, double* __restrict__ p, const double* __restrict__ v,
+    const double* __restrict__ rho_part, const double* __restrict__ tau_part, int nparts,
+    bicgstab_scalars* scal, long long it, long long max_iters, double goal)
+{
+    __shared__ double smem[fblock / wave_size];
+    if (fused_stopped(scal)) return;
+    const pair_sweep sw(n);
+    double2 r0 = make_double2(0.0, 0.0), p0 = r0, v0 = r0;
+    if (sw.first()) {
+        r0 = ld2(r, sw.i0);
+        p0 = ld2(p, sw.i0);
+        v0 = ld2(v, sw.i0);
+    }
+    const double rho = sum_partials_f(rho_part, nparts, smem);
+    const double tau = sqrt(sum_partials_f(tau_part, nparts, smem));
+    uint8_t st = 0;
+    if (it >= max_iters) {
+        st = 1 | GKOMI_STATUS_FINALIZED;
+    } else if (tau < goal * scal->orig_tau) {
+        st = GKOMI_STATUS_CONVERGED | 1 | GKOMI_STATUS_FINALIZED;
+    }
+    const double prev = scal->rho[(it + 1) & 1];
+    const double alpha = scal->alpha, omega = scal->omega;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal->rho[it & 1] = rho;
+        if (it < max_iters) scal->tau = tau;
+        if (st) {
+            scal->stop_iter = it;
+            scal->phase = 1;
+            scal->status = st;
+        }
+    }
+    if (st) return;
+    // bicgstab::step_1 (reference/solver/bicgstab_kernels.cpp)
+    const bool update = prev * omega != 0.0;
+    const double tmp = update ? rho / prev * alpha / omega : 0.0;
+    auto step1 = [&](double rv, double pv, double vv) { return update ? rv + tmp * (pv - omega * vv) : rv; };
+    if (sw.first()) st2(p, sw.i0, make_double2(step1(r0.x, p0.x, v0.x), step1(r0.y, p0.y, v0.y)));
+    for (int64_t i = sw.i0 + sw.step; i < sw.n2; i += sw.step) {
+        const double2 rv = ld2(r, i), pv = ld2(p, i), vv = ld2(v, i);
+        st2(p, i, make_double2(step1(rv.x, pv.x, vv.x), step1(rv.y, pv.y, vv.y)));
+    }
+    if (sw.tail(n)) p[n - 1] = step1(r[n - 1], p[n - 1], v[n - 1]);
+}
+
+// KC
+__global__ __launch_bounds__(fblock) void bicgstab_fused_step2_kernel(
+    int64_t n, const double* __restrict__ r, double* __restrict__ sv, const double* __restrict__ v,
+    const double* __restrict__ beta_part, int nparts, bicgstab_scalars* scal, long long it,
+    double* __restrict__ ss_part)
+{
+    __shared__ double smem[fblock / wave_size];
+    if (fused_stopped(scal)) return;
+    const pair_sweep sw(n);
+    double2 r0 = make_double2(0.0, 0.0), v0 = r0;
+    if (sw.first()) {
+        r0 = ld2(r, sw.i0);
+        v0 = ld2(v, sw.i0);
+    }
+    const double beta = sum_partials_f(beta_part, nparts, smem);
+    const double rho = scal->rho[it & 1];
+    const bool update = beta != 0.0;
+    const double alpha = update ? rho / beta : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal->alpha = alpha;
+    // bicgstab::step_2
+    auto step2 = [&](double rv, double vv) { return update ? rv - alpha * vv : rv; };
+    double a0 = 0.0, a1 = 0.0;
+    if (sw.first()) {
+        const double2 o = make_double2(step2(r0.x, v0.x), step2(r0.y, v0.y));
+        st2(sv, sw.i0, o);
+        a0 += o.x * o.x;
+        a1 += o.y * o.y;
+    }
+    for (int64_t i = sw.i0 + sw.step; i < sw.n2; i += sw.step) {
+        const double2 rv = ld2(r, i), vv = ld2(v, i);
+        const double2 o = make_double2(step2(rv.x, vv.x), step2(rv.y, vv.y));
+        st2(sv, i, o);
+        a0 += o.x * o.x;
+        a1 += o.y * o.y;
+    }
+    if (sw.tail(n)) {
+        const double o = step2(r[n - 1], v[n - 1]);
+        sv[n - 1] = o;
+        a0 += o * o;
+    }
+    __syncthreads();
+    const double total = block_reduce_sum<fblock>(a0 + a1, smem);
+    if (threadIdx.x == 0) ss_part[blockIdx.x] = total;
+}
+
+// KD0: a few workgroups are enough -- they only move data in the launch that stops
+__global__ __launch_bounds__(fblock) void bicgstab_fused_check2_kernel(
+    int64_t n, double* __restrict__ x, const double* __restrict__ y,
+    const double* __restrict__ ss_part, int nparts, bicgstab_scalars* scal, long long it,
+    double goal)
+{
+    __shared__ double smem[fblock / wave_size];
+    if (status_has_stopped(scal->status)) return;
+    // status2 / stop2_iter are this kernel's own: workgroup 0 may be writing
+    // them while a late workgroup of the same launch starts, so "stopped in an
+    // earlier launch" is read from the one 8-byte word
+    const long long stopped_at = scal->stop2_iter;
+    if (stopped_at >= 0 && stopped_at != it) return;
+    const double tau = sqrt(sum_partials_f(ss_part, nparts, smem));
+    if (!(tau < goal * scal->orig_tau)) return;
+    const double alpha = scal->alpha;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal->tau = tau;
+        scal->stop_iter = it;
+        scal->stop2_iter = it;
+        scal->phase = 2;
+        scal->status2 = GKOMI_STATUS_CONVERGED | 1 | GKOMI_STATUS_FINALIZED;
+    }
+    // bicgstab::finalize: x += alpha y
+    const int64_t step = static_cast<int64_t>(gridDim.x) * fblock;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x; i < n; i += step) {
+        x[i] += alpha * y[i];
+    }
+}
+
+// KE
+__global__ __launch_bounds__(fblock) void bicgstab_fused_step3_kernel(
+    int64_t n, double* __restrict__ x, double* __restrict__ r, const double* __restrict__ sv,
+    const double* __restrict__ t, const double* __restrict__ y, const double* __restrict__ z,
+    const double* __restrict__ rr, const double* __restrict__ gamma_part,
+    const double* __restrict__ tt_part, int nparts, bicgstab_scalars* scal,
+    double* __restrict__ rho_part, double* __restrict__ tau_part)
+{
+    __shared__ double smem[fblock / wave_size];
+    if (fused_stopped(scal)) return;
+    const pair_sweep sw(n);
+    double2 x0 = make_double2(0.0, 0.0), y0 = x0, z0 = x0, s0 = x0, t0 = x0, q0 = x0;
+    if (sw.first()) {
+        x0 = ld2(x, sw.i0);
+        y0 = ld2(y, sw.i0);
+        z0 = ld2(z, sw.i0);
+        s0 = ld2(sv, sw.i0);
+        t0 = ld2(t, sw.i0);
+        q0 = ld2(rr, sw.i0);
+    }
+    const double gamma = sum_partials_f(gamma_part, nparts, smem);
+    const double beta = sum_partials_f(tt_part, nparts, smem);
+    const double omega = beta != 0.0 ? gamma / beta : 0.0;
+    const double alpha = scal->alpha;
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal->omega = omega;
+    // bicgstab::step_3
+    double a0 = 0.0, a1 = 0.0;
+    auto step3 = [&](double xv, double yv, double zv, double svv, double tv, double qv, double* xo,
+                     double* ro) {
+        *xo = xv + (alpha * yv + omega * zv);
+        *ro = svv - omega * tv;
+        a0 += qv * *ro;
+        a1 += *ro * *ro;
+    };
+    if (sw.first()) {
+        double2 xo, ro;
+        step3(x0.x, y0.x, z0.x, s0.x, t0.x, q0.x, &xo.x, &ro.x);
+        step3(x0.y, y0.y, z0.y, s0.y, t0.y, q0.y, &xo.y, &ro.y);
+        st2(x, sw.i0, xo);
+        st2(r, sw.i0, ro);
+    }
+    for (int64_t i = sw.i0 + sw.step; i < sw.n2; i += sw.step) {
+        const double2 xv = ld2(x, i), yv = ld2(y, i), zv = ld2(z, i), svv = ld2(sv, i), tv = ld2(t, i),
+                      qv = ld2(rr, i);
+        double2 xo, ro;
+        step3(xv.x, yv.x, zv.x, svv.x, tv.x, qv.x, &xo.x, &ro.x);
+        step3(xv.y, yv.y, zv.y, svv.y, tv.y, qv.y, &xo.y, &ro.y);
+        st2(x, i, xo);
+        st2(r, i, ro);
+    }
+    if (sw.tail(n)) {
+        const int64_t i = n - 1;
+        double xo, ro;
+        step3(x[i], y[i], z[i], sv[i], t[i], rr[i], &xo, &ro);
+        x[i] = xo;
+        r[i] = ro;
+    }
+    __syncthreads();
+    const double t0s = block_reduce_sum<fblock>(a0, smem);
+    __syncthreads();
+    const double t1s = block_reduce_sum<fblock>(a1, smem);
+    if (threadIdx.x == 0) {
+        rho_part[blockIdx.x] = t0s;
+        tau_part[blockIdx.x] = t1s;
+    }
+}
+
+int bicgstab_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn precond,
+                        void* precond_ctx, const double* b, double* x, int64_t max_iters,
+                        double reduction_factor, int baseline, int64_t check_every, void* workspace,
+                        size_t workspace_bytes, double* host_info)
+{
+    const int64_t nrhs = 1;
+    if (n > INT32_MAX - 1024) return GKOMI_ENOTSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0) {  // the vector kernels move 16 B per lane
+        return bicgstab_solve_impl(s, n, 1, A, precond, precond_ctx, b, x, max_iters, reduction_factor,
+                                   baseline, check_every, workspace, workspace_bytes, host_info);
+    }
+    GKOMI_DRIVER_PROLOGUE(8);
+    double *r = V(0), *z = V(1), *y = V(2), *v = V(3), *sv = V(4), *t = V(5), *p = V(6), *rr = V(7);
+    GKOMI_TRY(gkomi_bicgstab_initialize_f64(s, n, 1, b, 1, r, 1, rr, 1, y, 1, sv, 1, t, 1, z, 1, v, 1, p,
+                                            1, sc, sc + 1, sc + 2, sc + 3, sc + 4, sc + 5,
+                                            c.stop_status));
+    GKOMI_TRY(c.start(b, x, r, baseline));
+    GKOMI_TRY(gkomi_dense_copy_f64(s, n, 1, r, 1, rr, 1));
+    hipStream_t stream = c.stream;
+    double* parts = reinterpret_cast<double*>(ws + l.parts);
+    bicgstab_scalars* scal = reinterpret_cast<bicgstab_scalars*>(parts);
+    double* part_rho = parts + 32;
+    double* part_tau = part_rho + fused_max_parts;
+    double* part_ss = part_tau + fused_max_parts;
+    const size_t per_spmv = static_cast<size_t>(n) / 256 + 2;
+    double* part_beta = part_ss + fused_max_parts;
+    double* part_gamma = part_beta + per_spmv;
+    double* part_tt = part_gamma + per_spmv;
+    int64_t gl = ceildiv(n / 2 + 1, fblock);  // 16 B per lane
+    if (gl > fused_max_parts) gl = fused_max_parts;
+    if (gl < 1) gl = 1;
+    const int g = static_cast<int>(gl);
+    const bool csr_epilogue = A.is_csr() && n > 0 && reinterpret_cast<uintptr_t>(A.vals) % 16 == 0 &&
+                              reinterpret_cast<uintptr_t>(A.col_idxs) % 8 == 0;
+    const int nb = csr_epilogue ? csr_spmv_dot_num_partials(static_cast<int>(n)) : g;
+    const bool swizzle = csr_auto_swizzle(n, A.nnz);
+    if (precond == nullptr) {  // Identity: y = p, z = s without the copies
+        y = p;
+        z = sv;
+    }
+    hipLaunchKernelGGL(bicgstab_fused_init_kernel, dim3(1), dim3(1), 0, stream, scal, c.orig_tau);
+    hipLaunchKernelGGL(fused_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, rr, r, r,
+                       static_cast<const bicgstab_scalars*>(nullptr), part_rho, part_tau);
+    GKOMI_TRY(check_launch());
+    // q = A in, partials of w.q (and q.q) -- in the SpMV epilogue when A is CSR
+    auto spmv_dots = [&](const double* in, double* out, const double* w, double* pw, double* pq) {
+        if (csr_epilogue) {
+            return csr_spmv_dot_launch(stream, static_cast<int>(n), A.nnz, A.row_ptrs, A.col_idxs,
+                                       A.vals, in, out, pw, &scal->status, swizzle, w, pq);
+        }
+        GKOMI_TRY(A.apply(s, 1, nullptr, in, nullptr, out));
+        hipLaunchKernelGGL(fused_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, w, out,
+                           out, static_cast<const bicgstab_scalars*>(scal), pw, pq);
+        return check_launch();
+    };
+    bicgstab_scalars h{};
+    long long it = 0;
+    bool done = false;
+    while (!done) {
+        for (int64_t k = 0; k < c.check_every && !done; ++k, ++it) {
+            hipLaunchKernelGGL(bicgstab_fused_step1_kernel, dim3(g), dim3(fblock), 0, stream, n, r, p, v,
+                               part_rho, part_tau, g, scal, it, static_cast<long long>(max_iters),
+                               reduction_factor);
+            if (it >= max_iters) {  // this launch stops for sure
+                ++it;
+                break;
+            }
+            if (precond != nullptr) GKOMI_TRY(precond(precond_ctx, s, p, y));
+            GKOMI_TRY(spmv_dots(y, v, rr, part_beta, nullptr));
+            hipLaunchKernelGGL(bicgstab_fused_step2_kernel, dim3(g), dim3(fblock), 0, stream, n, r, sv,
+                               v, part_beta, nb, scal, it, part_ss);
+            hipLaunchKernelGGL(bicgstab_fused_check2_kernel, dim3(g < 64 ? g : 64), dim3(fblock), 0, stream, n, x, y,
+                               part_ss, g, scal, it, reduction_factor);
+            if (precond != nullptr) GKOMI_TRY(precond(precond_ctx, s, sv, z));
+            GKOMI_TRY(spmv_dots(z, t, sv, part_gamma, part_tt));
+            hipLaunchKernelGGL(bicgstab_fused_step3_kernel, dim3(g), dim3(fblock), 0, stream, n, x, r,
+                               sv, t, y, z, rr, part_gamma, part_tt, nb, scal, part_rho, part_tau);
+        }
+        GKOMI_TRY(check_launch());
+        GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&h, scal, sizeof(h), hipMemcpyDeviceToHost, stream)));
+        GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
+        done = h.stop_iter >= 0;
+    }
+    const unsigned char st = h.status | h.status2;
+    if (host_info != nullptr) {
+        host_info[0] = static_cast<double>(h.stop_iter);
+        host_info[1] = (st & GKOMI_STATUS_CONVERGED) ? 1.0 : 0.0;
+        host_info[2] = h.tau;
+        host_info[3] = h.orig_tau;
+    }
+    return GKOMI_SUCCESS;
+}
+
 }  // namespace
+
+extern "C" int gkomi_bicgstab_solve_fused_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nnz, const int32_t* row_ptrs, const int32_t* col_idxs,
+    const double* vals, int spmv_strategy, int64_t max_row_nnz_hint, gkomi_apply_fn precond,
+    void* precond_ctx, const double* b, double* x, int64_t max_iters, double reduction_factor,
+    int baseline, int64_t check_every, void* workspace, size_t workspace_bytes, double* host_info)
+{
+    return bicgstab_fused_impl(s, n, make_csr_sysmat(n, nnz, row_ptrs, col_idxs, vals, spmv_strategy,
+                                                     max_row_nnz_hint),
+                               precond, precond_ctx, b, x, max_iters, reduction_factor, baseline,
+                               check_every, workspace, workspace_bytes, host_info);
+}
+
+extern "C" int gkomi_bicgstab_solve_fused_op_f64(
+    gkomi_stream_t s, int64_t n, gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
+    double reduction_factor, int baseline, int64_t check_every, void* workspace,
+    size_t workspace_bytes, double* host_info)
+{
+    if (matrix == nullptr) return GKOMI_EINVAL;
+    return bicgstab_fused_impl(s, n, make_op_sysmat(n, matrix, matrix_ctx), precond, precond_ctx, b, x,
+                               max_iters, reduction_factor, baseline, check_every, workspace,
+                               workspace_bytes, host_info);
+}
 
 extern "C" int gkomi_bicgstab_solve_f64_i32(
     gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,

@@ -47,9 +47,10 @@ def cg_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reducti
 
 
 def krylov_solve(gk, solver, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reduction=1e-10,
-                 baseline="rhs_norm", strategy=0, max_row_nnz=-1, precond=None, check_every=8):
+                 baseline="rhs_norm", strategy=0, max_row_nnz=-1, precond=None, check_every=8, fused=False):
     """solver in {"bicgstab", "fcg", "cgs"}: {Bicgstab,Fcg,Cgs}::apply with
-    Combined(Iteration(max_iters), ResidualNorm(reduction, baseline)); precond: None or a Preconditioner."""
+    Combined(Iteration(max_iters), ResidualNorm(reduction, baseline)); precond: None or a Preconditioner.
+    fused (bicgstab, one right-hand side): the 6-launch driver instead of the reference kernel sequence."""
     assert solver in ("bicgstab", "fcg", "cgs")
     b2 = b.reshape(n, -1)
     nrhs = b2.shape[1]
@@ -64,9 +65,14 @@ def krylov_solve(gk, solver, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1
     stream = torch.cuda.current_stream().cuda_stream
     fn = precond.fn if precond is not None else None
     ctx = precond.ctx_ptr if precond is not None else None
-    getattr(gk, solver + "_solve_f64_i32")(stream, n, nrhs, nnz, row_ptrs, col_idxs, vals, strategy, max_row_nnz, fn, ctx,
-                                           b2, x2, max_iters, reduction, BASELINES[baseline], check_every, ws, nbytes,
-                                           info)
+    if fused:
+        assert solver == "bicgstab" and nrhs == 1
+        gk.bicgstab_solve_fused_f64_i32(stream, n, nnz, row_ptrs, col_idxs, vals, strategy, max_row_nnz, fn, ctx, b2, x2,
+                                        max_iters, reduction, BASELINES[baseline], check_every, ws, nbytes, info)
+    else:
+        getattr(gk, solver + "_solve_f64_i32")(stream, n, nrhs, nnz, row_ptrs, col_idxs, vals, strategy, max_row_nnz, fn,
+                                               ctx, b2, x2, max_iters, reduction, BASELINES[baseline], check_every, ws,
+                                               nbytes, info)
     res, base = info[2::2].copy(), info[3::2].copy()
     return {"x": x2 if b.dim() > 1 else x2.reshape(n), "iterations": int(info[0]), "converged": bool(info[1]),
             "residual_norm": res, "baseline_norm": base,
@@ -124,7 +130,7 @@ def ir_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, relaxation_factor=1.0, 
 
 
 def solve_op(gk, solver, matrix, b, x=None, max_iters=1000, reduction=1e-10, baseline="rhs_norm", precond=None,
-             krylov_dim=100, check_every=8):
+             krylov_dim=100, check_every=8, fused=False):
     """Any solver in {"cg", "gmres", "bicgstab", "fcg", "cgs"} on a system matrix in
     any format (a gkomi.formats object): the *_solve_op_f64 drivers."""
     n = matrix.nrows
@@ -148,6 +154,12 @@ def solve_op(gk, solver, matrix, b, x=None, max_iters=1000, reduction=1e-10, bas
         ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
         gk.gmres_solve_op_f64(stream, n, nrhs, cb.fn, cb.ctx_ptr, fn, ctx, b2, x2, krylov_dim, max_iters, reduction,
                               BASELINES[baseline], ws, nbytes, info)
+    elif fused:
+        assert solver == "bicgstab" and nrhs == 1
+        nbytes = gk.krylov_workspace_bytes(n, 1)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+        gk.bicgstab_solve_fused_op_f64(stream, n, cb.fn, cb.ctx_ptr, fn, ctx, b2, x2, max_iters, reduction,
+                                       BASELINES[baseline], check_every, ws, nbytes, info)
     else:
         nbytes = gk.krylov_workspace_bytes(n, nrhs)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)

@@ -259,3 +259,114 @@ def test_solvers_on_every_matrix_format(gk, oracle, solver):
             assert res["iterations"] == base["iterations"] and host(res["x"]).tobytes() == host(base["x"]).tobytes()
         else:
             assert abs(res["iterations"] - base["iterations"]) <= max(2, base["iterations"] // 10)
+
+
+# ---- fused single-rhs BiCGSTAB (6 launches per iteration) ---------------------------
+def _convection(n3=12):
+    n, rp, ci, v = matgen.poisson_3d_7pt(n3)
+    v = v.copy()
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    v[ci == rows - 1] -= 0.5
+    v[ci == rows] += 0.5
+    return n, rp, ci, v
+
+
+@pytest.mark.parametrize("case", [c for c in G["solves"] if c["solver"] == "bicgstab"], ids=lambda c: c["name"])
+def test_fused_bicgstab_known_answers(gk, oracle, case):
+    n, rp, ci, v = dense_to_csr(case["A"])
+    res = solvers.krylov_solve(gk, "bicgstab", n, dev(rp), dev(ci), dev(v), dev(np.array(case["b"])),
+                               max_iters=case["max_iters"], reduction=case["reduction"], fused=True)
+    assert matgen.rel_err(host(res["x"]), case["expect_x"]) <= 4 * case["tol"], res
+    xe = np.zeros(n)
+    ite = oracle.ref_bicgstab_solve(n, rp, ci, v, np.array(case["b"]), xe, case["max_iters"], case["reduction"], 0)
+    if "DivergenceCheck" in case["name"]:
+        # badly conditioned on purpose: near machine precision the iteration
+        # count is rounding noise; the answer above is what the reference checks
+        assert res["iterations"] <= 2 * ite + 2
+    else:
+        assert abs(res["iterations"] - ite) <= max(2, ite // 4)
+
+
+@pytest.mark.parametrize("problem", ["poisson", "convection", "odd_size"])
+def test_fused_bicgstab_like_the_oracle_and_the_reference_sequence(gk, oracle, problem):
+    if problem == "poisson":
+        n, rp, ci, v = matgen.poisson_2d_5pt(40)
+    elif problem == "convection":
+        n, rp, ci, v = _convection()
+    else:
+        n, rp, ci, v = matgen.poisson_2d_5pt(37, 41)   # n = 1517: odd, not a multiple of any block
+    xs = np.sin(0.3 * np.arange(n))
+    b = np.zeros((n, 1))
+    oracle.ref_csr_spmv(n, 1, rp, ci, v, xs.reshape(n, 1), 1, b, 1)
+    xe = np.zeros(n)
+    ite = oracle.ref_bicgstab_solve(n, rp, ci, v, b[:, 0].copy(), xe, 2000, 1e-10, 0)
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    res = solvers.krylov_solve(gk, "bicgstab", n, rpd, cid, vd, dev(b[:, 0].copy()), max_iters=2000, reduction=1e-10,
+                               fused=True)
+    assert res["converged"] and res["rel_residual"] <= 1e-10
+    # BiCGSTAB's residual is erratic: a different (fixed) summation order of the
+    # dots moves the iteration at which 1e-10 is crossed by a few
+    assert abs(res["iterations"] - ite) <= max(3, ite // 4), (res["iterations"], ite)
+    assert matgen.rel_err(host(res["x"]), xs) < 1e-7
+    unfused = solvers.krylov_solve(gk, "bicgstab", n, rpd, cid, vd, dev(b[:, 0].copy()), max_iters=2000, reduction=1e-10)
+    assert abs(res["iterations"] - unfused["iterations"]) <= max(3, ite // 4)
+    assert matgen.rel_err(host(res["x"]), host(unfused["x"])) < 1e-8
+    for every in (1, 3, 50):
+        again = solvers.krylov_solve(gk, "bicgstab", n, rpd, cid, vd, dev(b[:, 0].copy()), max_iters=2000,
+                                     reduction=1e-10, check_every=every, fused=True)
+        assert again["iterations"] == res["iterations"] and again["converged"]
+        assert host(again["x"]).tobytes() == host(res["x"]).tobytes()
+        assert again["residual_norm"][0] == res["residual_norm"][0]
+    # the reported norm belongs to the residual of the returned x
+    r = b[:, 0] - np.add.reduceat(v * host(res["x"])[ci], rp[:-1])
+    assert abs(np.linalg.norm(r) - res["residual_norm"][0]) <= 1e-6 * np.linalg.norm(b) + 1e-3 * res["residual_norm"][0]
+
+
+def test_fused_bicgstab_stops_in_the_half_step_and_at_the_iteration_limit(gk, oracle):
+    # a multiple of the identity converges in the first half step: s = r - alpha v = 0,
+    # x += alpha y is the finalize branch (core/solver/bicgstab.cpp:196-203)
+    n = 5000
+    rp = np.arange(n + 1, dtype=np.int32)
+    ci = np.arange(n, dtype=np.int32)
+    v = np.full(n, 4.0)
+    b = np.cos(0.01 * np.arange(n))
+    for fused in (False, True):
+        res = solvers.krylov_solve(gk, "bicgstab", n, dev(rp), dev(ci), dev(v), dev(b), max_iters=50, reduction=1e-12,
+                                   fused=fused)
+        assert res["converged"] and res["iterations"] == 0, res
+        assert matgen.rel_err(host(res["x"]), b / 4.0) < 1e-15
+    # iteration limit: x after exactly 3 iterations equals the unfused x to rounding
+    n, rp, ci, v = _convection(10)
+    b = np.sin(0.1 * np.arange(n))
+    a = solvers.krylov_solve(gk, "bicgstab", n, dev(rp), dev(ci), dev(v), dev(b), max_iters=3, reduction=1e-14, fused=True)
+    u = solvers.krylov_solve(gk, "bicgstab", n, dev(rp), dev(ci), dev(v), dev(b), max_iters=3, reduction=1e-14)
+    assert a["iterations"] == 3 and not a["converged"] and u["iterations"] == 3
+    assert matgen.rel_err(host(a["x"]), host(u["x"])) < 1e-12
+    # zero iterations allowed: x stays the initial guess
+    z = solvers.krylov_solve(gk, "bicgstab", n, dev(rp), dev(ci), dev(v), dev(b), max_iters=0, reduction=1e-14, fused=True)
+    assert z["iterations"] == 0 and not z["converged"] and not host(z["x"]).any()
+
+
+def test_fused_bicgstab_with_preconditioners_and_formats(gk, oracle):
+    from gkomi import formats
+    n, rp, ci, v = _convection()
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    xs = np.sin(0.3 * np.arange(n))
+    b = np.zeros((n, 1))
+    oracle.ref_csr_spmv(n, 1, rp, ci, v, xs.reshape(n, 1), 1, b, 1)
+    bd = dev(b[:, 0].copy())
+    plain = solvers.krylov_solve(gk, "bicgstab", n, rpd, cid, vd, bd, max_iters=2000, reduction=1e-10, fused=True)
+    jac = solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=8)
+    ilu = solvers.par_ilu_generate(gk, n, rpd, cid, vd, iterations=5)
+    for pc in (jac, ilu):
+        pre = solvers.krylov_solve(gk, "bicgstab", n, rpd, cid, vd, bd, max_iters=2000, reduction=1e-10, precond=pc,
+                                   fused=True)
+        ref = solvers.krylov_solve(gk, "bicgstab", n, rpd, cid, vd, bd, max_iters=2000, reduction=1e-10, precond=pc)
+        assert pre["converged"] and matgen.rel_err(host(pre["x"]), xs) < 1e-7
+        assert abs(pre["iterations"] - ref["iterations"]) <= max(2, ref["iterations"] // 5)
+        assert pre["iterations"] <= plain["iterations"]
+    A = formats.Csr.from_host(gk, n, n, rp, ci, v)
+    for fmt in ("ell", "sellp", "coo", "hybrid"):
+        res = solvers.solve_op(gk, "bicgstab", A.to(fmt), bd, max_iters=2000, reduction=1e-10, fused=True)
+        assert res["converged"] and matgen.rel_err(host(res["x"]), xs) < 1e-7, fmt
+        assert abs(res["iterations"] - plain["iterations"]) <= max(2, plain["iterations"] // 5), fmt
