@@ -49,8 +49,17 @@ __device__ __forceinline__ int xcd_chunked_block(int bid, int per)
 typedef double nt_double2 __attribute__((ext_vector_type(2)));
 typedef int nt_int2 __attribute__((ext_vector_type(2)));
 
+// Pad: one spare LDS slot per 32 products, so that rows of even length (stride
+// 8, 16, 32 doubles between neighbouring lanes in the row-sum phase) spread
+// over the banks instead of hitting the same one (2-way instead of 32-way).
+template <bool Pad>
+__device__ __forceinline__ int lds_slot(int i)
+{
+    return Pad ? i + (i >> 5) : i;
+}
+
 template <int Block, int RowsPerThread, int Tile, bool Advanced, bool Swizzle,
-          bool Dot = false, bool NT = false>
+          bool Dot = false, bool NT = false, bool Pad = false>
 __global__ __launch_bounds__(Block) void csr_stream_kernel(
     int nrows, const int32_t* __restrict__ row_ptrs,
     const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
     constexpr int rows_per_block = Block * RowsPerThread;
     constexpr int pairs = Tile / (2 * Block);
     static_assert(Tile % (2 * Block) == 0, "tile must be a whole number of pair sweeps");
-    __shared__ __attribute__((aligned(16))) double prod[Tile];
+    __shared__ __attribute__((aligned(16))) double prod[Pad ? Tile + Tile / 32 : Tile];
 
     const int logical =
         Swizzle ? xcd_chunked_block(blockIdx.x, per_xcd) : blockIdx.x;
@@ -153,7 +162,13 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
                 pr.x = v[u].x * xv[u].x;
                 pr.y = v[u].y * xv[u].y;
             }
-            *reinterpret_cast<double2*>(prod + 2 * (tid + u * Block)) = pr;
+            if (Pad) {  // a pair never straddles a pad slot, but loses the 16-B alignment
+                const int slot = lds_slot<true>(2 * (tid + u * Block));
+                prod[slot] = pr.x;
+                prod[slot + 1] = pr.y;
+            } else {
+                *reinterpret_cast<double2*>(prod + 2 * (tid + u * Block)) = pr;
+            }
         }
         __syncthreads();
         // 3) one thread per row: add this tile's part of the row in order
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
             const int lo = max(ra[i], t0);
             const int hi = min(rb[i], t1);
             for (int k = lo; k < hi; ++k) {
-                sum[i] += prod[k - t0];
+                sum[i] += prod[lds_slot<Pad>(k - t0)];
             }
         }
         if (t1 < p1) __syncthreads();
@@ -485,7 +500,7 @@ __global__ __launch_bounds__(256) void csr_max_row_nnz_kernel(
     }
 }
 
-template <int Block, int RowsPerThread, int Tile, bool NT = false>
+template <int Block, int RowsPerThread, int Tile, bool NT = false, bool Pad = false>
 int launch_stream(hipStream_t stream, bool swizzle, int chunk, int nrows, int nrhs,
                   const int32_t* row_ptrs, const int32_t* col_idxs,
                   const double* vals, const double* b, int64_t b_stride,
@@ -502,7 +517,7 @@ int launch_stream(hipStream_t stream, bool swizzle, int chunk, int nrows, int nr
     dim3 grid(swz ? groups * per * num_xcd : nblocks, nrhs);
 #define GKOMI_LAUNCH(ADV, SWZ)                                                 \
     hipLaunchKernelGGL(                                                        \
-        (csr_stream_kernel<Block, RowsPerThread, Tile, ADV, SWZ, false, NT>),  \
+        (csr_stream_kernel<Block, RowsPerThread, Tile, ADV, SWZ, false, NT, Pad>), \
         grid,                                                                  \
         dim3(Block), 0, stream, nrows, row_ptrs, col_idxs, vals, b, b_stride,  \
         c, c_stride, alpha, beta, nblocks, per)
@@ -605,11 +620,14 @@ int csr_spmv_dot_num_partials(int nrows)
 // warm at 1M rows) and cost ~4 % once it streams from HBM (57.3 vs 59.6 us at
 // 4M rows) -- profiles/README.md.  The same threshold selects nontemporal
 // loads of vals / col_idxs: 54.6 vs 59.0 us at 4M rows (5.86 TB/s), but 15.6 vs
-// 13.8 us on a resident 1M-row matrix (profiles/r01_tune_nt.log).
+// 13.8 us on a resident 1M-row matrix (profiles/r01_tune_nt.log).  Crossover
+// measured warm (profiles/r01_tune_pad.log): 212 MB and 308 MB matrices still
+// gain from the cache (36.3 vs 39.9, 56.2 vs 58.5 us), 320 MB and 337 MB ones
+// from the nontemporal loads (54.2 vs 59.1, 69.6 vs 70.7 us) -> 288 MiB.
 bool csr_auto_swizzle(int64_t nrows, int64_t nnz)
 {
     if (nnz < 0) return true;
-    return 12 * nnz + 20 * nrows < (int64_t{192} << 20);
+    return 12 * nnz + 20 * nrows < (int64_t{288} << 20);
 }
 
 }  // namespace gkomi
@@ -660,7 +678,11 @@ extern "C" int gkomi_csr_spmv_f64_i32(
     if (automatic) {
         // 256 threads, 256 rows, 1536-nonzero tile: fastest measured
         no_swizzle = !csr_auto_swizzle(nrows, nnz);
-        variant = kind == GKOMI_CSR_STREAM ? (no_swizzle ? 14 : 5) : 0;
+        // rows of 32+ entries: the padded LDS tile (row-sum reads of
+        // neighbouring lanes are 32+ doubles apart) is 6-15 % faster, shorter
+        // rows lose 1-2 % to the split LDS stores (profiles/r01_tune_pad.log)
+        const bool pad = max_row_nnz_hint >= 32;
+        variant = kind == GKOMI_CSR_STREAM ? (no_swizzle ? (pad ? 16 : 14) : (pad ? 15 : 5)) : 0;
     }
 
 #define GKOMI_ARGS                                                            \
@@ -711,6 +733,8 @@ extern "C" int gkomi_csr_spmv_f64_i32(
         case 12: return launch_stream<256, 1, 1024>(stream, !no_swizzle, chunk, GKOMI_ARGS);
         case 13: return launch_stream<384, 1, 2304>(stream, !no_swizzle, chunk, GKOMI_ARGS);
         case 14: return launch_stream<256, 1, 1536, true>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 15: return launch_stream<256, 1, 1536, false, true>(stream, !no_swizzle, chunk, GKOMI_ARGS);
+        case 16: return launch_stream<256, 1, 1536, true, true>(stream, !no_swizzle, chunk, GKOMI_ARGS);
         default: return launch_stream<256, 1, 2048>(stream, !no_swizzle, chunk, GKOMI_ARGS);
         }
     }

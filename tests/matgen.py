@@ -67,6 +67,50 @@ def random_csr(nrows, ncols, min_nnz, max_nnz, seed, sort=True, dist="uniform"):
     return row_ptrs, cols, vals
 
 
+def stencil_3d_27pt(nx):
+    """27-point stencil on an nx^3 grid (FEM-like: up to 27 entries per row,
+    ascending columns): diagonal 26, off-diagonals -1."""
+    idx = np.arange(nx ** 3, dtype=np.int64)
+    i, j, k = idx // (nx * nx), (idx // nx) % nx, idx % nx
+    cols, valid = [], []
+    for di in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            for dk in (-1, 0, 1):
+                ok = (i + di >= 0) & (i + di < nx) & (j + dj >= 0) & (j + dj < nx) & (k + dk >= 0) & (k + dk < nx)
+                cols.append(idx + (di * nx + dj) * nx + dk)
+                valid.append(ok)
+    cols, valid = np.stack(cols, axis=1), np.stack(valid, axis=1)
+    vals = np.where(np.arange(27) == 13, 26.0, -1.0)[None, :].repeat(len(idx), axis=0)
+    row_ptrs = np.zeros(len(idx) + 1, dtype=np.int32)
+    np.cumsum(valid.sum(axis=1), out=row_ptrs[1:])
+    return len(idx), row_ptrs, cols[valid].astype(np.int32), np.ascontiguousarray(vals[valid])
+
+
+def random_rows_csr(nrows, ncols, counts, seed, local=None):
+    """Large random CSR without a Python loop over rows: row r gets counts[r]
+    columns (sorted; duplicates are merged by nudging, so rows stay valid), either
+    uniform over all columns or within +-local of the diagonal."""
+    rng = np.random.default_rng(seed)
+    counts = np.minimum(np.asarray(counts, dtype=np.int64), ncols)
+    row_ptrs = np.zeros(nrows + 1, dtype=np.int64)
+    np.cumsum(counts, out=row_ptrs[1:])
+    nnz = int(row_ptrs[-1])
+    rows = np.repeat(np.arange(nrows, dtype=np.int64), counts)
+    if local is None:
+        cols = rng.integers(0, ncols, size=nnz)
+    else:
+        cols = np.clip(rows * ncols // nrows + rng.integers(-local, local + 1, size=nnz), 0, ncols - 1)
+    order = np.lexsort((cols, rows))
+    cols = cols[order]
+    # duplicates inside a row: keep the first, drop the rest
+    keep = np.ones(nnz, dtype=bool)
+    keep[1:] = (cols[1:] != cols[:-1]) | (rows[1:] != rows[:-1])
+    rows, cols = rows[keep], cols[keep]
+    rp = np.zeros(nrows + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows, minlength=nrows), out=rp[1:])
+    return rp, cols.astype(np.int32), rng.standard_normal(len(cols))
+
+
 def read_mtx(path):
     """Minimal MatrixMarket reader (coordinate real/integer general|symmetric,
     array real general).  Returns ('coo', nrows, ncols, rows, cols, vals)

@@ -21,7 +21,8 @@ STRATEGIES = {"auto": 0, "stream": STREAM, "stream_v1": STREAM | (1 << 8),
               "stream_v4": STREAM | (4 << 8), "stream_noswz": STREAM | (1 << 16),
               "stream_v5": STREAM | (5 << 8), "stream_v8": STREAM | (8 << 8), "stream_v9": STREAM | (9 << 8),
               "stream_v13": STREAM | (13 << 8), "stream_v11_noswz": STREAM | (11 << 8) | (1 << 16),
-              "stream_spmm": STREAM | (20 << 8),
+              "stream_spmm": STREAM | (20 << 8), "stream_v15_pad": STREAM | (15 << 8),
+              "stream_v16_nt_pad": STREAM | (16 << 8) | (1 << 16), "stream_v14_nt": STREAM | (14 << 8) | (1 << 16),
               "vector": VECTOR, "vector64": VECTOR | (64 << 8), "vector2": VECTOR | (2 << 8), "balanced": 3}
 BITEXACT = {k for k in STRATEGIES if k.startswith("stream") or k == "auto"}
 
@@ -76,7 +77,8 @@ def test_random_532x231(gk, oracle, strategy, advanced, nrhs, sort):
         assert matgen.rel_err(got, expect) <= 1e-14
 
 
-@pytest.mark.parametrize("strategy", ["stream", "stream_v1", "stream_v3", "stream_v5", "stream_v8", "stream_v11_noswz", "vector", "balanced", "auto"])
+@pytest.mark.parametrize("strategy", ["stream", "stream_v1", "stream_v3", "stream_v5", "stream_v8", "stream_v11_noswz", "stream_v15_pad",
+                                      "stream_v16_nt_pad", "vector", "balanced", "auto"])
 def test_ragged_and_empty_rows(gk, oracle, strategy):
     # empty rows, rows longer than one LDS tile (8192), an empty last row
     rng = np.random.default_rng(7)
@@ -206,7 +208,8 @@ def test_full_size_poisson_p2_bitexact_and_linear(gk, oracle):
     A = DevCsr(n, n, rp, ci, v)
     xd = dev(x)
     expect = _oracle_apply(oracle, n, rp, ci, v, x)
-    for s in ("stream", "stream_v1", "stream_v2", "stream_noswz", "stream_v5", "stream_v8", "stream_v9", "stream_v13"):
+    for s in ("stream", "stream_v1", "stream_v2", "stream_noswz", "stream_v5", "stream_v8", "stream_v9", "stream_v13",
+              "stream_v14_nt", "stream_v15_pad", "stream_v16_nt_pad"):
         got = host(csr_apply(gk, A, xd, strategy=STRATEGIES[s]))
         assert np.array_equal(got, expect), s
     got2 = host(csr_apply(gk, A, xd, strategy=STRATEGIES["stream"]))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """benchmark/spmv of the reference (benchmark/spmv/spmv.cpp:66-290) over the C
 ABI: reads the same JSON test-case list on stdin ([{"filename": "A.mtx"}, ...];
-additionally {"stencil": "5pt"|"7pt", "size": N} for generated matrices),
+additionally {"stencil": "5pt"|"7pt"|"27pt", "size": N} and {"random": "uniform"|"local"|
+"powerlaw", "rows": N, "nnz_per_row": k} for generated matrices),
 writes the same result layout on stdout: per case "spmv": {format: {"storage",
 "max_relative_norm2", "time" [s], "repetitions", "completed"}}, "optimal":
 {"spmv": best format}; the answer every format is checked against is COO's,
@@ -23,7 +24,37 @@ from gkomi import formats
 def stencil_matrix(gk, kind, size):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import matgen
-    n, rp, ci, v = matgen.poisson_2d_5pt(size) if kind == "5pt" else matgen.poisson_3d_7pt(size)
+    gen = {"5pt": matgen.poisson_2d_5pt, "7pt": matgen.poisson_3d_7pt, "27pt": matgen.stencil_3d_27pt}[kind]
+    n, rp, ci, v = gen(size)
+    return formats.Csr.from_host(gk, n, n, rp, ci, v)
+
+
+def random_matrix(gk, case, seed):
+    """{"random": "uniform"|"local"|"powerlaw", "rows": N, "nnz_per_row": k}: stand-ins for
+    the irregular SuiteSparse classes (no SuiteSparse files offline)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import matgen
+    n, k = int(case["rows"]), int(case["nnz_per_row"])
+    rng = np.random.default_rng(seed)
+    kind = case["random"]
+    if kind == "powerlaw":  # most rows short, a heavy tail of long ones (web / circuit graphs)
+        counts = np.minimum(n // 4, np.maximum(1, (k * 0.5 * rng.pareto(1.3, size=n)).astype(np.int64)))
+    elif kind == "fixed":   # every row exactly k entries near the diagonal (LDS bank-conflict probe)
+        counts = np.full(n, k)
+    else:
+        counts = rng.integers(max(1, k // 2), k + k // 2 + 1, size=n)
+    if kind == "fixed":
+        # distinct columns by construction: a strided window around the diagonal
+        rows = np.repeat(np.arange(n, dtype=np.int64), k)
+        offs = np.tile((np.arange(k) - k // 2) * 3, n)
+        cols = np.clip(rows + offs, 0, n - 1)
+        keep = np.ones(len(cols), dtype=bool)
+        keep[1:] = (cols[1:] != cols[:-1]) | (rows[1:] != rows[:-1])
+        rows, cols = rows[keep], cols[keep]
+        rp = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(np.bincount(rows, minlength=n), out=rp[1:])
+        return formats.Csr.from_host(gk, n, n, rp, cols.astype(np.int32), rng.standard_normal(len(cols)))
+    rp, ci, v = matgen.random_rows_csr(n, n, counts, seed, local=int(case.get("bandwidth", 2000)) if kind == "local" else None)
     return formats.Csr.from_host(gk, n, n, rp, ci, v)
 
 
@@ -62,7 +93,12 @@ def main():
     rng = np.random.default_rng(args.seed)
     for case in cases:
         try:
-            A = formats.read_matrix(gk, case["filename"]) if "filename" in case else stencil_matrix(gk, case["stencil"], int(case["size"]))
+            if "filename" in case:
+                A = formats.read_matrix(gk, case["filename"])
+            elif "random" in case:
+                A = random_matrix(gk, case, args.seed)
+            else:
+                A = stencil_matrix(gk, case["stencil"], int(case["size"]))
         except Exception as e:  # keep going like the reference (--keep_errors)
             case["error"] = str(e)
             continue
@@ -82,7 +118,9 @@ def main():
                 den = torch.linalg.vector_norm(answer, dim=0)
                 entry["max_relative_norm2"] = float(torch.max(num / torch.where(den == 0, torch.ones_like(den), den)))
                 t, reps = timed(lambda: M.apply(b, x), args.warmup, args.min_repetitions, args.min_runtime)
-                entry.update(time=t, repetitions=reps, completed=True)
+                # not in the reference's schema: algorithmic GB/s (storage + b + x once)
+                entry.update(time=t, repetitions=reps, completed=True,
+                             bandwidth_gbs=(entry["storage"] + 8 * args.nrhs * (A.ncols + A.nrows)) / t / 1e9)
                 if best is None or t < best[1]:
                     best = (fmt, t)
             except Exception as e:
