@@ -139,6 +139,148 @@ __global__ __launch_bounds__(block) void sellp_spmv_kernel(
     }
 }
 
+// ---- ELL / SELL-P, several right-hand sides -------------------------------------
+// One thread per row with NR register accumulators: the matrix is read once per
+// NR columns of b (gridDim.y = nrhs re-reads it per column, like the
+// reference's kernels); b(col, j..j+NR-1) is contiguous in the row-major b.
+// Same per-(row, column) order as the single-column kernels -> bit-identical.
+template <int NR, bool Advanced, bool Vec>
+__device__ __forceinline__ void ell_like_row(const int32_t* __restrict__ col_idxs,
+                                             const double* __restrict__ vals, int64_t base,
+                                             int64_t step_elems, int64_t len,
+                                             const double* __restrict__ b, int64_t b_stride,
+                                             double* __restrict__ c_row, double alpha, double beta)
+{
+    constexpr int unroll = NR >= 8 ? 2 : 4;
+    double acc[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[j] = Advanced ? c_row[j] * beta : 0.0;
+    for (int64_t i = 0; i < len; i += unroll) {
+        double v[unroll];
+        int32_t col[unroll];
+#pragma unroll
+        for (int u = 0; u < unroll; ++u) {
+            const int64_t at = base + min(i + u, len - 1) * step_elems;
+            v[u] = vals[at];
+            col[u] = col_idxs[at];
+        }
+        double x[unroll][NR];
+#pragma unroll
+        for (int u = 0; u < unroll; ++u) {
+            const double* src = b + max(col[u], 0) * b_stride;  // padding (-1) reads row 0, unused
+            if (Vec) {
+#pragma unroll
+                for (int j = 0; j < NR; j += 2) {
+                    const double2 t = *reinterpret_cast<const double2*>(src + j);
+                    x[u][j] = t.x;
+                    x[u][j + 1] = t.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) x[u][j] = src[j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < unroll; ++u) {
+            if (i + u < len && col[u] != -1) {
+                const double av = Advanced ? alpha * v[u] : v[u];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) acc[j] += av * x[u][j];
+            }
+        }
+    }
+    if (Vec) {
+#pragma unroll
+        for (int j = 0; j < NR; j += 2) {
+            *reinterpret_cast<double2*>(c_row + j) = make_double2(acc[j], acc[j + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) c_row[j] = acc[j];
+    }
+}
+
+// Sellp = false: ELL (slice_size = stride, slice arrays unused)
+template <int NR, bool Advanced, bool Vec, bool Sellp>
+__global__ __launch_bounds__(block) void ell_like_multi_kernel(
+    int64_t nrows, int64_t num_stored, int64_t slice_size,
+    const uint64_t* __restrict__ slice_sets, const uint64_t* __restrict__ slice_lengths,
+    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    const double* __restrict__ b, int64_t b_stride, double* __restrict__ c, int64_t c_stride,
+    const double* __restrict__ alpha_p, const double* __restrict__ beta_p)
+{
+    b += blockIdx.y * NR;
+    c += blockIdx.y * NR;
+    double alpha = 1.0, beta = 0.0;
+    if (Advanced) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    const int64_t step = static_cast<int64_t>(gridDim.x) * block;
+    for (int64_t row = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; row < nrows;
+         row += step) {
+        int64_t base = row, len = num_stored;
+        if (Sellp) {
+            const int64_t slice = row / slice_size;
+            len = static_cast<int64_t>(slice_lengths[slice]);
+            base = static_cast<int64_t>(slice_sets[slice]) * slice_size + row % slice_size;
+        }
+        ell_like_row<NR, Advanced, Vec>(col_idxs, vals, base, slice_size, len, b, b_stride,
+                                        c + row * c_stride, alpha, beta);
+    }
+}
+
+template <int NR, bool Sellp>
+int launch_ell_like_multi(hipStream_t s, int64_t nrows, int slices, int64_t num_stored,
+                          int64_t slice_size, const uint64_t* slice_sets,
+                          const uint64_t* slice_lengths, const int32_t* col_idxs,
+                          const double* vals, const double* b, int64_t b_stride, double* c,
+                          int64_t c_stride, const double* alpha, const double* beta)
+{
+    dim3 grid(grid_for(nrows, block, 1 << 20), static_cast<unsigned>(slices));
+    const bool vec = reinterpret_cast<uintptr_t>(b) % 16 == 0 && reinterpret_cast<uintptr_t>(c) % 16 == 0 &&
+                     b_stride % 2 == 0 && c_stride % 2 == 0;
+#define GKOMI_ELLM(ADV, VEC)                                                                      \
+    hipLaunchKernelGGL((ell_like_multi_kernel<NR, ADV, VEC, Sellp>), grid, dim3(block), 0, s,     \
+                       nrows, num_stored, slice_size, slice_sets, slice_lengths, col_idxs, vals,  \
+                       b, b_stride, c, c_stride, alpha, beta)
+    if (alpha != nullptr) {
+        if (vec) GKOMI_ELLM(true, true); else GKOMI_ELLM(true, false);
+    } else {
+        if (vec) GKOMI_ELLM(false, true); else GKOMI_ELLM(false, false);
+    }
+#undef GKOMI_ELLM
+    return check_launch();
+}
+
+// columns [0, done) in passes of 8, 4 and 2; returns how many were handled (the
+// caller finishes an odd last column with the single-column kernel)
+template <bool Sellp>
+int ell_like_multi(hipStream_t s, int64_t nrows, int64_t nrhs, int64_t num_stored,
+                   int64_t slice_size, const uint64_t* slice_sets, const uint64_t* slice_lengths,
+                   const int32_t* col_idxs, const double* vals, const double* b, int64_t b_stride,
+                   double* c, int64_t c_stride, const double* alpha, const double* beta,
+                   int64_t* handled)
+{
+    int64_t done = 0;
+#define GKOMI_PASS(NRV)                                                                            \
+    if (nrhs - done >= NRV) {                                                                      \
+        const int slices = static_cast<int>((nrhs - done) / NRV);                                  \
+        const int err = launch_ell_like_multi<NRV, Sellp>(s, nrows, slices, num_stored, slice_size, \
+                                                          slice_sets, slice_lengths, col_idxs,     \
+                                                          vals, b + done, b_stride, c + done,      \
+                                                          c_stride, alpha, beta);                  \
+        if (err) return err;                                                                       \
+        done += static_cast<int64_t>(NRV) * slices;                                                \
+    }
+    GKOMI_PASS(8)
+    GKOMI_PASS(4)
+    GKOMI_PASS(2)
+#undef GKOMI_PASS
+    *handled = done;
+    return 0;
+}
+
 constexpr int coo_items = 6;
 constexpr int coo_tile = block * coo_items;  // 1536 nonzeros per workgroup
 
@@ -311,6 +453,17 @@ extern "C" int gkomi_ell_spmv_f64_i32(
     if (nrows == 0 || nrhs == 0) return GKOMI_SUCCESS;
     if (stride < nrows || b_stride < nrhs || c_stride < nrhs) return GKOMI_EINVAL;
     if (nrhs > 65535) return GKOMI_ENOTSUPPORTED;
+    if (nrhs >= 2) {
+        int64_t done = 0;
+        const int err = ell_like_multi<false>(to_stream(s), nrows, nrhs, num_stored_per_row, stride,
+                                              nullptr, nullptr, col_idxs, vals, b, b_stride, c, c_stride,
+                                              alpha, beta, &done);
+        if (err) return err;
+        if (done == nrhs) return GKOMI_SUCCESS;
+        b += done;
+        c += done;
+        nrhs -= done;
+    }
     dim3 grid(grid_for(nrows, block, 1 << 20), static_cast<unsigned>(nrhs));
     if (alpha != nullptr) {
         hipLaunchKernelGGL(ell_spmv_kernel<true>, grid, dim3(block), 0, to_stream(s), nrows,
@@ -336,6 +489,17 @@ extern "C" int gkomi_sellp_spmv_f64_i32(
     if (nrows == 0 || nrhs == 0) return GKOMI_SUCCESS;
     if (b_stride < nrhs || c_stride < nrhs) return GKOMI_EINVAL;
     if (nrhs > 65535) return GKOMI_ENOTSUPPORTED;
+    if (nrhs >= 2) {
+        int64_t done = 0;
+        const int err = ell_like_multi<true>(to_stream(s), nrows, nrhs, 0, slice_size, slice_sets,
+                                             slice_lengths, col_idxs, vals, b, b_stride, c, c_stride,
+                                             alpha, beta, &done);
+        if (err) return err;
+        if (done == nrhs) return GKOMI_SUCCESS;
+        b += done;
+        c += done;
+        nrhs -= done;
+    }
     dim3 grid(grid_for(nrows, block, 1 << 20), static_cast<unsigned>(nrhs));
     if (alpha != nullptr) {
         hipLaunchKernelGGL(sellp_spmv_kernel<true>, grid, dim3(block), 0, to_stream(s), nrows,

@@ -195,7 +195,7 @@ def test_conversions_bitexact_vs_oracle(gk, oracle, name):
             assert np.array_equal(host(h[key]), e[key]), (kw, key)
 
 
-@pytest.mark.parametrize("nrhs", [1, 3])
+@pytest.mark.parametrize("nrhs", [1, 3, 4, 15])
 @pytest.mark.parametrize("advanced", [False, True], ids=["simple", "advanced"])
 @pytest.mark.parametrize("name", sorted(MATS))
 def test_spmv_all_formats_vs_oracle(gk, oracle, name, advanced, nrhs):

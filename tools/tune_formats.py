@@ -89,6 +89,11 @@ for k_rhs in (2, 4, 8):
     mb = 12 * nnz + 4 * (n + 1) + 16 * n * k_rhs
     report(f"csr {k_rhs} rhs, multi-rhs kernel", lambda: gk.csr_spmv_f64_i32(s, n, n, k_rhs, nnz, rpd, cid, vd, xb, k_rhs, yb, k_rhs, None, None, 0, 5), mb)
     report(f"csr {k_rhs} rhs, one grid row per rhs", lambda: gk.csr_spmv_f64_i32(s, n, n, k_rhs, nnz, rpd, cid, vd, xb, k_rhs, yb, k_rhs, None, None, 1 | (5 << 8), 5), mb)
+for k_rhs in (4, 8):
+    xb = d(np.sin(0.01 * np.arange(n * k_rhs)).reshape(n, k_rhs))
+    yb = torch.empty((n, k_rhs), dtype=torch.float64, device="cuda")
+    report(f"ell {k_rhs} rhs", lambda: gk.ell_spmv_f64_i32(s, n, n, k_rhs, k, n, ecols, evals, xb, k_rhs, yb, k_rhs, None, None), 12 * n * k + 16 * n * k_rhs)
+    report(f"sellp {k_rhs} rhs", lambda: gk.sellp_spmv_f64_i32(s, n, n, k_rhs, 64, sets, lens, scols, svals, xb, k_rhs, yb, k_rhs, None, None), 12 * total + 16 * n * k_rhs)
 if os.environ.get("FORMATS_ONLY"):
     sys.exit(0)
 # Jacobi apply (max block size 32)
