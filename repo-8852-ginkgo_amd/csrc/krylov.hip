@@ -1267,6 +1267,291 @@ int fcg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, g
 
 }  // namespace
 
+// ---- fused FCG, one right-hand side: 3 launches per iteration -----------------------
+// (the structure of the fused CG of cg_solver.hip plus the vector t = r_new - r_old)
+//   FA  re-adds the partials of rho = r.z, rho_t = t.z and |r|^2, evaluates the
+//       criterion, p = z + (rho_t / prev_rho) p (fcg::step_1)
+//   FB  q = A p with the p.q partials in the SpMV epilogue
+//   FC  beta -> x += (rho/beta) p, r -= (rho/beta) q, t = r_new - r_old
+//       (fcg::step_2) and, without a preconditioner (z = r), the partials for
+//       the next FA; with one: z = M r, then a three-dot partials kernel
+namespace {
+
+struct fcg_scalars {
+    double rho[2];  // rho of iteration `it` lives in rho[it & 1]
+    double tau, orig_tau;
+    long long stop_iter;
+    unsigned char status;
+    unsigned char pad[7];
+};
+
+__global__ void fcg_fused_init_kernel(fcg_scalars* scal, const double* orig_tau)
+{
+    scal->rho[0] = 0.0;
+    scal->rho[1] = 1.0;  // prev_rho = 1 (fcg::initialize)
+    scal->tau = 0.0;
+    scal->orig_tau = orig_tau[0];
+    scal->stop_iter = -1;
+    scal->status = 0;
+}
+
+// p0[b] = sum r*z, p1[b] = sum t*z, p2[b] = sum r*r
+__global__ __launch_bounds__(fblock) void fused_dot3_partials_kernel(
+    int64_t n, const double* __restrict__ r, const double* __restrict__ z, const double* __restrict__ t,
+    const unsigned char* status, double* __restrict__ p0, double* __restrict__ p1,
+    double* __restrict__ p2)
+{
+    __shared__ double smem[fblock / wave_size];
+    if (status != nullptr && status_has_stopped(status[0])) return;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * fblock;
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x; i < n; i += step) {
+        const double rv = r[i], zv = z[i];
+        a += rv * zv;
+        b += t[i] * zv;
+        c += rv * rv;
+    }
+    const double ta = block_reduce_sum<fblock>(a, smem);
+    __syncthreads();
+    const double tb = block_reduce_sum<fblock>(b, smem);
+    __syncthreads();
+    const double tc = block_reduce_sum<fblock>(c, smem);
+    if (threadIdx.x == 0) {
+        p0[blockIdx.x] = ta;
+        p1[blockIdx.x] = tb;
+        p2[blockIdx.x] = tc;
+    }
+}
+
+// FA.  z may alias r (Identity).
+__global__ __launch_bounds__(fblock) void fcg_fused_step1_kernel(
+    int64_t n, double* __restrict__ p, const double* __restrict__ z,
+    const double* __restrict__ rho_part, const double* __restrict__ rhot_part,
+    const double* __restrict__ tau_part, int nparts, fcg_scalars* scal, long long it,
+    long long max_iters, double goal)
+{
+    __shared__ double smem[fblock / wave_size];
+    if (status_has_stopped(scal->status)) return;
+    const pair_sweep sw(n);
+    double2 z0 = make_double2(0.0, 0.0), p0 = z0;
+    if (sw.first()) {
+        z0 = ld2(z, sw.i0);
+        p0 = ld2(p, sw.i0);
+    }
+    const double rho = sum_partials_f(rho_part, nparts, smem);
+    const double rho_t = sum_partials_f(rhot_part, nparts, smem);
+    const double tau = sqrt(rho_part == tau_part ? rho : sum_partials_f(tau_part, nparts, smem));
+    uint8_t st = 0;
+    if (it >= max_iters) {
+        st = 1 | GKOMI_STATUS_FINALIZED;
+    } else if (tau < goal * scal->orig_tau) {
+        st = GKOMI_STATUS_CONVERGED | 1 | GKOMI_STATUS_FINALIZED;
+    }
+    const double prev = scal->rho[(it + 1) & 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal->rho[it & 1] = rho;
+        if (it < max_iters) scal->tau = tau;
+        if (st) {
+            scal->stop_iter = it;
+            scal->status = st;
+        }
+    }
+    if (st) return;
+    const bool restart = prev == 0.0;
+    const double tmp = restart ? 0.0 : rho_t / prev;
+    auto step1 = [&](double zv, double pv) { return restart ? zv : zv + tmp * pv; };
+    if (sw.first()) st2(p, sw.i0, make_double2(step1(z0.x, p0.x), step1(z0.y, p0.y)));
+    for (int64_t i = sw.i0 + sw.step; i < sw.n2; i += sw.step) {
+        const double2 zv = ld2(z, i), pv = ld2(p, i);
+        st2(p, i, make_double2(step1(zv.x, pv.x), step1(zv.y, pv.y)));
+    }
+    if (sw.tail(n)) p[n - 1] = step1(z[n - 1], p[n - 1]);
+}
+
+// FC.  With partials != nullptr (Identity): leaves r.r and t.r of the new r, t.
+__global__ __launch_bounds__(fblock) void fcg_fused_step2_kernel(
+    int64_t n, double* __restrict__ x, double* __restrict__ r, double* __restrict__ t,
+    const double* __restrict__ p, const double* __restrict__ q,
+    const double* __restrict__ beta_part, int nparts, fcg_scalars* scal, long long it,
+    double* __restrict__ rr_part, double* __restrict__ tr_part)
+{
+    __shared__ double smem[fblock / wave_size];
+    if (status_has_stopped(scal->status)) return;
+    const pair_sweep sw(n);
+    double2 x0 = make_double2(0.0, 0.0), r0 = x0, p0 = x0, q0 = x0, t0 = x0;
+    if (sw.first()) {
+        x0 = ld2(x, sw.i0);
+        r0 = ld2(r, sw.i0);
+        p0 = ld2(p, sw.i0);
+        q0 = ld2(q, sw.i0);
+        t0 = ld2(t, sw.i0);
+    }
+    const double beta = sum_partials_f(beta_part, nparts, smem);
+    const double rho = scal->rho[it & 1];
+    const bool update = beta != 0.0;
+    const double tmp = update ? rho / beta : 0.0;
+    double a0 = 0.0, a1 = 0.0;
+    // fcg::step_2; returns through the references, accumulates r.r and t.r
+    auto step2 = [&](double& xv, double& rv, double& tv, double pv, double qv) {
+        if (update) {
+            const double prev_r = rv;
+            xv += tmp * pv;
+            rv = prev_r - tmp * qv;
+            tv = rv - prev_r;
+        }
+        a0 += rv * rv;
+        a1 += tv * rv;
+    };
+    if (sw.first()) {
+        step2(x0.x, r0.x, t0.x, p0.x, q0.x);
+        step2(x0.y, r0.y, t0.y, p0.y, q0.y);
+        if (update) {
+            st2(x, sw.i0, x0);
+            st2(r, sw.i0, r0);
+            st2(t, sw.i0, t0);
+        }
+    }
+    for (int64_t i = sw.i0 + sw.step; i < sw.n2; i += sw.step) {
+        double2 xv = ld2(x, i), rv = ld2(r, i), tv = ld2(t, i);
+        const double2 pv = ld2(p, i), qv = ld2(q, i);
+        step2(xv.x, rv.x, tv.x, pv.x, qv.x);
+        step2(xv.y, rv.y, tv.y, pv.y, qv.y);
+        if (update) {
+            st2(x, i, xv);
+            st2(r, i, rv);
+            st2(t, i, tv);
+        }
+    }
+    if (sw.tail(n)) {
+        const int64_t i = n - 1;
+        double xv = x[i], rv = r[i], tv = t[i];
+        step2(xv, rv, tv, p[i], q[i]);
+        if (update) {
+            x[i] = xv;
+            r[i] = rv;
+            t[i] = tv;
+        }
+    }
+    if (rr_part == nullptr) return;
+    __syncthreads();
+    const double s0 = block_reduce_sum<fblock>(a0, smem);
+    __syncthreads();
+    const double s1 = block_reduce_sum<fblock>(a1, smem);
+    if (threadIdx.x == 0) {
+        rr_part[blockIdx.x] = s0;
+        tr_part[blockIdx.x] = s1;
+    }
+}
+
+int fcg_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn precond,
+                   void* precond_ctx, const double* b, double* x, int64_t max_iters,
+                   double reduction_factor, int baseline, int64_t check_every, void* workspace,
+                   size_t workspace_bytes, double* host_info)
+{
+    const int64_t nrhs = 1;
+    if (n > INT32_MAX - 1024) return GKOMI_ENOTSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0) {
+        return fcg_solve_impl(s, n, 1, A, precond, precond_ctx, b, x, max_iters, reduction_factor, baseline,
+                              check_every, workspace, workspace_bytes, host_info);
+    }
+    GKOMI_DRIVER_PROLOGUE(5);
+    double *r = V(0), *z = V(1), *p = V(2), *q = V(3), *t = V(4);
+    GKOMI_TRY(gkomi_fcg_initialize_f64(s, n, 1, b, 1, r, 1, z, 1, p, 1, q, 1, t, 1, sc + 1, sc + 2, sc + 3,
+                                       c.stop_status));
+    GKOMI_TRY(c.start(b, x, r, baseline));
+    // t = b from initialize, exactly like the reference (fcg.cpp:137 does not refresh it after r = b - A x)
+    hipStream_t stream = c.stream;
+    double* parts = reinterpret_cast<double*>(ws + l.parts);
+    fcg_scalars* scal = reinterpret_cast<fcg_scalars*>(parts);
+    double* part_rho = parts + 32;
+    double* part_rhot = part_rho + fused_max_parts;
+    double* part_tau = part_rhot + fused_max_parts;
+    double* part_beta = part_tau + fused_max_parts;
+    const size_t per_spmv = static_cast<size_t>(n) / 256 + 2;  // >= g: room for three arrays (layout)
+    int64_t gl = ceildiv(n / 2 + 1, fblock);
+    if (gl > fused_max_parts) gl = fused_max_parts;
+    if (gl < 1) gl = 1;
+    const int g = static_cast<int>(gl);
+    const bool csr_epilogue = A.is_csr() && n > 0 && reinterpret_cast<uintptr_t>(A.vals) % 16 == 0 &&
+                              reinterpret_cast<uintptr_t>(A.col_idxs) % 8 == 0;
+    const int nb = csr_epilogue ? csr_spmv_dot_num_partials(static_cast<int>(n)) : g;
+    const bool swizzle = csr_auto_swizzle(n, A.nnz);
+    const bool identity = precond == nullptr;
+    if (identity) z = r;
+    hipLaunchKernelGGL(fcg_fused_init_kernel, dim3(1), dim3(1), 0, stream, scal, c.orig_tau);
+    if (!identity) GKOMI_TRY(precond(precond_ctx, s, r, z));
+    hipLaunchKernelGGL(fused_dot3_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r, z, t,
+                       static_cast<const unsigned char*>(nullptr), part_rho, part_rhot, part_tau);
+    GKOMI_TRY(check_launch());
+    fcg_scalars h{};
+    long long it = 0;
+    bool done = false;
+    while (!done) {
+        for (int64_t k = 0; k < c.check_every && !done; ++k, ++it) {
+            hipLaunchKernelGGL(fcg_fused_step1_kernel, dim3(g), dim3(fblock), 0, stream, n, p, z, part_rho,
+                               part_rhot, identity ? part_rho : part_tau, g, scal, it,
+                               static_cast<long long>(max_iters), reduction_factor);
+            if (it >= max_iters) {
+                ++it;
+                break;
+            }
+            if (csr_epilogue) {
+                GKOMI_TRY(csr_spmv_dot_launch(stream, static_cast<int>(n), A.nnz, A.row_ptrs, A.col_idxs, A.vals,
+                                              p, q, part_beta, &scal->status, swizzle));
+            } else {
+                GKOMI_TRY(A.apply(s, 1, nullptr, p, nullptr, q));
+                // only p.q is wanted: the other two sums land in scratch
+                hipLaunchKernelGGL(fused_dot3_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, p, q, p,
+                                   &scal->status, part_beta, part_beta + per_spmv, part_beta + 2 * per_spmv);
+            }
+            hipLaunchKernelGGL(fcg_fused_step2_kernel, dim3(g), dim3(fblock), 0, stream, n, x, r, t, p, q,
+                               part_beta, nb, scal, it, identity ? part_rho : static_cast<double*>(nullptr),
+                               identity ? part_rhot : static_cast<double*>(nullptr));
+            if (!identity) {
+                GKOMI_TRY(precond(precond_ctx, s, r, z));
+                hipLaunchKernelGGL(fused_dot3_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r, z, t,
+                                   &scal->status, part_rho, part_rhot, part_tau);
+            }
+        }
+        GKOMI_TRY(check_launch());
+        GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&h, scal, sizeof(h), hipMemcpyDeviceToHost, stream)));
+        GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
+        done = h.stop_iter >= 0;
+    }
+    if (host_info != nullptr) {
+        host_info[0] = static_cast<double>(h.stop_iter);
+        host_info[1] = (h.status & GKOMI_STATUS_CONVERGED) ? 1.0 : 0.0;
+        host_info[2] = h.tau;
+        host_info[3] = h.orig_tau;
+    }
+    return GKOMI_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" int gkomi_fcg_solve_fused_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nnz, const int32_t* row_ptrs, const int32_t* col_idxs,
+    const double* vals, int spmv_strategy, int64_t max_row_nnz_hint, gkomi_apply_fn precond,
+    void* precond_ctx, const double* b, double* x, int64_t max_iters, double reduction_factor,
+    int baseline, int64_t check_every, void* workspace, size_t workspace_bytes, double* host_info)
+{
+    return fcg_fused_impl(s, n, make_csr_sysmat(n, nnz, row_ptrs, col_idxs, vals, spmv_strategy,
+                                                max_row_nnz_hint),
+                          precond, precond_ctx, b, x, max_iters, reduction_factor, baseline, check_every,
+                          workspace, workspace_bytes, host_info);
+}
+
+extern "C" int gkomi_fcg_solve_fused_op_f64(
+    gkomi_stream_t s, int64_t n, gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
+    double reduction_factor, int baseline, int64_t check_every, void* workspace,
+    size_t workspace_bytes, double* host_info)
+{
+    if (matrix == nullptr) return GKOMI_EINVAL;
+    return fcg_fused_impl(s, n, make_op_sysmat(n, matrix, matrix_ctx), precond, precond_ctx, b, x, max_iters,
+                          reduction_factor, baseline, check_every, workspace, workspace_bytes, host_info);
+}
+
 extern "C" int gkomi_fcg_solve_f64_i32(
     gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
     const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,

@@ -370,3 +370,69 @@ def test_fused_bicgstab_with_preconditioners_and_formats(gk, oracle):
         res = solvers.solve_op(gk, "bicgstab", A.to(fmt), bd, max_iters=2000, reduction=1e-10, fused=True)
         assert res["converged"] and matgen.rel_err(host(res["x"]), xs) < 1e-7, fmt
         assert abs(res["iterations"] - plain["iterations"]) <= max(2, plain["iterations"] // 5), fmt
+
+
+# ---- fused single-rhs FCG (3 launches per iteration) ----------------------------------
+@pytest.mark.parametrize("case", [c for c in G["solves"] if c["solver"] == "fcg"], ids=lambda c: c["name"])
+def test_fused_fcg_known_answers(gk, oracle, case):
+    n, rp, ci, v = dense_to_csr(case["A"])
+    res = solvers.krylov_solve(gk, "fcg", n, dev(rp), dev(ci), dev(v), dev(np.array(case["b"])),
+                               max_iters=case["max_iters"], reduction=case["reduction"], fused=True)
+    assert matgen.rel_err(host(res["x"]), case["expect_x"]) <= 4 * case["tol"], res
+    xe = np.zeros(n)
+    ite = oracle.ref_fcg_solve(n, rp, ci, v, np.array(case["b"]), xe, case["max_iters"], case["reduction"], 0)
+    assert res["iterations"] <= 2 * ite + 2 if "DivergenceCheck" in case["name"] else abs(res["iterations"] - ite) <= max(2, ite // 4)
+
+
+@pytest.mark.parametrize("problem", ["poisson", "odd_size", "nonzero_guess"])
+def test_fused_fcg_like_the_oracle_and_the_reference_sequence(gk, oracle, problem):
+    n, rp, ci, v = matgen.poisson_2d_5pt(40) if problem != "odd_size" else matgen.poisson_2d_5pt(37, 41)
+    xs = np.sin(0.3 * np.arange(n))
+    b = np.zeros((n, 1))
+    oracle.ref_csr_spmv(n, 1, rp, ci, v, xs.reshape(n, 1), 1, b, 1)
+    x0 = np.cos(0.1 * np.arange(n)) if problem == "nonzero_guess" else np.zeros(n)
+    xe = x0.copy()
+    ite = oracle.ref_fcg_solve(n, rp, ci, v, b[:, 0].copy(), xe, 2000, 1e-10, 0)
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    res = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, dev(b[:, 0].copy()), x=dev(x0.copy()), max_iters=2000,
+                               reduction=1e-10, fused=True)
+    assert res["converged"] and res["rel_residual"] <= 1e-10
+    assert abs(res["iterations"] - ite) <= max(2, ite // 10), (res["iterations"], ite)
+    assert matgen.rel_err(host(res["x"]), xs) < 1e-7
+    unfused = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, dev(b[:, 0].copy()), x=dev(x0.copy()), max_iters=2000,
+                                   reduction=1e-10)
+    assert abs(res["iterations"] - unfused["iterations"]) <= max(2, ite // 10)
+    for every in (1, 3, 50):
+        again = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, dev(b[:, 0].copy()), x=dev(x0.copy()), max_iters=2000,
+                                     reduction=1e-10, check_every=every, fused=True)
+        assert again["iterations"] == res["iterations"] and again["converged"]
+        assert host(again["x"]).tobytes() == host(res["x"]).tobytes()
+        assert again["residual_norm"][0] == res["residual_norm"][0]
+    r = b[:, 0] - np.add.reduceat(v * host(res["x"])[ci], rp[:-1])
+    assert abs(np.linalg.norm(r) - res["residual_norm"][0]) <= 1e-6 * np.linalg.norm(b) + 1e-3 * res["residual_norm"][0]
+
+
+def test_fused_fcg_with_preconditioner_formats_and_iteration_limit(gk, oracle):
+    from gkomi import formats
+    n, rp, ci, v = matgen.poisson_2d_5pt(48)
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    xs = np.sin(0.3 * np.arange(n))
+    b = np.zeros((n, 1))
+    oracle.ref_csr_spmv(n, 1, rp, ci, v, xs.reshape(n, 1), 1, b, 1)
+    bd = dev(b[:, 0].copy())
+    plain = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bd, max_iters=2000, reduction=1e-10, fused=True)
+    jac = solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=8)
+    pre = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bd, max_iters=2000, reduction=1e-10, precond=jac, fused=True)
+    ref = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bd, max_iters=2000, reduction=1e-10, precond=jac)
+    assert pre["converged"] and matgen.rel_err(host(pre["x"]), xs) < 1e-7
+    assert abs(pre["iterations"] - ref["iterations"]) <= max(2, ref["iterations"] // 10)
+    A = formats.Csr.from_host(gk, n, n, rp, ci, v)
+    for fmt in ("ell", "sellp", "coo", "hybrid"):
+        res = solvers.solve_op(gk, "fcg", A.to(fmt), bd, max_iters=2000, reduction=1e-10, fused=True)
+        assert res["converged"] and matgen.rel_err(host(res["x"]), xs) < 1e-7, fmt
+        assert abs(res["iterations"] - plain["iterations"]) <= max(2, plain["iterations"] // 10), fmt
+    a = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bd, max_iters=3, reduction=1e-14, fused=True)
+    u = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bd, max_iters=3, reduction=1e-14)
+    assert a["iterations"] == 3 and not a["converged"] and matgen.rel_err(host(a["x"]), host(u["x"])) < 1e-12
+    z = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bd, max_iters=0, reduction=1e-14, fused=True)
+    assert z["iterations"] == 0 and not z["converged"] and not host(z["x"]).any()

@@ -60,5 +60,7 @@ for name in ("poisson2d", "convection3d"):
     timed("bicgstab fused + jacobi(4)", lambda: solvers.krylov_solve(gk, "bicgstab", n, rpd, cid, vd, bv, precond=jac, fused=True, **kw))
     timed("cgs", lambda: solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bv, **kw))
     if name == "poisson2d":
-        timed("fcg", lambda: solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bv, **kw))
+        timed("fcg reference sequence", lambda: solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bv, **kw))
+        timed("fcg fused", lambda: solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bv, fused=True, check_every=16, **kw))
+        timed("fcg fused + jacobi(4)", lambda: solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bv, fused=True, precond=jac, check_every=16, **kw))
         timed("cg fused", lambda: solvers.cg_solve(gk, n, rpd, cid, vd, b, mode=1, check_every=16, **kw))
