@@ -853,6 +853,21 @@ int gkomi_bicgstab_solve_fused_op_f64(
     int64_t max_iters, double reduction_factor, int baseline,
     int64_t check_every, void* workspace, size_t workspace_bytes,
     double* host_info);
+/* Fused single right-hand-side CGS (core/solver/cgs.cpp:107-205 in 5 launches
+ * per iteration; conventions of gkomi_bicgstab_solve_fused_f64_i32). */
+int gkomi_cgs_solve_fused_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nnz, const int32_t* row_ptrs,
+    const int32_t* col_idxs, const double* vals, int spmv_strategy,
+    int64_t max_row_nnz_hint, gkomi_apply_fn precond, void* precond_ctx,
+    const double* b, double* x, int64_t max_iters, double reduction_factor,
+    int baseline, int64_t check_every, void* workspace, size_t workspace_bytes,
+    double* host_info);
+int gkomi_cgs_solve_fused_op_f64(
+    gkomi_stream_t s, int64_t n, gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x,
+    int64_t max_iters, double reduction_factor, int baseline,
+    int64_t check_every, void* workspace, size_t workspace_bytes,
+    double* host_info);
 /* Fused single right-hand-side FCG (core/solver/fcg.cpp:104-196 in 3 launches
  * per iteration; see gkomi_bicgstab_solve_fused_f64_i32 for the conventions). */
 int gkomi_fcg_solve_fused_f64_i32(

@@ -1618,6 +1618,315 @@ int cgs_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, g
 
 }  // namespace
 
+// ---- fused CGS, one right-hand side: 5 launches per iteration ------------------------
+//   GA  re-adds the partials of rho = r.r_tld and |r|^2, evaluates the criterion,
+//       u = r + beta q, p = u + beta (q + beta p) (cgs::step_1)
+//   GB  v_hat = A (M p) with the r_tld.v_hat partials in the SpMV epilogue
+//   GC  alpha, q = u - alpha v_hat, t = u + q (cgs::step_2)
+//   GD  A (M t)
+//   GE  x += alpha u_hat, r -= alpha t (cgs::step_3), partials for the next GA
+namespace {
+
+struct cgs_scalars {
+    double rho[2];
+    double alpha, beta, tau, orig_tau;
+    long long stop_iter;
+    unsigned char status;
+    unsigned char pad[7];
+};
+
+__global__ void cgs_fused_init_kernel(cgs_scalars* scal, const double* orig_tau)
+{
+    scal->rho[0] = 0.0;
+    scal->rho[1] = 1.0;  // prev_rho = alpha = beta = gamma = 1 (cgs::initialize)
+    scal->alpha = 1.0;
+    scal->beta = 1.0;
+    scal->tau = 0.0;
+    scal->orig_tau = orig_tau[0];
+    scal->stop_iter = -1;
+    scal->status = 0;
+}
+
+// GA
+__global__ __launch_bounds__(fblock) void cgs_fused_step1_kernel(
+    int64_t n, const double* __restrict__ r, double* __restrict__ u, double* __restrict__ p,
+    const double* __restrict__ q, const double* __restrict__ rho_part,
+    const double* __restrict__ tau_part, int nparts, cgs_scalars* scal, long long it,
+    long long max_iters, double goal)
+{
+    __shared__ double smem[fblock / wave_size];
+    if (status_has_stopped(scal->status)) return;
+    const pair_sweep sw(n);
+    double2 r0 = make_double2(0.0, 0.0), q0 = r0, p0 = r0;
+    if (sw.first()) {
+        r0 = ld2(r, sw.i0);
+        q0 = ld2(q, sw.i0);
+        p0 = ld2(p, sw.i0);
+    }
+    const double rho = sum_partials_f(rho_part, nparts, smem);
+    const double tau = sqrt(sum_partials_f(tau_part, nparts, smem));
+    uint8_t st = 0;
+    if (it >= max_iters) {
+        st = 1 | GKOMI_STATUS_FINALIZED;
+    } else if (tau < goal * scal->orig_tau) {
+        st = GKOMI_STATUS_CONVERGED | 1 | GKOMI_STATUS_FINALIZED;
+    }
+    const double prev = scal->rho[(it + 1) & 1];
+    const bool update = prev != 0.0;
+    // beta is rewritten only when prev_rho != 0, and then nobody reads the old value
+    const double bt = update ? rho / prev : scal->beta;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal->rho[it & 1] = rho;
+        if (it < max_iters) scal->tau = tau;
+        if (st) {
+            scal->stop_iter = it;
+            scal->status = st;
+        } else if (update) {
+            scal->beta = bt;
+        }
+    }
+    if (st) return;
+    auto step1 = [&](double rv, double qv, double pv, double* uo, double* po) {
+        const double uu = rv + bt * qv;
+        *uo = uu;
+        *po = uu + bt * (qv + bt * pv);
+    };
+    if (sw.first()) {
+        double2 uo, po;
+        step1(r0.x, q0.x, p0.x, &uo.x, &po.x);
+        step1(r0.y, q0.y, p0.y, &uo.y, &po.y);
+        st2(u, sw.i0, uo);
+        st2(p, sw.i0, po);
+    }
+    for (int64_t i = sw.i0 + sw.step; i < sw.n2; i += sw.step) {
+        const double2 rv = ld2(r, i), qv = ld2(q, i), pv = ld2(p, i);
+        double2 uo, po;
+        step1(rv.x, qv.x, pv.x, &uo.x, &po.x);
+        step1(rv.y, qv.y, pv.y, &uo.y, &po.y);
+        st2(u, i, uo);
+        st2(p, i, po);
+    }
+    if (sw.tail(n)) {
+        const int64_t i = n - 1;
+        double uo, po;
+        step1(r[i], q[i], p[i], &uo, &po);
+        u[i] = uo;
+        p[i] = po;
+    }
+}
+
+// GC
+__global__ __launch_bounds__(fblock) void cgs_fused_step2_kernel(
+    int64_t n, const double* __restrict__ u, const double* __restrict__ v_hat,
+    double* __restrict__ q, double* __restrict__ t, const double* __restrict__ gamma_part,
+    int nparts, cgs_scalars* scal, long long it)
+{
+    __shared__ double smem[fblock / wave_size];
+    if (status_has_stopped(scal->status)) return;
+    const pair_sweep sw(n);
+    double2 u0 = make_double2(0.0, 0.0), v0 = u0;
+    if (sw.first()) {
+        u0 = ld2(u, sw.i0);
+        v0 = ld2(v_hat, sw.i0);
+    }
+    const double gamma = sum_partials_f(gamma_part, nparts, smem);
+    const bool update = gamma != 0.0;
+    const double a = update ? scal->rho[it & 1] / gamma : scal->alpha;
+    if (update && blockIdx.x == 0 && threadIdx.x == 0) scal->alpha = a;
+    auto step2 = [&](double uv, double vv, double* qo, double* to) {
+        const double qq = uv - a * vv;
+        *qo = qq;
+        *to = uv + qq;
+    };
+    if (sw.first()) {
+        double2 qo, to;
+        step2(u0.x, v0.x, &qo.x, &to.x);
+        step2(u0.y, v0.y, &qo.y, &to.y);
+        st2(q, sw.i0, qo);
+        st2(t, sw.i0, to);
+    }
+    for (int64_t i = sw.i0 + sw.step; i < sw.n2; i += sw.step) {
+        const double2 uv = ld2(u, i), vv = ld2(v_hat, i);
+        double2 qo, to;
+        step2(uv.x, vv.x, &qo.x, &to.x);
+        step2(uv.y, vv.y, &qo.y, &to.y);
+        st2(q, i, qo);
+        st2(t, i, to);
+    }
+    if (sw.tail(n)) {
+        const int64_t i = n - 1;
+        double qo, to;
+        step2(u[i], v_hat[i], &qo, &to);
+        q[i] = qo;
+        t[i] = to;
+    }
+}
+
+// GE: x += alpha xdir, r -= alpha rdir; partials of r.r_tld and r.r
+__global__ __launch_bounds__(fblock) void cgs_fused_step3_kernel(
+    int64_t n, double* __restrict__ x, double* __restrict__ r, const double* __restrict__ xdir,
+    const double* __restrict__ rdir, const double* __restrict__ r_tld, cgs_scalars* scal,
+    double* __restrict__ rho_part, double* __restrict__ tau_part)
+{
+    __shared__ double smem[fblock / wave_size];
+    if (status_has_stopped(scal->status)) return;
+    const double alpha = scal->alpha;
+    const int64_t n2 = n / 2;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * fblock;
+    double a0 = 0.0, a1 = 0.0;
+    auto step3 = [&](double& xv, double& rv, double xd, double rd, double rt) {
+        xv += alpha * xd;
+        rv -= alpha * rd;
+        a0 += rv * rt;
+        a1 += rv * rv;
+    };
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x; i < n2; i += step) {
+        double2 xv = ld2(x, i), rv = ld2(r, i);
+        const double2 xd = ld2(xdir, i), rd = ld2(rdir, i), rt = ld2(r_tld, i);
+        step3(xv.x, rv.x, xd.x, rd.x, rt.x);
+        step3(xv.y, rv.y, xd.y, rd.y, rt.y);
+        st2(x, i, xv);
+        st2(r, i, rv);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        double xv = x[i], rv = r[i];
+        step3(xv, rv, xdir[i], rdir[i], r_tld[i]);
+        x[i] = xv;
+        r[i] = rv;
+    }
+    __syncthreads();
+    const double s0 = block_reduce_sum<fblock>(a0, smem);
+    __syncthreads();
+    const double s1 = block_reduce_sum<fblock>(a1, smem);
+    if (threadIdx.x == 0) {
+        rho_part[blockIdx.x] = s0;
+        tau_part[blockIdx.x] = s1;
+    }
+}
+
+int cgs_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn precond,
+                   void* precond_ctx, const double* b, double* x, int64_t max_iters,
+                   double reduction_factor, int baseline, int64_t check_every, void* workspace,
+                   size_t workspace_bytes, double* host_info)
+{
+    const int64_t nrhs = 1;
+    if (n > INT32_MAX - 1024) return GKOMI_ENOTSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0) {
+        return cgs_solve_impl(s, n, 1, A, precond, precond_ctx, b, x, max_iters, reduction_factor, baseline,
+                              check_every, workspace, workspace_bytes, host_info);
+    }
+    GKOMI_DRIVER_PROLOGUE(8);
+    double *r = V(0), *r_tld = V(1), *p = V(2), *q = V(3), *u = V(4), *u_hat = V(5), *v_hat = V(6),
+           *t = V(7);
+    GKOMI_TRY(gkomi_cgs_initialize_f64(s, n, 1, b, 1, r, 1, r_tld, 1, p, 1, q, 1, u, 1, u_hat, 1, v_hat, 1, t, 1,
+                                       sc, sc + 1, sc + 2, sc + 3, sc + 4, c.stop_status));
+    GKOMI_TRY(c.start(b, x, r, baseline));
+    GKOMI_TRY(gkomi_dense_copy_f64(s, n, 1, r, 1, r_tld, 1));
+    hipStream_t stream = c.stream;
+    double* parts = reinterpret_cast<double*>(ws + l.parts);
+    cgs_scalars* scal = reinterpret_cast<cgs_scalars*>(parts);
+    double* part_rho = parts + 32;
+    double* part_tau = part_rho + fused_max_parts;
+    double* part_gamma = part_tau + 2 * fused_max_parts;
+    const size_t per_spmv = static_cast<size_t>(n) / 256 + 2;
+    int64_t gl = ceildiv(n / 2 + 1, fblock);
+    if (gl > fused_max_parts) gl = fused_max_parts;
+    if (gl < 1) gl = 1;
+    const int g = static_cast<int>(gl);
+    const bool csr_epilogue = A.is_csr() && n > 0 && reinterpret_cast<uintptr_t>(A.vals) % 16 == 0 &&
+                              reinterpret_cast<uintptr_t>(A.col_idxs) % 8 == 0;
+    const int nb = csr_epilogue ? csr_spmv_dot_num_partials(static_cast<int>(n)) : g;
+    const bool swizzle = csr_auto_swizzle(n, A.nnz);
+    const bool identity = precond == nullptr;
+    hipLaunchKernelGGL(cgs_fused_init_kernel, dim3(1), dim3(1), 0, stream, scal, c.orig_tau);
+    // partials of r.r_tld and r.r (the third sum is scratch)
+    hipLaunchKernelGGL(fused_dot3_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r, r_tld, r,
+                       static_cast<const unsigned char*>(nullptr), part_rho, part_gamma + per_spmv, part_tau);
+    GKOMI_TRY(check_launch());
+    cgs_scalars h{};
+    long long it = 0;
+    bool done = false;
+    while (!done) {
+        for (int64_t k = 0; k < c.check_every && !done; ++k, ++it) {
+            hipLaunchKernelGGL(cgs_fused_step1_kernel, dim3(g), dim3(fblock), 0, stream, n, r, u, p, q, part_rho,
+                               part_tau, g, scal, it, static_cast<long long>(max_iters), reduction_factor);
+            if (it >= max_iters) {
+                ++it;
+                break;
+            }
+            // v_hat = A (M p), gamma = r_tld . v_hat
+            const double* mp = p;
+            if (!identity) {
+                GKOMI_TRY(precond(precond_ctx, s, p, t));
+                mp = t;
+            }
+            if (csr_epilogue) {
+                GKOMI_TRY(csr_spmv_dot_launch(stream, static_cast<int>(n), A.nnz, A.row_ptrs, A.col_idxs, A.vals,
+                                              mp, v_hat, part_gamma, &scal->status, swizzle, r_tld));
+            } else {
+                GKOMI_TRY(A.apply(s, 1, nullptr, mp, nullptr, v_hat));
+                hipLaunchKernelGGL(fused_dot3_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r_tld, v_hat,
+                                   r_tld, &scal->status, part_gamma, part_gamma + per_spmv,
+                                   part_gamma + 2 * per_spmv);
+            }
+            hipLaunchKernelGGL(cgs_fused_step2_kernel, dim3(g), dim3(fblock), 0, stream, n, u, v_hat, q, t,
+                               part_gamma, nb, scal, it);
+            // Identity: u_hat = t, and A t goes to the u_hat buffer; otherwise
+            // u_hat = M t and A u_hat overwrites t, as in the reference
+            const double *xdir, *rdir;
+            if (identity) {
+                GKOMI_TRY(A.apply(s, 1, nullptr, t, nullptr, u_hat));
+                xdir = t;
+                rdir = u_hat;
+            } else {
+                GKOMI_TRY(precond(precond_ctx, s, t, u_hat));
+                GKOMI_TRY(A.apply(s, 1, nullptr, u_hat, nullptr, t));
+                xdir = u_hat;
+                rdir = t;
+            }
+            hipLaunchKernelGGL(cgs_fused_step3_kernel, dim3(g), dim3(fblock), 0, stream, n, x, r, xdir, rdir,
+                               r_tld, scal, part_rho, part_tau);
+        }
+        GKOMI_TRY(check_launch());
+        GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&h, scal, sizeof(h), hipMemcpyDeviceToHost, stream)));
+        GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
+        done = h.stop_iter >= 0;
+    }
+    if (host_info != nullptr) {
+        host_info[0] = static_cast<double>(h.stop_iter);
+        host_info[1] = (h.status & GKOMI_STATUS_CONVERGED) ? 1.0 : 0.0;
+        host_info[2] = h.tau;
+        host_info[3] = h.orig_tau;
+    }
+    return GKOMI_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" int gkomi_cgs_solve_fused_f64_i32(
+    gkomi_stream_t s, int64_t n, int64_t nnz, const int32_t* row_ptrs, const int32_t* col_idxs,
+    const double* vals, int spmv_strategy, int64_t max_row_nnz_hint, gkomi_apply_fn precond,
+    void* precond_ctx, const double* b, double* x, int64_t max_iters, double reduction_factor,
+    int baseline, int64_t check_every, void* workspace, size_t workspace_bytes, double* host_info)
+{
+    return cgs_fused_impl(s, n, make_csr_sysmat(n, nnz, row_ptrs, col_idxs, vals, spmv_strategy,
+                                                max_row_nnz_hint),
+                          precond, precond_ctx, b, x, max_iters, reduction_factor, baseline, check_every,
+                          workspace, workspace_bytes, host_info);
+}
+
+extern "C" int gkomi_cgs_solve_fused_op_f64(
+    gkomi_stream_t s, int64_t n, gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x, int64_t max_iters,
+    double reduction_factor, int baseline, int64_t check_every, void* workspace,
+    size_t workspace_bytes, double* host_info)
+{
+    if (matrix == nullptr) return GKOMI_EINVAL;
+    return cgs_fused_impl(s, n, make_op_sysmat(n, matrix, matrix_ctx), precond, precond_ctx, b, x, max_iters,
+                          reduction_factor, baseline, check_every, workspace, workspace_bytes, host_info);
+}
+
 extern "C" int gkomi_cgs_solve_f64_i32(
     gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
     const int32_t* col_idxs, const double* vals, int spmv_strategy, int64_t max_row_nnz_hint,

@@ -66,7 +66,7 @@ def krylov_solve(gk, solver, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1
     fn = precond.fn if precond is not None else None
     ctx = precond.ctx_ptr if precond is not None else None
     if fused:
-        assert solver in ("bicgstab", "fcg") and nrhs == 1
+        assert solver in ("bicgstab", "fcg", "cgs") and nrhs == 1
         getattr(gk, solver + "_solve_fused_f64_i32")(stream, n, nnz, row_ptrs, col_idxs, vals, strategy, max_row_nnz, fn, ctx, b2, x2,
                                         max_iters, reduction, BASELINES[baseline], check_every, ws, nbytes, info)
     else:
@@ -155,7 +155,7 @@ def solve_op(gk, solver, matrix, b, x=None, max_iters=1000, reduction=1e-10, bas
         gk.gmres_solve_op_f64(stream, n, nrhs, cb.fn, cb.ctx_ptr, fn, ctx, b2, x2, krylov_dim, max_iters, reduction,
                               BASELINES[baseline], ws, nbytes, info)
     elif fused:
-        assert solver in ("bicgstab", "fcg") and nrhs == 1
+        assert solver in ("bicgstab", "fcg", "cgs") and nrhs == 1
         nbytes = gk.krylov_workspace_bytes(n, 1)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
         getattr(gk, solver + "_solve_fused_op_f64")(stream, n, cb.fn, cb.ctx_ptr, fn, ctx, b2, x2, max_iters, reduction,

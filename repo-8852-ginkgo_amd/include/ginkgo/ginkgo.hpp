@@ -1618,10 +1618,23 @@ inline int fcg_op_driver(gkomi_stream_t s, int64_t n, int64_t nrhs, gkomi_matrix
     if (nrhs == 1) return gkomi_fcg_solve_fused_op_f64(s, n, mfn, mctx, pfn, pctx, b, x, max_iters, reduction, baseline, check_every, ws, ws_bytes, info);
     return gkomi_fcg_solve_op_f64(s, n, nrhs, mfn, mctx, pfn, pctx, b, x, max_iters, reduction, baseline, check_every, ws, ws_bytes, info);
 }
+inline int cgs_driver(gkomi_stream_t s, int64_t n, int64_t nrhs, int64_t nnz, const int32_t* rp, const int32_t* ci, const double* v, int strategy, int64_t hint,
+                      gkomi_apply_fn pfn, void* pctx, const double* b, double* x, int64_t max_iters, double reduction, int baseline, int64_t check_every, void* ws,
+                      size_t ws_bytes, double* info)
+{
+    if (nrhs == 1) return gkomi_cgs_solve_fused_f64_i32(s, n, nnz, rp, ci, v, strategy, hint, pfn, pctx, b, x, max_iters, reduction, baseline, check_every, ws, ws_bytes, info);
+    return gkomi_cgs_solve_f64_i32(s, n, nrhs, nnz, rp, ci, v, strategy, hint, pfn, pctx, b, x, max_iters, reduction, baseline, check_every, ws, ws_bytes, info);
+}
+inline int cgs_op_driver(gkomi_stream_t s, int64_t n, int64_t nrhs, gkomi_matrix_apply_fn mfn, void* mctx, gkomi_apply_fn pfn, void* pctx, const double* b, double* x,
+                         int64_t max_iters, double reduction, int baseline, int64_t check_every, void* ws, size_t ws_bytes, double* info)
+{
+    if (nrhs == 1) return gkomi_cgs_solve_fused_op_f64(s, n, mfn, mctx, pfn, pctx, b, x, max_iters, reduction, baseline, check_every, ws, ws_bytes, info);
+    return gkomi_cgs_solve_op_f64(s, n, nrhs, mfn, mctx, pfn, pctx, b, x, max_iters, reduction, baseline, check_every, ws, ws_bytes, info);
+}
 }  // namespace detail
 GKOMI_KRYLOV_SOLVER(Bicgstab, detail::bicgstab_driver, detail::bicgstab_op_driver);
 GKOMI_KRYLOV_SOLVER(Fcg, detail::fcg_driver, detail::fcg_op_driver);
-GKOMI_KRYLOV_SOLVER(Cgs, gkomi_cgs_solve_f64_i32, gkomi_cgs_solve_op_f64);
+GKOMI_KRYLOV_SOLVER(Cgs, detail::cgs_driver, detail::cgs_op_driver);
 #undef GKOMI_KRYLOV_SOLVER
 
 // Bicg (include/ginkgo/core/solver/bicg.hpp): the transposed system matrix is

@@ -436,3 +436,70 @@ def test_fused_fcg_with_preconditioner_formats_and_iteration_limit(gk, oracle):
     assert a["iterations"] == 3 and not a["converged"] and matgen.rel_err(host(a["x"]), host(u["x"])) < 1e-12
     z = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bd, max_iters=0, reduction=1e-14, fused=True)
     assert z["iterations"] == 0 and not z["converged"] and not host(z["x"]).any()
+
+
+# ---- fused single-rhs CGS (5 launches per iteration) ----------------------------------
+@pytest.mark.parametrize("case", [c for c in G["solves"] if c["solver"] == "cgs"], ids=lambda c: c["name"])
+def test_fused_cgs_known_answers(gk, oracle, case):
+    n, rp, ci, v = dense_to_csr(case["A"])
+    res = solvers.krylov_solve(gk, "cgs", n, dev(rp), dev(ci), dev(v), dev(np.array(case["b"])),
+                               max_iters=case["max_iters"], reduction=case["reduction"], fused=True)
+    assert matgen.rel_err(host(res["x"]), case["expect_x"]) <= 4 * case["tol"], res
+    xe = np.zeros(n)
+    ite = oracle.ref_cgs_solve(n, rp, ci, v, np.array(case["b"]), xe, case["max_iters"], case["reduction"], 0)
+    assert res["iterations"] <= 2 * ite + 2 if "DivergenceCheck" in case["name"] else abs(res["iterations"] - ite) <= max(2, ite // 4)
+
+
+@pytest.mark.parametrize("problem", ["poisson", "convection", "odd_size"])
+def test_fused_cgs_like_the_oracle_and_the_reference_sequence(gk, oracle, problem):
+    if problem == "poisson":
+        n, rp, ci, v = matgen.poisson_2d_5pt(40)
+    elif problem == "convection":
+        n, rp, ci, v = _convection()
+    else:
+        n, rp, ci, v = matgen.poisson_2d_5pt(37, 41)
+    xs = np.sin(0.3 * np.arange(n))
+    b = np.zeros((n, 1))
+    oracle.ref_csr_spmv(n, 1, rp, ci, v, xs.reshape(n, 1), 1, b, 1)
+    xe = np.zeros(n)
+    ite = oracle.ref_cgs_solve(n, rp, ci, v, b[:, 0].copy(), xe, 2000, 1e-10, 0)
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    res = solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, dev(b[:, 0].copy()), max_iters=2000, reduction=1e-10, fused=True)
+    assert res["converged"] and res["rel_residual"] <= 1e-10
+    assert abs(res["iterations"] - ite) <= max(3, ite // 4), (res["iterations"], ite)
+    assert matgen.rel_err(host(res["x"]), xs) < 1e-6
+    unfused = solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, dev(b[:, 0].copy()), max_iters=2000, reduction=1e-10)
+    assert abs(res["iterations"] - unfused["iterations"]) <= max(3, ite // 4)
+    for every in (1, 3, 50):
+        again = solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, dev(b[:, 0].copy()), max_iters=2000, reduction=1e-10,
+                                     check_every=every, fused=True)
+        assert again["iterations"] == res["iterations"] and again["converged"]
+        assert host(again["x"]).tobytes() == host(res["x"]).tobytes()
+        assert again["residual_norm"][0] == res["residual_norm"][0]
+
+
+def test_fused_cgs_with_preconditioner_formats_and_iteration_limit(gk, oracle):
+    from gkomi import formats
+    n, rp, ci, v = _convection()
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    xs = np.sin(0.3 * np.arange(n))
+    b = np.zeros((n, 1))
+    oracle.ref_csr_spmv(n, 1, rp, ci, v, xs.reshape(n, 1), 1, b, 1)
+    bd = dev(b[:, 0].copy())
+    plain = solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bd, max_iters=2000, reduction=1e-10, fused=True)
+    for pc in (solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=8),
+               solvers.par_ilu_generate(gk, n, rpd, cid, vd, iterations=5)):
+        pre = solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bd, max_iters=2000, reduction=1e-10, precond=pc, fused=True)
+        ref = solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bd, max_iters=2000, reduction=1e-10, precond=pc)
+        assert pre["converged"] and matgen.rel_err(host(pre["x"]), xs) < 1e-6
+        assert abs(pre["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 4)
+    A = formats.Csr.from_host(gk, n, n, rp, ci, v)
+    for fmt in ("ell", "sellp", "coo", "hybrid"):
+        res = solvers.solve_op(gk, "cgs", A.to(fmt), bd, max_iters=2000, reduction=1e-10, fused=True)
+        assert res["converged"] and matgen.rel_err(host(res["x"]), xs) < 1e-6, fmt
+        assert abs(res["iterations"] - plain["iterations"]) <= max(3, plain["iterations"] // 4), fmt
+    a = solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bd, max_iters=3, reduction=1e-14, fused=True)
+    u = solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bd, max_iters=3, reduction=1e-14)
+    assert a["iterations"] == 3 and not a["converged"] and matgen.rel_err(host(a["x"]), host(u["x"])) < 1e-12
+    z = solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bd, max_iters=0, reduction=1e-14, fused=True)
+    assert z["iterations"] == 0 and not z["converged"] and not host(z["x"]).any()

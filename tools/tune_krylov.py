@@ -58,7 +58,8 @@ for name in ("poisson2d", "convection3d"):
     jac = solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=4)
     timed("bicgstab reference sequence + jacobi(4)", lambda: solvers.krylov_solve(gk, "bicgstab", n, rpd, cid, vd, bv, precond=jac, **kw))
     timed("bicgstab fused + jacobi(4)", lambda: solvers.krylov_solve(gk, "bicgstab", n, rpd, cid, vd, bv, precond=jac, fused=True, **kw))
-    timed("cgs", lambda: solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bv, **kw))
+    timed("cgs reference sequence", lambda: solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bv, **kw))
+    timed("cgs fused", lambda: solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bv, fused=True, check_every=16, **kw))
     if name == "poisson2d":
         timed("fcg reference sequence", lambda: solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bv, **kw))
         timed("fcg fused", lambda: solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bv, fused=True, check_every=16, **kw))
