@@ -163,11 +163,120 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // writes hessenberg(k+1) = ||next|| and scales next.  Same operations in the
 // same order as the reference (MGS), only the summation order of the dots
 // differs (two-stage, deterministic).
-constexpr int arnoldi_block = 256;
-constexpr int arnoldi_max_blocks = 2048;
+constexpr int arnoldi_block = 1024;
+constexpr int arnoldi_max_blocks = 1024;
 
-// deterministic sum of `count` partials by the whole workgroup
+// deterministic sum of `count` partials by the whole workgroup; the total is
+// identical in every thread of every workgroup
 __device__ double sum_partials(const double* __restrict__ partials, int count, double* smem)
+{
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += arnoldi_block) acc += partials[i];
+    acc = wave_reduce_sum(acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wave] = acc;
+    __syncthreads();
+    double total = 0.0;
+#pragma unroll
+    for (int w = 0; w < arnoldi_block / wave_size; ++w) total += smem[w];
+    return total;
+}
+
+__device__ __forceinline__ double2 ld2(const double* p, int64_t i)
+{
+    return reinterpret_cast<const double2*>(p)[i];
+}
+
+// next -= h_prev * prev (if prev), partial_out[block] = sum next * (with ? with : next).
+// 16 B per lane; the first sweep's loads are issued before the partials are
+// re-added (they do not depend on h_prev), so the reduction hides behind them.
+__global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_step_kernel(
+    int64_t n, double* __restrict__ next, const double* __restrict__ prev,
+    const double* __restrict__ with, const double* __restrict__ partial_in, int count_in,
+    double* __restrict__ h_prev_out, double* __restrict__ partial_out)
+{
+    __shared__ double smem[arnoldi_block / wave_size];
+    const int64_t n2 = n / 2;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * arnoldi_block;
+    const int64_t i0 = blockIdx.x * static_cast<int64_t>(arnoldi_block) + threadIdx.x;
+    double2 v0 = make_double2(0.0, 0.0), p0 = v0, w0 = v0;
+    if (i0 < n2) {
+        v0 = ld2(next, i0);
+        if (prev != nullptr) p0 = ld2(prev, i0);
+        if (with != nullptr) w0 = ld2(with, i0);
+    }
+    double h = 0.0;
+    if (prev != nullptr) {
+        h = sum_partials(partial_in, count_in, smem);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *h_prev_out = h;
+    }
+    double a0 = 0.0, a1 = 0.0;
+    double2* next2 = reinterpret_cast<double2*>(next);
+    if (i0 < n2) {
+        if (prev != nullptr) {
+            v0.x -= h * p0.x;
+            v0.y -= h * p0.y;
+            next2[i0] = v0;
+        }
+        a0 += v0.x * (with != nullptr ? w0.x : v0.x);
+        a1 += v0.y * (with != nullptr ? w0.y : v0.y);
+    }
+    for (int64_t i = i0 + step; i < n2; i += step) {
+        double2 v = ld2(next, i);
+        if (prev != nullptr) {
+            const double2 pv = ld2(prev, i);
+            v.x -= h * pv.x;
+            v.y -= h * pv.y;
+            next2[i] = v;
+        }
+        if (with != nullptr) {
+            const double2 wv = ld2(with, i);
+            a0 += v.x * wv.x;
+            a1 += v.y * wv.y;
+        } else {
+            a0 += v.x * v.x;
+            a1 += v.y * v.y;
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double v = next[n - 1];
+        if (prev != nullptr) {
+            v -= h * prev[n - 1];
+            next[n - 1] = v;
+        }
+        a0 += v * (with != nullptr ? with[n - 1] : v);
+    }
+    __syncthreads();
+    const double total = block_reduce_sum<arnoldi_block>(a0 + a1, smem);
+    if (threadIdx.x == 0) partial_out[blockIdx.x] = total;
+}
+
+// hn = sqrt(sum partials) -> *hn_out; next /= hn
+__global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_scale_kernel(
+    int64_t n, double* __restrict__ next, const double* __restrict__ partial_in, int count_in,
+    double* __restrict__ hn_out)
+{
+    __shared__ double smem[arnoldi_block / wave_size];
+    const int64_t n2 = n / 2;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * arnoldi_block;
+    const int64_t i0 = blockIdx.x * static_cast<int64_t>(arnoldi_block) + threadIdx.x;
+    double2 v0 = make_double2(0.0, 0.0);
+    if (i0 < n2) v0 = ld2(next, i0);
+    const double hn = sqrt(sum_partials(partial_in, count_in, smem));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *hn_out = hn;
+    double2* next2 = reinterpret_cast<double2*>(next);
+    if (i0 < n2) next2[i0] = make_double2(v0.x / hn, v0.y / hn);
+    for (int64_t i = i0 + step; i < n2; i += step) {
+        const double2 v = ld2(next, i);
+        next2[i] = make_double2(v.x / hn, v.y / hn);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) next[n - 1] /= hn;
+}
+
+// odd n: the basis vectors kb + n * i are only 8-byte aligned for odd i -> scalar
+// kernels (same algorithm, 8 B per lane)
+__device__ double sum_partials_block(const double* __restrict__ partials, int count, double* smem)
 {
     double acc = 0.0;
     for (int i = threadIdx.x; i < count; i += arnoldi_block) acc += partials[i];
@@ -175,7 +284,7 @@ __device__ double sum_partials(const double* __restrict__ partials, int count, d
 }
 
 // next -= h_prev * prev (if prev), partial_out[block] = sum next * (with ? with : next)
-__global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_step_kernel(
+__global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_step_scalar_kernel(
     int64_t n, double* __restrict__ next, const double* __restrict__ prev,
     const double* __restrict__ with, const double* __restrict__ partial_in, int count_in,
     double* __restrict__ h_prev_out, double* __restrict__ partial_out)
@@ -184,7 +293,7 @@ __global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_step_kernel(
     __shared__ double h_s;
     double h = 0.0;
     if (prev != nullptr) {
-        const double total = sum_partials(partial_in, count_in, smem);
+        const double total = sum_partials_block(partial_in, count_in, smem);
         if (threadIdx.x == 0) {
             h_s = total;
             if (blockIdx.x == 0) *h_prev_out = total;
@@ -208,13 +317,13 @@ __global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_step_kernel(
 }
 
 // hn = sqrt(sum partials) -> *hn_out; next /= hn
-__global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_scale_kernel(
+__global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_scale_scalar_kernel(
     int64_t n, double* __restrict__ next, const double* __restrict__ partial_in, int count_in,
     double* __restrict__ hn_out)
 {
     __shared__ double smem[arnoldi_block / wave_size];
     __shared__ double h_s;
-    const double total = sum_partials(partial_in, count_in, smem);
+    const double total = sum_partials_block(partial_in, count_in, smem);
     if (threadIdx.x == 0) {
         h_s = sqrt(total);
         if (blockIdx.x == 0) *hn_out = h_s;
@@ -444,19 +553,30 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A,
         if (nrhs == 1 && n > 0) {
             // fused modified Gram-Schmidt: one pass over next_k per basis vector
             const int blocks = static_cast<int>(
-                std::min<int64_t>(arnoldi_max_blocks, ceildiv(n, arnoldi_block)));
+                std::min<int64_t>(arnoldi_max_blocks, std::max<int64_t>(1, ceildiv(n / 2 + 1, arnoldi_block))));
             double* partial[2] = {D(l.partials), D(l.partials) + arnoldi_max_blocks};
             for (int64_t i = 0; i <= restart_iter + 1; ++i) {
                 const double* prev = i > 0 ? kb + n * (i - 1) : nullptr;
                 const double* with = i <= restart_iter ? kb + n * i : nullptr;
                 double* h_prev = i > 0 ? hess_iter + (i - 1) * h_stride : nullptr;
-                hipLaunchKernelGGL(gmres_arnoldi_step_kernel, dim3(blocks), dim3(arnoldi_block), 0,
-                                   stream, n, next_k, prev, with, partial[(i + 1) & 1], blocks,
-                                   h_prev, partial[i & 1]);
+                if (n % 2 == 0) {
+                    hipLaunchKernelGGL(gmres_arnoldi_step_kernel, dim3(blocks), dim3(arnoldi_block), 0,
+                                       stream, n, next_k, prev, with, partial[(i + 1) & 1], blocks,
+                                       h_prev, partial[i & 1]);
+                } else {
+                    hipLaunchKernelGGL(gmres_arnoldi_step_scalar_kernel, dim3(blocks), dim3(arnoldi_block), 0,
+                                       stream, n, next_k, prev, with, partial[(i + 1) & 1], blocks,
+                                       h_prev, partial[i & 1]);
+                }
             }
             double* hn = hess_iter + (restart_iter + 1) * h_stride;
-            hipLaunchKernelGGL(gmres_arnoldi_scale_kernel, dim3(blocks), dim3(arnoldi_block), 0,
-                               stream, n, next_k, partial[(restart_iter + 1) & 1], blocks, hn);
+            if (n % 2 == 0) {
+                hipLaunchKernelGGL(gmres_arnoldi_scale_kernel, dim3(blocks), dim3(arnoldi_block), 0,
+                                   stream, n, next_k, partial[(restart_iter + 1) & 1], blocks, hn);
+            } else {
+                hipLaunchKernelGGL(gmres_arnoldi_scale_scalar_kernel, dim3(blocks), dim3(arnoldi_block), 0,
+                                   stream, n, next_k, partial[(restart_iter + 1) & 1], blocks, hn);
+            }
             GKOMI_TRY(check_launch());
         } else {
             for (int64_t i = 0; i <= restart_iter; ++i) {

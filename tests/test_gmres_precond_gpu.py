@@ -115,6 +115,23 @@ def test_gmres_matches_oracle_nonsymmetric(gk, oracle, krylov_dim):
     assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(b)
 
 
+def test_gmres_odd_number_of_rows(gk, oracle):
+    # n odd: every second Krylov basis vector is only 8-byte aligned (the fused
+    # Arnoldi kernels then run their 8-byte variant)
+    n, rp, ci, v = matgen.poisson_2d_5pt(37, 41)
+    assert n % 2 == 1
+    v = v.copy()
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    v[ci == rows - 1] -= 0.4
+    v[ci == rows] += 0.4
+    b = np.cos(0.3 * np.arange(n))
+    xe = np.zeros(n)
+    it = oracle.ref_gmres_solve(n, rp, ci, v, None, None, b, xe, 20, 2000, 1e-10, 0, np.zeros(1))
+    res = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), krylov_dim=20, max_iters=2000, reduction=1e-10)
+    assert res["converged"] and abs(res["iterations"] - it) <= 1
+    assert matgen.rel_err(host(res["x"]), xe) <= 1e-6
+
+
 def test_gmres_iteration_limit_and_multiple_rhs(gk, oracle):
     n, rp, ci, v = convection_diffusion_3d(8)
     b = np.ones(n)
