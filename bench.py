@@ -106,12 +106,26 @@ def cpu_baseline(n, rp, ci, v, x, seconds):
         if el >= seconds or reps >= 100000:
             break
     nnz = int(rp[-1])
-    return {
+    base = {
         "value": round(2.0 * nnz * reps / el / 1e9, 3), "unit": "GFLOP/s",
         "cores": int(orc.oracle_num_threads()), "kind": "port",
         "sample": f"{reps} x omp csr::spmv on the same 1M-row 5-pt Poisson matrix ({el:.1f} s)",
         "gbs": round(algorithmic_bytes(n, n, nnz) * reps / el / 1e9, 2),
-    }, y
+    }
+    # the CG leg on the same cores: omp/ path of Cg::apply (oracle/cg.c omp_cg_solve),
+    # same system, right-hand side and criterion as the GPU "cg" entry
+    s = np.sin(np.arange(n, dtype=np.float64))
+    s /= np.linalg.norm(s)
+    b = np.empty((n, 1))
+    orc.omp_csr_spmv(n, 1, rp, ci, v, s.reshape(n, 1), 1, b, 1)
+    xs, rel = np.zeros(n), np.zeros(1)
+    t0 = time.perf_counter()
+    its = int(orc.omp_cg_solve(n, rp, ci, v, b[:, 0].copy(), xs, 20000, 1e-10, rel))
+    el_cg = time.perf_counter() - t0
+    base["cg"] = {"iterations": its, "seconds": round(el_cg, 4), "iters_per_sec": round(its / el_cg, 1),
+                  "final_residual_norm_rel": float(rel[0]),
+                  "sample": "one omp CG solve to 1e-10, sinus rhs (the GPU cg entry's system)"}
+    return base, y
 
 
 def main():

@@ -185,3 +185,63 @@ ORACLE_API i64 ref_cg_solve(i64 n, const i32* row_ptrs, const i32* col_idxs,
     free(q);
     return iter;
 }
+
+/* ---- CPU baseline of the CG leg of bench.py (never the checker) ---------------
+ * The omp/ path of Cg::apply_dense_impl (core/solver/cg.cpp:107-193, Identity
+ * preconditioner, one right-hand side): omp csr::spmv
+ * (omp/matrix/csr_kernels.cpp:76-99), the unified cg::step_1 / step_2 loops
+ * (common/unified/solver/cg_kernels.cpp:53-131) as `omp parallel for`, and the
+ * omp reductions (omp/base/kernel_launch_reduction.hpp:65-86: one partial per
+ * thread, added in thread order).  Returns the iteration count; the result
+ * depends on the thread count to rounding, so it is compared with nothing. */
+void omp_csr_spmv(i64, i64, const i32*, const i32*, const double*,
+                  const double*, i64, double*, i64);
+
+static double omp_dot(i64 n, const double* a, const double* b)
+{
+    double total = 0.0;
+#pragma omp parallel for reduction(+ : total) schedule(static)
+    for (i64 i = 0; i < n; ++i) total += a[i] * b[i];
+    return total;
+}
+
+ORACLE_API i64 omp_cg_solve(i64 n, const i32* row_ptrs, const i32* col_idxs,
+                            const double* vals, const double* b, double* x,
+                            i64 max_iters, double reduction, double* final_rel)
+{
+    double* r = (double*)malloc(sizeof(double) * (size_t)n);
+    double* p = (double*)calloc((size_t)n, sizeof(double));
+    double* q = (double*)malloc(sizeof(double) * (size_t)n);
+    /* r = b - A x */
+    omp_csr_spmv(n, 1, row_ptrs, col_idxs, vals, x, 1, q, 1);
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) r[i] = b[i] - q[i];
+    const double orig_tau = sqrt(omp_dot(n, b, b));
+    double prev_rho = 1.0, rho = 0.0, tau = 0.0;
+    i64 iter = -1;
+    while (1) {
+        rho = omp_dot(n, r, r); /* z = r */
+        ++iter;
+        tau = sqrt(rho);
+        if (iter >= max_iters || tau < reduction * orig_tau) break;
+        const double tmp = prev_rho == 0.0 ? 0.0 : rho / prev_rho;
+#pragma omp parallel for schedule(static)
+        for (i64 i = 0; i < n; ++i) p[i] = prev_rho == 0.0 ? r[i] : r[i] + tmp * p[i];
+        omp_csr_spmv(n, 1, row_ptrs, col_idxs, vals, p, 1, q, 1);
+        const double beta = omp_dot(n, p, q);
+        if (beta != 0.0) {
+            const double a = rho / beta;
+#pragma omp parallel for schedule(static)
+            for (i64 i = 0; i < n; ++i) {
+                x[i] += a * p[i];
+                r[i] -= a * q[i];
+            }
+        }
+        prev_rho = rho;
+    }
+    if (final_rel) *final_rel = orig_tau == 0.0 ? tau : tau / orig_tau;
+    free(r);
+    free(p);
+    free(q);
+    return iter;
+}
