@@ -289,18 +289,6 @@ int identity_or_precond(gkomi_apply_fn precond, void* ctx, gkomi_stream_t s,
     return precond(ctx, s, r, z);
 }
 
-unsigned char* pinned_flags()
-{
-    // one small pinned buffer per process for the asynchronous status polls
-    static unsigned char* buf = nullptr;
-    if (buf == nullptr) {
-        if (hipHostMalloc(reinterpret_cast<void**>(&buf), 256, hipHostMallocDefault) != hipSuccess) {
-            buf = nullptr;
-        }
-    }
-    return buf;
-}
-
 }  // namespace
 }  // namespace gkomi
 
@@ -417,8 +405,7 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
                              reinterpret_cast<uintptr_t>(col_idxs) % 8 == 0 &&
                              reinterpret_cast<uintptr_t>(x) % 16 == 0;
         if (!aligned) return GKOMI_ENOTSUPPORTED;
-        unsigned char* pinned = pinned_flags();
-        if (pinned == nullptr) return static_cast<int>(hipErrorOutOfMemory);
+        cg_scalars polled{};  // per call: concurrent solves on other streams / threads do not share it
         if (check_every < 1) check_every = 1;
         hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(1), 0, stream, scal, orig_tau,
                            baseline == 2 ? 1 : 0);
@@ -454,10 +441,10 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
                 }
             }
             GKOMI_TRY(check_launch());
-            GKOMI_TRY(static_cast<int>(hipMemcpyAsync(pinned, scal, sizeof(cg_scalars),
+            GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&polled, scal, sizeof(cg_scalars),
                                                       hipMemcpyDeviceToHost, stream)));
             GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
-            const cg_scalars* h = reinterpret_cast<const cg_scalars*>(pinned);
+            const cg_scalars* h = &polled;
             if (h->status & GKOMI_STATUS_ID_MASK) {
                 done = true;
                 iterations = h->stop_iter;
