@@ -89,7 +89,7 @@ def main():
                                                     max_iters=args.max_iters, reduction=args.rel_res_goal, precond=pc)
                         else:
                             r = solvers.krylov_solve(gk, sname, n, A.row_ptrs, A.col_idxs, A.vals, b, max_iters=args.max_iters,
-                                                     reduction=args.rel_res_goal, precond=pc)
+                                                     reduction=args.rel_res_goal, precond=pc, fused=True, check_every=16)
                         torch.cuda.synchronize()
                         el = time.perf_counter() - t0
                         best = el if best is None else min(best, el)
