@@ -374,6 +374,15 @@ int gkomi_jacobi_apply_adaptive_f64_i32(
     const int32_t* block_ptrs, const uint8_t* block_precisions,
     const double* blocks, int64_t nrhs, const double* alpha, const double* b,
     int64_t b_stride, const double* beta, double* x, int64_t x_stride);
+/* jacobi::transpose_jacobi (= conj_transpose_jacobi for real values;
+ * reference/preconditioner/jacobi_kernels.cpp:629-694, Jacobi::transpose,
+ * core/preconditioner/jacobi.cpp): every stored block transposed in its storage
+ * precision (block_precisions may be NULL = all fp64); out_blocks has the size
+ * of blocks and must not alias it.  The transposed preconditioner BiCG needs. */
+int gkomi_jacobi_transpose_f64_i32(gkomi_stream_t s, int64_t num_blocks,
+                                   int max_block_size, const int32_t* block_ptrs,
+                                   const uint8_t* block_precisions,
+                                   const double* blocks, double* out_blocks);
 /* scalar Jacobi (max_block_size == 1): csr::extract_diagonal
  * (reference/matrix/csr_kernels.cpp:1016-1034), jacobi::invert_diagonal
  * (:608-620), simple_scalar_apply / scalar_apply (:565-594) */

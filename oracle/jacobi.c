@@ -471,3 +471,28 @@ ORACLE_API void ref_jacobi_simple_scalar_apply(i64 nrows, i64 nrhs,
         for (i64 j = 0; j < nrhs; ++j)
             x[i * x_stride + j] = b[i * b_stride + j] * diag[i];
 }
+
+/* jacobi::transpose_jacobi (reference/preconditioner/jacobi_kernels.cpp:629-658;
+ * transpose_block = out[j + i*stride] = in[i + j*stride] in the block's
+ * resolved precision, matrix_operations / jacobi_kernels.cpp:597-608). */
+ORACLE_API void ref_jacobi_transpose(i64 num_blocks, const i64* scheme, const i32* block_ptrs,
+                                     const u8* block_precisions, const double* blocks,
+                                     double* out_blocks)
+{
+    const i64 stride = sch_stride(scheme);
+    const i64 gs = sch_group_size(scheme);
+    for (i64 i = 0; i < num_blocks; ++i) {
+        const i64 bs = block_ptrs[i + 1] - block_ptrs[i];
+        const u8 p = block_precisions ? block_precisions[i] : PR_P0N0;
+        const char* group = (const char*)(blocks + scheme[1] * (i >> scheme[2]));
+        char* out_group = (char*)(out_blocks + scheme[1] * (i >> scheme[2]));
+        const i64 block_ofs = scheme[0] * (i & (gs - 1));
+        const i64 esize = p == PR_P0N0 ? 8 : ((p == PR_P0N1 || p == PR_P1N0) ? 4 : 2);
+        for (i64 r = 0; r < bs; ++r) {
+            for (i64 c = 0; c < bs; ++c) {
+                memcpy(out_group + esize * (block_ofs + c + r * stride),
+                       group + esize * (block_ofs + r + c * stride), (size_t)esize);
+            }
+        }
+    }
+}

@@ -650,6 +650,43 @@ int pow2ceil(int v)
     return p;
 }
 
+// jacobi::transpose_jacobi (reference/preconditioner/jacobi_kernels.cpp:629-658):
+// every stored block transposed in its own storage precision -- a move of
+// 8-, 4- or 2-byte elements, so the result is bit-identical by construction.
+// One thread per (block, r, c) of the max_block_size^2 slots of a block.
+template <typename Elem>
+__device__ __forceinline__ void transpose_elem(const double* in_group, double* out_group,
+                                               int64_t block_ofs, int64_t stride, int r, int c)
+{
+    reinterpret_cast<Elem*>(out_group)[block_ofs + c + r * stride] =
+        reinterpret_cast<const Elem*>(in_group)[block_ofs + r + c * stride];
+}
+
+__global__ __launch_bounds__(block) void jacobi_transpose_kernel(
+    int64_t num_blocks, int max_bs, scheme_t scheme, const int32_t* __restrict__ block_ptrs,
+    const uint8_t* __restrict__ precisions, const double* __restrict__ in, double* __restrict__ out)
+{
+    const int64_t idx = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
+    const int64_t per = static_cast<int64_t>(max_bs) * max_bs;
+    const int64_t b = idx / per;
+    if (b >= num_blocks) return;
+    const int rc = static_cast<int>(idx - b * per);
+    const int r = rc % max_bs, c = rc / max_bs;
+    const int bs = block_ptrs[b + 1] - block_ptrs[b];
+    if (r >= bs || c >= bs) return;
+    const int64_t group_ofs = scheme.group_offset * (b >> scheme.group_power);
+    const int64_t block_ofs = scheme.block_offset * (b & ((int64_t{1} << scheme.group_power) - 1));
+    const int64_t stride = scheme.stride();
+    const int p = precisions != nullptr ? precisions[b] : pr_p0n0;
+    if (p == pr_p0n0) {
+        transpose_elem<double>(in + group_ofs, out + group_ofs, block_ofs, stride, r, c);
+    } else if (p == pr_p0n1 || p == pr_p1n0) {
+        transpose_elem<unsigned>(in + group_ofs, out + group_ofs, block_ofs, stride, r, c);
+    } else {
+        transpose_elem<unsigned short>(in + group_ofs, out + group_ofs, block_ofs, stride, r, c);
+    }
+}
+
 scheme_t make_scheme(int max_block_size)
 {
     const int s = pow2ceil(max_block_size);
@@ -919,5 +956,21 @@ extern "C" int gkomi_jacobi_scalar_apply_f64(gkomi_stream_t s, int64_t nrows, in
         hipLaunchKernelGGL(scalar_apply_kernel<false>, grid, dim3(block), 0, to_stream(s), nrows,
                            nrhs, inv_diag, alpha, b, b_stride, beta, x, x_stride);
     }
+    return check_launch();
+}
+
+extern "C" int gkomi_jacobi_transpose_f64_i32(gkomi_stream_t s, int64_t num_blocks, int max_block_size,
+                                              const int32_t* block_ptrs, const uint8_t* block_precisions,
+                                              const double* blocks, double* out_blocks)
+{
+    if (num_blocks < 0 || max_block_size < 1 || max_block_size > 32) return GKOMI_EINVAL;
+    if (num_blocks == 0) return GKOMI_SUCCESS;
+    if (blocks == out_blocks) return GKOMI_EINVAL;
+    const int64_t total = num_blocks * max_block_size * max_block_size;
+    const int64_t grid = ceildiv(total, block);
+    if (grid > INT32_MAX) return GKOMI_ENOTSUPPORTED;
+    hipLaunchKernelGGL(jacobi_transpose_kernel, dim3(static_cast<unsigned>(grid)), dim3(block), 0, to_stream(s),
+                       num_blocks, max_block_size, make_scheme(max_block_size), block_ptrs, block_precisions,
+                       blocks, out_blocks);
     return check_launch();
 }

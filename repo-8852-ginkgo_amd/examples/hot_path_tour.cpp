@@ -207,6 +207,19 @@ int main()
             r->compute_norm2(rn.get());
             std::cout << "bicg_iters " << bicg->get_last_iteration_count() << " converged " << bicg->has_converged() << " true_residual "
                       << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
+            // block-Jacobi is Transposable: BiCG applies M^-1 to r and M^-T to the shadow residual
+            sol->fill(0.0);
+            auto bicg_j = gko::solver::Bicg<double>::build()
+                              .with_criteria(gko::stop::Iteration::build().with_max_iters(2000u).on(exec),
+                                             gko::stop::ResidualNorm<double>::build().with_reduction_factor(1e-10).on(exec))
+                              .with_preconditioner(gko::preconditioner::Jacobi<double, int>::build().with_max_block_size(16u).on(exec))
+                              .on(exec)->generate(B);
+            bicg_j->apply(b.get(), sol.get());
+            r->copy_from(b.get());
+            B->apply(neg.get(), sol.get(), one.get(), r.get());
+            r->compute_norm2(rn.get());
+            std::cout << "bicg_jacobi_iters " << bicg_j->get_last_iteration_count() << " converged " << bicg_j->has_converged() << " true_residual "
+                      << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
             sol->fill(0.0);
             auto ir = gko::solver::Ir<double>::build()
                           .with_criteria(gko::stop::Iteration::build().with_max_iters(200u).on(exec),

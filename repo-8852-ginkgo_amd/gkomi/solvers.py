@@ -241,6 +241,23 @@ def jacobi_generate(gk, n, row_ptrs, col_idxs, vals, max_block_size=32, nrhs=1, 
     return p
 
 
+def jacobi_transpose(gk, pre):
+    """Jacobi::transpose (core/preconditioner/jacobi.cpp): the preconditioner of A^T,
+    every stored block transposed in its storage precision."""
+    if not hasattr(pre, "blocks"):
+        return pre   # scalar Jacobi (a diagonal) is its own transpose
+    s = torch.cuda.current_stream().cuda_stream
+    out = torch.zeros_like(pre.blocks)
+    c = pre.ctx
+    gk.jacobi_transpose_f64_i32(s, pre.num_blocks, c.max_block_size, pre.block_ptrs, pre.block_precisions, pre.blocks, out)
+    ctx = JacobiCtx(c.n, c.nrhs, c.num_blocks, c.max_block_size, 0, pre.block_ptrs.data_ptr(), out.data_ptr(),
+                    pre.block_precisions.data_ptr() if pre.block_precisions is not None else 0)
+    t = Preconditioner(gk, "gkomi_jacobi_apply_cb", ctx, (pre.block_ptrs, out, pre.block_precisions, pre.conditioning))
+    t.num_blocks, t.block_ptrs, t.blocks, t.block_precisions, t.conditioning = (
+        pre.num_blocks, pre.block_ptrs, out, pre.block_precisions, pre.conditioning)
+    return t
+
+
 def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False):
     """preconditioner::Ilu over given CSR factors L = (row_ptrs, col_idxs, vals), U likewise."""
     dv = L[2].device

@@ -1314,6 +1314,14 @@ struct matrix_callback {
 };
 }  // namespace detail
 
+// include/ginkgo/core/base/lin_op.hpp:433-455 (real values: conj_transpose == transpose)
+class Transposable {
+public:
+    virtual ~Transposable() = default;
+    virtual std::unique_ptr<LinOp> transpose() const = 0;
+    virtual std::unique_ptr<LinOp> conj_transpose() const { return this->transpose(); }
+};
+
 // include/ginkgo/core/base/types.hpp:257-400
 class precision_reduction {
 public:
@@ -1332,7 +1340,7 @@ private:
 
 namespace preconditioner {
 template <typename V = double, typename I = int32>
-class Jacobi : public LinOp {
+class Jacobi : public LinOp, public Transposable {
 public:
     class Factory : public LinOpFactory {
     public:
@@ -1366,7 +1374,21 @@ public:
         return out;
     }
     std::vector<double> get_conditioning() const { return conditioning_.to_host(); }
+    // Jacobi::transpose (core/preconditioner/jacobi.cpp): same blocks structure,
+    // every stored block transposed in its storage precision (jacobi::transpose_jacobi)
+    std::unique_ptr<LinOp> transpose() const override
+    {
+        std::unique_ptr<Jacobi> t(new Jacobi(*this));
+        if (max_block_size_ > 1 && num_blocks_ > 0) {
+            t->blocks_ = array<V>(exec_, blocks_.get_num_elems());
+            GKOMI_CALL(gkomi_jacobi_transpose_f64_i32(nullptr, num_blocks_, max_block_size_, block_ptrs_.get_const_data(),
+                                                      precisions_.get_num_elems() > 0 ? precisions_.get_const_data() : nullptr, blocks_.get_const_data(),
+                                                      t->blocks_.get_data()));
+        }  // scalar Jacobi: a diagonal is its own transpose
+        return std::unique_ptr<LinOp>(t.release());
+    }
 protected:
+    Jacobi(const Jacobi&) = default;
     Jacobi(std::shared_ptr<const Executor> exec, uint32 max_bs, const std::vector<precision_reduction>* storage, double accuracy, std::shared_ptr<const LinOp> A)
         : LinOp(exec, A->get_size()), max_block_size_(max_bs), block_ptrs_(exec), blocks_(exec), precisions_(exec), conditioning_(exec)
     {
@@ -1638,8 +1660,9 @@ GKOMI_KRYLOV_SOLVER(Cgs, detail::cgs_driver, detail::cgs_op_driver);
 #undef GKOMI_KRYLOV_SOLVER
 
 // Bicg (include/ginkgo/core/solver/bicg.hpp): the transposed system matrix is
-// built once at generate (the reference rebuilds it in every apply); only the
-// Identity preconditioner here -- the mirror has no Transposable preconditioners.
+// built once at generate (the reference rebuilds it in every apply), and so is
+// the transposed preconditioner (bicg.cpp:169-171 asks the preconditioner for its
+// Transposable interface: Jacobi here).
 template <typename V = double>
 class Bicg : public LinOp {
 public:
@@ -1653,7 +1676,12 @@ protected:
     Bicg(const Factory* f, std::shared_ptr<const LinOp> A) : LinOp(f->get_executor(), gko::transpose(A->get_size())), A_(std::move(A)), settings_(f->settings())
     {
         if (size_[0] != size_[1]) throw DimensionMismatch(__FILE__, __LINE__, "Bicg needs a square system matrix");
-        if (f->precond_ || f->precond_factory_) GKO_NOT_SUPPORTED("Bicg: preconditioners need a transpose, which this mirror does not provide");
+        precond_ = f->precond_ ? f->precond_ : (f->precond_factory_ ? std::shared_ptr<const LinOp>(f->precond_factory_->generate_impl(A_)) : nullptr);
+        if (precond_) {
+            auto tr = dynamic_cast<const Transposable*>(precond_.get());
+            if (tr == nullptr) GKO_NOT_SUPPORTED("Bicg: the preconditioner must be Transposable");
+            precond_t_ = std::shared_ptr<const LinOp>(tr->conj_transpose());
+        }
         At_ = as<const matrix::Csr<V, int32>>(A_.get())->transpose();
     }
     void apply_impl(const LinOp* b, LinOp* x) const override
@@ -1665,9 +1693,12 @@ protected:
         if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
         array<char> ws(exec_, gkomi_krylov_workspace_bytes(n, nrhs));
         std::vector<double> info(2 + 2 * nrhs, 0.0);
+        ::gko::detail::linop_callback cb{precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
+        ::gko::detail::linop_callback cbt{precond_t_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
+        auto pfn = precond_ ? &::gko::detail::linop_callback::call : nullptr;
         GKOMI_CALL(gkomi_bicg_solve_f64_i32(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
                                             At_->get_const_row_ptrs(), At_->get_const_col_idxs(), At_->get_const_values(), csr->get_strategy()->get_code(), csr->get_max_row_nnz(),
-                                            nullptr, nullptr, nullptr, nullptr, db->get_const_values(), dx->get_values(), settings_.max_iters, settings_.reduction_factor,
+                                            pfn, precond_ ? &cb : nullptr, pfn, precond_ ? &cbt : nullptr, db->get_const_values(), dx->get_values(), settings_.max_iters, settings_.reduction_factor,
                                             detail::baseline_code(settings_.baseline), 8, ws.get_data(), ws.get_num_elems(), info.data()));
         last_iters_ = static_cast<int64_t>(info[0]);
         last_converged_ = info[1] != 0.0;
@@ -1681,6 +1712,7 @@ protected:
         dx->add_scaled(matrix::detail_fmt::dense(alpha), x_clone.get());
     }
     std::shared_ptr<const LinOp> A_;
+    std::shared_ptr<const LinOp> precond_, precond_t_;
     std::unique_ptr<matrix::Csr<V, int32>> At_;
     stop::criterion_settings settings_;
     mutable int64_t last_iters_{-1};

@@ -97,6 +97,9 @@ def test_hot_path_tour(bins):
     # (asynchronous sweeps: the factor, hence the count, varies a little from run to run)
     assert int(kv["cg_ic_iters"][0]) < 0.7 * int(kv["cg_jacobi_iters"][0])
     assert kv["bicg_iters"][2] == "1" and float(kv["bicg_iters"][4]) < 1e-8
+    # Jacobi::transpose gives BiCG its transposed preconditioner: fewer iterations
+    assert kv["bicg_jacobi_iters"][2] == "1" and float(kv["bicg_jacobi_iters"][4]) < 1e-8
+    assert int(kv["bicg_jacobi_iters"][0]) < int(kv["bicg_iters"][0])
     # IR stops at its iteration limit or at the loose goal; either way the residual it reports is the true one
     assert float(kv["ir_jacobi_iters"][4]) < 1.0 and (kv["ir_jacobi_iters"][2] == "1") == (float(kv["ir_jacobi_iters"][4]) < 1e-2)
     # device assembly: duplicates summed, explicit zeros dropped, Csr::read on the device

@@ -408,3 +408,56 @@ def test_find_blocks_degenerate_sizes(gk, oracle):
         enb = oracle.ref_jacobi_find_blocks(n, rp, ci2, 5, eptrs)
         nb, ptrs = gpu_find_blocks(gk, n, dev(rp), dev(ci2), 5)
         assert nb == enb and np.array_equal(host(ptrs)[:nb + 1], eptrs[:nb + 1])
+
+
+@pytest.mark.parametrize("max_bs", [1, 3, 8, 13, 32])
+@pytest.mark.parametrize("storage", [0x00, "mixed"])
+def test_transpose_bitexact_vs_oracle_and_known_answers(gk, oracle, max_bs, storage):
+    """jacobi::transpose_jacobi: every block transposed in its storage
+    precision -- byte for byte the oracle's result (NaN padding included: the
+    slots outside the blocks are never written)."""
+    n, rp, ci, v, _ = block_structured_matrix(157, max_bs, seed=40 + max_bs)
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    eptrs = np.zeros(n + 1, np.int32)
+    nb = oracle.ref_jacobi_find_blocks(n, rp, ci, max_bs, eptrs)
+    ptrs = dev(eptrs)
+    req = [0x01, 0x00, 0x02, 0x10, 0x11, 0x20, 0xff] if storage == "mixed" else [0x00]
+    blocks, cond, prec = gpu_generate_adaptive(gk, n, rpd, cid, vd, ptrs, nb, max_bs, req, 1e-2)
+    es, eb, ec, ep = oracle_generate_adaptive(oracle, n, rp, ci, v, eptrs[:nb + 1], nb, max_bs, req, 1e-2)
+    eout = np.full_like(eb, np.nan)
+    oracle.ref_jacobi_transpose(nb, es, eptrs, ep, eb, eout)
+    out = torch.full_like(blocks, float("nan"))
+    gk.jacobi_transpose_f64_i32(stream_ptr(), nb, max_bs, ptrs, prec, blocks, out)
+    assert host(out).tobytes() == eout.tobytes()
+    back = torch.full_like(blocks, float("nan"))
+    gk.jacobi_transpose_f64_i32(stream_ptr(), nb, max_bs, ptrs, prec, out, back)
+    gb, bb = host(blocks), host(back)
+    written = ~np.isnan(bb)
+    assert np.array_equal(bb[written], gb[written])   # transposing twice gives the blocks back
+    # applying the transposed preconditioner = multiplying with the transposed inverse
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal((n, 1))
+    x = torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")
+    gk.jacobi_apply_adaptive_f64_i32(stream_ptr(), nb, max_bs, ptrs, prec, out, 1, None, dev(b), 1, None, x, 1)
+    ex = np.zeros((n, 1))
+    oracle.ref_jacobi_apply_adaptive(nb, es, eptrs, ep, eout, 1, 1.0, b, 1, 0.0, ex, 1)
+    assert np.array_equal(host(x), ex)
+
+
+def test_transposed_known_blocks(gk):
+    # reference/test/preconditioner/jacobi_kernels.cpp:331-392
+    n, rp, ci, v = mtx()
+    T = G["transposed_blocks"]
+    ptrs = dev(np.array(G["block_pointers"], np.int32))
+    blocks, _ = gpu_generate(gk, n, dev(rp), dev(ci), dev(v), ptrs, 2, G["max_block_size"])
+    out = torch.full_like(blocks, float("nan"))
+    gk.jacobi_transpose_f64_i32(stream_ptr(), 2, G["max_block_size"], ptrs, None, blocks, out)
+    s = gpu_scheme(gk, G["max_block_size"])
+    ob = host(out)
+    p = int(s[3])
+
+    def blk(b, bs):
+        off = int(s[1]) * (b >> int(s[2])) + int(s[0]) * (b & ((1 << int(s[2])) - 1))
+        return np.array([[ob[off + r + c * p] for c in range(bs)] for r in range(bs)])
+    assert np.allclose(blk(0, 2), T["b1"], rtol=0, atol=G["tol"])
+    assert np.allclose(blk(1, 3), T["b2"], rtol=0, atol=G["tol"])

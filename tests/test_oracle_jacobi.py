@@ -229,3 +229,32 @@ def test_adaptive_with_full_precision_equals_plain(oracle):
     s, blocks, cond = generate(oracle, n, rp, ci, v, list(ptrs), 8, 64, cond=True)
     s2, blocks2, cond2, prec = generate_adaptive(oracle, n, rp, ci, v, list(ptrs), 8, [0], stride=64)
     assert np.array_equal(np.nan_to_num(blocks), np.nan_to_num(blocks2)) and np.array_equal(cond, cond2) and not prec.any()
+
+
+@pytest.mark.parametrize("stride", [32, 64])
+def test_transposes_diagonal_blocks(oracle, stride):
+    """jacobi_kernels.cpp:331-392: CanTransposeDiagonalBlocks and
+    ...WithAdaptivePrecision (transpose == conj_transpose for real values)"""
+    n, rp, ci, v = mtx()
+    T = G["transposed_blocks"]
+    ptrs = np.array(G["block_pointers"], np.int32)
+    s, blocks, _ = generate(oracle, n, rp, ci, v, G["block_pointers"], G["max_block_size"], stride)
+    out = np.full_like(blocks, np.nan)
+    oracle.ref_jacobi_transpose(2, s, ptrs, None, blocks, out)
+    assert np.allclose(block_of(s, out, 0, 2), T["b1"], rtol=0, atol=R)
+    assert np.allclose(block_of(s, out, 1, 3), T["b2"], rtol=0, atol=R)
+    assert np.array_equal(block_of(s, out, 1, 3), block_of(s, blocks, 1, 3).T)   # a move, not arithmetic
+    back = np.full_like(blocks, np.nan)
+    oracle.ref_jacobi_transpose(2, s, ptrs, None, out, back)
+    assert np.array_equal(block_of(s, back, 0, 2), block_of(s, blocks, 0, 2))
+    if stride != 32:
+        return   # with 64 lanes per group both blocks share a group, hence one precision
+    # adaptive: block 0 stored in float, block 1 in double
+    s, blocks, cond, prec = generate_adaptive(oracle, n, rp, ci, v, G["block_pointers"],
+                                              A["max_block_size_group_of_one"], A["block_precisions"], stride=stride)
+    out = np.full_like(blocks, np.nan)
+    oracle.ref_jacobi_transpose(2, s, ptrs, prec, blocks, out)
+    b1 = reduced_block_of(s, out, 0, 2, 1)
+    assert b1.dtype == np.float32 and np.allclose(b1, T["b1"], rtol=0, atol=A["half_tol"])
+    assert np.array_equal(b1, reduced_block_of(s, blocks, 0, 2, 1).T)
+    assert np.allclose(block_of(s, out, 1, 3), T["b2"], rtol=0, atol=R)
