@@ -220,6 +220,19 @@ int main()
             r->compute_norm2(rn.get());
             std::cout << "bicg_jacobi_iters " << bicg_j->get_last_iteration_count() << " converged " << bicg_j->has_converged() << " true_residual "
                       << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
+            // ... and so is Ilu: (U^-1 L^-1)^T = the lower solve with U^T, then the upper solve with L^T
+            sol->fill(0.0);
+            auto bicg_i = gko::solver::Bicg<double>::build()
+                              .with_criteria(gko::stop::Iteration::build().with_max_iters(2000u).on(exec),
+                                             gko::stop::ResidualNorm<double>::build().with_reduction_factor(1e-10).on(exec))
+                              .with_preconditioner(gko::preconditioner::Ilu<double, int>::build().with_factorization_iterations(20u).on(exec))
+                              .on(exec)->generate(B);
+            bicg_i->apply(b.get(), sol.get());
+            r->copy_from(b.get());
+            B->apply(neg.get(), sol.get(), one.get(), r.get());
+            r->compute_norm2(rn.get());
+            std::cout << "bicg_ilu_iters " << bicg_i->get_last_iteration_count() << " converged " << bicg_i->has_converged() << " true_residual "
+                      << exec->copy_val_to_host(rn->get_const_values()) / std::sqrt(double(n)) << "\n";
             sol->fill(0.0);
             auto ir = gko::solver::Ir<double>::build()
                           .with_criteria(gko::stop::Iteration::build().with_max_iters(200u).on(exec),

@@ -1948,7 +1948,7 @@ protected:
 
 namespace preconditioner {
 template <typename V = double, typename I = int32>
-class Ilu : public LinOp {
+class Ilu : public LinOp, public Transposable {
 public:
     class Factory : public LinOpFactory {
     public:
@@ -1962,12 +1962,26 @@ public:
     static Factory build() { return Factory{}; }
     std::shared_ptr<const LinOp> get_l_solver() const { return l_solver_; }
     std::shared_ptr<const LinOp> get_u_solver() const { return u_solver_; }
+    // Ilu::transpose (include/ginkgo/core/preconditioner/ilu.hpp:200-230): (U^-1 L^-1)^T =
+    // L^-T U^-T, i.e. the lower solver of U^T followed by the upper solver of L^T
+    std::unique_ptr<LinOp> transpose() const override
+    {
+        std::unique_ptr<Ilu> t(new Ilu(exec_, size_));
+        t->l_factor_ = std::shared_ptr<const matrix::Csr<V, I>>(u_factor_->transpose());
+        t->u_factor_ = std::shared_ptr<const matrix::Csr<V, I>>(l_factor_->transpose());
+        t->l_solver_ = solver::LowerTrs<V, I>::build().on(exec_)->generate(t->l_factor_);
+        t->u_solver_ = solver::UpperTrs<V, I>::build().on(exec_)->generate(t->u_factor_);
+        return std::unique_ptr<LinOp>(t.release());
+    }
 protected:
+    Ilu(std::shared_ptr<const Executor> exec, dim<2> size) : LinOp(std::move(exec), size) {}
     Ilu(std::shared_ptr<const Executor> exec, size_type iterations, std::shared_ptr<const LinOp> A) : LinOp(exec, A->get_size())
     {
         auto fact = factorization::ParIlu<V, I>::build().with_iterations(iterations).on(exec)->generate(std::move(A));
-        l_solver_ = solver::LowerTrs<V, I>::build().on(exec)->generate(fact->get_l_factor());
-        u_solver_ = solver::UpperTrs<V, I>::build().on(exec)->generate(fact->get_u_factor());
+        l_factor_ = fact->get_l_factor();
+        u_factor_ = fact->get_u_factor();
+        l_solver_ = solver::LowerTrs<V, I>::build().on(exec)->generate(l_factor_);
+        u_solver_ = solver::UpperTrs<V, I>::build().on(exec)->generate(u_factor_);
     }
     void apply_impl(const LinOp* b, LinOp* x) const override
     {
@@ -1984,6 +1998,7 @@ protected:
         dx->scale(matrix::detail_fmt::dense(beta));
         dx->add_scaled(matrix::detail_fmt::dense(alpha), x_clone.get());
     }
+    std::shared_ptr<const matrix::Csr<V, I>> l_factor_, u_factor_;
     std::shared_ptr<const LinOp> l_solver_, u_solver_;
 };
 }  // namespace preconditioner
@@ -2051,8 +2066,10 @@ protected:
 namespace preconditioner {
 // Ic::apply = L^-1 then L^-H (ic.hpp: two triangular solves, like Ilu)
 template <typename V = double, typename I = int32>
-class Ic : public LinOp {
+class Ic : public LinOp, public Transposable {
 public:
+    // (L L^T)^-1 is symmetric: the transpose applies the same two solves
+    std::unique_ptr<LinOp> transpose() const override { return std::unique_ptr<LinOp>(new Ic(*this)); }
     class Factory : public LinOpFactory {
     public:
         Factory() : LinOpFactory(nullptr) {}
@@ -2066,6 +2083,7 @@ public:
     std::shared_ptr<const LinOp> get_l_solver() const { return l_solver_; }
     std::shared_ptr<const LinOp> get_lh_solver() const { return lh_solver_; }
 protected:
+    Ic(const Ic&) = default;
     Ic(std::shared_ptr<const Executor> exec, size_type iterations, std::shared_ptr<const LinOp> A) : LinOp(exec, A->get_size())
     {
         auto fact = factorization::ParIc<V, I>::build().with_iterations(iterations).on(exec)->generate(std::move(A));

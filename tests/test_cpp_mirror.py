@@ -100,6 +100,8 @@ def test_hot_path_tour(bins):
     # Jacobi::transpose gives BiCG its transposed preconditioner: fewer iterations
     assert kv["bicg_jacobi_iters"][2] == "1" and float(kv["bicg_jacobi_iters"][4]) < 1e-8
     assert int(kv["bicg_jacobi_iters"][0]) < int(kv["bicg_iters"][0])
+    assert kv["bicg_ilu_iters"][2] == "1" and float(kv["bicg_ilu_iters"][4]) < 1e-8
+    assert int(kv["bicg_ilu_iters"][0]) < int(kv["bicg_jacobi_iters"][0])
     # IR stops at its iteration limit or at the loose goal; either way the residual it reports is the true one
     assert float(kv["ir_jacobi_iters"][4]) < 1.0 and (kv["ir_jacobi_iters"][2] == "1") == (float(kv["ir_jacobi_iters"][4]) < 1e-2)
     # device assembly: duplicates summed, explicit zeros dropped, Csr::read on the device
