@@ -22,7 +22,30 @@ bytes_ = 12 * nnz + 4 * (n + 1) + 16 * n
 d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 x = np.sin(0.01 * np.arange(n)).reshape(n, 1)
 ncopies = max(2, int(700e6 // bytes_))
-copies = [(d(rp), d(ci), d(v), d(x), torch.empty((n, 1), dtype=torch.float64, device="cuda")) for _ in range(ncopies)]
+def arena_copy():
+    """all five arrays of one copy carved out of ONE allocation (2 MiB-aligned pieces):
+    does the cold number depend on how the allocator scatters them?"""
+    al = 1 << 21
+    sizes = [rp.nbytes, ci.nbytes, v.nbytes, x.nbytes, 8 * n]
+    offs, off = [], 0
+    for sz in sizes:
+        offs.append(off)
+        off += (sz + al - 1) // al * al
+    buf = torch.empty(off + al, dtype=torch.uint8, device="cuda")
+    base = (-buf.data_ptr()) % al
+    def view(o, sz, dtype, shape=None):
+        t = buf[base + o: base + o + sz].view(dtype)
+        return t.reshape(shape) if shape else t
+    out = (view(offs[0], sizes[0], torch.int32), view(offs[1], sizes[1], torch.int32), view(offs[2], sizes[2], torch.float64),
+           view(offs[3], sizes[3], torch.float64, (n, 1)), view(offs[4], sizes[4], torch.float64, (n, 1)))
+    out[0].copy_(d(rp)); out[1].copy_(d(ci)); out[2].copy_(d(v)); out[3].copy_(d(x))
+    return out + (buf,)
+
+
+if os.environ.get("TUNE_ARENA"):
+    copies = [arena_copy() for _ in range(ncopies)]
+else:
+    copies = [(d(rp), d(ci), d(v), d(x), torch.empty((n, 1), dtype=torch.float64, device="cuda")) for _ in range(ncopies)]
 s = torch.cuda.current_stream().cuda_stream
 STREAM, VECTOR = 1, 2
 variants = {"stream_v0(256,1,2048)": STREAM, "v1(256,2,4096)": STREAM | (1 << 8), "v2(512,1,4096)": STREAM | (2 << 8),
