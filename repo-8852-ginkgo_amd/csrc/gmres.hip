@@ -336,6 +336,20 @@ __global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_scale_scalar_kern
     }
 }
 
+// first iteration at which every column had stopped (-1 until then): the
+// criterion runs on the device at every iteration, the host looks every
+// `gmres_check_every` iterations and before every restart
+struct gmres_stop_record {
+    long long iter;
+};
+constexpr int64_t gmres_check_every = 4;
+
+__global__ void gmres_record_stop_kernel(const uint8_t* __restrict__ flags, long long iter,
+                                         gmres_stop_record* record)
+{
+    if (flags[0] && record->iter < 0) record->iter = iter;
+}
+
 struct gmres_layout {
     size_t residual, pv, before, after, kb, hess, gsin, gcos, rnc, y, small, fin, red, partials, total;
 };
@@ -356,7 +370,7 @@ gmres_layout make_layout(int64_t n, int64_t nrhs, int64_t d)
     l.rnc = off; off += align_up(sizeof(double) * static_cast<size_t>((d + 1) * nrhs), 256);
     l.y = off; off += align_up(sizeof(double) * static_cast<size_t>(d * nrhs), 256);
     // residual_norm, orig_tau, one, neg_one (nrhs each), then stop_status + flags
-    l.small = off; off += align_up(sizeof(double) * 4 * static_cast<size_t>(nrhs) + nrhs + 16, 256);
+    l.small = off; off += align_up(sizeof(double) * 4 * static_cast<size_t>(nrhs) + nrhs + 48, 256);
     l.fin = off; off += align_up(sizeof(uint64_t) * static_cast<size_t>(nrhs), 256);
     l.red = off; off += align_up(gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8, 256);
     l.partials = off; off += align_up(sizeof(double) * 2 * arnoldi_max_blocks, 256);
@@ -525,19 +539,45 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A,
     long long total_iter = -1;
     int64_t restart_iter = 0;
     int converged = 0;
-    uint8_t host_flags[2] = {0, 0};
+    // The criterion is evaluated on the device at every iteration, exactly where
+    // the reference evaluates it; stopped columns are frozen by their statuses
+    // (final_iter_nums, residual_norm, the Givens data no longer change), so the
+    // iterations the host lets run before it looks change nothing in x.
+    gmres_stop_record* record = reinterpret_cast<gmres_stop_record*>(dev_flags + 8);
+    gmres_stop_record host_record{-1};
+    GKOMI_TRY(static_cast<int>(hipMemcpyAsync(record, &host_record, sizeof(host_record), hipMemcpyHostToDevice, stream)));
+    GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
+    int64_t unpolled = 0;
+    auto poll = [&]() -> int {
+        unpolled = 0;
+        GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&host_record, record, sizeof(host_record), hipMemcpyDeviceToHost, stream)));
+        return static_cast<int>(hipStreamSynchronize(stream));
+    };
     while (true) {
         ++total_iter;
         bool stop = false;
         if (total_iter >= max_iters) {
-            GKOMI_TRY(gkomi_set_all_statuses(s, nrhs, id_iteration, 0, stop_status));
+            GKOMI_TRY(poll());  // converged during the iterations not looked at yet?
+            if (host_record.iter >= 0) {
+                converged = 1;
+                total_iter = host_record.iter;
+            } else {
+                GKOMI_TRY(gkomi_set_all_statuses(s, nrhs, id_iteration, 0, stop_status));
+            }
             stop = true;
         } else {
             // the criterion gets residual_norm directly (gmres.cpp:240-246), not finalized
             GKOMI_TRY(gkomi_residual_norm_f64(s, nrhs, residual_norm, orig_tau, reduction_factor,
-                                              id_residual, 0, stop_status, dev_flags, host_flags));
-            stop = host_flags[0] != 0;
-            converged = stop ? 1 : 0;
+                                              id_residual, 0, stop_status, dev_flags, nullptr));
+            hipLaunchKernelGGL(gmres_record_stop_kernel, dim3(1), dim3(1), 0, stream, dev_flags, total_iter, record);
+            if (++unpolled >= gmres_check_every || restart_iter == krylov_dim) {
+                GKOMI_TRY(poll());
+                if (host_record.iter >= 0) {
+                    stop = true;
+                    converged = 1;
+                    total_iter = host_record.iter;
+                }
+            }
         }
         if (stop) break;
         if (restart_iter == krylov_dim) {
