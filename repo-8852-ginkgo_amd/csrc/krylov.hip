@@ -928,7 +928,7 @@ __global__ __launch_bounds__(fblock) void bicgstab_fused_step1_kernel(
     const double alpha = scal->alpha, omega = scal->omega;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         scal->rho[it & 1] = rho;
-        if (it < max_iters) scal->tau = tau;
+        scal->tau = tau;  // also at the iteration limit: the norm of the residual that is returned
         if (st) {
             scal->stop_iter = it;
             scal->phase = 1;
@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__(fblock) void fcg_fused_step1_kernel(
     const double prev = scal->rho[(it + 1) & 1];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         scal->rho[it & 1] = rho;
-        if (it < max_iters) scal->tau = tau;
+        scal->tau = tau;  // also at the iteration limit: the norm of the residual that is returned
         if (st) {
             scal->stop_iter = it;
             scal->status = st;
@@ -1677,7 +1677,7 @@ __global__ __launch_bounds__(fblock) void cgs_fused_step1_kernel(
     const double bt = update ? rho / prev : scal->beta;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         scal->rho[it & 1] = rho;
-        if (it < max_iters) scal->tau = tau;
+        scal->tau = tau;  // also at the iteration limit: the norm of the residual that is returned
         if (st) {
             scal->stop_iter = it;
             scal->status = st;

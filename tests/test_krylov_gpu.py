@@ -342,6 +342,10 @@ def test_fused_bicgstab_stops_in_the_half_step_and_at_the_iteration_limit(gk, or
     u = solvers.krylov_solve(gk, "bicgstab", n, dev(rp), dev(ci), dev(v), dev(b), max_iters=3, reduction=1e-14)
     assert a["iterations"] == 3 and not a["converged"] and u["iterations"] == 3
     assert matgen.rel_err(host(a["x"]), host(u["x"])) < 1e-12
+    # the reported norm is that of the residual of the returned x, also at the iteration limit
+    r3 = b - np.add.reduceat(v * host(a["x"])[ci], rp[:-1])
+    assert abs(np.linalg.norm(r3) - a["residual_norm"][0]) <= 1e-9 * np.linalg.norm(b)
+    assert abs(u["residual_norm"][0] - a["residual_norm"][0]) <= 1e-9 * np.linalg.norm(b)
     # zero iterations allowed: x stays the initial guess
     z = solvers.krylov_solve(gk, "bicgstab", n, dev(rp), dev(ci), dev(v), dev(b), max_iters=0, reduction=1e-14, fused=True)
     assert z["iterations"] == 0 and not z["converged"] and not host(z["x"]).any()
@@ -434,6 +438,9 @@ def test_fused_fcg_with_preconditioner_formats_and_iteration_limit(gk, oracle):
     a = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bd, max_iters=3, reduction=1e-14, fused=True)
     u = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bd, max_iters=3, reduction=1e-14)
     assert a["iterations"] == 3 and not a["converged"] and matgen.rel_err(host(a["x"]), host(u["x"])) < 1e-12
+    r3 = b[:, 0] - np.add.reduceat(v * host(a["x"])[ci], rp[:-1])
+    assert abs(np.linalg.norm(r3) - a["residual_norm"][0]) <= 1e-9 * np.linalg.norm(b)
+    assert abs(u["residual_norm"][0] - a["residual_norm"][0]) <= 1e-9 * np.linalg.norm(b)
     z = solvers.krylov_solve(gk, "fcg", n, rpd, cid, vd, bd, max_iters=0, reduction=1e-14, fused=True)
     assert z["iterations"] == 0 and not z["converged"] and not host(z["x"]).any()
 
@@ -501,6 +508,9 @@ def test_fused_cgs_with_preconditioner_formats_and_iteration_limit(gk, oracle):
     a = solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bd, max_iters=3, reduction=1e-14, fused=True)
     u = solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bd, max_iters=3, reduction=1e-14)
     assert a["iterations"] == 3 and not a["converged"] and matgen.rel_err(host(a["x"]), host(u["x"])) < 1e-12
+    r3 = b[:, 0] - np.add.reduceat(v * host(a["x"])[ci], rp[:-1])
+    assert abs(np.linalg.norm(r3) - a["residual_norm"][0]) <= 1e-9 * np.linalg.norm(b)
+    assert abs(u["residual_norm"][0] - a["residual_norm"][0]) <= 1e-9 * np.linalg.norm(b)
     z = solvers.krylov_solve(gk, "cgs", n, rpd, cid, vd, bd, max_iters=0, reduction=1e-14, fused=True)
     assert z["iterations"] == 0 and not z["converged"] and not host(z["x"]).any()
 
