@@ -18,7 +18,7 @@ def cg_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reducti
     b: (n,) or (n, nrhs) float64 device tensor.  precond: None (Identity) or an
     integer address / ctypes function pointer of a gkomi_apply_fn.
     Returns dict(x, iterations, converged, residual_norm, baseline_norm, rel_residual)."""
-    b2 = b.reshape(n, -1)
+    b2 = b.reshape(n, -1) if n > 0 else b.reshape(0, b.shape[1] if b.dim() > 1 else 1)
     nrhs = b2.shape[1]
     if mode == 1 and nrhs != 1:
         mode = 0
@@ -52,7 +52,7 @@ def krylov_solve(gk, solver, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1
     Combined(Iteration(max_iters), ResidualNorm(reduction, baseline)); precond: None or a Preconditioner.
     fused (bicgstab, one right-hand side): the 6-launch driver instead of the reference kernel sequence."""
     assert solver in ("bicgstab", "fcg", "cgs")
-    b2 = b.reshape(n, -1)
+    b2 = b.reshape(n, -1) if n > 0 else b.reshape(0, b.shape[1] if b.dim() > 1 else 1)
     nrhs = b2.shape[1]
     if x is None:
         x = torch.zeros_like(b2)
@@ -84,7 +84,7 @@ def bicg_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reduc
     """Bicg::apply: the transposed system matrix is built once here (csr::transpose)
     unless `transposed` = (row_ptrs, col_idxs, vals) is given; precond_t is the
     transposed preconditioner (pass the same object for a symmetric one)."""
-    b2 = b.reshape(n, -1)
+    b2 = b.reshape(n, -1) if n > 0 else b.reshape(0, b.shape[1] if b.dim() > 1 else 1)
     nrhs = b2.shape[1]
     if x is None:
         x = torch.zeros_like(b2)
@@ -110,7 +110,7 @@ def ir_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, relaxation_factor=1.0, 
              reduction=1e-10, baseline="rhs_norm", strategy=0, max_row_nnz=-1):
     """Ir::apply with x as the initial guess; inner: None (Richardson) or a
     Preconditioner-like object whose apply approximates A^-1."""
-    b2 = b.reshape(n, -1)
+    b2 = b.reshape(n, -1) if n > 0 else b.reshape(0, b.shape[1] if b.dim() > 1 else 1)
     nrhs = b2.shape[1]
     if x is None:
         x = torch.zeros_like(b2)
@@ -134,7 +134,7 @@ def solve_op(gk, solver, matrix, b, x=None, max_iters=1000, reduction=1e-10, bas
     """Any solver in {"cg", "gmres", "bicgstab", "fcg", "cgs"} on a system matrix in
     any format (a gkomi.formats object): the *_solve_op_f64 drivers."""
     n = matrix.nrows
-    b2 = b.reshape(n, -1)
+    b2 = b.reshape(n, -1) if n > 0 else b.reshape(0, b.shape[1] if b.dim() > 1 else 1)
     nrhs = b2.shape[1]
     if x is None:
         x = torch.zeros_like(b2)
@@ -273,7 +273,7 @@ def gmres_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, krylov_dim=100, max_
                 baseline="rhs_norm", strategy=0, max_row_nnz=-1, precond=None):
     """Gmres with Combined(Iteration(max_iters), ResidualNorm(reduction, baseline)).
     precond: None or a Preconditioner."""
-    b2 = b.reshape(n, -1)
+    b2 = b.reshape(n, -1) if n > 0 else b.reshape(0, b.shape[1] if b.dim() > 1 else 1)
     nrhs = b2.shape[1]
     if x is None:
         x = torch.zeros_like(b2)

@@ -539,3 +539,19 @@ def test_bicg_with_block_jacobi_and_its_transpose(gk, oracle):
     pa = solvers.bicg_solve(gk, n, rpd, cid, vd, bd, max_iters=2000, reduction=1e-10, precond=ad, precond_t=ad_t)
     assert pa["converged"] and matgen.rel_err(host(pa["x"]), xs) < 1e-7
     assert abs(pa["iterations"] - pre["iterations"]) <= max(3, pre["iterations"] // 4)
+
+
+@pytest.mark.parametrize("solver", ["bicgstab", "fcg", "cgs"])
+@pytest.mark.parametrize("fused", [False, True], ids=["sequence", "fused"])
+def test_empty_and_one_row_systems(gk, solver, fused):
+    """Degenerate sizes must not trip the launch geometry: n = 0 (norms are 0, the
+    criterion 0 < 0 never fires: the iteration limit stops it) and n = 1."""
+    rp = dev(np.zeros(1, np.int32))
+    empty_i = torch.zeros(0, dtype=torch.int32, device="cuda:0")
+    empty_d = torch.zeros(0, dtype=torch.float64, device="cuda:0")
+    res = solvers.krylov_solve(gk, solver, 0, rp, empty_i, empty_d, torch.zeros((0, 1), dtype=torch.float64, device="cuda:0"),
+                               max_iters=2, reduction=1e-10, fused=fused)
+    assert res["iterations"] == 2 and not res["converged"]
+    one = solvers.krylov_solve(gk, solver, 1, dev(np.array([0, 1], np.int32)), dev(np.array([0], np.int32)), dev(np.array([4.0])),
+                               dev(np.array([2.0])), max_iters=5, reduction=1e-12, fused=fused)
+    assert one["converged"] and abs(float(host(one["x"])[0]) - 0.5) < 1e-15
