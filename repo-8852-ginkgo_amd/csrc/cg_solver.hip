@@ -310,7 +310,7 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
     const int32_t* row_ptrs = A.row_ptrs;
     const int32_t* col_idxs = A.col_idxs;
     const double* vals = A.vals;
-    if (mode == 1 && !A.is_csr()) mode = 0;  // the fused path needs the CSR arrays
+    if (mode == 1 && (!A.is_csr() || n == 0)) mode = 0;  // the fused path needs the CSR arrays (and rows)
     if (n < 0 || nrhs <= 0 || max_iters < 0) return GKOMI_EINVAL;
     if (baseline < 0 || baseline > 2 || (mode != 0 && mode != 1)) return GKOMI_EINVAL;
     if (mode == 1 && nrhs != 1) return GKOMI_ENOTSUPPORTED;

@@ -555,3 +555,21 @@ def test_empty_and_one_row_systems(gk, solver, fused):
     one = solvers.krylov_solve(gk, solver, 1, dev(np.array([0, 1], np.int32)), dev(np.array([0], np.int32)), dev(np.array([4.0])),
                                dev(np.array([2.0])), max_iters=5, reduction=1e-12, fused=fused)
     assert one["converged"] and abs(float(host(one["x"])[0]) - 0.5) < 1e-15
+
+
+def test_cg_and_gmres_on_empty_and_one_row_systems(gk):
+    rp = dev(np.zeros(1, np.int32))
+    empty_i = torch.zeros(0, dtype=torch.int32, device="cuda:0")
+    empty_d = torch.zeros(0, dtype=torch.float64, device="cuda:0")
+    b0 = torch.zeros((0, 1), dtype=torch.float64, device="cuda:0")
+    for mode in (0, 1):
+        res = solvers.cg_solve(gk, 0, rp, empty_i, empty_d, b0, max_iters=2, reduction=1e-10, mode=mode)
+        assert res["iterations"] == 2 and not res["converged"]
+        one = solvers.cg_solve(gk, 1, dev(np.array([0, 1], np.int32)), dev(np.array([0], np.int32)), dev(np.array([4.0])),
+                               dev(np.array([[2.0]])), max_iters=5, reduction=1e-12, mode=mode)
+        assert one["converged"] and abs(float(host(one["x"]).reshape(-1)[0]) - 0.5) < 1e-15
+    res = solvers.gmres_solve(gk, 0, rp, empty_i, empty_d, b0, krylov_dim=3, max_iters=2, reduction=1e-10)
+    assert res["iterations"] == 2 and not res["converged"]
+    one = solvers.gmres_solve(gk, 1, dev(np.array([0, 1], np.int32)), dev(np.array([0], np.int32)), dev(np.array([4.0])),
+                              dev(np.array([[2.0]])), krylov_dim=3, max_iters=5, reduction=1e-12)
+    assert one["converged"] and abs(float(host(one["x"]).reshape(-1)[0]) - 0.5) < 1e-14
