@@ -110,9 +110,17 @@ class Csr:
         self.gk.convert_ptrs_to_idxs_i32(_stream(self.vals), self.row_ptrs, self.nrows, rows)
         return rows
 
+    # benchmark/utils/formats.hpp:272-290: "csr" = automatical, "csri" = load_balance,
+    # "csrm" = merge_path, "csrc" = classical, "csrs" = sparselib (served by the automatic
+    # kernel here, like Csr::sparselib in the C++ mirror); GKOMI_CSR_* codes of include/gkomi.h
+    CSR_STRATEGIES = {"csr": 0, "csrs": 0, "csrm": 1, "csrc": 2, "csri": 3}
+
     def to(self, fmt, **kw):
-        if fmt == "csr":
-            return self
+        if fmt in self.CSR_STRATEGIES:
+            code = self.CSR_STRATEGIES[fmt]
+            if code == self.strategy:
+                return self
+            return Csr(self.gk, self.nrows, self.ncols, self.row_ptrs, self.col_idxs, self.vals, code)
         return {"coo": Coo, "ell": Ell, "sellp": Sellp, "hybrid": Hybrid}[fmt].from_csr(self, **kw)
 
 

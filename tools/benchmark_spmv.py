@@ -80,7 +80,9 @@ def timed(fn, warmup, min_reps, min_seconds):
 
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--formats", default="csr,coo,ell,sellp,hybrid")
+    ap.add_argument("--formats", default="csr,coo,ell,sellp,hybrid",
+                    help="as benchmark/utils/formats.hpp: csr (automatical), csri (load_balance), csrm (merge_path), "
+                         "csrc (classical), csrs, coo, ell, sellp, hybrid")
     ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--min_repetitions", type=int, default=10)
