@@ -208,13 +208,25 @@ __global__ __launch_bounds__(fblock) void cg_dot2_partials_kernel(
 {
     __shared__ double smem[fblock / wave_size];
     if (scal != nullptr && status_has_stopped(scal->status)) return;
+    // r and z are workspace vectors (256-B aligned): 16 B per lane
     const int64_t step = static_cast<int64_t>(gridDim.x) * fblock;
-    double a = 0.0, bb = 0.0;
+    const int64_t n2 = n / 2;
+    const double2* r2 = reinterpret_cast<const double2*>(r);
+    const double2* z2 = reinterpret_cast<const double2*>(z);
+    double a = 0.0, bb = 0.0, a1 = 0.0, b1 = 0.0;
     for (int64_t i = blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x;
-         i < n; i += step) {
-        const double rv = r[i];
-        a += rv * z[i];
-        bb += rv * rv;
+         i < n2; i += step) {
+        const double2 rv = r2[i], zv = z2[i];
+        a += rv.x * zv.x;
+        a1 += rv.y * zv.y;
+        bb += rv.x * rv.x;
+        b1 += rv.y * rv.y;
+    }
+    a += a1;
+    bb += b1;
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        a += r[n - 1] * z[n - 1];
+        bb += r[n - 1] * r[n - 1];
     }
     const double ta = block_reduce_sum<fblock>(a, smem);
     __syncthreads();

@@ -1305,11 +1305,35 @@ __global__ __launch_bounds__(fblock) void fused_dot3_partials_kernel(
     if (status != nullptr && status_has_stopped(status[0])) return;
     const int64_t step = static_cast<int64_t>(gridDim.x) * fblock;
     double a = 0.0, b = 0.0, c = 0.0;
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x; i < n; i += step) {
-        const double rv = r[i], zv = z[i];
-        a += rv * zv;
-        b += t[i] * zv;
-        c += rv * rv;
+    const bool vec = ((reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(z) |
+                       reinterpret_cast<uintptr_t>(t)) & 15) == 0;
+    if (vec) {  // 16 B per lane
+        const int64_t n2 = n / 2;
+        double a1 = 0.0, b1 = 0.0, c1 = 0.0;
+        for (int64_t i = blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x; i < n2; i += step) {
+            const double2 rv = ld2(r, i), zv = ld2(z, i), tv = ld2(t, i);
+            a += rv.x * zv.x;
+            a1 += rv.y * zv.y;
+            b += tv.x * zv.x;
+            b1 += tv.y * zv.y;
+            c += rv.x * rv.x;
+            c1 += rv.y * rv.y;
+        }
+        a += a1;
+        b += b1;
+        c += c1;
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            a += r[n - 1] * z[n - 1];
+            b += t[n - 1] * z[n - 1];
+            c += r[n - 1] * r[n - 1];
+        }
+    } else {
+        for (int64_t i = blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x; i < n; i += step) {
+            const double rv = r[i], zv = z[i];
+            a += rv * zv;
+            b += t[i] * zv;
+            c += rv * rv;
+        }
     }
     const double ta = block_reduce_sum<fblock>(a, smem);
     __syncthreads();
