@@ -80,7 +80,9 @@ enum {
     GKOMI_CSR_AUTO = 0,    /* "automatical": pick from row statistics        */
     GKOMI_CSR_STREAM = 1,  /* row-block streaming through LDS, bit-exact      */
     GKOMI_CSR_VECTOR = 2,  /* "classical": one sub-wave per row               */
-    GKOMI_CSR_BALANCED = 3 /* "load_balance": nnz-split + segmented reduction */
+    GKOMI_CSR_BALANCED = 3, /* "load_balance": nnz-split + segmented reduction */
+    GKOMI_CSR_SPLIT = 4    /* nnz-split streaming through LDS over srow, bit-exact
+                              (gkomi_csr_spmv_srow_f64_i32 only)               */
 };
 
 /* csr::spmv  c = A b   and   csr::advanced_spmv  c = alpha A b + beta c.
@@ -95,6 +97,37 @@ int gkomi_csr_spmv_f64_i32(gkomi_stream_t stream, int64_t nrows, int64_t ncols,
                            int64_t c_stride, const double* alpha,
                            const double* beta, int strategy,
                            int64_t max_row_nnz_hint);
+
+/* Csr::make_srow (include/ginkgo/core/matrix/csr.hpp:1139-1157; load_balance::process
+ * :395-459 fills srow with the row each wavefront's share of the nonzeros starts
+ * in).  Ours: srow[t] = first row whose row_ptrs entry is >= t * tile, for
+ * t = 0 .. nnz / tile + 1 -- the rows that START in every tile of `tile`
+ * nonzeros.  Built once per matrix (whenever row_ptrs changes) into a caller-owned
+ * device int32 array of gkomi_csr_srow_entries(nnz, tile) entries;
+ * gkomi_csr_srow_tile() is the tile the kernels are tuned for.  One small launch,
+ * no synchronisation. */
+int64_t gkomi_csr_srow_tile(void);
+int64_t gkomi_csr_srow_entries(int64_t nnz, int64_t tile);
+int gkomi_csr_make_srow_i32(gkomi_stream_t stream, int64_t nrows, int64_t nnz,
+                            const int32_t* row_ptrs, int64_t tile, int32_t* srow,
+                            int64_t nsrow);
+
+/* csr::spmv / advanced_spmv of a matrix that carries its srow (the reference's
+ * Csr always does: csr.hpp:1265-1266, passed to the kernels by
+ * hip/matrix/csr_kernels.hip.cpp:293-309).  Same contract as
+ * gkomi_csr_spmv_f64_i32; with srow the automatic strategy cuts the work by
+ * nonzeros (GKOMI_CSR_SPLIT) for matrices of short rows, whose streaming loads
+ * then do not wait for row_ptrs.  srow == NULL: identical to
+ * gkomi_csr_spmv_f64_i32.  max_row_nnz_hint stays advisory: a longer row is
+ * still summed correctly, only slowly. */
+int gkomi_csr_spmv_srow_f64_i32(gkomi_stream_t stream, int64_t nrows, int64_t ncols,
+                                int64_t nrhs, int64_t nnz, const int32_t* row_ptrs,
+                                const int32_t* col_idxs, const double* vals,
+                                const double* b, int64_t b_stride, double* c,
+                                int64_t c_stride, const double* alpha,
+                                const double* beta, int strategy,
+                                int64_t max_row_nnz_hint, const int32_t* srow,
+                                int64_t srow_tile);
 
 /* ell::compute_max_row_nnz analogue on a CSR row_ptrs array
  * (reference/matrix/ell_kernels.cpp:159-170 / csr strategy statistics).
@@ -422,6 +455,46 @@ int gkomi_upper_trs_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
  * (the role of the nan_produced guard, cuda/solver/common_trs_kernels.cuh:444-449) */
 int gkomi_trs_check_overrun(gkomi_stream_t s, const void* workspace,
                             int* host_flag);
+
+/* ---- triangular solves with an analysis phase = LowerTrs/UpperTrs::generate ----
+ * The reference analyses the factor once at generate() (hipsparseXcsrsv2_analysis into
+ * its SolveStruct, hip/solver/common_trs_kernels.hip.hpp:61-253; sync-free CUDA variant
+ * cuda/solver/common_trs_kernels.cuh:374-455) and solves with the result at every
+ * apply.  Ours, in the same two steps:
+ *   symbolic  dependency level of every row, rows sorted by level, 64-row slices:
+ *             blocking (returns the sizes the caller needs to allocate the plan);
+ *             host_out = { nslices, entries (SELL slots), nlevels }
+ *   numeric   the factor once more in level order, dependencies only, column-major
+ *             inside each slice, diagonal apart -> `plan` (device memory of
+ *             gkomi_trs_plan_bytes(nslices, entries) bytes); re-run when the values
+ *             of the factor change (same sparsity: same symbolic workspace)
+ *   solve     x = L^-1 b / U^-1 b from the plan alone (row_ptrs/col_idxs/vals are not
+ *             read again); one wave per slice, rows that become ready together,
+ *             bit-identical to reference/solver/{lower,upper}_trs_kernels.cpp:90-123.
+ *             x and b must not alias.
+ * A solve that hits its spin bound leaves NaNs in x and raises a STICKY flag in the
+ * plan (gkomi_trs_plan_check_overrun; cleared only by a new numeric phase). */
+size_t gkomi_trs_symbolic_workspace_bytes(int64_t n);
+int gkomi_trs_analyse_symbolic_i32(gkomi_stream_t s, int64_t n,
+                                   const int32_t* row_ptrs,
+                                   const int32_t* col_idxs, int lower,
+                                   void* workspace, size_t workspace_bytes,
+                                   int64_t* host_out);
+size_t gkomi_trs_plan_bytes(int64_t nslices, int64_t entries);
+int gkomi_trs_analyse_numeric_f64_i32(gkomi_stream_t s, int64_t n,
+                                      const int32_t* row_ptrs,
+                                      const int32_t* col_idxs,
+                                      const double* vals, int lower,
+                                      const void* symbolic_workspace,
+                                      int64_t nslices, int64_t entries,
+                                      int64_t nlevels, void* plan,
+                                      size_t plan_bytes);
+int gkomi_trs_solve_plan_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
+                             void* plan, int64_t nslices, int64_t entries,
+                             int unit_diag, const double* b, int64_t b_stride,
+                             double* x, int64_t x_stride);
+int gkomi_trs_plan_check_overrun(gkomi_stream_t s, const void* plan,
+                                 int* host_flag);
 
 /* ---- ParILU(0) (core/factorization/par_ilu.cpp:74-163) -------------------- */
 size_t gkomi_factorization_workspace_bytes(int64_t nrows);

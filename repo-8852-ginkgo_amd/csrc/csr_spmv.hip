@@ -27,6 +27,9 @@ namespace gkomi {
 namespace {
 
 constexpr int num_xcd = 8;
+// over-read of the nonzero-split kernel: rows up to split_max_over + 1 entries
+// are summed from LDS alone
+constexpr int split_max_over = 64;
 
 // Blocks are dealt round-robin to the 8 XCDs (MI355X_MICROARCH.md §Workgroup
 // dispatch).  Give each XCD one contiguous chunk of row blocks so that the
@@ -48,6 +51,10 @@ __device__ __forceinline__ int xcd_chunked_block(int bid, int per)
 // launch is skipped when stop_status[0] says the solver has stopped.
 typedef double nt_double2 __attribute__((ext_vector_type(2)));
 typedef int nt_int2 __attribute__((ext_vector_type(2)));
+// pairs of the nonzero-split kernel: 16/8 bytes per lane, but only element-aligned
+// when the pair was pulled back to the end of the arrays
+typedef double split_double2 __attribute__((ext_vector_type(2), aligned(8)));
+typedef int split_int2 __attribute__((ext_vector_type(2), aligned(4)));
 
 // Pad: one spare LDS slot per 32 products, so that rows of even length (stride
 // 8, 16, 32 doubles between neighbouring lanes in the row-sum phase) spread
@@ -211,6 +218,275 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
             if (tid == 0) dot_partial2[logical] = total2;
         }
     }
+}
+
+
+// sum += prod[lo .. hi) left to right (hi <= cap, the number of valid LDS slots),
+// eight LDS reads in flight per step instead of one read per dependent add
+__device__ __forceinline__ double add_products(double sum, const double* prod, int lo, int hi, int cap)
+{
+    for (int k = lo; k < hi; k += 8) {
+        double p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = prod[min(k + u, cap - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum = k + u < hi ? sum + p[u] : sum;
+    }
+    return sum;
+}
+
+// c[i] = v, written through to memory at once when WT (agent-scope store): the
+// 8 B per row then leave the L2 while the kernel still streams, not in the
+// write-back at its end
+template <bool WT>
+__device__ __forceinline__ void store_result(double* p, double v)
+{
+    if (WT) {
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *p = v;
+    }
+}
+
+// ---- nonzero-split stream kernel (needs srow) ---------------------------------
+//
+// The stream kernel above cannot issue a single streaming load before
+// row_ptrs[r0] has come back: three dependent memory round trips (row_ptrs ->
+// vals/col_idxs -> b) per workgroup, which is what a cold 15-us launch spends
+// its fill and drain on.  Here the work is cut by NONZEROS: workgroup t owns the
+// rows that START inside nonzeros [t*Tile, (t+1)*Tile), so the addresses of its
+// streaming loads depend on nothing but blockIdx and go out first.  Which rows
+// those are comes from `srow` (srow[t] = first row with row_ptrs[row] >=
+// t*Tile), built once per matrix -- the role of Csr::srow_ of the reference's
+// load_balance strategy (csr.hpp:395-459, 1139-1157).  A row that starts in the
+// tile may end behind it: the workgroup also reads the next `over` nonzeros
+// (over >= longest row - 1; the kernel is selected for short rows only), so
+// every row is summed by ONE thread, left to right, from its own products:
+// bit-identical to the reference for any row lengths, no atomics, no carries.
+// col_idxs are requested before vals: vector-memory results return in order,
+// so the gathers of b start while the values are still in flight.
+template <int Block, int Tile, int MaxOver, bool Advanced, bool Swizzle,
+          bool Dot = false, bool NT = false, bool ColsFirst = true, bool WT = false>
+__global__ __launch_bounds__(Block) void csr_split_kernel(
+    int nrows, int nnz, const int32_t* __restrict__ row_ptrs,
+    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
+    int64_t c_stride, const double* __restrict__ alpha_p,
+    const double* __restrict__ beta_p, const int32_t* __restrict__ srow,
+    int ntiles, int per_xcd, int over,
+    double* __restrict__ dot_partial = nullptr,
+    const uint8_t* __restrict__ stop_status = nullptr,
+    const double* __restrict__ dot_w = nullptr,
+    double* __restrict__ dot_partial2 = nullptr
+#ifdef GKOMI_TIMELINE
+    , unsigned long long* __restrict__ stamps = nullptr
+#endif
+    )
+{
+    constexpr int pairs = Tile / (2 * Block);
+    static_assert(Tile % (2 * Block) == 0, "tile must be a whole number of pair sweeps");
+    static_assert(MaxOver <= 2 * Block && MaxOver % 2 == 0, "one extra pair per lane at most");
+    // tools/spmv_timeline.hip only: per-workgroup phase stamps (100 MHz
+    // s_memrealtime, comparable across CUs) into a buffer nothing else reads
+#ifdef GKOMI_TIMELINE
+#define GKOMI_STAMP(slot)                                                           \
+    do {                                                                            \
+        if (stamps != nullptr && threadIdx.x == 0) {                                \
+            asm volatile("" ::: "memory");                                          \
+            stamps[8 * (Swizzle ? xcd_chunked_block(blockIdx.x, per_xcd) : blockIdx.x) + (slot)] = \
+                __builtin_amdgcn_s_memrealtime();                                   \
+            asm volatile("" ::: "memory");                                          \
+        }                                                                           \
+    } while (0)
+#else
+#define GKOMI_STAMP(slot) do { } while (0)
+#endif
+    __shared__ __attribute__((aligned(16))) double prod[Tile + MaxOver];
+
+    const int logical =
+        Swizzle ? xcd_chunked_block(blockIdx.x, per_xcd) : blockIdx.x;
+    if (logical >= ntiles) return;
+    if (Dot && status_has_stopped(stop_status[0])) return;
+    b += blockIdx.y;
+    c += blockIdx.y;
+    const int tid = threadIdx.x;
+    const int t0 = logical * Tile;
+    GKOMI_STAMP(0);
+#ifdef GKOMI_TIMELINE
+    if (stamps != nullptr && threadIdx.x == 0) {
+        stamps[8 * logical + 5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // XCC_ID[3:0]
+        stamps[8 * logical + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    }
+#endif
+    // the rows that start in this tile (scalar loads, back long before the
+    // streaming loads below)
+    const int row_begin = srow[logical];
+    const int row_end = srow[logical + 1];
+
+    // 1) streaming loads: addresses known from the block index alone.  Branch-
+    //    free (a branch per load makes the compiler drain the loads before it):
+    //    a pair that would start at or behind the last nonzero reads the last
+    //    two nonzeros instead -- valid columns, products nobody adds -- and the
+    //    lane that owns nonzero nnz-1 of an odd nnz picks it out of that pair.
+    double2 v[pairs + 1];
+    int2 ci[pairs + 1];
+    auto load_cols = [&](int u, int k) {
+        const split_int2* src = reinterpret_cast<const split_int2*>(col_idxs + min(k, nnz - 2));
+        const split_int2 tc = NT ? __builtin_nontemporal_load(src) : *src;
+        ci[u] = make_int2(k == nnz - 1 ? tc.y : tc.x, tc.y);
+    };
+    auto load_vals = [&](int u, int k) {
+        const split_double2* src = reinterpret_cast<const split_double2*>(vals + min(k, nnz - 2));
+        const split_double2 tv = NT ? __builtin_nontemporal_load(src) : *src;
+        v[u] = make_double2(k == nnz - 1 ? tv.y : tv.x, tv.y);
+    };
+    // the pairs behind the tile (rows that start in the tile and end behind
+    // it); lanes past `over` repeat the last useful pair (one request)
+    const int k_over = t0 + Tile + 2 * min(tid, max(over / 2 - 1, 0));
+    if (ColsFirst) {
+#pragma unroll
+        for (int u = 0; u < pairs; ++u) load_cols(u, t0 + 2 * (tid + u * Block));
+        load_cols(pairs, k_over);
+#pragma unroll
+        for (int u = 0; u < pairs; ++u) load_vals(u, t0 + 2 * (tid + u * Block));
+        load_vals(pairs, k_over);
+    } else {
+#pragma unroll
+        for (int u = 0; u < pairs; ++u) {
+            load_vals(u, t0 + 2 * (tid + u * Block));
+            load_cols(u, t0 + 2 * (tid + u * Block));
+        }
+        load_vals(pairs, k_over);
+        load_cols(pairs, k_over);
+    }
+
+    // 2) row_ptrs of the rows that start in this tile
+    double alpha = 1.0, beta = 0.0;
+    if (Advanced) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    // two rounds of rows are kept in registers (a 1536-nonzero tile of the
+    // 5-pt stencil starts 307 rows); more rounds re-read row_ptrs on demand
+    int ra[2], rb[2];
+    double c0[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // (kept under its own branch up here: loaded unconditionally, the
+        // compiler sinks the loads into the row loop behind the barrier)
+        const int row = row_begin + tid + i * Block;
+        ra[i] = rb[i] = t0;
+        c0[i] = 0.0;
+        if (row < row_end) {
+            ra[i] = NT ? __builtin_nontemporal_load(row_ptrs + row) : row_ptrs[row];
+            rb[i] = NT ? __builtin_nontemporal_load(row_ptrs + row + 1) : row_ptrs[row + 1];
+            // advanced: c = beta*c first, then accumulate (reference :119-126)
+            if (Advanced) c0[i] = c[row * c_stride];
+        }
+    }
+
+    // 3) gather b (every loaded column is a stored one: always in bounds), products -> LDS
+    double2 xv[pairs + 1];
+#pragma unroll
+    for (int u = 0; u <= pairs; ++u) {
+        xv[u].x = b[ci[u].x * b_stride];
+        xv[u].y = b[ci[u].y * b_stride];
+    }
+#pragma unroll
+    for (int u = 0; u <= pairs; ++u) {
+        double2 pr;
+        if (Advanced) {
+            pr.x = (alpha * v[u].x) * xv[u].x;  // reference order: (valpha * val) * b
+            pr.y = (alpha * v[u].y) * xv[u].y;
+        } else {
+            pr.x = v[u].x * xv[u].x;
+            pr.y = v[u].y * xv[u].y;
+        }
+        if (u < pairs) {
+            *reinterpret_cast<double2*>(prod + 2 * (tid + u * Block)) = pr;
+        } else {
+            // unconditional (lanes past `over` repeat the last useful pair and
+            // store the same product to the same slot): a branch here makes the
+            // compiler sink the pair's loads into it, behind all the others
+            *reinterpret_cast<double2*>(prod + (k_over - t0)) = pr;
+        }
+    }
+    GKOMI_STAMP(1);
+    __syncthreads();
+    GKOMI_STAMP(2);
+
+    // 4) one thread per row, left to right
+    const double* w = Dot && dot_w != nullptr ? dot_w : b;
+    const int64_t w_stride = Dot && dot_w != nullptr ? 1 : b_stride;
+    double pq = 0.0, qq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = row_begin + tid + i * Block;
+        if (row < row_end) {
+            double sum = Advanced ? c0[i] * beta : 0.0;
+            const int hi = rb[i] - t0;
+            sum = add_products(sum, prod, ra[i] - t0, min(hi, Tile + over), Tile + MaxOver);
+            // a row longer than the caller's hint promised: finish it from memory
+            for (int k = max(ra[i] - t0, Tile + over); k < hi; ++k) {
+                const double val = Advanced ? alpha * vals[t0 + k] : vals[t0 + k];
+                sum += val * b[col_idxs[t0 + k] * b_stride];
+            }
+            store_result<WT>(c + row * c_stride, sum);
+            if (Dot) {
+                pq += w[row * w_stride] * sum;
+                qq += sum * sum;
+            }
+        }
+    }
+    for (int row = row_begin + tid + 2 * Block; row < row_end; row += Block) {
+        double sum = Advanced ? c[row * c_stride] * beta : 0.0;
+        const int lo = row_ptrs[row] - t0;
+        const int hi = row_ptrs[row + 1] - t0;
+        sum = add_products(sum, prod, lo, min(hi, Tile + over), Tile + MaxOver);
+        for (int k = max(lo, Tile + over); k < hi; ++k) {
+            const double val = Advanced ? alpha * vals[t0 + k] : vals[t0 + k];
+            sum += val * b[col_idxs[t0 + k] * b_stride];
+        }
+        store_result<WT>(c + row * c_stride, sum);
+        if (Dot) {
+            pq += w[row * w_stride] * sum;
+            qq += sum * sum;
+        }
+    }
+    GKOMI_STAMP(3);
+    if (Dot) {
+        __shared__ double red[Block / wave_size];
+        __syncthreads();
+        const double total = block_reduce_sum<Block>(pq, red);
+        if (tid == 0) dot_partial[logical] = total;
+        if (dot_partial2 != nullptr) {
+            __syncthreads();
+            const double total2 = block_reduce_sum<Block>(qq, red);
+            if (tid == 0) dot_partial2[logical] = total2;
+        }
+    }
+#undef GKOMI_STAMP
+}
+
+// srow[t] = first row in [0, nrows] whose row_ptrs entry is >= t * tile
+// (lower bound; nrows if there is none), for t = 0 .. ntiles.
+__global__ __launch_bounds__(256) void csr_make_srow_kernel(
+    int nrows, const int32_t* __restrict__ row_ptrs, int tile, int ntiles,
+    int32_t* __restrict__ srow)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t > ntiles) return;
+    const int64_t target = static_cast<int64_t>(t) * tile;
+    int lo = 0, hi = nrows;  // answer in [lo, hi]
+    while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        if (row_ptrs[mid] >= target) {
+            hi = mid;
+        } else {
+            lo = mid + 1;
+        }
+    }
+    srow[t] = lo;
 }
 
 
@@ -575,6 +851,32 @@ int launch_vector(hipStream_t stream, int nrows, int nrhs,
     return check_launch();
 }
 
+template <int Block, int Tile, bool NT, bool WT>
+int launch_split(hipStream_t stream, bool swizzle, int nrows, int nnz,
+                 const int32_t* row_ptrs, const int32_t* col_idxs,
+                 const double* vals, const double* b, int64_t b_stride,
+                 double* c, int64_t c_stride, const double* alpha,
+                 const double* beta, const int32_t* srow, int over)
+{
+    constexpr int MaxOver = split_max_over;
+    const int ntiles = nnz / Tile + 1;
+    const int per = static_cast<int>(ceildiv(ntiles, num_xcd));
+    const bool swz = swizzle && ntiles >= 2 * num_xcd;
+    dim3 grid(swz ? per * num_xcd : ntiles, 1);
+#define GKOMI_LAUNCH(ADV, SWZ)                                                 \
+    hipLaunchKernelGGL(                                                        \
+        (csr_split_kernel<Block, Tile, MaxOver, ADV, SWZ, false, NT, true, WT>), \
+        grid, dim3(Block), 0, stream, nrows, nnz, row_ptrs, col_idxs, vals, b, \
+        b_stride, c, c_stride, alpha, beta, srow, ntiles, per, over)
+    if (alpha != nullptr) {
+        if (swz) GKOMI_LAUNCH(true, true); else GKOMI_LAUNCH(true, false);
+    } else {
+        if (swz) GKOMI_LAUNCH(false, true); else GKOMI_LAUNCH(false, false);
+    }
+#undef GKOMI_LAUNCH
+    return check_launch();
+}
+
 }  // namespace
 }  // namespace gkomi
 
@@ -633,6 +935,31 @@ bool csr_auto_swizzle(int64_t nrows, int64_t nnz)
 }  // namespace gkomi
 
 
+extern "C" int64_t gkomi_csr_srow_tile(void) { return 1536; }
+
+extern "C" int64_t gkomi_csr_srow_entries(int64_t nnz, int64_t tile)
+{
+    if (nnz < 0 || tile <= 0) return 0;
+    return nnz / tile + 2;
+}
+
+extern "C" int gkomi_csr_make_srow_i32(gkomi_stream_t stream_, int64_t nrows, int64_t nnz,
+                                       const int32_t* row_ptrs, int64_t tile, int32_t* srow,
+                                       int64_t nsrow)
+{
+    using namespace gkomi;
+    if (nrows < 0 || nnz < 0 || tile <= 0 || tile % 2 != 0) return GKOMI_EINVAL;
+    if (nrows > INT32_MAX - 1024 || nnz > INT32_MAX - 2 * tile - 1024 || tile > (1 << 20)) {
+        return GKOMI_ENOTSUPPORTED;
+    }
+    if (nsrow < gkomi_csr_srow_entries(nnz, tile)) return GKOMI_EWORKSPACE;
+    const int ntiles = static_cast<int>(nnz / tile) + 1;
+    hipLaunchKernelGGL(csr_make_srow_kernel, dim3(static_cast<unsigned>(ceildiv(ntiles + 1, 256))),
+                       dim3(256), 0, to_stream(stream_), static_cast<int>(nrows), row_ptrs,
+                       static_cast<int>(tile), ntiles, srow);
+    return check_launch();
+}
+
 extern "C" int gkomi_csr_spmv_f64_i32(
     gkomi_stream_t stream_, int64_t nrows, int64_t ncols, int64_t nrhs,
     int64_t nnz, const int32_t* row_ptrs, const int32_t* col_idxs,
@@ -640,6 +967,19 @@ extern "C" int gkomi_csr_spmv_f64_i32(
     const double* b, int64_t b_stride, double* c, int64_t c_stride,
     const double* alpha, const double* beta, int strategy,
     int64_t max_row_nnz_hint)
+{
+    return gkomi_csr_spmv_srow_f64_i32(stream_, nrows, ncols, nrhs, nnz, row_ptrs, col_idxs, vals,
+                                       b, b_stride, c, c_stride, alpha, beta, strategy,
+                                       max_row_nnz_hint, nullptr, 0);
+}
+
+extern "C" int gkomi_csr_spmv_srow_f64_i32(
+    gkomi_stream_t stream_, int64_t nrows, int64_t ncols, int64_t nrhs,
+    int64_t nnz, const int32_t* row_ptrs, const int32_t* col_idxs,
+    const double* vals,
+    const double* b, int64_t b_stride, double* c, int64_t c_stride,
+    const double* alpha, const double* beta, int strategy,
+    int64_t max_row_nnz_hint, const int32_t* srow, int64_t srow_tile)
 {
     using namespace gkomi;
     if (nrows < 0 || ncols < 0 || nrhs < 0) return GKOMI_EINVAL;
@@ -660,12 +1000,18 @@ extern "C" int gkomi_csr_spmv_f64_i32(
     const bool automatic = kind == GKOMI_CSR_AUTO;
     const bool aligned = (reinterpret_cast<uintptr_t>(vals) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(col_idxs) % 8 == 0);
+    const bool split_ok = srow != nullptr && aligned && nnz >= 2 &&
+                          nnz <= INT32_MAX - 2 * srow_tile - 1024 &&
+                          (srow_tile == 1024 || srow_tile == 1536 || srow_tile == 2048);
+    if (kind == GKOMI_CSR_SPLIT && !split_ok) return srow == nullptr ? GKOMI_EINVAL : GKOMI_ENOTSUPPORTED;
     if (kind == GKOMI_CSR_AUTO) {
-        // the role of Csr::automatical (csr.hpp:526-705): short rows stream,
-        // long rows go one sub-wave per row
-        // short rows stream; long rows one sub-wave per row; when a few rows
+        // the role of Csr::automatical (csr.hpp:526-705): short rows stream
+        // (cut by nonzeros when the matrix carries its srow, by rows otherwise);
+        // long rows one sub-wave per row; when a few rows
         // dwarf the average (max > 64 x mean) split by nonzeros instead
-        if (max_row_nnz_hint < 0 || max_row_nnz_hint <= 256) {
+        if (split_ok && r == 1 && max_row_nnz_hint >= 0 && max_row_nnz_hint <= split_max_over + 1) {
+            kind = GKOMI_CSR_SPLIT;
+        } else if (max_row_nnz_hint < 0 || max_row_nnz_hint <= 256) {
             kind = GKOMI_CSR_STREAM;
         } else if (nnz > 0 && max_row_nnz_hint > 64 * (nnz / nrows + 1)) {
             kind = GKOMI_CSR_BALANCED;
@@ -714,6 +1060,42 @@ extern "C" int gkomi_csr_spmv_f64_i32(
         if (r - done == 1) {
             return launch_stream<256, 1, 1536>(stream, !no_swizzle, chunk, n, 1, row_ptrs, col_idxs, vals,
                                                b + done, b_stride, c + done, c_stride, alpha, beta);
+        }
+        return GKOMI_SUCCESS;
+    }
+    if (kind == GKOMI_CSR_SPLIT) {
+        if (automatic) variant = no_swizzle ? 2 : 0;  // nontemporal streams past the Infinity Cache
+        // longest row - 1 nonzeros may lie behind the tile a row starts in
+        int over = split_max_over;
+        if (max_row_nnz_hint >= 1 && max_row_nnz_hint <= split_max_over) {
+            over = static_cast<int>((max_row_nnz_hint - 1 + 1) / 2 * 2);
+        } else if (max_row_nnz_hint == 0) {
+            over = 0;
+        }
+        const int z = static_cast<int>(nnz);
+        for (int j = 0; j < r; ++j) {  // explicit strategy with several columns: one launch each
+            int err = GKOMI_EINVAL;
+#define GKOMI_SPLIT_ARGS                                                            \
+    stream, !no_swizzle, n, z, row_ptrs, col_idxs, vals, b + j, b_stride, c + j,    \
+        c_stride, alpha, beta, srow, over
+            // variant bits: 2 = nontemporal streams, 4 = write-through stores of c
+#define GKOMI_SPLIT_TILE(BLOCK, TILE)                                               \
+    switch ((variant >> 1) & 3) {                                                   \
+    case 0: err = launch_split<BLOCK, TILE, false, false>(GKOMI_SPLIT_ARGS); break; \
+    case 1: err = launch_split<BLOCK, TILE, true, false>(GKOMI_SPLIT_ARGS); break;  \
+    case 2: err = launch_split<BLOCK, TILE, false, true>(GKOMI_SPLIT_ARGS); break;  \
+    default: err = launch_split<BLOCK, TILE, true, true>(GKOMI_SPLIT_ARGS); break;  \
+    }
+            if (srow_tile == 1536) {
+                GKOMI_SPLIT_TILE(256, 1536)
+            } else if (srow_tile == 1024) {
+                GKOMI_SPLIT_TILE(256, 1024)
+            } else {
+                GKOMI_SPLIT_TILE(256, 2048)
+            }
+#undef GKOMI_SPLIT_TILE
+#undef GKOMI_SPLIT_ARGS
+            if (err) return err;
         }
         return GKOMI_SUCCESS;
     }

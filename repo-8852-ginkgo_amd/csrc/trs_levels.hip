@@ -1,0 +1,479 @@
+// Sparse triangular solves with an ANALYSIS phase = solver::LowerTrs/UpperTrs::generate
+// (the reference runs hipsparseXcsrsv2_analysis there and keeps the result in its
+// SolveStruct: hip/solver/common_trs_kernels.hip.hpp:61-253; the CUDA sync-free
+// variant cuda/solver/common_trs_kernels.cuh:374-455).  Numerical contract =
+// reference/solver/lower_trs_kernels.cpp:90-120, upper_trs_kernels.cpp:90-123.
+//
+// Why: the analysis-free kernel of trs.hip hands rows to lanes in storage order,
+// so the 64 lanes of a wave hold a dependency CHAIN (r needs r-1): one useful
+// lane per pass.  Here `generate` computes the dependency level of every row,
+// sorts the rows by level (stable) and stores the factor once more in that order
+// as 64-row slices, column-major inside a slice (SELL-64 of the dependencies
+// only, the diagonal apart).  A wave then owns 64 rows that become ready
+// TOGETHER: its loads are coalesced, every lane has work in every pass, and
+// the critical path is one memory hand-off per LEVEL instead of one LDS
+// hand-off per row of a chain plus one memory hand-off per grid line.
+//
+// The solve stays sync-free: x[row] doubles as its own ready flag (sentinel
+// NaN payload, ONE agent-scope store to publish, agent-scope loads to poll --
+// MI355X_MICROARCH.md's data-tagged granule), slices are handed out by an
+// atomic ticket in level order (every dependency of a slice lives in a slice
+// with a smaller-or-equal ticket, i.e. in a wave that has started), a lane
+// publishes the moment its row is complete (a slice may straddle two levels), no
+// lane waits inside a loop another lane of its wave must leave, spins are
+// bounded and raise a STICKY flag in the plan instead of hanging.
+// Per row the subtractions run in storage order -> bit-identical to the reference.
+#include "common.hpp"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace gkomi {
+namespace {
+
+constexpr int slice = 64;        // rows per wave
+constexpr int solve_block = 256; // 4 slices per ticket
+constexpr int window = 8;        // dependency entries a lane keeps in registers
+constexpr unsigned long long sentinel_bits = 0x7ff8dead0badbeefull;
+constexpr long long max_rounds = 1ll << 22;
+
+struct plan_header {
+    int64_t n;
+    int64_t nslices;
+    int64_t nlevels;
+    int64_t entries;       // SELL slots (multiple of 64)
+    unsigned int ticket;
+    unsigned int overrun;  // sticky: zeroed when the plan is built, never by a solve
+    int32_t lower;
+    int32_t pad_;
+};
+
+struct plan_layout {
+    size_t perm, slice_off, diag, cols, vals, total;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+plan_layout make_plan_layout(int64_t nslices, int64_t entries)
+{
+    plan_layout l{};
+    size_t off = 256;
+    l.perm = off; off += align_up(sizeof(int32_t) * nslices * slice, 256);
+    l.slice_off = off; off += align_up(sizeof(int32_t) * (nslices + 1), 256);
+    l.diag = off; off += align_up(sizeof(double) * nslices * slice, 256);
+    l.cols = off; off += align_up(sizeof(int32_t) * entries, 256);
+    l.vals = off; off += align_up(sizeof(double) * entries, 256);
+    l.total = off;
+    return l;
+}
+
+// symbolic workspace: levels[n] | sorted levels[n] | rows[n] | perm[n] | dep count[n] |
+// slice_len[nslices + 1] | slice_off[nslices + 1] | flags | rocPRIM temporary
+struct symbolic_layout {
+    size_t level, level_sorted, rows, perm, cnt, slice_len, slice_off, flags, tmp, tmp_bytes, total;
+};
+
+symbolic_layout make_symbolic_layout(int64_t n)
+{
+    symbolic_layout l{};
+    const int64_t nslices = ceildiv(n, slice);
+    const size_t vec = align_up(sizeof(int32_t) * static_cast<size_t>(n > 0 ? n : 1), 256);
+    size_t off = 0;
+    l.level = off; off += vec;
+    l.level_sorted = off; off += vec;
+    l.rows = off; off += vec;
+    l.perm = off; off += vec;
+    l.cnt = off; off += vec;
+    l.slice_len = off; off += align_up(sizeof(int32_t) * (nslices + 1), 256);
+    l.slice_off = off; off += align_up(sizeof(int32_t) * (nslices + 1), 256);
+    l.flags = off; off += 256;
+    size_t sort_bytes = 0, scan_bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, static_cast<int32_t*>(nullptr),
+                                    static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
+                                    static_cast<int32_t*>(nullptr), static_cast<size_t>(n > 0 ? n : 1), 0,
+                                    32, hipStreamDefault);
+    (void)rocprim::exclusive_scan(nullptr, scan_bytes, static_cast<int32_t*>(nullptr),
+                                  static_cast<int32_t*>(nullptr), 0,
+                                  static_cast<size_t>(nslices + 1), rocprim::plus<int32_t>(),
+                                  hipStreamDefault);
+    l.tmp_bytes = align_up(sort_bytes > scan_bytes ? sort_bytes : scan_bytes, 256) + 256;
+    l.tmp = off; off += l.tmp_bytes;
+    l.total = off;
+    return l;
+}
+
+template <bool Lower>
+__device__ __forceinline__ bool is_dep(int col, int row)
+{
+    return Lower ? col < row : col > row;
+}
+
+// level[row] = 1 + max level of its dependencies (0 without any): chaotic
+// in-place relaxation, monotone from 0, run until a whole batch changes nothing.
+// It also leaves the number of dependencies of the row in cnt.
+template <bool Lower>
+__global__ __launch_bounds__(256) void trs_relax_levels_kernel(
+    int32_t n, const int32_t* __restrict__ row_ptrs, const int32_t* __restrict__ col_idxs,
+    int32_t* level, int32_t* __restrict__ cnt, int32_t* __restrict__ changed)
+{
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int begin = row < n ? row_ptrs[row] : 0;
+    const int end = row < n ? row_ptrs[row + 1] : 0;
+    int mine = row < n ? level[row] : 0;
+    bool any_change = false;
+    // a wave repeats its sweep while it still moves (the lanes of a wave read
+    // each other's levels one sweep late: a dependency chain inside the wave
+    // would otherwise need one LAUNCH per link)
+    for (int rep = 0; rep < 64; ++rep) {
+        int lvl = 0, deps = 0;
+        for (int k = begin; k < end; ++k) {
+            const int col = col_idxs[k];
+            if (is_dep<Lower>(col, row) && col >= 0 && col < n) {
+                lvl = max(lvl, __hip_atomic_load(level + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1);
+                ++deps;
+            }
+        }
+        const bool moved = row < n && lvl != mine;
+        if (row < n && rep == 0) cnt[row] = deps;
+        if (moved) {
+            mine = lvl;
+            __hip_atomic_store(level + row, lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            any_change = true;
+        }
+        if (!__any(moved)) break;
+    }
+    if (any_change) *changed = 1;
+}
+
+__global__ __launch_bounds__(256) void trs_iota_kernel(int32_t n, int32_t* __restrict__ rows)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) rows[i] = i;
+}
+
+// one wave per slice: longest dependency list among its rows; entry nslices = 0
+__global__ __launch_bounds__(256) void trs_slice_len_kernel(
+    int32_t n, int32_t nslices, const int32_t* __restrict__ perm, const int32_t* __restrict__ cnt,
+    int32_t* __restrict__ slice_len, const int32_t* __restrict__ level_sorted,
+    int32_t* __restrict__ nlevels)
+{
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (s > nslices) return;
+    if (s == nslices) {
+        if (lane == 0) {
+            slice_len[s] = 0;
+            *nlevels = n > 0 ? level_sorted[n - 1] + 1 : 0;
+        }
+        return;
+    }
+    const int i = s * slice + lane;
+    int m = i < n ? cnt[perm[i]] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if (lane == 0) slice_len[s] = m * slice;
+}
+
+// numeric phase: the factor once more, rows in level order, dependencies only,
+// column-major inside every 64-row slice; -1 pads; the diagonal (last stored
+// occurrence, like the reference's loop) apart
+template <bool Lower>
+__global__ __launch_bounds__(256) void trs_fill_plan_kernel(
+    int32_t n, int32_t nslices, const int32_t* __restrict__ row_ptrs,
+    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    const int32_t* __restrict__ perm_in, const int32_t* __restrict__ slice_off_in,
+    int32_t* __restrict__ perm, int32_t* __restrict__ slice_off, double* __restrict__ diag,
+    int32_t* __restrict__ cols, double* __restrict__ pvals)
+{
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (s > nslices) return;
+    if (s == nslices) {
+        if (lane == 0) slice_off[s] = slice_off_in[s];
+        return;
+    }
+    const int off = slice_off_in[s];
+    const int len = (slice_off_in[s + 1] - off) / slice;
+    if (lane == 0) slice_off[s] = off;
+    const int i = s * slice + lane;
+    const int row = i < n ? perm_in[i] : -1;
+    perm[i] = row;
+    double d = 1.0;
+    int e = 0;
+    if (row >= 0) {
+        for (int k = row_ptrs[row]; k < row_ptrs[row + 1]; ++k) {
+            const int col = col_idxs[k];
+            if (col == row) d = vals[k];
+            if (is_dep<Lower>(col, row) && col >= 0 && col < n) {
+                cols[off + e * slice + lane] = col;
+                pvals[off + e * slice + lane] = vals[k];
+                ++e;
+            }
+        }
+    }
+    diag[i] = d;
+    for (; e < len; ++e) {
+        cols[off + e * slice + lane] = -1;
+        pvals[off + e * slice + lane] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void trs_plan_prepare_kernel(int64_t n, double* __restrict__ x,
+                                                              int64_t x_stride,
+                                                              plan_header* __restrict__ hdr)
+{
+    const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
+    if (gid == 0) hdr->ticket = 0;
+    for (int64_t i = gid; i < n; i += static_cast<int64_t>(gridDim.x) * 256) {
+        reinterpret_cast<unsigned long long*>(x)[i * x_stride] = sentinel_bits;
+    }
+}
+
+__device__ __forceinline__ unsigned long long poll(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(solve_block) void trs_level_solve_kernel(
+    plan_header* hdr, const int32_t* __restrict__ perm, const int32_t* __restrict__ slice_off,
+    const double* __restrict__ diag, const int32_t* __restrict__ cols,
+    const double* __restrict__ pvals, bool unit_diag, const double* __restrict__ b,
+    int64_t b_stride, double* x, int64_t x_stride)
+{
+    __shared__ unsigned int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&hdr->ticket, 1u);
+    __syncthreads();
+    const int64_t s = static_cast<int64_t>(s_ticket) * (solve_block / slice) + (threadIdx.x >> 6);
+    if (s >= hdr->nslices) return;
+    const int lane = threadIdx.x & 63;
+    const int row = perm[s * slice + lane];
+    const int off = slice_off[s];
+    const int len = (slice_off[s + 1] - off) / slice;
+    unsigned long long* xb = reinterpret_cast<unsigned long long*>(x);
+    double sum = row >= 0 ? b[row * b_stride] : 0.0;
+    const double d = diag[s * slice + lane];
+    bool published = row < 0;
+    auto publish = [&]() {
+        const double xr = unit_diag ? sum : sum / d;
+        __hip_atomic_store(xb + row * x_stride, static_cast<unsigned long long>(__double_as_longlong(xr)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        published = true;
+    };
+    long long rounds = 0;
+    bool gave_up = false;
+    for (int e0 = 0; e0 < len && !gave_up; e0 += window) {
+        int c[window];
+        double v[window];
+        unsigned long long xs[window];
+#pragma unroll
+        for (int w = 0; w < window; ++w) {  // coalesced: 64 consecutive slots per entry
+            const int e = min(e0 + w, len - 1);
+            c[w] = cols[off + e * slice + lane];
+            v[w] = pvals[off + e * slice + lane];
+            if (e0 + w >= len) c[w] = -1;
+        }
+#pragma unroll
+        for (int w = 0; w < window; ++w) {  // all polls of the window in flight together
+            xs[w] = c[w] >= 0 ? poll(xb + c[w] * x_stride) : 0ull;
+        }
+        int cur = 0;
+        while (true) {
+            // consume, in storage order, what has arrived
+#pragma unroll
+            for (int w = 0; w < window; ++w) {
+                if (cur == w) {
+                    if (c[w] < 0) {  // the row has no further dependency: publish at once
+                        if (!published) publish();
+                        cur = window;
+                    } else if (xs[w] != sentinel_bits) {
+                        sum -= v[w] * __longlong_as_double(static_cast<long long>(xs[w]));
+                        ++cur;
+                    }
+                }
+            }
+            if (__all(cur == window)) break;
+            if (++rounds > max_rounds) {
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+            for (int w = 0; w < window; ++w) {
+                if (w >= cur && c[w] >= 0 && xs[w] == sentinel_bits) xs[w] = poll(xb + c[w] * x_stride);
+            }
+        }
+    }
+    if (gave_up) {
+        if (lane == 0) atomicExch(&hdr->overrun, 1u);
+        return;  // unsolved rows keep the sentinel NaN
+    }
+    if (!published) publish();
+}
+
+template <bool Lower>
+int analyse_symbolic(hipStream_t stream, int64_t n, const int32_t* row_ptrs, const int32_t* col_idxs,
+                     void* workspace, size_t workspace_bytes, int64_t* host_out)
+{
+    const symbolic_layout l = make_symbolic_layout(n);
+    if (workspace == nullptr || workspace_bytes < l.total) return GKOMI_EWORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    int32_t* level = reinterpret_cast<int32_t*>(ws + l.level);
+    int32_t* level_sorted = reinterpret_cast<int32_t*>(ws + l.level_sorted);
+    int32_t* rows = reinterpret_cast<int32_t*>(ws + l.rows);
+    int32_t* perm = reinterpret_cast<int32_t*>(ws + l.perm);
+    int32_t* cnt = reinterpret_cast<int32_t*>(ws + l.cnt);
+    int32_t* slice_len = reinterpret_cast<int32_t*>(ws + l.slice_len);
+    int32_t* slice_off = reinterpret_cast<int32_t*>(ws + l.slice_off);
+    int32_t* flags = reinterpret_cast<int32_t*>(ws + l.flags);  // [0] changed, [1] nlevels
+    const int32_t n32 = static_cast<int32_t>(n);
+    const int32_t nslices = static_cast<int32_t>(ceildiv(n, slice));
+    host_out[0] = host_out[1] = host_out[2] = 0;
+    if (n == 0) return GKOMI_SUCCESS;
+    int err = static_cast<int>(hipMemsetAsync(level, 0, sizeof(int32_t) * n, stream));
+    if (err) return err;
+    const dim3 grid(static_cast<unsigned>(ceildiv(n, 256)));
+    // the fixed point is reached after at most (longest dependency path) sweeps;
+    // a sweep usually settles many levels (rows are visited roughly in order)
+    constexpr int batch = 16;
+    for (int64_t sweeps = 0; sweeps <= n + batch; sweeps += batch) {
+        err = static_cast<int>(hipMemsetAsync(flags, 0, sizeof(int32_t), stream));
+        if (err) return err;
+        for (int i = 0; i < batch; ++i) {
+            hipLaunchKernelGGL(trs_relax_levels_kernel<Lower>, grid, dim3(256), 0, stream, n32,
+                               row_ptrs, col_idxs, level, cnt, flags);
+        }
+        int32_t changed = 0;
+        err = static_cast<int>(hipMemcpyAsync(&changed, flags, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        if (err) return err;
+        err = static_cast<int>(hipStreamSynchronize(stream));
+        if (err) return err;
+        if (!changed) break;
+    }
+    hipLaunchKernelGGL(trs_iota_kernel, grid, dim3(256), 0, stream, n32, rows);
+    size_t tmp_bytes = l.tmp_bytes;
+    // stable: rows of one level keep their storage order (deterministic layout)
+    err = static_cast<int>(rocprim::radix_sort_pairs(ws + l.tmp, tmp_bytes, level, level_sorted, rows, perm,
+                                                     static_cast<size_t>(n), 0, 32, stream));
+    if (err) return err;
+    hipLaunchKernelGGL(trs_slice_len_kernel, dim3(static_cast<unsigned>(ceildiv(nslices + 1, 4))), dim3(256),
+                       0, stream, n32, nslices, perm, cnt, slice_len, level_sorted, flags + 1);
+    tmp_bytes = l.tmp_bytes;
+    err = static_cast<int>(rocprim::exclusive_scan(ws + l.tmp, tmp_bytes, slice_len, slice_off, 0,
+                                                   static_cast<size_t>(nslices + 1),
+                                                   rocprim::plus<int32_t>(), stream));
+    if (err) return err;
+    int32_t h[2] = {0, 0};
+    err = static_cast<int>(hipMemcpyAsync(&h[0], slice_off + nslices, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    if (err) return err;
+    err = static_cast<int>(hipMemcpyAsync(&h[1], flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    if (err) return err;
+    err = static_cast<int>(hipStreamSynchronize(stream));
+    if (err) return err;
+    if (h[0] < 0) return GKOMI_ENOTSUPPORTED;  // more than 2^31 slots
+    host_out[0] = nslices;
+    host_out[1] = h[0];
+    host_out[2] = h[1];
+    return check_launch();
+}
+
+}  // namespace
+}  // namespace gkomi
+
+using namespace gkomi;
+
+extern "C" size_t gkomi_trs_symbolic_workspace_bytes(int64_t n)
+{
+    if (n < 0 || n > INT32_MAX - 1024) return 0;
+    return make_symbolic_layout(n).total;
+}
+
+extern "C" int gkomi_trs_analyse_symbolic_i32(gkomi_stream_t s, int64_t n, const int32_t* row_ptrs,
+                                              const int32_t* col_idxs, int lower, void* workspace,
+                                              size_t workspace_bytes, int64_t* host_out)
+{
+    if (n < 0 || host_out == nullptr) return GKOMI_EINVAL;
+    if (n > INT32_MAX - 1024) return GKOMI_ENOTSUPPORTED;
+    return lower ? analyse_symbolic<true>(to_stream(s), n, row_ptrs, col_idxs, workspace, workspace_bytes, host_out)
+                 : analyse_symbolic<false>(to_stream(s), n, row_ptrs, col_idxs, workspace, workspace_bytes, host_out);
+}
+
+extern "C" size_t gkomi_trs_plan_bytes(int64_t nslices, int64_t entries)
+{
+    if (nslices < 0 || entries < 0) return 0;
+    return make_plan_layout(nslices, entries).total;
+}
+
+extern "C" int gkomi_trs_analyse_numeric_f64_i32(gkomi_stream_t s, int64_t n, const int32_t* row_ptrs,
+                                                 const int32_t* col_idxs, const double* vals, int lower,
+                                                 const void* symbolic_workspace, int64_t nslices,
+                                                 int64_t entries, int64_t nlevels, void* plan,
+                                                 size_t plan_bytes)
+{
+    if (n < 0 || nslices != ceildiv(n, slice) || entries < 0 || entries % slice != 0) return GKOMI_EINVAL;
+    const plan_layout pl = make_plan_layout(nslices, entries);
+    if (plan == nullptr || plan_bytes < pl.total || symbolic_workspace == nullptr) return GKOMI_EWORKSPACE;
+    hipStream_t stream = to_stream(s);
+    plan_header h{};
+    h.n = n; h.nslices = nslices; h.nlevels = nlevels; h.entries = entries;
+    h.ticket = 0; h.overrun = 0; h.lower = lower ? 1 : 0;
+    int err = static_cast<int>(hipMemcpyAsync(plan, &h, sizeof(h), hipMemcpyHostToDevice, stream));
+    if (err) return err;
+    err = static_cast<int>(hipStreamSynchronize(stream));  // h lives on this stack frame
+    if (err || n == 0) return err;
+    const symbolic_layout sl = make_symbolic_layout(n);
+    const char* sw = static_cast<const char*>(symbolic_workspace);
+    char* p = static_cast<char*>(plan);
+    const dim3 grid(static_cast<unsigned>(ceildiv(nslices + 1, 4)));
+#define GKOMI_FILL(LOWER)                                                                             \
+    hipLaunchKernelGGL(trs_fill_plan_kernel<LOWER>, grid, dim3(256), 0, stream, static_cast<int32_t>(n), \
+                       static_cast<int32_t>(nslices), row_ptrs, col_idxs, vals,                         \
+                       reinterpret_cast<const int32_t*>(sw + sl.perm),                                  \
+                       reinterpret_cast<const int32_t*>(sw + sl.slice_off),                             \
+                       reinterpret_cast<int32_t*>(p + pl.perm), reinterpret_cast<int32_t*>(p + pl.slice_off), \
+                       reinterpret_cast<double*>(p + pl.diag), reinterpret_cast<int32_t*>(p + pl.cols),  \
+                       reinterpret_cast<double*>(p + pl.vals))
+    if (lower) GKOMI_FILL(true); else GKOMI_FILL(false);
+#undef GKOMI_FILL
+    return check_launch();
+}
+
+extern "C" int gkomi_trs_solve_plan_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, void* plan,
+                                        int64_t nslices, int64_t entries, int unit_diag,
+                                        const double* b, int64_t b_stride, double* x, int64_t x_stride)
+{
+    if (n < 0 || nrhs < 0 || b_stride < nrhs || x_stride < nrhs) return GKOMI_EINVAL;
+    if (n == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    if (plan == nullptr || nslices != ceildiv(n, slice)) return GKOMI_EINVAL;
+    if (x == b) return GKOMI_EINVAL;  // x carries the ready flags
+    const plan_layout pl = make_plan_layout(nslices, entries);
+    char* p = static_cast<char*>(plan);
+    plan_header* hdr = reinterpret_cast<plan_header*>(p);
+    hipStream_t stream = to_stream(s);
+    const unsigned tickets = static_cast<unsigned>(ceildiv(nslices, solve_block / slice));
+    for (int64_t j = 0; j < nrhs; ++j) {
+        hipLaunchKernelGGL(trs_plan_prepare_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, n, x + j,
+                           x_stride, hdr);
+        hipLaunchKernelGGL(trs_level_solve_kernel, dim3(tickets), dim3(solve_block), 0, stream, hdr,
+                           reinterpret_cast<const int32_t*>(p + pl.perm),
+                           reinterpret_cast<const int32_t*>(p + pl.slice_off),
+                           reinterpret_cast<const double*>(p + pl.diag),
+                           reinterpret_cast<const int32_t*>(p + pl.cols),
+                           reinterpret_cast<const double*>(p + pl.vals), unit_diag != 0, b + j, b_stride,
+                           x + j, x_stride);
+        const int err = check_launch();
+        if (err) return err;
+    }
+    return GKOMI_SUCCESS;
+}
+
+extern "C" int gkomi_trs_plan_check_overrun(gkomi_stream_t s, const void* plan, int* host_flag)
+{
+    if (plan == nullptr || host_flag == nullptr) return GKOMI_EINVAL;
+    plan_header h{};
+    hipStream_t stream = to_stream(s);
+    int err = static_cast<int>(hipMemcpyAsync(&h, plan, sizeof(h), hipMemcpyDeviceToHost, stream));
+    if (err) return err;
+    err = static_cast<int>(hipStreamSynchronize(stream));
+    *host_flag = static_cast<int>(h.overrun);
+    return err;
+}

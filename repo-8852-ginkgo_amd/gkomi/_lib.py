@@ -95,6 +95,8 @@ class _Lib:
                 fn.restype = ctypes.c_char_p
             elif ret.strip() == "size_t":
                 fn.restype = ctypes.c_size_t
+            elif ret.strip() == "int64_t":
+                fn.restype = ctypes.c_int64
             else:
                 fn.restype = ctypes.c_int
             setattr(self, name[len("gkomi_"):], self._wrap(name, fn, ret, params))

@@ -258,6 +258,45 @@ def jacobi_transpose(gk, pre):
     return t
 
 
+class TrsPlan:
+    """solver::LowerTrs / UpperTrs after generate(): the analysed factor
+    (gkomi_trs_analyse_{symbolic,numeric}) and its solve."""
+
+    def __init__(self, gk, n, row_ptrs, col_idxs, vals, lower):
+        self.gk, self.n, self.lower = gk, int(n), bool(lower)
+        self.row_ptrs, self.col_idxs = row_ptrs, col_idxs
+        dv = vals.device
+        s = torch.cuda.current_stream().cuda_stream
+        nb = gk.trs_symbolic_workspace_bytes(n)
+        self.symbolic = torch.empty(max(nb, 8), dtype=torch.uint8, device=dv)
+        out = (ctypes.c_int64 * 3)()
+        gk.trs_analyse_symbolic_i32(s, n, row_ptrs, col_idxs, int(self.lower), self.symbolic, nb, ctypes.addressof(out))
+        self.nslices, self.entries, self.nlevels = (int(v) for v in out)
+        self.plan_bytes = gk.trs_plan_bytes(self.nslices, self.entries)
+        self.plan = torch.empty(max(self.plan_bytes, 8), dtype=torch.uint8, device=dv)
+        self.refresh(vals)
+
+    def refresh(self, vals):
+        """new values, same sparsity pattern: numeric phase only"""
+        s = torch.cuda.current_stream().cuda_stream
+        self.vals = vals
+        self.gk.trs_analyse_numeric_f64_i32(s, self.n, self.row_ptrs, self.col_idxs, vals, int(self.lower),
+                                            self.symbolic, self.nslices, self.entries, self.nlevels, self.plan,
+                                            self.plan_bytes)
+
+    def solve(self, b, x, unit_diag=False):
+        s = torch.cuda.current_stream().cuda_stream
+        b2, x2 = b.reshape(self.n, -1), x.reshape(self.n, -1)
+        self.gk.trs_solve_plan_f64(s, self.n, b2.shape[1], self.plan, self.nslices, self.entries, int(unit_diag),
+                                   b2, b2.stride(0), x2, x2.stride(0))
+        return x
+
+    def overrun(self):
+        flag = ctypes.c_int(0)
+        self.gk.trs_plan_check_overrun(torch.cuda.current_stream().cuda_stream, self.plan, ctypes.addressof(flag))
+        return bool(flag.value)
+
+
 def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False):
     """preconditioner::Ilu over given CSR factors L = (row_ptrs, col_idxs, vals), U likewise."""
     dv = L[2].device

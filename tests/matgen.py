@@ -168,3 +168,72 @@ def rel_err(a, b):
     if den == 0.0:
         return 0.0 if num == 0.0 else float("inf")
     return (num / den) ** 0.5
+
+
+# ---- offline stand-ins of the SuiteSparse matrices named by BASELINE.json ----
+# (thermal2 / atmosmodd are not in the container)
+
+def permute_symmetric(n, rp, ci, v, seed=42):
+    """P A P^T with a fixed random permutation, rows and columns sorted."""
+    rng = np.random.default_rng(seed)
+    inv = np.argsort(rng.permutation(n))
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    pr, pc = inv[rows], inv[ci]
+    order = np.lexsort((pc, pr))
+    return coo_to_csr(n, pr[order].astype(np.int32), pc[order].astype(np.int32), v[order])
+
+
+def t2_like_permuted(g=1108, seed=42):
+    """"T2-like" of SURVEY 8(d): 2-D 5-pt Poisson g x g (n = 1 227 664 at 1108)
+    under a fixed random symmetric permutation that destroys the banded locality."""
+    n, rp, ci, v = poisson_2d_5pt(g)
+    rp2, ci2, v2 = permute_symmetric(n, rp, ci, v, seed)
+    return n, rp2, ci2, v2
+
+
+def diffusion_2d_patch_ordered(g=1104, patch=(4, 8), seed=7, contrast=3.0, coarse=16):
+    """Second thermal2 stand-in: -div(k grad u) on a g x g cell grid, k piecewise
+    constant on coarse x coarse cell blocks with log10 k uniform in
+    +-contrast/2, harmonic-mean edge coefficients, Dirichlet boundary; cells
+    numbered patch by patch (patch[0] x patch[1] cells = 32 consecutive rows),
+    the locality a FEM ordering has and a lexicographic grid lacks: one block of
+    block-Jacobi(32) is one patch.  SPD, <= 5 entries per row, columns sorted."""
+    rng = np.random.default_rng(seed)
+    pi, pj = patch
+    assert g % pi == 0 and g % pj == 0
+    nb = (g + coarse - 1) // coarse
+    kc = 10.0 ** (rng.uniform(-contrast / 2, contrast / 2, size=(nb, nb)))
+    k = np.repeat(np.repeat(kc, coarse, axis=0), coarse, axis=1)[:g, :g]
+    i, j = np.meshgrid(np.arange(g), np.arange(g), indexing="ij")
+    # cell (i, j) -> index: patches row-major, cells row-major inside a patch
+    idx = ((i // pi) * (g // pj) + (j // pj)) * (pi * pj) + (i % pi) * pj + (j % pj)
+    hm = lambda a, b: 2.0 * a * b / (a + b)
+    n = g * g
+    rows, cols, vals = [], [], []
+    diag = np.zeros((g, g))
+    for di, dj in ((-1, 0), (0, -1), (0, 1), (1, 0)):
+        ii, jj = i + di, j + dj
+        inside = (ii >= 0) & (ii < g) & (jj >= 0) & (jj < g)
+        w = np.where(inside, hm(k, k[np.clip(ii, 0, g - 1), np.clip(jj, 0, g - 1)]), k)  # boundary: own k
+        diag += w
+        rows.append(idx[inside])
+        cols.append(idx[ii[inside], jj[inside]])
+        vals.append(-w[inside])
+    rows.append(idx.ravel())
+    cols.append(idx.ravel())
+    vals.append(diag.ravel())
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    order = np.lexsort((cols, rows))
+    rp, ci, v = coo_to_csr(n, rows[order].astype(np.int32), cols[order].astype(np.int32), vals[order])
+    return n, rp, ci, v
+
+
+def at_like(g=108, upwind=0.5):
+    """"AT-like" of SURVEY 8(d): 3-D 7-pt convection-diffusion g^3 (n = 1 259 712
+    at 108), nonsymmetric (upwind term on the k-1 neighbour)."""
+    n, rp, ci, v = poisson_3d_7pt(g)
+    v = v.copy()
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    v[ci == rows - 1] -= upwind
+    v[ci == rows] += upwind
+    return n, rp, ci, v

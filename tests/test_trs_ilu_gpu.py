@@ -218,3 +218,125 @@ def test_sort_by_column_index_and_is_sorted(gk, oracle):
     assert flag.value == 1 == oracle.ref_csr_is_sorted_by_column_index(n, rp, ec)
     gk.csr_is_sorted_by_column_index_i32(stream_ptr(), 0, dev(rp[:1]), cd, ws, 8, ctypes.addressof(flag))
     assert flag.value == 1
+
+
+# ---- analysed solves: LowerTrs / UpperTrs::generate + apply (csrc/trs_levels.hip) ----------
+
+def trs_plan(gk, which, n, rp, ci, v, unit, b, check=None):
+    import gkomi.solvers as solvers
+    plan = solvers.TrsPlan(gk, n, dev(rp), dev(ci), dev(v), which == "lower")
+    nrhs = b.shape[1]
+    x = torch.full((n, nrhs), 777.0, dtype=torch.float64, device="cuda:0")
+    plan.solve(dev(b), x, unit)
+    assert not plan.overrun(), "analysed triangular solve hit its spin bound"
+    if check is not None:
+        check(plan)
+    return host(x)
+
+
+def reference_levels(n, rp, ci, lower):
+    lvl = np.zeros(n, np.int64)
+    order = range(n) if lower else range(n - 1, -1, -1)
+    for r in order:
+        cols = ci[rp[r]:rp[r + 1]]
+        deps = cols[cols < r] if lower else cols[cols > r]
+        if len(deps):
+            lvl[r] = lvl[deps].max() + 1
+    return lvl
+
+
+@pytest.mark.parametrize("which", ["lower", "upper"])
+def test_trs_plan_known_answers(gk, which):
+    g = G[which]
+    for case in g["cases"]:
+        rp, ci, v = matgen.dense_to_csr(g[case["matrix"]])
+        b = np.array(case["b"], np.float64)
+        x = trs_plan(gk, which, len(b), rp, ci, v, case["unit"], b)
+        assert matgen.rel_err(x, case["expect"]) <= case["tol"], case["name"]
+
+
+@pytest.mark.parametrize("which", ["lower", "upper"])
+@pytest.mark.parametrize("n,band", [(1, None), (63, None), (64, None), (257, None), (5000, 40), (100_000, 700)])
+@pytest.mark.parametrize("unit", [False, True])
+def test_trs_plan_bitexact_vs_oracle(gk, oracle, which, n, band, unit):
+    rp, ci, v = random_triangular(n, which == "lower", seed=n + unit, band=band)
+    rng = np.random.default_rng(5)
+
+    def check(plan):
+        if n <= 5000:   # the analysis itself: level count and the level-sorted permutation
+            lvl = reference_levels(n, rp, ci, which == "lower")
+            assert plan.nlevels == int(lvl.max()) + 1 and plan.nslices == (n + 63) // 64
+            perm = host(plan.plan[256:256 + 4 * plan.nslices * 64].view(torch.int32))
+            assert np.array_equal(perm[:n], np.argsort(lvl, kind="stable"))
+            assert np.all(perm[n:] == -1)
+
+    for nrhs in (1, 2):
+        b = rng.standard_normal((n, nrhs))
+        e = np.zeros_like(b)
+        (oracle.ref_lower_trs_solve if which == "lower" else oracle.ref_upper_trs_solve)(
+            n, nrhs, rp, ci, v, int(unit), b, nrhs, e, nrhs)
+        x = trs_plan(gk, which, n, rp, ci, v, unit, b, check)
+        assert np.array_equal(x, e)
+
+
+def test_trs_plan_rows_longer_than_the_register_window(gk, oracle):
+    # up to 40 dependencies per row: several windows of 8, padding inside a slice
+    n = 3000
+    rp, ci, v = random_triangular(n, True, seed=9, max_off=40, band=300)
+    b = np.random.default_rng(2).standard_normal((n, 1))
+    e = np.zeros_like(b)
+    oracle.ref_lower_trs_solve(n, 1, rp, ci, v, 0, b, 1, e, 1)
+    assert np.array_equal(trs_plan(gk, "lower", n, rp, ci, v, False, b), e)
+
+
+def test_trs_plan_long_dependency_chain(gk, oracle):
+    # every row its own level: slices straddle 64 levels, lanes publish one by one
+    n = 3000
+    rp = np.arange(0, 2 * n + 1, 2, dtype=np.int32) - 1
+    rp[0] = 0
+    ci = np.empty(2 * n - 1, np.int32)
+    v = np.empty(2 * n - 1)
+    ci[0], v[0] = 0, 2.0
+    ci[1::2], v[1::2] = np.arange(0, n - 1), -1.0
+    ci[2::2], v[2::2] = np.arange(1, n), 2.0
+    b = np.ones((n, 1))
+    e = np.zeros_like(b)
+    oracle.ref_lower_trs_solve(n, 1, rp, ci, v, 0, b, 1, e, 1)
+    assert np.array_equal(trs_plan(gk, "lower", n, rp, ci, v, False, b,
+                                   lambda plan: (plan.nlevels == n) or pytest.fail("levels")), e)
+
+
+def test_trs_plan_nan_results_do_not_hang(gk, oracle):
+    rp, ci, v = matgen.dense_to_csr([[1e-300, 0, 0], [1.0, 2.0, 0], [1.0, 1.0, 3.0]])
+    v = v.copy()
+    v[0] = 0.0
+    x = trs_plan(gk, "lower", 3, rp, ci, v, False, np.zeros((3, 1)))
+    assert np.isnan(x).all()
+
+
+def test_trs_plan_ilu0_apply_and_refresh(gk, oracle):
+    """Ilu::apply with analysed factors on config 4's structure; new values through the
+    numeric phase alone (the symbolic analysis depends on the sparsity pattern only)."""
+    import gkomi.solvers as solvers
+    n, rp, ci, v = matgen.poisson_3d_7pt(24)
+    f = ilu_util.oracle_par_ilu(oracle, n, rp, ci, v)
+    lrp, lc, lv = f["L"]
+    urp, uc, uv = f["U"]
+    b = np.sin(0.1 * np.arange(n)).reshape(n, 1)
+    y, e = np.zeros_like(b), np.zeros_like(b)
+    oracle.ref_lower_trs_solve(n, 1, lrp, lc, lv, 0, b, 1, y, 1)
+    oracle.ref_upper_trs_solve(n, 1, urp, uc, uv, 0, y, 1, e, 1)
+    pl = solvers.TrsPlan(gk, n, dev(lrp), dev(lc), dev(lv), True)
+    pu = solvers.TrsPlan(gk, n, dev(urp), dev(uc), dev(uv), False)
+    assert pl.nlevels == pu.nlevels == 3 * 23 + 1
+    yd = torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")
+    xd = torch.zeros_like(yd)
+    pl.solve(dev(b), yd)
+    pu.solve(yd, xd)
+    assert np.array_equal(host(yd), y) and np.array_equal(host(xd), e)
+    lv2 = lv * 1.25
+    y2 = np.zeros_like(b)
+    oracle.ref_lower_trs_solve(n, 1, lrp, lc, lv2, 0, b, 1, y2, 1)
+    pl.refresh(dev(lv2))
+    pl.solve(dev(b), yd)
+    assert np.array_equal(host(yd), y2) and not pl.overrun() and not pu.overrun()

@@ -57,6 +57,11 @@ variants = {"stream_v0(256,1,2048)": STREAM, "v1(256,2,4096)": STREAM | (1 << 8)
             "v11(128,1,768)": STREAM | (11 << 8), "v12(256,1,1024)": STREAM | (12 << 8), "v13(384,1,2304)": STREAM | (13 << 8),
             "v9_noswz": STREAM | (9 << 8) | (1 << 16), "v11_noswz": STREAM | (11 << 8) | (1 << 16),
             "v14(256,1,1536,nt)": STREAM | (14 << 8), "v14_noswz": STREAM | (14 << 8) | (1 << 16)}
+SPLIT = 4
+# nonzero-split kernel over srow: (tile, variant bits: 2 = nontemporal, 4 = write-through stores, 256 = no XCD chunking)
+for tile in (1024, 1536, 2048):
+    for name, bits in (("", 0), ("_nt", 2), ("_wt", 4), ("_nt_wt", 6), ("_noswz", 256), ("_nt_noswz", 258), ("_nt_wt_noswz", 262)):
+        variants[f"split{tile}{name}"] = (SPLIT | ((bits & 0xff) << 8) | ((bits >> 8) << 16), tile)
 if os.environ.get("TUNE_ONLY"):
     variants = {k: v for k, v in variants.items() if any(t in k for t in os.environ["TUNE_ONLY"].split(","))}
 extra = [a for a in sys.argv[2:]]
@@ -64,12 +69,36 @@ for e in extra:
     variants[f"custom_{e}"] = int(e, 0)
 
 
+srows = {}
+
+
+def srow_of(copy_index, tile):
+    """every copy carries its own srow (like its own row_ptrs): cold means cold"""
+    key = (copy_index, tile)
+    if key not in srows:
+        cnt = int(gk.csr_srow_entries(nnz, tile))
+        t = torch.empty(cnt, dtype=torch.int32, device="cuda")
+        gk.csr_make_srow_i32(s, n, nnz, copies[copy_index][0], tile, t, cnt)
+        srows[key] = t
+    return srows[key]
+
+
 def run(strategy, cold, reps=200):
+    tile = None
+    if isinstance(strategy, tuple):
+        strategy, tile = strategy
+        for i in range(ncopies):
+            srow_of(i, tile)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(reps):
-        c = copies[i % ncopies] if cold else copies[0]
-        gk.csr_spmv_f64_i32(s, n, n, 1, nnz, c[0], c[1], c[2], c[3], 1, c[4], 1, None, None, strategy, 5)
+        j = i % ncopies if cold else 0
+        c = copies[j]
+        if tile is None:
+            gk.csr_spmv_f64_i32(s, n, n, 1, nnz, c[0], c[1], c[2], c[3], 1, c[4], 1, None, None, strategy, 5)
+        else:
+            gk.csr_spmv_srow_f64_i32(s, n, n, 1, nnz, c[0], c[1], c[2], c[3], 1, c[4], 1, None, None, strategy, 5,
+                                     srows[(j, tile)], tile)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps

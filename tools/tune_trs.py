@@ -29,7 +29,22 @@ def run(name, n, rp, ci, v, reps=5):
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e3 / reps
     flag = ctypes.c_int(0); gk.trs_check_overrun(s, tws, ctypes.addressof(flag))
-    print(f"{name:34s} n={n:8d} nnz={len(v):9d}  {t:10.1f} us  {t/n*1e3:8.2f} ns/row  overrun={flag.value}")
+    xe = x.clone()
+    # the analysed solve (LowerTrs::generate = level analysis, then the level-ordered kernel)
+    import time, gkomi.solvers as solvers
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    plan = solvers.TrsPlan(gk, n, rpd, cid, vd, True)
+    torch.cuda.synchronize(); t_an = (time.perf_counter() - t0) * 1e3
+    fp = lambda: plan.solve(b, x)
+    fp(); torch.cuda.synchronize()
+    same = bool(torch.equal(x, xe))
+    e0.record()
+    for _ in range(reps): fp()
+    e1.record(); torch.cuda.synchronize()
+    tp = e0.elapsed_time(e1) * 1e3 / reps
+    print(f"{name:34s} n={n:8d} nnz={len(v):9d}  {t:10.1f} us  {t/n*1e3:8.2f} ns/row  overrun={flag.value} | "
+          f"analysed: {tp:10.1f} us  levels {plan.nlevels:6d}  slots {plan.entries:9d}  analysis {t_an:7.1f} ms  "
+          f"identical={same} overrun={int(plan.overrun())}")
 
 
 quick = os.environ.get("TRS_QUICK")
