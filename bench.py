@@ -1,30 +1,42 @@
 #!/usr/bin/env python3
-"""Headline benchmark (BASELINE.json): CSR SpMV GFLOP/s + achieved HBM GB/s on
-the 1M-row 5-pt Poisson matrix (configs[1], SURVEY.md 8(d) "P2"), plus CG
-iterations/s to 1e-10 on the same matrix, with the reference's omp/ path
-(restated in oracle/, kind "port") timed on the host cores in the same run.
+"""Headline benchmark (BASELINE.json): CSR SpMV GFLOP/s + achieved HBM GB/s, CG
+iterations/s to 1e-10, next to the reference's omp/ path (restated in oracle/,
+kind "port") on the host cores of the same box.
 
     python bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path = one `Csr::apply` (y = A x) over the
-rank's matrix.  Inputs are resident in HBM before the timed region.  The
-headline `value` is measured COLD: steps rotate over enough independent
-copies of (A, x, y) that the 256 MiB Infinity Cache cannot hold them between
-two uses (the 80 MB problem would otherwise be served on-die); the warm
-(same-matrix, reference benchmark/spmv methodology) figure is reported next
-to it under "warm".
-
-N > 1 (one process per GPU under torch.distributed / RCCL): weak scaling of
-the row-partitioned distributed SpMV -- every rank owns a 1000 x 1000 slab of
-a (1000 N) x 1000 grid, exchanges its two boundary grid rows with its
-neighbours over RCCL and applies local + non-local parts
-(core/distributed/matrix.cpp:307-335).
+N = 1  (configs[1], SURVEY.md 8(d) "P2"): a step = one `Csr::apply` (y = A x) on
+       the 1M-row 5-pt Poisson matrix.  Inputs are resident in HBM before the
+       timed region.  `value` is measured COLD: steps rotate over 8 independent
+       copies of (A, srow, x, y) -- 640 MB, so the 256 MiB Infinity Cache cannot
+       serve the 80 MB problem on-die -- and the strategy word carries
+       GKOMI_CSR_STREAMING, the caller's statement that its working set exceeds
+       the cache (nontemporal matrix streams).  The warm figure (same matrix
+       every step = the reference's benchmark/spmv methodology, automatic
+       strategy) is reported under "warm", CG on P2 under "cg", and the one-GPU
+       anchor of the multi-GPU curve (P3: 256^3 7-pt Poisson, SpMV + CG to
+       1e-10) under "p3".
+N > 1  (configs[4], "P3", one process per GPU under torch.distributed): STRONG
+       scaling of the row-partitioned 16.7M-row 256^3 7-pt Poisson problem:
+       a step = one distributed apply (pack -> halo exchange over RCCL || local
+       SpMV -> non-local rows), `value` = 2 nnz(global) / max-over-ranks time;
+       "cg" = row-partitioned CG to 1e-10 without an iteration cap (native fused
+       driver, csrc/dist_cg.hip, over its own RCCL communicator).
+       GKOMI_BENCH_FORCE_DIST=1 runs that code path with a world of one rank.
 """
-import argparse
-import json
 import os
-import sys
-import time
+
+# the CPU baseline's OpenMP runtime reads these when it starts; the
+# unbound variant runs in a child process that overrides them
+os.environ.setdefault("OMP_PROC_BIND", "true")
+os.environ.setdefault("OMP_PLACES", "cores")
+
+import argparse  # noqa: E402
+import json  # noqa: E402
+import statistics  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "repo-8852-ginkgo_amd"), os.path.join(ROOT, "tests")):
@@ -32,10 +44,11 @@ for p in (os.path.join(ROOT, "repo-8852-ginkgo_amd"), os.path.join(ROOT, "tests"
         sys.path.insert(0, p)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, MI355X_MICROARCH.md "HBM3E peak BW"
-GRID = 1000            # P2: 1000 x 1000 grid per GPU
+GRID = 1000            # P2: 1000 x 1000 grid
+TRIALS = 3
+GKOMI_CSR_STREAMING = 1 << 24
 
 
 def algorithmic_bytes(nrows, ncols, nnz):
@@ -61,22 +74,92 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--strategy", type=int, default=0, help="C-ABI strategy word (0 = automatic)")
+    ap.add_argument("--strategy", type=int, default=0, help="C-ABI strategy word of the cold leg (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cg", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--dist-cg-iters", type=int, default=300, help="iteration cap of the N > 1 CG leg")
+    ap.add_argument("--no-p3", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--p3-grid", type=int, default=256, help="grid of the 3-D problem (256 = BASELINE config 5)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def dev(a, device):
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+# ---- CPU baseline (child processes: the OpenMP binding is fixed when the runtime starts) ----
+
+def cpu_baseline_child(seconds):
+    """Reference omp/ CSR SpMV + CG (oracle port, omp/matrix/csr_kernels.cpp:76-99,
+    core/solver/cg.cpp:107-193 on omp kernels) on this host's cores, first-touch
+    placed; prints one JSON line."""
+    import matgen
+    import oracle_lib
+    orc = oracle_lib.load()
+    n, rp, ci, v = matgen.poisson_2d_5pt(GRID)
+    x = np.sin(0.01 * np.arange(n))
+    nnz = int(rp[-1])
+    h = orc.omp_bench_create(n, rp, ci, v, x)
+    orc.omp_bench_spmv(h, 3)
+    t0 = time.perf_counter()
+    orc.omp_bench_spmv(h, 20)
+    per = (time.perf_counter() - t0) / 20
+    reps = max(20, int(seconds / max(per, 1e-6)))
+    t0 = time.perf_counter()
+    orc.omp_bench_spmv(h, reps)
+    el = time.perf_counter() - t0
+    y = np.zeros(n)
+    orc.omp_bench_get_y(h, y)
+    s = np.sin(np.arange(n, dtype=np.float64))
+    s /= np.linalg.norm(s)
+    b = np.zeros((n, 1))
+    orc.ref_csr_spmv(n, 1, rp, ci, v, s.reshape(n, 1), 1, b, 1)
+    xs, rel = np.zeros(n), np.zeros(1)
+    t0 = time.perf_counter()
+    its = int(orc.omp_bench_cg(h, b[:, 0].copy(), xs, 20000, 1e-10, rel))
+    el_cg = time.perf_counter() - t0
+    orc.omp_bench_destroy(h)
+    numa = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node")]) \
+        if os.path.isdir("/sys/devices/system/node") else 1
+    out = {"value": round(2.0 * nnz * reps / el / 1e9, 3), "unit": "GFLOP/s",
+           "cores": os.cpu_count(), "threads": int(orc.omp_bench_threads()), "numa_nodes": numa, "kind": "port",
+           "omp_proc_bind": os.environ.get("OMP_PROC_BIND", ""), "omp_places": os.environ.get("OMP_PLACES", ""),
+           "sample": f"{reps} x omp csr::spmv on the same 1M-row 5-pt Poisson matrix ({el:.1f} s), "
+                     "arrays first-touched by the threads that stream them",
+           "gbs": round(algorithmic_bytes(n, n, nnz) * reps / el / 1e9, 2),
+           "cg": {"iterations": its, "seconds": round(el_cg, 4), "iters_per_sec": round(its / el_cg, 1),
+                  "final_residual_norm_rel": float(rel[0]),
+                  "sample": "one omp CG solve to 1e-10 (Cg::apply_dense_impl on omp kernels), sinus rhs: the GPU cg entry's system"},
+           "y_checksum": float(np.sum(y))}
+    print(json.dumps(out))
 
 
-TRIALS = 3
+def cpu_baseline(seconds):
+    """bound (OMP_PROC_BIND=true, OMP_PLACES=cores) and unbound runs; the faster SpMV is the headline."""
+    runs = {}
+    for name, env in (("bound", {"OMP_PROC_BIND": "true", "OMP_PLACES": "cores"}),
+                      ("unbound", {"OMP_PROC_BIND": "false", "OMP_PLACES": ""})):
+        e = dict(os.environ)
+        e.update(env)
+        if not env["OMP_PLACES"]:
+            e.pop("OMP_PLACES", None)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-seconds", str(seconds)],
+                               env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            runs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as ex:  # noqa: BLE001 - reported in the line
+            runs[name] = {"error": repr(ex)[:200]}
+    good = {k: v for k, v in runs.items() if "value" in v}
+    if not good:
+        return {"error": runs}
+    best = max(good, key=lambda k: good[k]["value"])
+    out = dict(good[best])
+    out["binding"] = best
+    out["runs"] = {k: ({"gflops": v["value"], "gbs": v["gbs"], "cg_iters_per_sec": v["cg"]["iters_per_sec"]}
+                       if "value" in v else v) for k, v in runs.items()}
+    return out
 
 
-def time_loop(fn, steps, barrier):
+# ---- timing helpers ----
+
+def time_loop(torch, fn, steps, barrier):
     """Exactly `steps` calls bracketed by barrier + synchronize; returns
     (wall seconds, HIP-event seconds on the launch stream)."""
     barrier()
@@ -94,45 +177,12 @@ def time_loop(fn, steps, barrier):
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
 
 
-def cpu_baseline(n, rp, ci, v, x, seconds):
-    """Reference omp/ CSR SpMV (oracle port, omp/matrix/csr_kernels.cpp:76-99)
-    on this host's cores, bounded to ~`seconds` of work."""
-    import oracle_lib
-    orc = oracle_lib.load()
-    y = np.empty((n, 1))
-    orc.omp_csr_spmv(n, 1, rp, ci, v, x, 1, y, 1)  # warm-up, first touch
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        orc.omp_csr_spmv(n, 1, rp, ci, v, x, 1, y, 1)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or reps >= 100000:
-            break
-    nnz = int(rp[-1])
-    base = {
-        "value": round(2.0 * nnz * reps / el / 1e9, 3), "unit": "GFLOP/s",
-        "cores": int(orc.oracle_num_threads()), "kind": "port",
-        "sample": f"{reps} x omp csr::spmv on the same 1M-row 5-pt Poisson matrix ({el:.1f} s)",
-        "gbs": round(algorithmic_bytes(n, n, nnz) * reps / el / 1e9, 2),
-    }
-    # the CG leg on the same cores: omp/ path of Cg::apply (oracle/cg.c omp_cg_solve),
-    # same system, right-hand side and criterion as the GPU "cg" entry
-    s = np.sin(np.arange(n, dtype=np.float64))
-    s /= np.linalg.norm(s)
-    b = np.empty((n, 1))
-    orc.omp_csr_spmv(n, 1, rp, ci, v, s.reshape(n, 1), 1, b, 1)
-    xs, rel = np.zeros(n), np.zeros(1)
-    t0 = time.perf_counter()
-    its = int(orc.omp_cg_solve(n, rp, ci, v, b[:, 0].copy(), xs, 20000, 1e-10, rel))
-    el_cg = time.perf_counter() - t0
-    base["cg"] = {"iterations": its, "seconds": round(el_cg, 4), "iters_per_sec": round(its / el_cg, 1),
-                  "final_residual_norm_rel": float(rel[0]),
-                  "sample": "one omp CG solve to 1e-10, sinus rhs (the GPU cg entry's system)"}
-    return base, y
-
-
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        cpu_baseline_child(args.cpu_seconds)
+        return
+    import torch
     # stdout carries exactly one JSON line: whatever libraries print on fd 1
     # (RCCL's version banner, ...) is sent to stderr instead
     sys.stdout.flush()
@@ -141,11 +191,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # GKOMI_BENCH_FORCE_DIST=1 rehearses the N > 1 code path (Partition,
-    # halo plan, RCCL all-to-all-v, distributed CG) with a world of one rank
     distributed = world > 1 or os.environ.get("GKOMI_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    dist = None
     if distributed:
         import torch.distributed as dist
         if not dist.is_initialized():
@@ -164,177 +213,262 @@ def main():
     import matgen
     gk = gkomi.lib()
     stream = torch.cuda.current_stream().cuda_stream
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
-    n, rp, ci, v = matgen.poisson_2d_5pt(GRID)
-    nnz = int(rp[-1])
-    x_host = np.sin(0.01 * (np.arange(n) + rank * n)).reshape(n, 1)
-    bytes_per_launch = algorithmic_bytes(n, n, nnz)
-    flops_per_launch = 2.0 * nnz
+    def timed_region(step_fn, steps):
+        """TRIALS timed regions of exactly `steps` steps (barrier + synchronize on both sides, max
+        over ranks per region).  The line reports the best region (the box's host stalls a call by
+        ~10 ms every few hundred ms, tools/stall_probe.py) next to the median and all of them."""
+        regions = []
+        for _ in range(TRIALS):
+            wall, ev = time_loop(torch, step_fn, steps, barrier)
+            if distributed:
+                t = torch.tensor([wall, ev], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                wall, ev = float(t[0].item()), float(t[1].item())
+            regions.append((wall, ev))
+        best = min(regions)
+        return best, regions
 
-    if distributed:
-        import gkomi.distributed as gd
-        # same cache state as the one-GPU line: every rank rotates over 8 copies
-        # of its slab (local + non-local CSR, x, y: ~80 MB each)
-        ncopies = 8
-        copies = [gd.poisson_slab_matrix(gk, GRID, rank, world, device) for _ in range(ncopies)]
-        dmat = copies[0]
-        flops_per_launch = 2.0 * dmat.global_nnz_local_rows
-        xs = [dev(x_host, device) for _ in range(ncopies)]
-        ys = [torch.empty((n, 1), dtype=torch.float64, device=device) for _ in range(ncopies)]
+    def spread(regions, steps):
+        us = [w / steps * 1e6 for w, _ in regions]
+        return {"best_us_per_step": round(min(us), 3), "median_us_per_step": round(statistics.median(us), 3),
+                "all_us_per_step": [round(u, 3) for u in us]}
 
-        def step_cold(i):
-            copies[i % ncopies].apply(xs[i % ncopies], ys[i % ncopies])
-        step_warm = step_cold
-    else:
-        # enough copies that a copy's lines are evicted from the 256 MiB
-        # Infinity Cache before it is used again
-        ncopies = 8
+    def make_srow(rp_d, n, nnz):
+        tile = int(gk.csr_srow_tile())
+        t = torch.empty(int(gk.csr_srow_entries(nnz, tile)), dtype=torch.int32, device=device)
+        gk.csr_make_srow_i32(stream, n, nnz, rp_d, tile, t, t.numel())
+        return t, tile
+
+    out = {}
+    if not distributed:
+        # ---------------- N = 1: P2, configs[1] ----------------
+        n, rp, ci, v = matgen.poisson_2d_5pt(GRID)
+        nnz = int(rp[-1])
+        x_host = np.sin(0.01 * np.arange(n)).reshape(n, 1)
+        bytes_per_launch = algorithmic_bytes(n, n, nnz)
+        flops_per_launch = 2.0 * nnz
+        ncopies = 8  # a copy's lines are evicted from the 256 MiB Infinity Cache before its next use
         copies = []
         for _ in range(ncopies):
-            copies.append((dev(rp, device), dev(ci, device), dev(v, device),
-                           dev(x_host, device), torch.empty((n, 1), dtype=torch.float64, device=device)))
+            c = [dev(rp), dev(ci), dev(v), dev(x_host), torch.empty((n, 1), dtype=torch.float64, device=device)]
+            c += list(make_srow(c[0], n, nnz))   # Csr::make_srow: part of the matrix, like its row_ptrs
+            copies.append(c)
+        cold_strategy = args.strategy if args.strategy else GKOMI_CSR_STREAMING
 
-        def launch(c):
-            gk.csr_spmv_f64_i32(stream, n, n, 1, nnz, c[0], c[1], c[2], c[3], 1, c[4], 1, None, None,
-                                args.strategy, 5)
+        def launch(c, strategy):
+            gk.csr_spmv_srow_f64_i32(stream, n, n, 1, nnz, c[0], c[1], c[2], c[3], 1, c[4], 1, None, None,
+                                     strategy, 5, c[5], c[6])
 
-        def step_cold(i):
-            launch(copies[i % ncopies])
-
-        def step_warm(i):
-            launch(copies[0])
-
-    for i in range(args.warmup):
-        step_cold(i)
-    # TRIALS timed regions of exactly `steps` steps each (barrier + synchronize on
-    # both sides, max over ranks per region); the line reports the best region:
-    # the host of the GPU box hiccups for ~10 ms every few hundred ms
-    # (tools/stall_probe.py), which a 7 ms region either catches or not
-    def timed_region(step_fn):
-        best = None
-        for _ in range(TRIALS):
-            wall, ev = time_loop(step_fn, args.steps, barrier)
-            if distributed:
-                t = torch.tensor([wall], dtype=torch.float64, device=device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                wall = float(t.item())
-            if best is None or wall < best[0]:
-                best = (wall, ev)
-        return best
-
-    wall, ev = timed_region(step_cold)
-    ms_per_step = wall / args.steps * 1e3
-    gflops = flops_per_launch * world * args.steps / wall / 1e9
-
-    out = {
-        "metric": "CSR SpMV GFLOP/s (fp64, 1M-row 5-pt Poisson per GPU)",
-        "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-        "timing": f"best of {TRIALS} timed regions of {args.steps} steps",
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "benchmark/spmv: CSR fp64/int32 y=Ax on 1000x1000 5-pt Poisson "
-                               "(n=1e6, nnz=4996000) per GPU, x=sin(0.01 i)",
-                   "cache_state": f"cold: rotating over {ncopies} copies (> 256 MiB Infinity Cache)",
-                   "partition": "one GPU" if not distributed else f"{world} row slabs, RCCL halo exchange",
-                   "strategy": args.strategy},
-    }
-
-    if rank == 0:
-        # dominant kernel's launch duration from HIP events on the launch
-        # stream over the timed region (back-to-back launches: includes the
-        # ~1.5 us dependent-launch boundary, so it is an upper bound of the
-        # rocprofv3 kernel duration in profiles/)
+        step_cold = lambda i: launch(copies[i % ncopies], cold_strategy)
+        step_warm = lambda i: launch(copies[0], 0)
+        for i in range(args.warmup):
+            step_cold(i)
+        (wall, ev), regions = timed_region(step_cold, args.steps)
+        out = {
+            "metric": "CSR SpMV GFLOP/s (fp64, 1M-row 5-pt Poisson per GPU)",
+            "value": round(flops_per_launch * args.steps / wall / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 5),
+            "timing": f"best of {TRIALS} timed regions of {args.steps} steps", "timing_spread": spread(regions, args.steps),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "benchmark/spmv: CSR fp64/int32 y=Ax on 1000x1000 5-pt Poisson "
+                                   "(n=1e6, nnz=4996000), x=sin(0.01 i)",
+                       "cache_state": f"cold: rotating over {ncopies} copies (> 256 MiB Infinity Cache)",
+                       "partition": "one GPU", "strategy": cold_strategy,
+                       "strategy_note": "automatic + GKOMI_CSR_STREAMING (caller's working set exceeds the "
+                                        "Infinity Cache); the matrix carries its srow (Csr::make_srow)"},
+        }
         kern_s = ev / args.steps
         achieved = bytes_per_launch / kern_s / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                           "traffic": traffic_from_profiles() if not distributed else None,
-                           "kernel": "csr_stream_kernel" if not distributed else "distributed apply",
-                           "bytes_per_launch": bytes_per_launch,
+        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(),
+                           "kernel": "csr_split_kernel", "bytes_per_launch": bytes_per_launch,
                            "us_per_launch": round(kern_s * 1e6, 3)}
-    if not distributed:
         for i in range(args.warmup):
             step_warm(i)
-        wwall, wev = timed_region(step_warm)
+        (wwall, wev), wregions = timed_region(step_warm, args.steps)
         out["warm"] = {"gflops": round(flops_per_launch * args.steps / wwall / 1e9, 2),
                        "gbs": round(bytes_per_launch * args.steps / wev / 1e9, 1),
-                       "us_per_launch": round(wev / args.steps * 1e6, 3),
-                       "note": "same matrix every step (benchmark/spmv methodology); 80 MB working "
-                               "set is Infinity-Cache resident"}
+                       "us_per_launch": round(wev / args.steps * 1e6, 3), "timing_spread": spread(wregions, args.steps),
+                       "note": "same matrix every step (benchmark/spmv methodology), automatic strategy; the 80 MB "
+                               "working set is Infinity-Cache resident"}
 
-    if not distributed and not args.no_cg and hasattr(gk, "cg_solve_f64_i32"):
         import gkomi.solvers as solvers
-        c = copies[0]
-        s = np.sin(np.arange(n, dtype=np.float64))
-        s /= np.linalg.norm(s)
-        sb = dev(s.reshape(n, 1), device)
-        b = torch.empty((n, 1), dtype=torch.float64, device=device)
-        gk.csr_spmv_f64_i32(stream, n, n, 1, nnz, c[0], c[1], c[2], sb, 1, b, 1, None, None, 0, 5)
 
-        def timed_cg(rhs):
-            solvers.cg_solve(gk, n, c[0], c[1], c[2], rhs, max_iters=20000, reduction=1e-10, check_every=32)  # warm-up
-            # best of 3 whole solves: now and then one call stalls for ~70 ms on
-            # this box (seen in every driver, also in plain torch calls), which
-            # says nothing about the solver
-            best = None
-            for _ in range(3):
+        def timed_cg(nn, a, rhs, check_every=32):
+            solvers.cg_solve(gk, nn, a[0], a[1], a[2], rhs, max_iters=50000, reduction=1e-10, check_every=check_every)
+            runs = []
+            for _ in range(3):  # best of 3 whole solves (the same host stalls), all of them reported
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                res = solvers.cg_solve(gk, n, c[0], c[1], c[2], rhs, max_iters=20000, reduction=1e-10, check_every=32)
+                res = solvers.cg_solve(gk, nn, a[0], a[1], a[2], rhs, max_iters=50000, reduction=1e-10,
+                                       check_every=check_every)
                 torch.cuda.synchronize()
-                el = time.perf_counter() - t0
-                if best is None or el < best[1]:
-                    best = (res, el)
-            return best
+                runs.append((time.perf_counter() - t0, res))
+            el, res = min(runs, key=lambda r: r[0])
+            return res, el, [round(r[0], 5) for r in runs]
 
-        # per iteration: 11 n values + matrix = 88 MB + 64 MB at P2
-        cg_bytes = 11 * 8 * n + (12 * nnz + 4 * (n + 1))
-        res, el = timed_cg(b)
-        xerr = float(torch.linalg.norm(res["x"] - sb) / torch.linalg.norm(sb))
-        out["cg"] = {"metric": "CG iters/sec to 1e-10 (fused driver, Identity preconditioner, sinus rhs "
-                               "b = A s/|s|, benchmark/solver default)",
-                     "iterations": res["iterations"], "seconds": round(el, 5), "timing": "best of 3 solves",
-                     "iters_per_sec": round(res["iterations"] / el, 1),
-                     "achieved_gbs": round(cg_bytes * res["iterations"] / el / 1e9, 1),
-                     "final_residual_norm_rel": res["rel_residual"], "solution_rel_err": xerr,
-                     "converged": bool(res["converged"])}
-        ones = torch.ones((n, 1), dtype=torch.float64, device=device)
-        res, el = timed_cg(ones)
-        out["cg_rhs_ones"] = {"iterations": res["iterations"], "seconds": round(el, 5),
-                              "iters_per_sec": round(res["iterations"] / el, 1),
-                              "achieved_gbs": round(cg_bytes * res["iterations"] / el / 1e9, 1),
-                              "final_residual_norm_rel": res["rel_residual"], "converged": bool(res["converged"])}
+        def sinus_system(nn, a, nz, hint):
+            s = np.sin(np.arange(nn, dtype=np.float64))
+            s /= np.linalg.norm(s)
+            sb = dev(s.reshape(nn, 1))
+            b = torch.empty((nn, 1), dtype=torch.float64, device=device)
+            gk.csr_spmv_f64_i32(stream, nn, nn, 1, nz, a[0], a[1], a[2], sb, 1, b, 1, None, None, 0, hint)
+            return sb, b
 
-    if distributed and not args.no_cg:
-        # config 5 in small: row-partitioned CG (core/solver/cg.cpp on distributed
-        # vectors: local kernels + all-reduced dots, criterion on every iteration)
-        nloc = dmat.num_local_rows
-        bd = torch.ones((nloc, 1), dtype=torch.float64, device=device)
-        xd = torch.zeros((nloc, 1), dtype=torch.float64, device=device)
-        gd.cg(dmat, bd, xd, max_iters=50, reduction=1e-10)  # warm-up
-        xd.zero_()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        its, conv = gd.cg(dmat, bd, xd, max_iters=args.dist_cg_iters, reduction=1e-10)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        t = torch.tensor([el], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-        out["cg"] = {"metric": "row-partitioned CG iterations/sec (reference kernel sequence, criterion evaluated "
-                               "on the device every iteration, b = 1)", "iterations": int(its), "converged": bool(conv),
-                     "seconds": round(el, 5), "iters_per_sec": round(its / el, 1),
-                     "global_rows": int(n) * world}
+        if not args.no_cg:
+            c = copies[0]
+            sb, b = sinus_system(n, c, nnz, 5)
+            cg_bytes = 11 * 8 * n + (12 * nnz + 4 * (n + 1))  # per iteration: 11 n values + matrix (DESIGN.md 4.3)
+            res, el, all_s = timed_cg(n, c, b)
+            out["cg"] = {"metric": "CG iters/sec to 1e-10 (fused driver, Identity preconditioner, sinus rhs "
+                                   "b = A s/|s|, benchmark/solver default)",
+                         "iterations": res["iterations"], "seconds": round(el, 5), "timing": "best of 3 solves",
+                         "all_seconds": all_s, "iters_per_sec": round(res["iterations"] / el, 1),
+                         "achieved_gbs": round(cg_bytes * res["iterations"] / el / 1e9, 1),
+                         "final_residual_norm_rel": res["rel_residual"],
+                         "solution_rel_err": float(torch.linalg.norm(res["x"] - sb) / torch.linalg.norm(sb)),
+                         "converged": bool(res["converged"])}
+            ones = torch.ones((n, 1), dtype=torch.float64, device=device)
+            res, el, all_s = timed_cg(n, c, ones)
+            out["cg_rhs_ones"] = {"iterations": res["iterations"], "seconds": round(el, 5), "all_seconds": all_s,
+                                  "iters_per_sec": round(res["iterations"] / el, 1),
+                                  "achieved_gbs": round(cg_bytes * res["iterations"] / el / 1e9, 1),
+                                  "final_residual_norm_rel": res["rel_residual"], "converged": bool(res["converged"])}
+        got_p2 = copies[0][4].cpu().numpy().copy()
 
-    if rank == 0 and not distributed and not args.no_cpu_baseline:
-        base, y_cpu = cpu_baseline(n, rp, ci, v, x_host, args.cpu_seconds)
-        out["cpu_baseline"] = base
-        # the baseline doubles as an end-of-run parity check of what was timed
-        got = copies[0][4].cpu().numpy()
-        out["parity_vs_oracle"] = "bit-exact" if np.array_equal(got, y_cpu) else \
-            f"rel err {matgen.rel_err(got, y_cpu):.3e}"
+        if not args.no_p3:
+            # the one-GPU anchor of the strong-scaling curve: BASELINE config 5's matrix on one GPU
+            del copies[1:]
+            g = args.p3_grid
+            n3, rp3, ci3, v3 = matgen.poisson_3d_7pt(g)
+            nnz3 = int(rp3[-1])
+            a3 = [dev(rp3), dev(ci3), dev(v3)]
+            del rp3, ci3, v3
+            x3 = dev(np.sin(0.01 * np.arange(n3)).reshape(n3, 1))
+            y3 = torch.empty((n3, 1), dtype=torch.float64, device=device)
+            srow3, tile3 = make_srow(a3[0], n3, nnz3)
+            step3 = lambda i: gk.csr_spmv_srow_f64_i32(stream, n3, n3, 1, nnz3, a3[0], a3[1], a3[2], x3, 1, y3, 1,
+                                                       None, None, 0, 7, srow3, tile3)
+            for i in range(5):
+                step3(i)
+            steps3 = max(10, args.steps // 10)
+            (w3, e3), r3 = timed_region(step3, steps3)
+            b3 = algorithmic_bytes(n3, n3, nnz3)
+            p3 = {"workload": f"{g}^3 7-pt Poisson (n={n3}, nnz={nnz3}) on one GPU: the N=1 point of the N>1 lines",
+                  "spmv_gflops": round(2.0 * nnz3 * steps3 / w3 / 1e9, 2), "spmv_us": round(e3 / steps3 * 1e6, 2),
+                  "spmv_gbs": round(b3 * steps3 / e3 / 1e9, 1), "spmv_frac_of_8tbs": round(b3 * steps3 / e3 / 1e9 / HBM_PEAK_GBS, 4),
+                  "timing_spread": spread(r3, steps3)}
+            if not args.no_cg:
+                sb3, bb3 = sinus_system(n3, a3, nnz3, 7)
+                res, el, all_s = timed_cg(n3, a3, bb3)
+                p3["cg"] = {"iterations": res["iterations"], "seconds": round(el, 5), "all_seconds": all_s,
+                            "iters_per_sec": round(res["iterations"] / el, 1), "converged": bool(res["converged"]),
+                            "final_residual_norm_rel": res["rel_residual"],
+                            "solution_rel_err": float(torch.linalg.norm(res["x"] - sb3) / torch.linalg.norm(sb3))}
+            out["p3"] = p3
+            del a3, x3, y3, srow3
+
+        if not args.no_cpu_baseline:
+            base = cpu_baseline(args.cpu_seconds)
+            out["cpu_baseline"] = base
+            # end-of-run parity check of what was timed, against the oracle (reference/ SpMV)
+            import oracle_lib
+            orc = oracle_lib.load()
+            y_ref = np.empty((n, 1))
+            orc.ref_csr_spmv(n, 1, rp, ci, v, x_host, 1, y_ref, 1)
+            out["parity_vs_oracle"] = "bit-exact" if np.array_equal(got_p2, y_ref) else \
+                f"rel err {matgen.rel_err(got_p2, y_ref):.3e}"
+    else:
+        # ---------------- N > 1: P3, configs[4], strong scaling ----------------
+        import gkomi.distributed as gd
+        g = args.p3_grid
+        n_global = g ** 3
+        part = gd.Partition.build_from_global_size_uniform(gk, world, n_global)
+        lo, hi = int(part.range_bounds[rank]), int(part.range_bounds[rank + 1])
+        rows, cols, vals = gd.poisson3d_rows(g, lo, hi)
+        nnz_local = len(vals)
+        nnz_global = 7 * n_global - 6 * g * g
+        M = gd.Matrix(gd.GpuOps(gk, device)).read_distributed(rows, cols, vals, part)
+        del rows, cols, vals
+        n_loc = M.num_local_rows
+        driver = "python: torch.distributed collectives (no RCCL handle for the native driver)"
+        comm = A = None
+        try:
+            comm = gd.RcclComm(gk, device)
+            A = gd.NativeMatrix(M)
+            driver = "native: csrc/dist_cg.hip over its own RCCL communicator"
+        except Exception as ex:  # noqa: BLE001 - the portable path takes over, and says so
+            driver += f" [{repr(ex)[:120]}]"
+            comm = A = None
+        x = dev(np.sin(0.01 * np.arange(lo, hi)).reshape(n_loc, 1))
+        y = torch.empty((n_loc, 1), dtype=torch.float64, device=device)
+        if A is not None:
+            step = lambda i: A.apply(comm, x, y)
+        else:
+            step = lambda i: M.apply(x, y)
+        for i in range(max(3, args.warmup // 4)):
+            step(i)
+        steps = max(10, args.steps // 4)
+        (wall, ev), regions = timed_region(step, steps)
+        local_bytes = algorithmic_bytes(n_loc, n_loc + M.non_local[1], nnz_local)
+        out = {
+            "metric": f"distributed CSR SpMV GFLOP/s (fp64, {g}^3 7-pt Poisson, row-partitioned over {world} GPUs)",
+            "value": round(2.0 * nnz_global * steps / wall / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world,
+            "steps": steps, "warmup": max(3, args.warmup // 4), "ms_per_step": round(wall / steps * 1e3, 5),
+            "timing": f"best of {TRIALS} timed regions of {steps} steps", "timing_spread": spread(regions, steps),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"distributed-solver: row-partitioned y=Ax and CG on {g}^3 7-pt Poisson "
+                                   f"(n={n_global}, nnz={nnz_global}), {world} contiguous row slabs, RCCL halo exchange",
+                       "partition": f"{world} row slabs of {n_global // world} rows; halo "
+                                    f"{M.recv_count} doubles in / {M.send_count} out on rank {rank}",
+                       "driver": driver},
+            "roofline": {"bound": "hbm", "achieved": round(local_bytes * steps / ev / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(local_bytes * steps / ev / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "distributed apply (rank 0's share: local block + non-local rows)",
+                         "bytes_per_launch": local_bytes, "us_per_launch": round(ev / steps * 1e6, 3)},
+        }
+        if not args.no_cg:
+            # sinus right-hand side of benchmark/solver: b = A s / |s|, s_i = sin(i)
+            s_loc = np.sin(np.arange(lo, hi, dtype=np.float64))
+            nrm = torch.tensor([float(np.sum(s_loc * s_loc))], dtype=torch.float64, device=device)
+            dist.all_reduce(nrm)
+            sd = dev((s_loc / np.sqrt(float(nrm.item()))).reshape(n_loc, 1))
+            b = torch.empty((n_loc, 1), dtype=torch.float64, device=device)
+            (A.apply(comm, sd, b) if A is not None else M.apply(sd, b))
+            torch.cuda.synchronize()
+
+            def solve():
+                xs = torch.zeros((n_loc, 1), dtype=torch.float64, device=device)
+                if A is not None:
+                    r = A.cg(comm, b, xs, max_iters=100000, reduction=1e-10, check_every=32)
+                    return xs, r["iterations"], r["converged"], r["residual_norm"] / max(r["baseline_norm"], 1e-300)
+                it, conv = gd.cg_fused(M, b, xs, max_iters=100000, reduction=1e-10, check_every=32)
+                return xs, it, conv, None
+
+            solve()
+            runs = []
+            for _ in range(3):
+                barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                xs, its, conv, rel = solve()
+                torch.cuda.synchronize()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                runs.append(float(t.item()))
+            err = torch.stack([torch.sum((xs - sd) ** 2), torch.sum(sd ** 2)])
+            dist.all_reduce(err)
+            el = min(runs)
+            out["cg"] = {"metric": "row-partitioned CG to 1e-10 (no iteration cap), sinus rhs b = A s/|s|",
+                         "iterations": int(its), "converged": bool(conv), "seconds": round(el, 5),
+                         "all_seconds": [round(r, 5) for r in runs], "timing": "best of 3 solves, max over ranks",
+                         "iters_per_sec": round(its / el, 1), "final_residual_norm_rel": rel,
+                         "solution_rel_err": float(torch.sqrt(err[0] / err[1]).item()), "global_rows": n_global}
+        if A is not None:
+            A.close()
+            comm.close()
 
     if rank == 0:
         sys.stdout.flush()

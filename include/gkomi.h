@@ -41,7 +41,9 @@ enum {
     GKOMI_EINVAL = -1,       /* bad argument (gko::BadDimension / ValueMismatch) */
     GKOMI_ENOTSUPPORTED = -2, /* gko::NotSupported */
     GKOMI_ENOTIMPL = -3,      /* gko::NotImplemented */
-    GKOMI_EWORKSPACE = -4     /* workspace too small */
+    GKOMI_EWORKSPACE = -4,    /* workspace too small */
+    GKOMI_ECOMM = -5,         /* a collective failed (gko::MpiError's role) */
+    GKOMI_ETRS_OVERRUN = -6   /* a triangular solve hit its spin bound: x holds NaNs */
 };
 
 /* stopping_status bit layout (include/ginkgo/core/stop/stopping_status.hpp:144-147) */
@@ -84,6 +86,13 @@ enum {
     GKOMI_CSR_SPLIT = 4    /* nnz-split streaming through LDS over srow, bit-exact
                               (gkomi_csr_spmv_srow_f64_i32 only)               */
 };
+/* OR-ed into the strategy word: the caller's working set between two applies of
+ * this matrix exceeds the 256 MiB Infinity Cache (a Krylov basis, other
+ * matrices, ...), so the matrix arrays will come from HBM anyway: the automatic
+ * strategy then streams them with nontemporal loads (no cache allocation),
+ * which is what it does by itself for matrices larger than the cache.  Pure
+ * speed (cold 18.6 -> 16.6 us on the 1M-row 5-pt matrix), never results. */
+#define GKOMI_CSR_STREAMING (1 << 24)
 
 /* csr::spmv  c = A b   and   csr::advanced_spmv  c = alpha A b + beta c.
  * alpha == NULL && beta == NULL selects the simple form (c is never read).
@@ -436,8 +445,8 @@ int gkomi_jacobi_scalar_apply_f64(gkomi_stream_t s, int64_t nrows,
 /* x = L^-1 b / x = U^-1 b for a CSR matrix whose other triangle (if stored) is
  * ignored; unit_diag as solver::LowerTrs/UpperTrs::parameters (triangular.hpp:117-132).
  * x and b must not alias.  workspace: gkomi_trs_workspace_bytes() bytes of
- * device memory (the reference's SolveStruct; generate() needs no analysis
- * here).  reference/solver/lower_trs_kernels.cpp:90-120, upper_trs_kernels.cpp:90-123 */
+ * ZEROED device memory (the reference's SolveStruct; generate() needs no analysis
+ * for this variant).  reference/solver/lower_trs_kernels.cpp:90-120, upper_trs_kernels.cpp:90-123 */
 size_t gkomi_trs_workspace_bytes(void);
 int gkomi_lower_trs_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
                                   const int32_t* row_ptrs,
@@ -451,8 +460,11 @@ int gkomi_upper_trs_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
                                   int unit_diag, const double* b,
                                   int64_t b_stride, double* x, int64_t x_stride,
                                   void* workspace, size_t workspace_bytes);
-/* *host_flag != 0 if the last solve on this workspace hit its spin bound
- * (the role of the nan_produced guard, cuda/solver/common_trs_kernels.cuh:444-449) */
+/* *host_flag != 0 if a solve on this workspace hit its spin bound since the workspace
+ * was zeroed by its owner (sticky: a later solve does not clear it; the role of the
+ * nan_produced guard, cuda/solver/common_trs_kernels.cuh:444-449).  The solver drivers
+ * of this library ask once per solve and return GKOMI_ETRS_OVERRUN for an Ilu
+ * preconditioner (gkomi_ilu_apply_cb) whose solves gave up. */
 int gkomi_trs_check_overrun(gkomi_stream_t s, const void* workspace,
                             int* host_flag);
 
@@ -463,7 +475,8 @@ int gkomi_trs_check_overrun(gkomi_stream_t s, const void* workspace,
  * apply.  Ours, in the same two steps:
  *   symbolic  dependency level of every row, rows sorted by level, 64-row slices:
  *             blocking (returns the sizes the caller needs to allocate the plan);
- *             host_out = { nslices, entries (SELL slots), nlevels }
+ *             host_out = { nslices, entries (SELL slots), nlevels, max_deps (longest
+ *             dependency list of a row; -1 for the solve = unknown) }
  *   numeric   the factor once more in level order, dependencies only, column-major
  *             inside each slice, diagonal apart -> `plan` (device memory of
  *             gkomi_trs_plan_bytes(nslices, entries) bytes); re-run when the values
@@ -491,8 +504,8 @@ int gkomi_trs_analyse_numeric_f64_i32(gkomi_stream_t s, int64_t n,
                                       size_t plan_bytes);
 int gkomi_trs_solve_plan_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
                              void* plan, int64_t nslices, int64_t entries,
-                             int unit_diag, const double* b, int64_t b_stride,
-                             double* x, int64_t x_stride);
+                             int64_t max_deps, int unit_diag, const double* b,
+                             int64_t b_stride, double* x, int64_t x_stride);
 int gkomi_trs_plan_check_overrun(gkomi_stream_t s, const void* plan,
                                  int* host_flag);
 
@@ -823,6 +836,103 @@ int gkomi_dist_build_local_nonlocal_fill(
     int32_t* non_local_col_idxs, double* non_local_vals, int32_t* gather_idxs,
     int32_t* recv_sizes, int64_t* non_local_to_global);
 
+/* ---- communicator (the role of gko::experimental::mpi::communicator for
+ *      core/distributed/{matrix,vector}.cpp) -------------------------------------
+ * The distributed drivers below only see this record: a context pointer and the
+ * two collectives the path needs, so any transport can stand behind it.
+ *   allreduce_sum_f64  in place on `count` doubles in device memory, ordered on
+ *                      stream s; every rank ends with the same bits
+ *                      (vector.cpp:317-409: MPI_Allreduce of the local results)
+ *   alltoallv          rank p gets send_counts[p] elements from send_offsets[p] on
+ *                      and delivers recv_counts[p] at recv_offsets[p]; counts and
+ *                      offsets are HOST arrays of `size` entries, in elements of
+ *                      elem_bytes bytes; device buffers; ordered on stream s
+ *                      (matrix.cpp:198-224, 263-303: all_to_all_v)
+ * gkomi_comm_rccl_*: the RCCL transport, one rank per GPU of a node (xGMI).  RCCL is
+ * opened at run time; GKOMI_ENOTSUPPORTED if it cannot be.  Bootstrap like NCCL:
+ * rank 0 draws a unique id (gkomi_comm_unique_id_bytes() bytes), every rank gets
+ * it over whatever channel the launcher has and calls create (collective). */
+typedef struct gkomi_comm {
+    void* self;
+    int rank;
+    int size;
+    int (*allreduce_sum_f64)(void* self, gkomi_stream_t s, double* buf, int64_t count);
+    int (*alltoallv)(void* self, gkomi_stream_t s, const void* send,
+                     const int64_t* send_counts, const int64_t* send_offsets,
+                     void* recv, const int64_t* recv_counts,
+                     const int64_t* recv_offsets, int elem_bytes);
+} gkomi_comm;
+int64_t gkomi_comm_unique_id_bytes(void);
+int64_t gkomi_comm_rccl_available(void);
+int gkomi_comm_rccl_unique_id(void* id_out);
+int gkomi_comm_rccl_create(const void* id_in, int rank, int size, gkomi_comm* out);
+int gkomi_comm_rccl_destroy(gkomi_comm* comm);
+/* thin callers of the two function pointers (for bindings that cannot call through
+ * a struct member) */
+int gkomi_comm_allreduce_sum_f64(const gkomi_comm* comm, gkomi_stream_t s,
+                                 double* buf, int64_t count);
+int gkomi_comm_alltoallv(const gkomi_comm* comm, gkomi_stream_t s, const void* send,
+                         const int64_t* send_counts, const int64_t* send_offsets,
+                         void* recv, const int64_t* recv_counts,
+                         const int64_t* recv_offsets, int elem_bytes);
+
+/* ---- distributed::Matrix of one rank (core/distributed/matrix.hpp: local_mtx_,
+ *      non_local_mtx_, gather_idxs_, send/recv sizes and offsets, one rhs) -------- */
+typedef struct gkomi_dist_matrix {
+    int64_t n_local;            /* rows owned = columns of the local block */
+    int64_t n_halo;             /* columns of the non-local block = x entries received */
+    int64_t l_nnz;              /* local block, CSR */
+    const int32_t* l_row_ptrs;
+    const int32_t* l_col_idxs;
+    const double* l_vals;
+    int64_t l_max_row_nnz;      /* hint, -1 unknown */
+    const int32_t* l_srow;      /* optional (gkomi_csr_make_srow_i32), else NULL */
+    int64_t l_srow_tile;
+    int64_t nl_rows;            /* non-local block, reduced to its non-empty rows */
+    int64_t nl_nnz;             /*   (gkomi_dist_nonlocal_rows_i32)               */
+    const int32_t* nl_row_idxs; /* nl_rows local row indices, ascending */
+    const int32_t* nl_row_ptrs; /* nl_rows + 1 */
+    const int32_t* nl_col_idxs; /* into the received halo, 0 .. n_halo-1 */
+    const double* nl_vals;
+    int64_t send_total;
+    const int32_t* gather_idxs; /* device: local rows to send, grouped by receiver */
+    const int64_t* send_counts; /* host arrays, comm size entries each */
+    const int64_t* send_offsets;
+    const int64_t* recv_counts;
+    const int64_t* recv_offsets;
+    double* send_buf;           /* device, send_total doubles */
+    double* recv_buf;           /* device, n_halo doubles */
+} gkomi_dist_matrix;
+/* side stream + events of the overlapped halo exchange (one per rank / thread) */
+typedef struct gkomi_dist_ctx gkomi_dist_ctx;
+int gkomi_dist_ctx_create(gkomi_dist_ctx** out);
+int gkomi_dist_ctx_destroy(gkomi_dist_ctx* ctx);
+/* rows of the non-local block that have entries: row_idxs_out[k] ascending and
+ * compact_ptrs_out[k], k = 0 .. count (both sized n_local + 1); blocking (*host_count) */
+size_t gkomi_dist_nonlocal_rows_workspace_bytes(int64_t n_local);
+int gkomi_dist_nonlocal_rows_i32(gkomi_stream_t s, int64_t n_local,
+                                 const int32_t* row_ptrs, int32_t* row_idxs_out,
+                                 int32_t* compact_ptrs_out, void* workspace,
+                                 size_t workspace_bytes, int64_t* host_count);
+/* Matrix::apply_impl (matrix.cpp:307-335), one right-hand side: x = A b on the local
+ * rows; the halo exchange overlaps the local SpMV.  Collective: every rank calls it. */
+int gkomi_dist_matrix_apply_f64(gkomi_stream_t s, const gkomi_comm* comm,
+                                gkomi_dist_ctx* ctx, const gkomi_dist_matrix* A,
+                                const double* b, double* x);
+/* Cg::apply_dense_impl on distributed vectors (core/solver/cg.cpp:107-193), fused:
+ * three local kernels + two all-reduces (rho and tau^2 together, beta) + one halo
+ * exchange per iteration, scalars device-resident, host poll every check_every
+ * iterations.  precond: rank-local gkomi_apply_fn or NULL.  baseline / host_info as
+ * gkomi_cg_solve_f64_i32 (host_info: 4 doubles).  Collective; blocks until done. */
+size_t gkomi_dist_cg_workspace_bytes(int64_t n_local, int64_t nl_rows);
+int gkomi_dist_cg_solve_f64(gkomi_stream_t s, const gkomi_comm* comm,
+                            gkomi_dist_ctx* ctx, const gkomi_dist_matrix* A,
+                            gkomi_apply_fn precond, void* precond_ctx,
+                            const double* b, double* x, int64_t max_iters,
+                            double reduction_factor, int baseline, int check_every,
+                            void* workspace, size_t workspace_bytes,
+                            double* host_info);
+
 /* ---- preconditioners as solver callbacks ---------------------------------
  * Ready-made gkomi_apply_fn implementations and their context records, the
  * generated state of preconditioner::Jacobi / preconditioner::Ilu.  All
@@ -1003,6 +1113,16 @@ typedef struct gkomi_ilu_ctx {
     size_t trs_workspace_bytes;
     int32_t l_unit_diag;     /* ParIlu stores the unit diagonal of L explicitly: 0 */
     int32_t pad_;
+    /* analysed factors (gkomi_trs_analyse_*): when non-NULL the level-scheduled
+     * solve replaces the analysis-free one for that factor */
+    void* l_plan;
+    int64_t l_nslices;
+    int64_t l_entries;
+    int64_t l_max_deps;
+    void* u_plan;
+    int64_t u_nslices;
+    int64_t u_entries;
+    int64_t u_max_deps;
 } gkomi_ilu_ctx;
 int gkomi_jacobi_apply_cb(void* ctx, gkomi_stream_t s, const double* in,
                           double* out);

@@ -30,6 +30,7 @@
 typedef int32_t i32;
 typedef int64_t i64;
 typedef uint8_t u8;
+typedef uint64_t u64;
 
 #define ORACLE_API __attribute__((visibility("default")))
 

@@ -1021,14 +1021,19 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
     }
     if (kind == GKOMI_CSR_BALANCED && (!aligned || nnz < 0)) kind = GKOMI_CSR_VECTOR;
     if (kind == GKOMI_CSR_STREAM && !aligned) kind = GKOMI_CSR_VECTOR;
+    // nontemporal matrix streams: for a matrix that will not be found in the
+    // Infinity Cache at its next use -- larger than the cache, or the caller
+    // says so (GKOMI_CSR_STREAMING: its working set between two applies is)
+    bool nt = false;
     if (automatic) {
         // 256 threads, 256 rows, 1536-nonzero tile: fastest measured
         no_swizzle = !csr_auto_swizzle(nrows, nnz);
+        nt = no_swizzle || ((strategy & GKOMI_CSR_STREAMING) != 0);
         // rows of 32+ entries: the padded LDS tile (row-sum reads of
         // neighbouring lanes are 32+ doubles apart) is 6-15 % faster, shorter
         // rows lose 1-2 % to the split LDS stores (profiles/r01_tune_pad.log)
         const bool pad = max_row_nnz_hint >= 32;
-        variant = kind == GKOMI_CSR_STREAM ? (no_swizzle ? (pad ? 16 : 14) : (pad ? 15 : 5)) : 0;
+        variant = kind == GKOMI_CSR_STREAM ? (nt ? (pad ? 16 : 14) : (pad ? 15 : 5)) : 0;
     }
 
 #define GKOMI_ARGS                                                            \
@@ -1064,7 +1069,7 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
         return GKOMI_SUCCESS;
     }
     if (kind == GKOMI_CSR_SPLIT) {
-        if (automatic) variant = no_swizzle ? 2 : 0;  // nontemporal streams past the Infinity Cache
+        if (automatic) variant = nt ? 2 : 0;
         // longest row - 1 nonzeros may lie behind the tile a row starts in
         int over = split_max_over;
         if (max_row_nnz_hint >= 1 && max_row_nnz_hint <= split_max_over) {

@@ -646,7 +646,8 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A,
         host_info[0] = static_cast<double>(total_iter);
         host_info[1] = static_cast<double>(converged);
     }
-    return static_cast<int>(hipStreamSynchronize(stream));
+    GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
+    return precond_status(precond, precond_ctx, s);
 }
 }  // namespace
 

@@ -13,6 +13,10 @@ int csr_spmv_dot_launch(hipStream_t stream, int nrows, int64_t nnz,
 int csr_spmv_dot_num_partials(int nrows);
 bool csr_auto_swizzle(int64_t nrows, int64_t nnz);
 
+// end-of-solve health check of a preconditioner callback (blocking): 0 or an error such as
+// GKOMI_ETRS_OVERRUN when one of the ILU's triangular solves gave up (precond.hip)
+int precond_status(gkomi_apply_fn precond, void* ctx, gkomi_stream_t s);
+
 // The system matrix of a solver driver: CSR arrays (op == nullptr) or any
 // format behind a gkomi_matrix_apply_fn (Ell, Sellp, Coo, Hybrid, a user LinOp).
 struct sysmat {

@@ -490,7 +490,8 @@ struct driver_common {
             host_info[0] = static_cast<double>(iter);
             host_info[1] = static_cast<double>(converged);
         }
-        return static_cast<int>(hipStreamSynchronize(stream));
+        GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
+        return precond_status(precond, precond_ctx, s);
     }
 };
 
@@ -1180,7 +1181,7 @@ int bicgstab_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_appl
         host_info[2] = h.tau;
         host_info[3] = h.orig_tau;
     }
-    return GKOMI_SUCCESS;
+    return precond_status(precond, precond_ctx, s);
 }
 
 }  // namespace
@@ -1548,7 +1549,7 @@ int fcg_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn 
         host_info[2] = h.tau;
         host_info[3] = h.orig_tau;
     }
-    return GKOMI_SUCCESS;
+    return precond_status(precond, precond_ctx, s);
 }
 
 }  // namespace
@@ -1923,7 +1924,7 @@ int cgs_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn 
         host_info[2] = h.tau;
         host_info[3] = h.orig_tau;
     }
-    return GKOMI_SUCCESS;
+    return precond_status(precond, precond_ctx, s);
 }
 
 }  // namespace

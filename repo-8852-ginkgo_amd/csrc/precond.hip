@@ -3,7 +3,7 @@
 // (core/preconditioner/jacobi.cpp apply_impl -> jacobi::simple_apply) and of
 // preconditioner::Ilu (include/ginkgo/core/preconditioner/ilu.hpp:265-286:
 // L^-1 into a cached intermediate, then U^-1).
-#include "common.hpp"
+#include "internal.hpp"
 
 extern "C" int gkomi_jacobi_apply_cb(void* ctx_, gkomi_stream_t s, const double* in, double* out)
 {
@@ -28,13 +28,42 @@ extern "C" int gkomi_ilu_apply_cb(void* ctx_, gkomi_stream_t s, const double* in
 {
     const gkomi_ilu_ctx* c = static_cast<const gkomi_ilu_ctx*>(ctx_);
     if (c == nullptr) return GKOMI_EINVAL;
-    int err = gkomi_lower_trs_solve_f64_i32(s, c->n, c->nrhs, c->l_row_ptrs, c->l_col_idxs,
-                                            c->l_vals, c->l_unit_diag, in, c->nrhs, c->intermediate,
-                                            c->nrhs, c->trs_workspace, c->trs_workspace_bytes);
+    // factors analysed at generate (LowerTrs / UpperTrs::generate): the level-scheduled solves
+    int err = c->l_plan != nullptr
+                  ? gkomi_trs_solve_plan_f64(s, c->n, c->nrhs, c->l_plan, c->l_nslices, c->l_entries,
+                                             c->l_max_deps, c->l_unit_diag, in, c->nrhs, c->intermediate, c->nrhs)
+                  : gkomi_lower_trs_solve_f64_i32(s, c->n, c->nrhs, c->l_row_ptrs, c->l_col_idxs,
+                                                  c->l_vals, c->l_unit_diag, in, c->nrhs, c->intermediate,
+                                                  c->nrhs, c->trs_workspace, c->trs_workspace_bytes);
     if (err) return err;
+    if (c->u_plan != nullptr) {
+        return gkomi_trs_solve_plan_f64(s, c->n, c->nrhs, c->u_plan, c->u_nslices, c->u_entries, c->u_max_deps, 0,
+                                        c->intermediate, c->nrhs, out, c->nrhs);
+    }
     return gkomi_upper_trs_solve_f64_i32(s, c->n, c->nrhs, c->u_row_ptrs, c->u_col_idxs, c->u_vals,
                                          0, c->intermediate, c->nrhs, out, c->nrhs,
                                          c->trs_workspace, c->trs_workspace_bytes);
+}
+
+// A triangular solve that gave up leaves NaNs in z and the solver then never converges: the
+// drivers ask once, at the end of a solve, whether that is what happened (the flags are sticky).
+int gkomi::precond_status(gkomi_apply_fn precond, void* ctx_, gkomi_stream_t s)
+{
+    if (precond != gkomi_ilu_apply_cb || ctx_ == nullptr) return GKOMI_SUCCESS;
+    const gkomi_ilu_ctx* c = static_cast<const gkomi_ilu_ctx*>(ctx_);
+    int flag = 0, any = 0;
+    if (c->trs_workspace != nullptr && (c->l_plan == nullptr || c->u_plan == nullptr)) {
+        const int err = gkomi_trs_check_overrun(s, c->trs_workspace, &flag);
+        if (err) return err;
+        any |= flag;
+    }
+    for (const void* plan : {static_cast<const void*>(c->l_plan), static_cast<const void*>(c->u_plan)}) {
+        if (plan == nullptr) continue;
+        const int err = gkomi_trs_plan_check_overrun(s, plan, &flag);
+        if (err) return err;
+        any |= flag;
+    }
+    return any ? GKOMI_ETRS_OVERRUN : GKOMI_SUCCESS;
 }
 
 // ---- system matrices as callbacks (gkomi_matrix_apply_fn) --------------------------------

@@ -43,6 +43,8 @@ extern "C" const char* gkomi_error_string(int code)
     case GKOMI_ENOTSUPPORTED: return "gkomi: not supported";
     case GKOMI_ENOTIMPL: return "gkomi: not implemented";
     case GKOMI_EWORKSPACE: return "gkomi: workspace too small";
+    case GKOMI_ECOMM: return "gkomi: a collective of the communicator failed";
+    case GKOMI_ETRS_OVERRUN: return "gkomi: a triangular solve hit its spin bound";
     default: break;
     }
     if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));

@@ -31,6 +31,8 @@
 // 8(d) says; bytes 12*nnz + 4(n+1) + 16n.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace gkomi {
 namespace {
 
@@ -40,7 +42,7 @@ constexpr int window = 6;      // dependency entries of a row parked in LDS
 constexpr int lds_passes = 4;  // at most this many LDS-only passes between two looks at memory
 constexpr int max_idle = 8;    // x s_sleep(4) = 256 cycles each
 constexpr unsigned long long sentinel_bits = 0x7ff8dead0badbeefull;
-constexpr long long max_rounds = 1ll << 23;
+constexpr long long default_max_rounds = 1ll << 23;
 
 struct trs_workspace {
     unsigned int ticket;
@@ -52,10 +54,7 @@ __global__ __launch_bounds__(prep_block) void trs_prepare_kernel(int64_t n, doub
                                                                 trs_workspace* __restrict__ ws)
 {
     const int64_t gid = blockIdx.x * static_cast<int64_t>(prep_block) + threadIdx.x;
-    if (gid == 0) {
-        ws->ticket = 0;
-        ws->overrun = 0;
-    }
+    if (gid == 0) ws->ticket = 0;  // overrun is sticky: zeroed by whoever creates the workspace
     for (int64_t i = gid; i < n; i += static_cast<int64_t>(gridDim.x) * prep_block) {
         reinterpret_cast<unsigned long long*>(x)[i * x_stride] = sentinel_bits;
     }
@@ -68,7 +67,7 @@ template <bool Lower>
 __global__ __launch_bounds__(block) void trs_syncfree_kernel(
     int32_t n, const int32_t* __restrict__ row_ptrs, const int32_t* __restrict__ col_idxs,
     const double* __restrict__ vals, bool unit_diag, const double* __restrict__ b,
-    int64_t b_stride, double* x, int64_t x_stride, trs_workspace* ws)
+    int64_t b_stride, double* x, int64_t x_stride, trs_workspace* ws, long long max_rounds)
 {
     __shared__ unsigned long long s_x[block];  // results of this chunk, sentinel = pending
     __shared__ int s_pos[window][block];       // dependency positions of the row
@@ -251,6 +250,9 @@ int trs_solve(gkomi_stream_t s, int64_t n, int64_t nrhs, const int32_t* row_ptrs
     if (x == b) return GKOMI_EINVAL;  // x is used as the ready flags
     if (n > INT32_MAX - block) return GKOMI_ENOTSUPPORTED;  // rows are int32 indices
     const int64_t chunks = ceildiv(n, block);
+    // GKOMI_TRS_MAX_ROUNDS: test hook that makes a solve give up early (tests/test_trs_ilu_gpu.py)
+    const char* env_rounds = getenv("GKOMI_TRS_MAX_ROUNDS");
+    const long long max_rounds = env_rounds != nullptr && env_rounds[0] != 0 ? atoll(env_rounds) : default_max_rounds;
     hipStream_t stream = to_stream(s);
     trs_workspace* ws = static_cast<trs_workspace*>(workspace);
     for (int64_t j = 0; j < nrhs; ++j) {
@@ -259,7 +261,7 @@ int trs_solve(gkomi_stream_t s, int64_t n, int64_t nrhs, const int32_t* row_ptrs
         hipLaunchKernelGGL(trs_syncfree_kernel<Lower>, dim3(static_cast<unsigned>(chunks)),
                            dim3(block), 0, stream, static_cast<int32_t>(n), row_ptrs, col_idxs, vals,
                            unit_diag != 0,
-                           b + j, b_stride, x + j, x_stride, ws);
+                           b + j, b_stride, x + j, x_stride, ws, max_rounds);
         int err = check_launch();
         if (err) return err;
     }

@@ -11,19 +11,32 @@
 // as 64-row slices, column-major inside a slice (SELL-64 of the dependencies
 // only, the diagonal apart).  A wave then owns 64 rows that become ready
 // TOGETHER: its loads are coalesced, every lane has work in every pass, and
-// the critical path is one memory hand-off per LEVEL instead of one LDS
-// hand-off per row of a chain plus one memory hand-off per grid line.
+// the critical path is one memory hand-off per LEVEL.
 //
-// The solve stays sync-free: x[row] doubles as its own ready flag (sentinel
-// NaN payload, ONE agent-scope store to publish, agent-scope loads to poll --
-// MI355X_MICROARCH.md's data-tagged granule), slices are handed out by an
-// atomic ticket in level order (every dependency of a slice lives in a slice
-// with a smaller-or-equal ticket, i.e. in a wave that has started), a lane
-// publishes the moment its row is complete (a slice may straddle two levels), no
-// lane waits inside a loop another lane of its wave must leave, spins are
-// bounded and raise a STICKY flag in the plan instead of hanging.
+// The solve stays sync-free, in "position space": the plan carries its own copy
+// xp of the solution in level order, and the stored column indices are
+// POSITIONS in that order.  xp[pos] doubles as its own ready flag (sentinel NaN
+// payload, ONE agent-scope store to publish, agent-scope loads to poll --
+// MI355X_MICROARCH.md's data-tagged granule); since the dependencies of 64
+// consecutive positions are themselves (nearly) consecutive positions of the
+// level before, a poll instruction touches a handful of cache lines instead of
+// 64.  Slices are handed out by an atomic ticket in level order (every
+// dependency of a slice lives in a slice with a smaller-or-equal ticket, i.e. in
+// a wave that has started); a lane publishes the moment its row is complete (a
+// slice may straddle levels); no lane waits inside a loop another lane of its
+// wave must leave; spins are bounded and raise a STICKY flag instead of hanging.
+//
+// Who polls: many waves are resident, the front is a few of them.  A wave
+// far behind the front must not poll its dependencies (the fabric would carry
+// nothing else), so it first watches ONE position per wave -- a scout: the last
+// row of the level 16 before its own at a 4-us cadence, then the last row of
+// the level 2 before its own at a 0.25-us cadence -- and only then polls its
+// real dependencies.  Scouts are hints: correctness never depends on them.
 // Per row the subtractions run in storage order -> bit-identical to the reference.
 #include "common.hpp"
+
+#include <algorithm>
+#include <cstdlib>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -32,10 +45,18 @@ namespace gkomi {
 namespace {
 
 constexpr int slice = 64;        // rows per wave
-constexpr int solve_block = 256; // 4 slices per ticket
-constexpr int window = 8;        // dependency entries a lane keeps in registers
+constexpr int solve_block = 1024; // 16 slices per ticket
+constexpr int default_scout_far = 16;  // levels between a slice and its far / near scout
+constexpr int default_scout_near = 2;
+
+// tuning knobs (tools/tune_trs.py): an environment variable overrides the default
+inline int tuning(const char* name, int fallback)
+{
+    const char* v = getenv(name);
+    return v != nullptr && v[0] != 0 ? atoi(v) : fallback;
+}
 constexpr unsigned long long sentinel_bits = 0x7ff8dead0badbeefull;
-constexpr long long max_rounds = 1ll << 22;
+constexpr long long default_max_rounds = 1ll << 22;
 
 struct plan_header {
     int64_t n;
@@ -47,9 +68,10 @@ struct plan_header {
     int32_t lower;
     int32_t pad_;
 };
+static_assert(sizeof(plan_header) <= 256, "the plan header has 256 bytes");
 
 struct plan_layout {
-    size_t perm, slice_off, diag, cols, vals, total;
+    size_t perm, slice_off, scout, diag, xp, cols, vals, total;
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -60,7 +82,9 @@ plan_layout make_plan_layout(int64_t nslices, int64_t entries)
     size_t off = 256;
     l.perm = off; off += align_up(sizeof(int32_t) * nslices * slice, 256);
     l.slice_off = off; off += align_up(sizeof(int32_t) * (nslices + 1), 256);
+    l.scout = off; off += align_up(sizeof(int32_t) * 2 * (nslices + 1), 256);
     l.diag = off; off += align_up(sizeof(double) * nslices * slice, 256);
+    l.xp = off; off += align_up(sizeof(double) * nslices * slice, 256);
     l.cols = off; off += align_up(sizeof(int32_t) * entries, 256);
     l.vals = off; off += align_up(sizeof(double) * entries, 256);
     l.total = off;
@@ -151,6 +175,14 @@ __global__ __launch_bounds__(256) void trs_iota_kernel(int32_t n, int32_t* __res
     if (i < n) rows[i] = i;
 }
 
+// inv[row] = position of the row in level order
+__global__ __launch_bounds__(256) void trs_invert_perm_kernel(int32_t n, const int32_t* __restrict__ perm,
+                                                             int32_t* __restrict__ inv)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) inv[perm[i]] = i;
+}
+
 // one wave per slice: longest dependency list among its rows; entry nslices = 0
 __global__ __launch_bounds__(256) void trs_slice_len_kernel(
     int32_t n, int32_t nslices, const int32_t* __restrict__ perm, const int32_t* __restrict__ cnt,
@@ -171,19 +203,42 @@ __global__ __launch_bounds__(256) void trs_slice_len_kernel(
     int m = i < n ? cnt[perm[i]] : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
-    if (lane == 0) slice_len[s] = m * slice;
+    if (lane == 0) {
+        slice_len[s] = m * slice;
+        atomicMax(nlevels + 1, m * slice);  // flags[2]: the longest slice (integer max: order-free)
+    }
 }
 
-// numeric phase: the factor once more, rows in level order, dependencies only,
-// column-major inside every 64-row slice; -1 pads; the diagonal (last stored
-// occurrence, like the reference's loop) apart
+// first position in level order whose level is >= want (n if none)
+__device__ __forceinline__ int first_position_of_level(const int32_t* __restrict__ level_sorted, int n, int want)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        if (level_sorted[mid] >= want) {
+            hi = mid;
+        } else {
+            lo = mid + 1;
+        }
+    }
+    return lo;
+}
+
+// numeric phase: the factor once more, rows in level order, dependencies only
+// (as POSITIONS in level order), column-major inside every 64-row slice; -1
+// pads; the diagonal (last stored occurrence, like the reference's loop) apart.
+// scout[2 s], scout[2 s + 1]: the positions slice s watches before it polls its
+// dependencies -- the last row of the level `scout_far` / `scout_near` levels
+// before the slice's first level (-1: none).
 template <bool Lower>
 __global__ __launch_bounds__(256) void trs_fill_plan_kernel(
     int32_t n, int32_t nslices, const int32_t* __restrict__ row_ptrs,
     const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
-    const int32_t* __restrict__ perm_in, const int32_t* __restrict__ slice_off_in,
-    int32_t* __restrict__ perm, int32_t* __restrict__ slice_off, double* __restrict__ diag,
-    int32_t* __restrict__ cols, double* __restrict__ pvals)
+    const int32_t* __restrict__ perm_in, const int32_t* __restrict__ inv,
+    const int32_t* __restrict__ slice_off_in, const int32_t* __restrict__ level_sorted,
+    int32_t* __restrict__ perm, int32_t* __restrict__ slice_off, int32_t* __restrict__ scout,
+    double* __restrict__ diag, int32_t* __restrict__ cols, double* __restrict__ pvals, int scout_far,
+    int scout_near)
 {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -194,7 +249,12 @@ __global__ __launch_bounds__(256) void trs_fill_plan_kernel(
     }
     const int off = slice_off_in[s];
     const int len = (slice_off_in[s + 1] - off) / slice;
-    if (lane == 0) slice_off[s] = off;
+    if (lane == 0) {
+        slice_off[s] = off;
+        const int lvl = level_sorted[s * slice];
+        scout[2 * s] = lvl >= scout_far ? first_position_of_level(level_sorted, n, lvl - scout_far + 1) - 1 : -1;
+        scout[2 * s + 1] = lvl >= scout_near ? first_position_of_level(level_sorted, n, lvl - scout_near + 1) - 1 : -1;
+    }
     const int i = s * slice + lane;
     const int row = i < n ? perm_in[i] : -1;
     perm[i] = row;
@@ -205,7 +265,7 @@ __global__ __launch_bounds__(256) void trs_fill_plan_kernel(
             const int col = col_idxs[k];
             if (col == row) d = vals[k];
             if (is_dep<Lower>(col, row) && col >= 0 && col < n) {
-                cols[off + e * slice + lane] = col;
+                cols[off + e * slice + lane] = inv[col];
                 pvals[off + e * slice + lane] = vals[k];
                 ++e;
             }
@@ -218,14 +278,13 @@ __global__ __launch_bounds__(256) void trs_fill_plan_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void trs_plan_prepare_kernel(int64_t n, double* __restrict__ x,
-                                                              int64_t x_stride,
+__global__ __launch_bounds__(256) void trs_plan_prepare_kernel(int64_t slots, double* __restrict__ xp,
                                                               plan_header* __restrict__ hdr)
 {
     const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
     if (gid == 0) hdr->ticket = 0;
-    for (int64_t i = gid; i < n; i += static_cast<int64_t>(gridDim.x) * 256) {
-        reinterpret_cast<unsigned long long*>(x)[i * x_stride] = sentinel_bits;
+    for (int64_t i = gid; i < slots; i += static_cast<int64_t>(gridDim.x) * 256) {
+        reinterpret_cast<unsigned long long*>(xp)[i] = sentinel_bits;
     }
 }
 
@@ -234,80 +293,131 @@ __device__ __forceinline__ unsigned long long poll(const unsigned long long* p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Tried and dropped (profiles/r02_trs.log): running the whole solve on ONE XCD (first wave elects
+// its XCC_ID, the others leave, persistent waves take slices by ticket) so that the hand-off goes
+// through that XCD's L2 -- 557 vs 587 us on the 108^3 factor, both slower than this version: the
+// pass a wave repeats per hand-off, not the fabric round trip, is what a level costs, and one
+// ticket per slice is 20 k atomics on one word.
+// window = dependency entries a lane keeps in registers: 4 when no row of the
+// factor has more (the pass a wave repeats per hand-off is then half as long),
+// 8 otherwise.
+template <int window>
 __global__ __launch_bounds__(solve_block) void trs_level_solve_kernel(
     plan_header* hdr, const int32_t* __restrict__ perm, const int32_t* __restrict__ slice_off,
-    const double* __restrict__ diag, const int32_t* __restrict__ cols,
-    const double* __restrict__ pvals, bool unit_diag, const double* __restrict__ b,
-    int64_t b_stride, double* x, int64_t x_stride)
+    const int32_t* __restrict__ scout, const double* __restrict__ diag,
+    const int32_t* __restrict__ cols, const double* __restrict__ pvals, double* xp, bool unit_diag,
+    const double* __restrict__ b, int64_t b_stride, double* __restrict__ x, int64_t x_stride,
+    int naps_between_polls, long long max_rounds)
 {
+    const int lane = threadIdx.x & 63;
+    // one ticket per workgroup = solve_block / 64 consecutive slices, one per wave (a ticket per
+    // wave would put 20 k atomics on one word: ~11 ns each, more than the whole solve should take)
     __shared__ unsigned int s_ticket;
     if (threadIdx.x == 0) s_ticket = atomicAdd(&hdr->ticket, 1u);
     __syncthreads();
-    const int64_t s = static_cast<int64_t>(s_ticket) * (solve_block / slice) + (threadIdx.x >> 6);
-    if (s >= hdr->nslices) return;
-    const int lane = threadIdx.x & 63;
-    const int row = perm[s * slice + lane];
-    const int off = slice_off[s];
-    const int len = (slice_off[s + 1] - off) / slice;
-    unsigned long long* xb = reinterpret_cast<unsigned long long*>(x);
-    double sum = row >= 0 ? b[row * b_stride] : 0.0;
-    const double d = diag[s * slice + lane];
-    bool published = row < 0;
-    auto publish = [&]() {
-        const double xr = unit_diag ? sum : sum / d;
-        __hip_atomic_store(xb + row * x_stride, static_cast<unsigned long long>(__double_as_longlong(xr)),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        published = true;
-    };
-    long long rounds = 0;
+    unsigned long long* xb = reinterpret_cast<unsigned long long*>(xp);
+    const int64_t nslices = hdr->nslices;
     bool gave_up = false;
-    for (int e0 = 0; e0 < len && !gave_up; e0 += window) {
+    {
+        const int64_t s = static_cast<int64_t>(s_ticket) * (solve_block / slice) + (threadIdx.x >> 6);
+        if (s >= nslices) return;
+        const int64_t mine = s * slice + lane;  // my position in level order
+        const int row = perm[mine];
+        const int off = slice_off[s];
+        const int len = (slice_off[s + 1] - off) / slice;
+        double sum = row >= 0 ? b[row * b_stride] : 0.0;
+        const double d = diag[mine];
+        bool done = row < 0;
+        auto publish = [&]() {
+            const double xr = unit_diag ? sum : sum / d;
+            // the flag-carrying copy: ONE 8-byte store into the XCD's L2, then the caller's x
+            __hip_atomic_store(xb + mine, static_cast<unsigned long long>(__double_as_longlong(xr)),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x[row * x_stride] = xr;
+            done = true;
+        };
+        // every lane walks its own row through a register window of `window`
+        // dependencies (a wave-wide window would deadlock: a lane of a slice that
+        // straddles levels may wait for a longer row of its own wave)
         int c[window];
         double v[window];
         unsigned long long xs[window];
-#pragma unroll
-        for (int w = 0; w < window; ++w) {  // coalesced: 64 consecutive slots per entry
-            const int e = min(e0 + w, len - 1);
-            c[w] = cols[off + e * slice + lane];
-            v[w] = pvals[off + e * slice + lane];
-            if (e0 + w >= len) c[w] = -1;
-        }
-#pragma unroll
-        for (int w = 0; w < window; ++w) {  // all polls of the window in flight together
-            xs[w] = c[w] >= 0 ? poll(xb + c[w] * x_stride) : 0ull;
-        }
-        int cur = 0;
-        while (true) {
-            // consume, in storage order, what has arrived
+        int next = 0;      // first entry of the row not yet in the window
+        int cur = window;  // window position to consume next; window = empty
+        auto fill = [&]() {  // coalesced where the lanes walk together: 64 consecutive slots per entry
 #pragma unroll
             for (int w = 0; w < window; ++w) {
-                if (cur == w) {
+                const int e = min(next + w, len - 1);
+                c[w] = cols[off + e * slice + lane];
+                v[w] = pvals[off + e * slice + lane];
+                if (next + w >= len) c[w] = -1;
+            }
+            next += window;
+            cur = 0;
+        };
+        auto ask = [&](bool all) {  // polls of the window, all in flight together
+#pragma unroll
+            for (int w = 0; w < window; ++w) {
+                if (all) {
+                    xs[w] = c[w] >= 0 ? poll(xb + c[w]) : 0ull;
+                } else if (w >= cur && c[w] >= 0 && xs[w] == sentinel_bits) {
+                    xs[w] = poll(xb + c[w]);
+                }
+            }
+        };
+        // the matrix data of the first window travels while the wave waits its turn
+        if (!done && len > 0) fill();
+        // scouts (wave-uniform): far one slowly, near one quickly; bounded, hints only
+        {
+            const int far = scout[2 * s], near = scout[2 * s + 1];
+            if (far >= 0) {
+                for (int naps = 0; naps < (1 << 14) && poll(xb + far) == sentinel_bits; ++naps) {
+                    __builtin_amdgcn_s_sleep(127);
+                }
+            }
+            if (near >= 0) {
+                for (int naps = 0; naps < (1 << 16) && poll(xb + near) == sentinel_bits; ++naps) {
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+        }
+        if (!done && len > 0) ask(true);
+        long long rounds = 0;
+        // consume, in storage order, what has arrived; refill / publish on the way
+        auto advance = [&]() {
+            if (!done && cur == window) {
+                if (next >= len) {
+                    publish();  // no (further) dependency
+                } else {
+                    fill();
+                    ask(true);
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < window; ++w) {
+                if (!done && cur == w) {
                     if (c[w] < 0) {  // the row has no further dependency: publish at once
-                        if (!published) publish();
-                        cur = window;
+                        publish();
                     } else if (xs[w] != sentinel_bits) {
                         sum -= v[w] * __longlong_as_double(static_cast<long long>(xs[w]));
                         ++cur;
                     }
                 }
             }
-            if (__all(cur == window)) break;
+        };
+        while (true) {
+            advance();
+            if (__all(done)) break;
+            if (__all(done || cur == window)) continue;  // only refills / publishes pending: no wait
             if (++rounds > max_rounds) {
                 gave_up = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-            for (int w = 0; w < window; ++w) {
-                if (w >= cur && c[w] >= 0 && xs[w] == sentinel_bits) xs[w] = poll(xb + c[w] * x_stride);
-            }
+            for (int i = 0; i < naps_between_polls; ++i) __builtin_amdgcn_s_sleep(1);
+            if (!done) ask(false);
         }
     }
-    if (gave_up) {
-        if (lane == 0) atomicExch(&hdr->overrun, 1u);
-        return;  // unsolved rows keep the sentinel NaN
-    }
-    if (!published) publish();
+    if (gave_up && lane == 0) atomicExch(&hdr->overrun, 1u);  // unsolved rows keep the sentinel NaN
 }
 
 template <bool Lower>
@@ -327,7 +437,7 @@ int analyse_symbolic(hipStream_t stream, int64_t n, const int32_t* row_ptrs, con
     int32_t* flags = reinterpret_cast<int32_t*>(ws + l.flags);  // [0] changed, [1] nlevels
     const int32_t n32 = static_cast<int32_t>(n);
     const int32_t nslices = static_cast<int32_t>(ceildiv(n, slice));
-    host_out[0] = host_out[1] = host_out[2] = 0;
+    host_out[0] = host_out[1] = host_out[2] = host_out[3] = 0;
     if (n == 0) return GKOMI_SUCCESS;
     int err = static_cast<int>(hipMemsetAsync(level, 0, sizeof(int32_t) * n, stream));
     if (err) return err;
@@ -336,7 +446,7 @@ int analyse_symbolic(hipStream_t stream, int64_t n, const int32_t* row_ptrs, con
     // a sweep usually settles many levels (rows are visited roughly in order)
     constexpr int batch = 16;
     for (int64_t sweeps = 0; sweeps <= n + batch; sweeps += batch) {
-        err = static_cast<int>(hipMemsetAsync(flags, 0, sizeof(int32_t), stream));
+        err = static_cast<int>(hipMemsetAsync(flags, 0, 4 * sizeof(int32_t), stream));
         if (err) return err;
         for (int i = 0; i < batch; ++i) {
             hipLaunchKernelGGL(trs_relax_levels_kernel<Lower>, grid, dim3(256), 0, stream, n32,
@@ -355,6 +465,7 @@ int analyse_symbolic(hipStream_t stream, int64_t n, const int32_t* row_ptrs, con
     err = static_cast<int>(rocprim::radix_sort_pairs(ws + l.tmp, tmp_bytes, level, level_sorted, rows, perm,
                                                      static_cast<size_t>(n), 0, 32, stream));
     if (err) return err;
+    hipLaunchKernelGGL(trs_invert_perm_kernel, grid, dim3(256), 0, stream, n32, perm, rows);  // rows := inverse
     hipLaunchKernelGGL(trs_slice_len_kernel, dim3(static_cast<unsigned>(ceildiv(nslices + 1, 4))), dim3(256),
                        0, stream, n32, nslices, perm, cnt, slice_len, level_sorted, flags + 1);
     tmp_bytes = l.tmp_bytes;
@@ -362,10 +473,12 @@ int analyse_symbolic(hipStream_t stream, int64_t n, const int32_t* row_ptrs, con
                                                    static_cast<size_t>(nslices + 1),
                                                    rocprim::plus<int32_t>(), stream));
     if (err) return err;
-    int32_t h[2] = {0, 0};
+    int32_t h[3] = {0, 0, 0};
     err = static_cast<int>(hipMemcpyAsync(&h[0], slice_off + nslices, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     if (err) return err;
     err = static_cast<int>(hipMemcpyAsync(&h[1], flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    if (err) return err;
+    err = static_cast<int>(hipMemcpyAsync(&h[2], flags + 2, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     if (err) return err;
     err = static_cast<int>(hipStreamSynchronize(stream));
     if (err) return err;
@@ -373,6 +486,7 @@ int analyse_symbolic(hipStream_t stream, int64_t n, const int32_t* row_ptrs, con
     host_out[0] = nslices;
     host_out[1] = h[0];
     host_out[2] = h[1];
+    host_out[3] = h[2] / slice;  // longest dependency list of a row
     return check_launch();
 }
 
@@ -428,17 +542,21 @@ extern "C" int gkomi_trs_analyse_numeric_f64_i32(gkomi_stream_t s, int64_t n, co
     hipLaunchKernelGGL(trs_fill_plan_kernel<LOWER>, grid, dim3(256), 0, stream, static_cast<int32_t>(n), \
                        static_cast<int32_t>(nslices), row_ptrs, col_idxs, vals,                         \
                        reinterpret_cast<const int32_t*>(sw + sl.perm),                                  \
+                       reinterpret_cast<const int32_t*>(sw + sl.rows),                                  \
                        reinterpret_cast<const int32_t*>(sw + sl.slice_off),                             \
+                       reinterpret_cast<const int32_t*>(sw + sl.level_sorted),                          \
                        reinterpret_cast<int32_t*>(p + pl.perm), reinterpret_cast<int32_t*>(p + pl.slice_off), \
+                       reinterpret_cast<int32_t*>(p + pl.scout),                                        \
                        reinterpret_cast<double*>(p + pl.diag), reinterpret_cast<int32_t*>(p + pl.cols),  \
-                       reinterpret_cast<double*>(p + pl.vals))
+                       reinterpret_cast<double*>(p + pl.vals), tuning("GKOMI_TRS_FAR", default_scout_far),  \
+                       tuning("GKOMI_TRS_NEAR", default_scout_near))
     if (lower) GKOMI_FILL(true); else GKOMI_FILL(false);
 #undef GKOMI_FILL
     return check_launch();
 }
 
 extern "C" int gkomi_trs_solve_plan_f64(gkomi_stream_t s, int64_t n, int64_t nrhs, void* plan,
-                                        int64_t nslices, int64_t entries, int unit_diag,
+                                        int64_t nslices, int64_t entries, int64_t max_deps, int unit_diag,
                                         const double* b, int64_t b_stride, double* x, int64_t x_stride)
 {
     if (n < 0 || nrhs < 0 || b_stride < nrhs || x_stride < nrhs) return GKOMI_EINVAL;
@@ -449,17 +567,28 @@ extern "C" int gkomi_trs_solve_plan_f64(gkomi_stream_t s, int64_t n, int64_t nrh
     char* p = static_cast<char*>(plan);
     plan_header* hdr = reinterpret_cast<plan_header*>(p);
     hipStream_t stream = to_stream(s);
-    const unsigned tickets = static_cast<unsigned>(ceildiv(nslices, solve_block / slice));
+    const unsigned groups = static_cast<unsigned>(ceildiv(nslices, solve_block / slice));
+    const char* env_rounds = getenv("GKOMI_TRS_MAX_ROUNDS");
+    const long long max_rounds = env_rounds != nullptr && env_rounds[0] != 0 ? atoll(env_rounds) : default_max_rounds;
+    const int naps = tuning("GKOMI_TRS_NAP", 1);
     for (int64_t j = 0; j < nrhs; ++j) {
-        hipLaunchKernelGGL(trs_plan_prepare_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, n, x + j,
-                           x_stride, hdr);
-        hipLaunchKernelGGL(trs_level_solve_kernel, dim3(tickets), dim3(solve_block), 0, stream, hdr,
-                           reinterpret_cast<const int32_t*>(p + pl.perm),
-                           reinterpret_cast<const int32_t*>(p + pl.slice_off),
-                           reinterpret_cast<const double*>(p + pl.diag),
-                           reinterpret_cast<const int32_t*>(p + pl.cols),
-                           reinterpret_cast<const double*>(p + pl.vals), unit_diag != 0, b + j, b_stride,
-                           x + j, x_stride);
+        hipLaunchKernelGGL(trs_plan_prepare_kernel, dim3(grid_for(nslices * slice, 256)), dim3(256), 0, stream,
+                           nslices * slice, reinterpret_cast<double*>(p + pl.xp), hdr);
+#define GKOMI_SOLVE(WINDOW)                                                                                   \
+    hipLaunchKernelGGL((trs_level_solve_kernel<WINDOW>), dim3(groups), dim3(solve_block), 0, stream, hdr,      \
+                       reinterpret_cast<const int32_t*>(p + pl.perm),                                         \
+                       reinterpret_cast<const int32_t*>(p + pl.slice_off),                                    \
+                       reinterpret_cast<const int32_t*>(p + pl.scout),                                        \
+                       reinterpret_cast<const double*>(p + pl.diag),                                          \
+                       reinterpret_cast<const int32_t*>(p + pl.cols),                                         \
+                       reinterpret_cast<const double*>(p + pl.vals), reinterpret_cast<double*>(p + pl.xp),    \
+                       unit_diag != 0, b + j, b_stride, x + j, x_stride, naps, max_rounds)
+        if (max_deps >= 0 && max_deps <= 4) {
+            GKOMI_SOLVE(4);
+        } else {
+            GKOMI_SOLVE(8);
+        }
+#undef GKOMI_SOLVE
         const int err = check_launch();
         if (err) return err;
     }

@@ -157,6 +157,9 @@ class GpuOps:
         n, k = x.shape
         self.gk.dense_fill_f64(self.stream(), n, k, x, x.stride(0), value)
 
+    def copy_scalar(self, src, dst):
+        self.gk.dense_copy_f64(self.stream(), 1, src.numel(), src, src.numel(), dst, dst.numel())
+
     def residual_check(self, tau, orig_tau, reduction, stop, flags):
         """ResidualNorm::check_impl: returns all_converged (blocking 2-byte copy)."""
         host = np.zeros(2, np.uint8)
@@ -205,6 +208,11 @@ class Matrix:
         self.gather_idxs = ops.empty(max(sum(self.send_sizes), 1), torch.int32)[:sum(self.send_sizes)]
         dist.all_to_all_single(self.gather_idxs, recv_gather, self.send_sizes, self.recv_sizes, group=self.group)
         self.send_count, self.recv_count = sum(self.send_sizes), sum(self.recv_sizes)
+        # whether the apply exchanges anything is decided ONCE and for ALL ranks (a rank
+        # without neighbours still takes part in the collective, matrix.cpp:263-303)
+        any_halo = torch.tensor([self.send_count + self.recv_count], dtype=torch.int64, device=recv_sizes.device)
+        dist.all_reduce(any_halo, op=dist.ReduceOp.MAX, group=self.group)
+        self._any_halo = int(any_halo.item()) > 0
         self._bufs = {}
         self._one = ops.tensor(np.array([1.0]))
         return self
@@ -221,8 +229,8 @@ class Matrix:
         nrhs = b.shape[1]
         send, recv = self._buffers(nrhs)
         ops.row_gather(self.gather_idxs, self.send_count, b, send)
-        if self.send_count == 0 and self.recv_count == 0:
-            ops.spmv(self.local, b, x)  # no neighbours: nothing to exchange
+        if not self._any_halo:
+            ops.spmv(self.local, b, x)  # no rank has neighbours: nothing to exchange anywhere
         else:
             # the collective runs on the backend's own stream (RCCL) behind the
             # pack kernel; the local SpMV is launched meanwhile and the wait only
@@ -301,6 +309,192 @@ def cg(matrix, b, x, max_iters=1000, reduction=1e-10, check_every=8):
         prev_rho, rho = rho, prev_rho
 
 
+def cg_fused(matrix, b, x, max_iters=1000, reduction=1e-10, check_every=8):
+    """The communication schedule of the native fused driver (csrc/dist_cg.hip) over
+    any `ops`: per iteration ONE two-element all-reduce for rho = r.z and tau^2 = r.r,
+    one for beta = p.q, the halo exchange overlapped with the local SpMV, the criterion
+    on the device, the host looking every `check_every` iterations.  Same iterates as
+    cg() up to the order of the reductions; Identity preconditioner, one or more
+    right-hand sides.  Returns (iterations, converged)."""
+    ops = matrix.ops
+    n, k = b.shape
+    r, z, p, q = (ops.empty((n, k), torch.float64) for _ in range(4))
+    f = lambda m=k: ops.empty((m,), torch.float64)
+    prev_rho, rho, beta, tau, orig = f(), f(), f(), f(), f()
+    pair = f(2 * k)                      # {r.z per column, r.r per column}: one all-reduce
+    stop = ops.empty((k,), torch.uint8)
+    ws = ops.reduction_workspace(n, k)
+    flags = ops.empty((2,), torch.uint8)
+    running = ops.tensor(np.zeros(1, np.int64))
+    one = ops.tensor(np.ones(1))
+    ops.cg_initialize(b, r, z, p, q, prev_rho, rho, stop)
+    matrix.apply(x, q)
+    ops.sub_scaled(one, q, r)
+    ops.fill(q, 0.0)
+    ops.local_squared_norm2(b, orig, ws)
+    dist.all_reduce(orig, op=dist.ReduceOp.SUM, group=matrix.group)
+    ops.sqrt_(orig)
+    check_every = max(1, int(check_every))
+    it = -1
+    while True:
+        ops.copy(r, z)                   # Identity preconditioner
+        ops.local_dot(r, z, pair[:k], ws)
+        ops.local_squared_norm2(r, pair[k:], ws)
+        dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=matrix.group)
+        ops.copy_scalar(pair[:k], rho)
+        ops.copy_scalar(pair[k:], tau)
+        ops.sqrt_(tau)
+        it += 1
+        if it >= max_iters:
+            done = int(running.item())
+            return (done, True) if done < it else (it, False)
+        ops.residual_check_device(tau, orig, reduction, stop, flags)
+        running += (flags[0:1] == 0)
+        if (it + 1) % check_every == 0 and int(flags[0].item()):
+            return int(running.item()), True
+        ops.cg_step_1(p, z, rho, prev_rho, stop)
+        matrix.apply(p, q)
+        ops.local_dot(p, q, beta, ws)
+        dist.all_reduce(beta, op=dist.ReduceOp.SUM, group=matrix.group)
+        ops.cg_step_2(x, r, p, q, beta, rho, stop)
+        prev_rho, rho = rho, prev_rho
+
+
+# ---- native path: C-ABI communicator + distributed matrix + fused CG (csrc/comm.hip, dist_cg.hip) ----
+
+class CommStruct(ctypes.Structure):
+    """gkomi_comm (include/gkomi.h)."""
+    _fields_ = [("self", ctypes.c_void_p), ("rank", ctypes.c_int), ("size", ctypes.c_int),
+                ("allreduce_sum_f64", ctypes.c_void_p), ("alltoallv", ctypes.c_void_p)]
+
+
+class DistMatrixStruct(ctypes.Structure):
+    """gkomi_dist_matrix (include/gkomi.h)."""
+    _fields_ = [("n_local", ctypes.c_int64), ("n_halo", ctypes.c_int64), ("l_nnz", ctypes.c_int64),
+                ("l_row_ptrs", ctypes.c_void_p), ("l_col_idxs", ctypes.c_void_p), ("l_vals", ctypes.c_void_p),
+                ("l_max_row_nnz", ctypes.c_int64), ("l_srow", ctypes.c_void_p), ("l_srow_tile", ctypes.c_int64),
+                ("nl_rows", ctypes.c_int64), ("nl_nnz", ctypes.c_int64), ("nl_row_idxs", ctypes.c_void_p),
+                ("nl_row_ptrs", ctypes.c_void_p), ("nl_col_idxs", ctypes.c_void_p), ("nl_vals", ctypes.c_void_p),
+                ("send_total", ctypes.c_int64), ("gather_idxs", ctypes.c_void_p),
+                ("send_counts", ctypes.c_void_p), ("send_offsets", ctypes.c_void_p),
+                ("recv_counts", ctypes.c_void_p), ("recv_offsets", ctypes.c_void_p),
+                ("send_buf", ctypes.c_void_p), ("recv_buf", ctypes.c_void_p)]
+
+
+class RcclComm:
+    """gkomi_comm over RCCL, bootstrapped through the torch.distributed group that
+    launched the ranks (the unique id is the only thing that travels there)."""
+
+    def __init__(self, gk, device, group=None):
+        self.gk = gk
+        if not gk.comm_rccl_available():
+            raise RuntimeError("RCCL could not be opened: the native distributed path needs it")
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        nb = int(gk.comm_unique_id_bytes())
+        ident = np.zeros(nb, np.uint8)
+        if rank == 0:
+            gk.comm_rccl_unique_id(ident)
+        t = torch.from_numpy(ident)
+        if dist.get_backend(group) == "nccl":
+            t = t.to(device)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = t.cpu().numpy().copy()
+        self.struct = CommStruct()
+        gk.comm_rccl_create(ident, rank, world, ctypes.addressof(self.struct))
+        self.ptr = ctypes.addressof(self.struct)
+        self.rank, self.size = rank, world
+
+    def close(self):
+        if self.struct.self:
+            self.gk.comm_rccl_destroy(self.ptr)
+
+
+class NativeMatrix:
+    """gkomi_dist_matrix of a Matrix that went through read_distributed (GpuOps), plus the
+    side stream / events of its overlapped exchange."""
+
+    def __init__(self, matrix):
+        self._build(matrix.ops, matrix.num_local_rows, matrix.local, matrix.non_local, matrix.send_sizes,
+                    matrix.recv_sizes, matrix.gather_idxs)
+
+    @classmethod
+    def from_parts(cls, ops, n_local, local, non_local, send_sizes, recv_sizes, gather_idxs):
+        """local / non_local = (nrows, ncols, nnz, row_ptrs, col_idxs, vals) device CSR blocks,
+        send/recv sizes per peer, gather_idxs (device int32) grouped by receiver."""
+        self = cls.__new__(cls)
+        self._build(ops, n_local, local, non_local, send_sizes, recv_sizes, gather_idxs)
+        return self
+
+    def _build(self, ops, n_loc, local, non_local, send_sizes, recv_sizes, gather_idxs):
+        gk = ops.gk
+        self.gk, self.ops, self.num_local_rows = gk, ops, n_loc
+        self._keep = (local, non_local, gather_idxs)
+        s = ops.stream()
+        send_count = int(sum(send_sizes))
+        _, _, l_nnz, l_rp, l_ci, l_v = local
+        _, n_halo, nl_nnz, nl_rp, nl_ci, nl_v = non_local
+        # the rows of the non-local block that have entries
+        nb = gk.dist_nonlocal_rows_workspace_bytes(n_loc)
+        ws = ops.empty(max(nb, 8), torch.uint8)
+        self.nl_row_idxs = ops.empty(n_loc + 1, torch.int32)
+        self.nl_row_ptrs = ops.empty(n_loc + 1, torch.int32)
+        cnt = ctypes.c_int64(0)
+        gk.dist_nonlocal_rows_i32(s, n_loc, nl_rp, self.nl_row_idxs, self.nl_row_ptrs, ws, nb, ctypes.addressof(cnt))
+        self.nl_rows = int(cnt.value)
+        # srow of the local block (Csr::make_srow)
+        tile = int(gk.csr_srow_tile())
+        self.max_row_nnz = -1
+        if n_loc > 0:
+            mx = ops.empty(1, torch.int32)
+            gk.csr_max_row_nnz_i32(s, n_loc, l_rp, mx)
+            self.max_row_nnz = int(mx.item())
+        self.srow = ops.empty(max(int(gk.csr_srow_entries(l_nnz, tile)), 1), torch.int32)
+        if l_nnz >= 2:
+            gk.csr_make_srow_i32(s, n_loc, l_nnz, l_rp, tile, self.srow, self.srow.numel())
+        self.send_counts = np.array(send_sizes, np.int64)
+        self.recv_counts = np.array(recv_sizes, np.int64)
+        self.send_offsets = np.concatenate([[0], np.cumsum(self.send_counts)[:-1]]).astype(np.int64)
+        self.recv_offsets = np.concatenate([[0], np.cumsum(self.recv_counts)[:-1]]).astype(np.int64)
+        assert len(self.send_counts) == len(self.recv_counts) and int(self.recv_counts.sum()) == n_halo
+        self.send_buf = ops.empty(max(send_count, 1), torch.float64)
+        self.recv_buf = ops.empty(max(n_halo, 1), torch.float64)
+        self.struct = DistMatrixStruct(
+            n_loc, n_halo, l_nnz, l_rp.data_ptr(), l_ci.data_ptr(), l_v.data_ptr(), self.max_row_nnz,
+            self.srow.data_ptr() if l_nnz >= 2 else None, tile, self.nl_rows, nl_nnz, self.nl_row_idxs.data_ptr(),
+            self.nl_row_ptrs.data_ptr(), nl_ci.data_ptr(), nl_v.data_ptr(), send_count,
+            gather_idxs.data_ptr(), self.send_counts.ctypes.data, self.send_offsets.ctypes.data,
+            self.recv_counts.ctypes.data, self.recv_offsets.ctypes.data, self.send_buf.data_ptr(),
+            self.recv_buf.data_ptr())
+        self.ptr = ctypes.addressof(self.struct)
+        ctx = ctypes.c_void_p(0)
+        gk.dist_ctx_create(ctypes.addressof(ctx))
+        self.ctx = ctx.value
+
+    def close(self):
+        if self.ctx:
+            self.gk.dist_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def apply(self, comm, b, x):
+        """Matrix::apply_impl, one right-hand side (gkomi_dist_matrix_apply_f64)."""
+        self.gk.dist_matrix_apply_f64(self.ops.stream(), comm.ptr, self.ctx, self.ptr, b, x)
+        return x
+
+    def cg(self, comm, b, x, max_iters=1000, reduction=1e-10, baseline="rhs_norm", check_every=16, precond=None):
+        """gkomi_dist_cg_solve_f64.  Returns dict(iterations, converged, residual_norm, baseline_norm)."""
+        ops = self.ops
+        nb = self.gk.dist_cg_workspace_bytes(self.num_local_rows, self.nl_rows)
+        if getattr(self, "_ws", None) is None or self._ws.numel() < nb:
+            self._ws = ops.empty(nb, torch.uint8)
+        info = np.zeros(4, np.float64)
+        self.gk.dist_cg_solve_f64(ops.stream(), comm.ptr, self.ctx, self.ptr, precond.fn if precond is not None else None,
+                                  precond.ctx_ptr if precond is not None else None, b, x, max_iters, reduction,
+                                  {"rhs_norm": 0, "initial_resnorm": 1, "absolute": 2}[baseline], check_every,
+                                  self._ws, nb, info)
+        return {"iterations": int(info[0]), "converged": bool(info[1]), "residual_norm": float(info[2]),
+                "baseline_norm": float(info[3])}
+
+
 def poisson_slab_rows(grid, rank, world):
     """COO entries (global int64 indices, row-major) of rank's rows of the 5-pt
     Poisson matrix on a (grid*world) x grid mesh, row = i*grid + j: the bench's
@@ -315,6 +509,21 @@ def poisson_slab_rows(grid, rank, world):
     vals = np.broadcast_to(np.array([-1.0, -1.0, 4.0, -1.0, -1.0]), cols.shape)
     rows = np.broadcast_to(row[:, None], cols.shape)
     return rows[valid], cols[valid], np.ascontiguousarray(vals[valid]), nx * ny
+
+
+def poisson3d_rows(g, lo, hi):
+    """COO entries (global int64 indices, row-major, ascending columns) of rows [lo, hi) of the
+    7-pt Poisson matrix on a g^3 grid, row = (i*g + j)*g + k: BASELINE config 5 (g = 256) cut into
+    contiguous row slabs; every rank generates only its own rows."""
+    idx = np.arange(lo, hi, dtype=np.int64)
+    k = idx % g
+    j = (idx // g) % g
+    i = idx // (g * g)
+    cols = np.stack([idx - g * g, idx - g, idx - 1, idx, idx + 1, idx + g, idx + g * g], axis=1)
+    valid = np.stack([i > 0, j > 0, k > 0, np.ones(len(idx), bool), k < g - 1, j < g - 1, i < g - 1], axis=1)
+    vals = np.broadcast_to(np.array([-1.0, -1.0, -1.0, 6.0, -1.0, -1.0, -1.0]), cols.shape)
+    rows = np.broadcast_to(idx[:, None], cols.shape)
+    return rows[valid], cols[valid], np.ascontiguousarray(vals[valid])
 
 
 def poisson_slab_matrix(gk, grid, rank, world, device, group=None):

@@ -185,7 +185,11 @@ class IluCtx(ctypes.Structure):
                 ("l_row_ptrs", ctypes.c_void_p), ("l_col_idxs", ctypes.c_void_p), ("l_vals", ctypes.c_void_p),
                 ("u_row_ptrs", ctypes.c_void_p), ("u_col_idxs", ctypes.c_void_p), ("u_vals", ctypes.c_void_p),
                 ("intermediate", ctypes.c_void_p), ("trs_workspace", ctypes.c_void_p),
-                ("trs_workspace_bytes", ctypes.c_size_t), ("l_unit_diag", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+                ("trs_workspace_bytes", ctypes.c_size_t), ("l_unit_diag", ctypes.c_int32), ("pad_", ctypes.c_int32),
+                ("l_plan", ctypes.c_void_p), ("l_nslices", ctypes.c_int64), ("l_entries", ctypes.c_int64),
+                ("l_max_deps", ctypes.c_int64),
+                ("u_plan", ctypes.c_void_p), ("u_nslices", ctypes.c_int64), ("u_entries", ctypes.c_int64),
+                ("u_max_deps", ctypes.c_int64)]
 
 
 class Preconditioner:
@@ -269,9 +273,9 @@ class TrsPlan:
         s = torch.cuda.current_stream().cuda_stream
         nb = gk.trs_symbolic_workspace_bytes(n)
         self.symbolic = torch.empty(max(nb, 8), dtype=torch.uint8, device=dv)
-        out = (ctypes.c_int64 * 3)()
+        out = (ctypes.c_int64 * 4)()
         gk.trs_analyse_symbolic_i32(s, n, row_ptrs, col_idxs, int(self.lower), self.symbolic, nb, ctypes.addressof(out))
-        self.nslices, self.entries, self.nlevels = (int(v) for v in out)
+        self.nslices, self.entries, self.nlevels, self.max_deps = (int(v) for v in out)
         self.plan_bytes = gk.trs_plan_bytes(self.nslices, self.entries)
         self.plan = torch.empty(max(self.plan_bytes, 8), dtype=torch.uint8, device=dv)
         self.refresh(vals)
@@ -287,7 +291,7 @@ class TrsPlan:
     def solve(self, b, x, unit_diag=False):
         s = torch.cuda.current_stream().cuda_stream
         b2, x2 = b.reshape(self.n, -1), x.reshape(self.n, -1)
-        self.gk.trs_solve_plan_f64(s, self.n, b2.shape[1], self.plan, self.nslices, self.entries, int(unit_diag),
+        self.gk.trs_solve_plan_f64(s, self.n, b2.shape[1], self.plan, self.nslices, self.entries, self.max_deps, int(unit_diag),
                                    b2, b2.stride(0), x2, x2.stride(0))
         return x
 
@@ -297,15 +301,35 @@ class TrsPlan:
         return bool(flag.value)
 
 
-def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False):
-    """preconditioner::Ilu over given CSR factors L = (row_ptrs, col_idxs, vals), U likewise."""
+# a level must hold this many rows on average for the level-scheduled solve to pay: below it
+# (chains, narrow bands) the analysis-free kernel with its in-workgroup LDS hand-offs is faster
+TRS_PLAN_MIN_ROWS_PER_LEVEL = 64
+
+
+def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True):
+    """preconditioner::Ilu over given CSR factors L = (row_ptrs, col_idxs, vals), U likewise.
+    analyse: LowerTrs / UpperTrs::generate -- the dependency-level analysis of both factors; a factor
+    whose levels are wide enough is then solved by the level-scheduled kernel (True / False / "force")."""
     dv = L[2].device
     inter = torch.zeros((n, nrhs), dtype=torch.float64, device=dv)
     nb = gk.trs_workspace_bytes()
     tws = torch.zeros(nb, dtype=torch.uint8, device=dv)
+    plans = [None, None]
+    if analyse and n > 0:
+        for i, (f, lower) in enumerate(((L, True), (U, False))):
+            plan = TrsPlan(gk, n, f[0], f[1], f[2], lower)
+            if analyse == "force" or n >= TRS_PLAN_MIN_ROWS_PER_LEVEL * max(plan.nlevels, 1):
+                plans[i] = plan
+    pl, pu = plans
     ctx = IluCtx(n, nrhs, L[0].data_ptr(), L[1].data_ptr(), L[2].data_ptr(), U[0].data_ptr(), U[1].data_ptr(),
-                 U[2].data_ptr(), inter.data_ptr(), tws.data_ptr(), nb, int(l_unit_diag), 0)
-    return Preconditioner(gk, "gkomi_ilu_apply_cb", ctx, (L, U, inter, tws))
+                 U[2].data_ptr(), inter.data_ptr(), tws.data_ptr(), nb, int(l_unit_diag), 0,
+                 pl.plan.data_ptr() if pl else None, pl.nslices if pl else 0, pl.entries if pl else 0,
+                 pl.max_deps if pl else -1,
+                 pu.plan.data_ptr() if pu else None, pu.nslices if pu else 0, pu.entries if pu else 0,
+                 pu.max_deps if pu else -1)
+    p = Preconditioner(gk, "gkomi_ilu_apply_cb", ctx, (L, U, inter, tws, pl, pu))
+    p.l_plan, p.u_plan = pl, pu
+    return p
 
 
 def gmres_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, krylov_dim=100, max_iters=1000, reduction=1e-10,

@@ -96,6 +96,9 @@ class OracleOps:
     def fill(self, x, value):
         self.o.ref_dense_fill(x.shape[0], x.shape[1], self._np(x), x.stride(0), value)
 
+    def copy_scalar(self, src, dst):
+        self.o.ref_dense_copy(1, src.numel(), self._np(src), src.numel(), self._np(dst), dst.numel())
+
     def residual_check_device(self, tau, orig_tau, reduction, stop, flags):
         self.o.ref_residual_norm(tau.numel(), self._np(tau), self._np(orig_tau), reduction, 2, 1, self._np(stop),
                                  self._np(flags))

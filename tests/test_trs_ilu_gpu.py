@@ -340,3 +340,32 @@ def test_trs_plan_ilu0_apply_and_refresh(gk, oracle):
     pl.refresh(dev(lv2))
     pl.solve(dev(b), yd)
     assert np.array_equal(host(yd), y2) and not pl.overrun() and not pu.overrun()
+
+
+@pytest.mark.parametrize("analyse", [False, "force"])
+def test_trs_overrun_is_sticky_and_surfaces_as_an_error(gk, oracle, monkeypatch, analyse):
+    """a triangular solve that gives up used to erase its own flag at the next
+    solve and no driver looked at it.  Now the flag is sticky and the solver drivers return
+    GKOMI_ETRS_OVERRUN for an Ilu preconditioner whose solves gave up."""
+    import gkomi
+    import gkomi.solvers as solvers
+    n, rp, ci, v = matgen.poisson_2d_5pt(40)
+    f = ilu_util.oracle_par_ilu(oracle, n, rp, ci, v)
+    L = tuple(dev(a) for a in f["L"])
+    U = tuple(dev(a) for a in f["U"])
+    pre = solvers.ilu_from_factors(gk, n, L, U, analyse=analyse)
+    b = dev(np.ones(n))
+    ok = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), b, krylov_dim=30, max_iters=200, reduction=1e-10, precond=pre)
+    assert ok["converged"]
+    monkeypatch.setenv("GKOMI_TRS_MAX_ROUNDS", "1")      # test hook: give up after one look at a dependency
+    with pytest.raises(gkomi._lib.GkomiError) as e:
+        solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), b, krylov_dim=30, max_iters=20, reduction=1e-10, precond=pre)
+    assert e.value.code == -6                            # GKOMI_ETRS_OVERRUN
+    monkeypatch.delenv("GKOMI_TRS_MAX_ROUNDS")
+    # sticky: a later, healthy solve with the same preconditioner still reports it
+    with pytest.raises(gkomi._lib.GkomiError):
+        solvers.cg_solve(gk, n, dev(rp), dev(ci), dev(v), b, max_iters=5, reduction=1e-10, precond=pre)
+    # a fresh preconditioner (fresh workspace / plans) is healthy again
+    pre2 = solvers.ilu_from_factors(gk, n, L, U, analyse=analyse)
+    assert solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), b, krylov_dim=30, max_iters=200, reduction=1e-10,
+                               precond=pre2)["converged"]

@@ -46,13 +46,19 @@ tu = ev_time(lambda: gk.upper_trs_solve_f64_i32(s, n, 1, U[0], U[1], U[2], 0, y,
 flag = ctypes.c_int(0); gk.trs_check_overrun(s, tws, ctypes.addressof(flag))
 print(f"AT-like {g3}^3: n={n} nnz={len(v)}  ParILU(5 sweeps) generate {t_gen*1e3:.1f} ms, L nnz {lnnz}, U nnz {unnz}")
 print(f"  lower trs {tl:9.1f} us ({(12*lnnz+20*n)/tl/1e3:6.1f} GB/s)   upper trs {tu:9.1f} us ({(12*unnz+20*n)/tu/1e3:6.1f} GB/s)  overrun={flag.value}")
-pre = solvers.ilu_from_factors(gk, n, L, U)
-for prec, name in ((None, "none"), (pre, "ParILU")):
+pre_plain = solvers.ilu_from_factors(gk, n, L, U, analyse=False)
+t0 = time.perf_counter(); pre = solvers.ilu_from_factors(gk, n, L, U); torch.cuda.synchronize()
+print(f"  LowerTrs/UpperTrs generate (level analysis of both factors): {1e3*(time.perf_counter()-t0):.1f} ms, "
+      f"levels {pre.l_plan.nlevels if pre.l_plan else '-'} / {pre.u_plan.nlevels if pre.u_plan else '-'}")
+if pre.l_plan is not None:
+    tl2 = ev_time(lambda: pre.l_plan.solve(b, y)); tu2 = ev_time(lambda: pre.u_plan.solve(y, z))
+    print(f"  analysed: lower trs {tl2:9.1f} us   upper trs {tu2:9.1f} us   overrun={int(pre.l_plan.overrun() or pre.u_plan.overrun())}")
+for prec, name in ((None, "none"), (pre_plain, "ParILU (analysis-free trs)"), (pre, "ParILU (analysed trs)")):
     solvers.gmres_solve(gk, n, rpd, cid, vd, b, krylov_dim=30, max_iters=3000, reduction=1e-10, precond=prec)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     r = solvers.gmres_solve(gk, n, rpd, cid, vd, b, krylov_dim=30, max_iters=3000, reduction=1e-10, precond=prec)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
-    print(f"  GMRES(30) precond={name:7s}: {r['iterations']:5d} iters {el*1e3:9.2f} ms  {el/max(r['iterations'],1)*1e6:8.1f} us/it converged={r['converged']} rel_res={r['rel_residual']:.2e}")
+    print(f"  GMRES(30) precond={name:26s}: {r['iterations']:5d} iters {el*1e3:9.2f} ms  {el/max(r['iterations'],1)*1e6:8.1f} us/it converged={r['converged']} rel_res={r['rel_residual']:.2e}")
 
 # ---- T2-like: permuted 2-D Poisson, CG + block-Jacobi(32) ----
 n, rp, ci, v = matgen.poisson_2d_5pt(g2)

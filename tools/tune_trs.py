@@ -47,6 +47,25 @@ def run(name, n, rp, ci, v, reps=5):
           f"identical={same} overrun={int(plan.overrun())}")
 
 
+if os.environ.get("TRS_SWEEP"):
+    # scout distances / poll cadence of the analysed solve on the config-4 factor shape
+    import gkomi.solvers as solvers
+    nn, rp, ci, v = matgen.poisson_3d_7pt(int(os.environ.get("TRS_SWEEP_GRID", "108")))
+    lrp, lci, lv = lower_of(nn, rp, ci, v)
+    rpd, cid, vd = d(lrp), d(lci), d(lv)
+    b = torch.ones((nn, 1), dtype=torch.float64, device="cuda"); x = torch.zeros_like(b)
+    for near in (1, 2, 3, 4):
+        for far in (8, 16, 32):
+            for nap in (0, 1, 4):
+                os.environ.update(GKOMI_TRS_NEAR=str(near), GKOMI_TRS_FAR=str(far), GKOMI_TRS_NAP=str(nap))
+                plan = solvers.TrsPlan(gk, nn, rpd, cid, vd, True)
+                plan.solve(b, x); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5): plan.solve(b, x)
+                e1.record(); torch.cuda.synchronize()
+                print(f"near {near} far {far:2d} nap {nap}: {e0.elapsed_time(e1) * 1e3 / 5:8.1f} us  overrun={int(plan.overrun())}", flush=True)
+    sys.exit(0)
 quick = os.environ.get("TRS_QUICK")
 n = 1 << 20
 run("diagonal (no dependencies)", n, np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), np.full(n, 2.0))
