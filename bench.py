@@ -24,19 +24,13 @@ N > 1  (configs[4], "P3", one process per GPU under torch.distributed): STRONG
        driver, csrc/dist_cg.hip, over its own RCCL communicator).
        GKOMI_BENCH_FORCE_DIST=1 runs that code path with a world of one rank.
 """
+import argparse
+import json
 import os
-
-# the CPU baseline's OpenMP runtime reads these when it starts (SURVEY 8(d)); the
-# unbound variant runs in a child process that overrides them
-os.environ.setdefault("OMP_PROC_BIND", "true")
-os.environ.setdefault("OMP_PLACES", "cores")
-
-import argparse  # noqa: E402
-import json  # noqa: E402
-import statistics  # noqa: E402
-import subprocess  # noqa: E402
-import sys  # noqa: E402
-import time  # noqa: E402
+import statistics
+import subprocess
+import sys
+import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "repo-8852-ginkgo_amd"), os.path.join(ROOT, "tests")):
@@ -119,7 +113,9 @@ def cpu_baseline_child(seconds):
     numa = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node")]) \
         if os.path.isdir("/sys/devices/system/node") else 1
     out = {"value": round(2.0 * nnz * reps / el / 1e9, 3), "unit": "GFLOP/s",
-           "cores": os.cpu_count(), "threads": int(orc.omp_bench_threads()), "numa_nodes": numa, "kind": "port",
+           "cores": int(orc.omp_bench_threads()), "threads": int(orc.omp_bench_threads()),
+           "host_cpus": os.cpu_count(), "cpus_allowed": len(os.sched_getaffinity(0)), "numa_nodes": numa, "kind": "port",
+           "omp_num_threads": os.environ.get("OMP_NUM_THREADS", ""),
            "omp_proc_bind": os.environ.get("OMP_PROC_BIND", ""), "omp_places": os.environ.get("OMP_PLACES", ""),
            "sample": f"{reps} x omp csr::spmv on the same 1M-row 5-pt Poisson matrix ({el:.1f} s), "
                      "arrays first-touched by the threads that stream them",
@@ -132,14 +128,16 @@ def cpu_baseline_child(seconds):
 
 
 def cpu_baseline(seconds):
-    """bound (OMP_PROC_BIND=true, OMP_PLACES=cores) and unbound runs; the faster SpMV is the headline."""
+    """The omp/ path on every CPU this process may use, in child processes (the OpenMP runtime
+    fixes its binding when it starts): unbound, OMP_PROC_BIND=true and
+    OMP_PROC_BIND=true + OMP_PLACES=cores; the fastest SpMV is the headline, all are reported."""
     runs = {}
-    for name, env in (("bound", {"OMP_PROC_BIND": "true", "OMP_PLACES": "cores"}),
-                      ("unbound", {"OMP_PROC_BIND": "false", "OMP_PLACES": ""})):
-        e = dict(os.environ)
+    ncpu = str(len(os.sched_getaffinity(0)))
+    for name, env in (("unbound", {"OMP_PROC_BIND": "false"}), ("bound", {"OMP_PROC_BIND": "true"}),
+                      ("bound_cores", {"OMP_PROC_BIND": "true", "OMP_PLACES": "cores"})):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("OMP_") and not k.startswith("GOMP_")}
         e.update(env)
-        if not env["OMP_PLACES"]:
-            e.pop("OMP_PLACES", None)
+        e["OMP_NUM_THREADS"] = ncpu
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-seconds", str(seconds)],
                                env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
@@ -152,8 +150,8 @@ def cpu_baseline(seconds):
     best = max(good, key=lambda k: good[k]["value"])
     out = dict(good[best])
     out["binding"] = best
-    out["runs"] = {k: ({"gflops": v["value"], "gbs": v["gbs"], "cg_iters_per_sec": v["cg"]["iters_per_sec"]}
-                       if "value" in v else v) for k, v in runs.items()}
+    out["runs"] = {k: ({"gflops": v["value"], "gbs": v["gbs"], "threads": v["threads"],
+                        "cg_iters_per_sec": v["cg"]["iters_per_sec"]} if "value" in v else v) for k, v in runs.items()}
     return out
 
 
@@ -367,6 +365,10 @@ def main():
                             "iters_per_sec": round(res["iterations"] / el, 1), "converged": bool(res["converged"]),
                             "final_residual_norm_rel": res["rel_residual"],
                             "solution_rel_err": float(torch.linalg.norm(res["x"] - sb3) / torch.linalg.norm(sb3))}
+                res, el, all_s = timed_cg(n3, a3, torch.ones((n3, 1), dtype=torch.float64, device=device))
+                p3["cg_rhs_ones"] = {"iterations": res["iterations"], "seconds": round(el, 5), "all_seconds": all_s,
+                                     "iters_per_sec": round(res["iterations"] / el, 1), "converged": bool(res["converged"]),
+                                     "final_residual_norm_rel": res["rel_residual"]}
             out["p3"] = p3
             del a3, x3, y3, srow3
 
@@ -439,33 +441,40 @@ def main():
             (A.apply(comm, sd, b) if A is not None else M.apply(sd, b))
             torch.cuda.synchronize()
 
-            def solve():
+            def solve(rhs):
                 xs = torch.zeros((n_loc, 1), dtype=torch.float64, device=device)
                 if A is not None:
-                    r = A.cg(comm, b, xs, max_iters=100000, reduction=1e-10, check_every=32)
+                    r = A.cg(comm, rhs, xs, max_iters=100000, reduction=1e-10, check_every=32)
                     return xs, r["iterations"], r["converged"], r["residual_norm"] / max(r["baseline_norm"], 1e-300)
-                it, conv = gd.cg_fused(M, b, xs, max_iters=100000, reduction=1e-10, check_every=32)
+                it, conv = gd.cg_fused(M, rhs, xs, max_iters=100000, reduction=1e-10, check_every=32)
                 return xs, it, conv, None
 
-            solve()
-            runs = []
-            for _ in range(3):
-                barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                xs, its, conv, rel = solve()
-                torch.cuda.synchronize()
-                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                runs.append(float(t.item()))
+            def timed_solve(rhs):
+                solve(rhs)
+                runs = []
+                for _ in range(3):
+                    barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    xs, its, conv, rel = solve(rhs)
+                    torch.cuda.synchronize()
+                    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    runs.append(float(t.item()))
+                el = min(runs)
+                return xs, {"iterations": int(its), "converged": bool(conv), "seconds": round(el, 5),
+                            "all_seconds": [round(r, 5) for r in runs], "timing": "best of 3 solves, max over ranks",
+                            "iters_per_sec": round(its / el, 1), "final_residual_norm_rel": rel, "global_rows": n_global}
+
+            xs, res = timed_solve(b)
             err = torch.stack([torch.sum((xs - sd) ** 2), torch.sum(sd ** 2)])
             dist.all_reduce(err)
-            el = min(runs)
-            out["cg"] = {"metric": "row-partitioned CG to 1e-10 (no iteration cap), sinus rhs b = A s/|s|",
-                         "iterations": int(its), "converged": bool(conv), "seconds": round(el, 5),
-                         "all_seconds": [round(r, 5) for r in runs], "timing": "best of 3 solves, max over ranks",
-                         "iters_per_sec": round(its / el, 1), "final_residual_norm_rel": rel,
-                         "solution_rel_err": float(torch.sqrt(err[0] / err[1]).item()), "global_rows": n_global}
+            res["metric"] = "row-partitioned CG to 1e-10 (no iteration cap), sinus rhs b = A s/|s| (benchmark/solver default)"
+            res["solution_rel_err"] = float(torch.sqrt(err[0] / err[1]).item())
+            out["cg"] = res
+            _, res1 = timed_solve(torch.ones((n_loc, 1), dtype=torch.float64, device=device))
+            res1["metric"] = "row-partitioned CG to 1e-10 (no iteration cap), b = 1"
+            out["cg_rhs_ones"] = res1
         if A is not None:
             A.close()
             comm.close()

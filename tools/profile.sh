@@ -9,11 +9,11 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --steps 200 --warmup 20"
+ARGS="--no-cpu-baseline --no-p3 --steps 200 --warmup 20"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS --no-cg > $OUT/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $ARGS --no-cg > $OUT/pmc_write.log 2>&1 || exit 1
 # calibration of FETCH_SIZE on a known byte count in a comparable access mix
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_membench -- python3 $ROOT/tools/membench.py 1000 > $OUT/pmc_fetch_membench.log 2>&1 || exit 1
-python3 $ROOT/tools/summarize_profile.py $OUT > $OUT/summary.md
+python3 $ROOT/tools/summarize_profile.py $OUT $OUT/traffic.json > $OUT/summary.md
 cat $OUT/summary.md

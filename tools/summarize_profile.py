@@ -32,13 +32,17 @@ if st:
               f"{float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |")
 tr = find("trace", "kernel_trace.csv")
 if tr:
-    # the plain (non-advanced, no dot epilogue) instantiation, swizzled or not
-    rows = [r for r in csv.DictReader(open(tr)) if "csr_stream_kernel<256, 1, 1536, false, true, false" in r["Kernel_Name"]
-            or "csr_stream_kernel<256, 1, 1536, false, false, false" in r["Kernel_Name"]]
-    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
-    if len(d) >= 440:
-        print(f"\ncsr_stream_kernel, bench order = 20 warm-up + 200 cold (rotating copies) + 20 + 200 warm: "
-              f"cold mean {statistics.mean(d[20:220])/1e3:.2f} us, warm mean {statistics.mean(d[240:440])/1e3:.2f} us")
+    # bench.py's cold leg runs the nontemporal instantiation of the nonzero-split kernel
+    # (template arguments ..., Dot = false, NT = true, ...), its warm leg the plain one
+    by = {}
+    for r in csv.DictReader(open(tr)):
+        if "csr_split_kernel" in r["Kernel_Name"]:
+            by.setdefault(short(r["Kernel_Name"]), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, d in sorted(by.items()):
+        leg = "cold leg (rotating copies, nontemporal streams)" if "false, true, false, true" in k else \
+            "warm leg (same matrix every step)" if "false, true, false, false" in k else "other"
+        print(f"\n`{k}`: {len(d)} launches, mean {statistics.mean(d)/1e3:.2f} us, median {statistics.median(d)/1e3:.2f} us, "
+              f"min {min(d)/1e3:.2f} us -- {leg}")
 
 
 def pmc(sub, counter):
@@ -68,3 +72,16 @@ if cal:
     for k, v in cal.items():
         print(f"- `{k}`: mean FETCH_SIZE {statistics.mean(v):.0f} KiB over {len(v)} launches "
               f"-> {statistics.mean(v)*1024/71952004:.3f} of the bytes actually read")
+
+# per-launch HBM traffic of the cold leg's kernel for bench.py's roofline.traffic
+cold = [k for k in set(fetch) & set(write) if "csr_split_kernel" in k and "false, true, false, true" in k]
+if cold and len(sys.argv) > 2:
+    import json
+    k = cold[0]
+    t = int((2 * statistics.mean(fetch[k]) + statistics.mean(write[k])) * 1024)
+    json.dump({"kernel": k, "fetch_size_kib_mean": statistics.mean(fetch[k]), "write_size_kib_mean": statistics.mean(write[k]),
+               "traffic_bytes_per_launch": t,
+               "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024: the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md, "
+                          "calibrated in the same run on tools/membench.hip",
+               "algorithmic_bytes_per_launch": 79952004}, open(sys.argv[2], "w"), indent=1)
+    print(f"\nHBM traffic per launch of the cold leg: {t} B vs 79952004 algorithmic ({t/79952004:.3f}x) -> {sys.argv[2]}")
