@@ -254,10 +254,12 @@ class CudaExecutor {
 public:
     static std::shared_ptr<Executor> create(int, std::shared_ptr<Executor>, bool = false,
                                             allocation_mode = allocation_mode::device) { GKO_NOT_COMPILED(cuda); }
+    static int get_num_devices() { return 0; }
 };
 class DpcppExecutor {
 public:
     static std::shared_ptr<Executor> create(int, std::shared_ptr<Executor>, std::string = "all") { GKO_NOT_COMPILED(dpcpp); }
+    static int get_num_devices(std::string = "all") { return 0; }
 };
 
 namespace detail {
@@ -384,7 +386,13 @@ T* as(U* p)
 // ---- matrix_data + MatrixMarket I/O (include/ginkgo/core/base/mtx_io.hpp) -----------
 template <typename V = double, typename I = int32>
 struct matrix_data {
-    struct nonzero_type { I row; I column; V value; };
+    struct nonzero_type {
+        nonzero_type() = default;
+        nonzero_type(I r, I c, V v) : row(r), column(c), value(v) {}
+        I row{};
+        I column{};
+        V value{};
+    };
     dim<2> size;
     std::vector<nonzero_type> nonzeros;
     void ensure_row_major_order()
@@ -1266,6 +1274,16 @@ private:
 };
 }  // namespace stop
 
+namespace detail {
+// A system whose solve is a collective: implemented by experimental::distributed::Matrix
+// (distributed.hpp); the solvers hand such a system to its own driver.
+struct distributed_system {
+    virtual ~distributed_system() = default;
+    virtual void cg_solve(const LinOp* b, LinOp* x, const stop::criterion_settings& settings, const LinOp* precond, int64_t* iters,
+                          bool* converged) const = 0;
+};
+}  // namespace detail
+
 // ---- preconditioners -----------------------------------------------------------------
 namespace detail {
 // a LinOp as a gkomi_apply_fn for the native solver drivers
@@ -1506,6 +1524,11 @@ protected:
     void apply_impl(const LinOp* b, LinOp* x) const override
     {
         ::gko::detail::require_device(exec_, "cg::apply");
+        if (auto ds = dynamic_cast<const ::gko::detail::distributed_system*>(A_.get())) {
+            // experimental::distributed::Matrix + Vectors: the row-partitioned driver
+            ds->cg_solve(b, x, settings_, precond_.get(), &last_iters_, &last_converged_);
+            return;
+        }
         auto csr = dynamic_cast<const matrix::Csr<V, int32>*>(A_.get());
         auto db = matrix::detail_fmt::dense(b); auto dx = matrix::detail_fmt::dense(x);
         const int64_t n = size_[0], nrhs = db->cols();
@@ -2110,5 +2133,7 @@ protected:
 }  // namespace preconditioner
 
 }  // namespace gko
+
+#include "distributed.hpp"
 
 #endif  // GKOMI_GINKGO_HPP_

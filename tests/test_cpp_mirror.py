@@ -107,3 +107,50 @@ def test_hot_path_tour(bins):
     # device assembly: duplicates summed, explicit zeros dropped, Csr::read on the device
     assert kv["assembly_nnz"][0] == kv["assembly_nnz"][2] and float(kv["assembly_nnz"][4]) == 0.0
     assert kv["dimension_check"] == ["ok"]
+
+
+REF_DIST_EXAMPLE = "/root/reference/examples/distributed-solver/distributed-solver.cpp"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DIST_EXAMPLE), reason="reference tree not mounted")
+def test_reference_distributed_solver_source_compiles_unchanged(tmp_path):
+    """examples/distributed-solver/distributed-solver.cpp of the reference, read where it lies:
+    gko::experimental::{mpi, distributed} of the mirror (no MPI in this image: one process per GPU,
+    RCCL underneath) carry every name it uses."""
+    out = tmp_path / "ref_distributed_solver"
+    r = subprocess.run(["g++", "-std=c++14", f"-I{PKG}/include", REF_DIST_EXAMPLE, "-o", str(out),
+                        f"-L{PKG}/lib", "-lgkomi", f"-Wl,-rpath,{PKG}/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # on a host executor the solve is refused, loudly (no CPU kernels in this backend)
+    run = subprocess.run([str(out), "reference", "50"], capture_output=True, text=True)
+    assert run.returncode != 0 and "NotCompiled" in run.stderr
+
+
+def test_distributed_example_on_host_executor_raises_not_compiled(bins):
+    r = subprocess.run([os.path.join(bins, "distributed_solver"), "reference", "50"], capture_output=True, text=True)
+    assert r.returncode == 3 and "NotCompiled" in r.stderr
+
+
+@pytest.mark.gpu
+def test_distributed_solver_example_on_hip_one_rank(bins, oracle):
+    """The mirror's Partition / Vector / Matrix / Cg on distributed vectors over RCCL, one rank: the
+    3-pt stencil system of the reference example, checked against the oracle's CG."""
+    import matgen
+    n = 2000
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([os.path.join(bins, "distributed_solver"), "hip", str(n)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    kv = {line.split(":")[0].strip(): line.split(":", 1)[1].strip() for line in r.stdout.splitlines() if ":" in line}
+    assert int(kv["Num ranks"]) == 1 and int(kv["Converged"]) == 1
+    assert kv["Local rows / halo in / halo out on rank 0"].split() == [str(n), "0", "0"]
+    assert float(kv["Final Res norm"]) <= 2e-8
+    rows = np.repeat(np.arange(n), 3)
+    cols = rows + np.tile([-1, 0, 1], n)
+    vals = np.tile([-1.0, 2.0, -1.0], n)
+    keep = (cols >= 0) & (cols < n)
+    rp, ci, v = matgen.coo_to_csr(n, rows[keep].astype(np.int32), cols[keep].astype(np.int32), vals[keep])
+    b = np.sin(0.01 * np.arange(n))
+    xe = np.zeros(n)
+    ite = oracle.ref_cg_solve(n, rp, ci, v, b, xe, 20 * n, 1e-8, 2, None, 0)
+    assert abs(int(kv["Iterations"]) - ite) <= 2
+    assert abs(float(kv["Solution norm"]) - np.linalg.norm(xe)) <= 1e-6 * np.linalg.norm(xe)
