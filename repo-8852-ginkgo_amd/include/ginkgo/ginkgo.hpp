@@ -781,7 +781,7 @@ public:
     const V* get_const_values() const noexcept { return values_.get_const_data(); }
     I* get_col_idxs() noexcept { return col_idxs_.get_data(); }
     const I* get_const_col_idxs() const noexcept { return col_idxs_.get_const_data(); }
-    I* get_row_ptrs() noexcept { return row_ptrs_.get_data(); }
+    I* get_row_ptrs() noexcept { srow_valid_ = false; return row_ptrs_.get_data(); }  // the caller may rewrite them
     const I* get_const_row_ptrs() const noexcept { return row_ptrs_.get_const_data(); }
     size_type get_num_stored_elements() const noexcept { return values_.get_num_elems(); }
     std::shared_ptr<strategy_type> get_strategy() const noexcept { return strategy_; }
@@ -807,6 +807,7 @@ public:
         col_idxs_ = array<I>(exec_, ci.begin(), ci.end());
         values_ = array<V>(exec_, v.begin(), v.end());
         set_size(data.size);
+        invalidate_srow();
     }
     // Csr::read(device_matrix_data) (core/matrix/csr.cpp:445-470): takes the
     // arrays over as they are (row-major order is the caller's job) and builds
@@ -827,6 +828,7 @@ public:
         GKOMI_CALL(gkomi_convert_idxs_to_ptrs_i32(nullptr, arrays.row_idxs.get_const_data(), arrays.row_idxs.get_num_elems(), size[0], row_ptrs_.get_data(),
                                                   ws.get_data(), ws.get_num_elems()));
         max_row_nnz_ = -1;
+        invalidate_srow();
     }
     void write(mat_data& data) const
     {
@@ -867,6 +869,7 @@ public:
     void adopt(const dim<2>& size, array<I> rp, array<I> ci, array<V> v)
     {
         row_ptrs_ = std::move(rp); col_idxs_ = std::move(ci); values_ = std::move(v); set_size(size); max_row_nnz_ = -1;
+        invalidate_srow();
     }
 protected:
     Csr(std::shared_ptr<const Executor> exec, const dim<2>& size, size_type nnz, std::shared_ptr<strategy_type> strategy)
@@ -877,16 +880,47 @@ protected:
     {
         detail::require_device(exec_, "csr::spmv");
         auto db = detail_fmt::dense(b); auto dx = detail_fmt::dense(x);
-        GKOMI_CALL(gkomi_csr_spmv_f64_i32(nullptr, size_[0], size_[1], db->cols(), get_num_stored_elements(), get_const_row_ptrs(), get_const_col_idxs(),
-                                          get_const_values(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(),
-                                          alpha ? detail_fmt::dense(alpha)->get_const_values() : nullptr,
-                                          beta ? detail_fmt::dense(beta)->get_const_values() : nullptr, strategy_->get_code(), max_row_nnz_));
+        make_srow();
+        GKOMI_CALL(gkomi_csr_spmv_srow_f64_i32(nullptr, size_[0], size_[1], db->cols(), get_num_stored_elements(), get_const_row_ptrs(), get_const_col_idxs(),
+                                               get_const_values(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(),
+                                               alpha ? detail_fmt::dense(alpha)->get_const_values() : nullptr,
+                                               beta ? detail_fmt::dense(beta)->get_const_values() : nullptr, strategy_->get_code(), max_row_nnz_,
+                                               get_num_srow_elements() ? get_const_srow() : nullptr, srow_tile_));
     }
+public:
+    // Csr::srow_ / make_srow (csr.hpp:1139-1157, 1265-1266): the tile start rows of the nonzero-split
+    // kernel, rebuilt whenever row_ptrs may have changed (read / adopt / conversions reset it)
+    const I* get_const_srow() const noexcept { return srow_.get_const_data(); }
+    size_type get_num_srow_elements() const noexcept { return srow_.get_num_elems(); }
+    void make_srow() const
+    {
+        if (srow_valid_ || !exec_->is_device()) return;
+        const int64_t nnz = static_cast<int64_t>(get_num_stored_elements());
+        if (nnz >= 2 && max_row_nnz_ < 0) {  // row statistics of the strategy objects (csr.hpp:526-705)
+            array<I> mx(exec_, 1);
+            GKOMI_CALL(gkomi_csr_max_row_nnz_i32(nullptr, size_[0], get_const_row_ptrs(), mx.get_data()));
+            max_row_nnz_ = exec_->copy_val_to_host(mx.get_const_data());
+        }
+        srow_tile_ = gkomi_csr_srow_tile();
+        if (nnz >= 2) {
+            srow_ = array<I>(exec_, static_cast<size_type>(gkomi_csr_srow_entries(nnz, srow_tile_)));
+            GKOMI_CALL(gkomi_csr_make_srow_i32(nullptr, size_[0], nnz, get_const_row_ptrs(), srow_tile_, srow_.get_data(),
+                                               static_cast<int64_t>(srow_.get_num_elems())));
+        } else {
+            srow_ = array<I>(exec_, 0);
+        }
+        srow_valid_ = true;
+    }
+    void invalidate_srow() const { srow_valid_ = false; }
+protected:
     array<V> values_;
     array<I> col_idxs_;
     array<I> row_ptrs_;
     std::shared_ptr<strategy_type> strategy_;
-    int64_t max_row_nnz_{-1};
+    mutable int64_t max_row_nnz_{-1};
+    mutable array<I> srow_;
+    mutable int64_t srow_tile_{0};
+    mutable bool srow_valid_{false};
 };
 
 template <typename V = double, typename I = int32>
@@ -1243,6 +1277,7 @@ struct criterion_settings {
     int64_t max_iters{std::numeric_limits<int64_t>::max() / 4};
     double reduction_factor{-1.0};  // < 0: no residual criterion
     mode baseline{mode::rhs_norm};
+    bool implicit{false};           // ImplicitResidualNorm: sqrt of the solver's implicit r.z instead of ||r||
 };
 class CriterionFactory {
 public:
@@ -1272,6 +1307,45 @@ private:
     V factor_{static_cast<V>(1e-15)};  // residual_norm.hpp:65
     mode baseline_{mode::rhs_norm};
 };
+// stop::ImplicitResidualNorm (include/ginkgo/core/stop/residual_norm.hpp:193-244; kernel
+// stop::implicit_residual_norm): the criterion on sqrt(|r.z|), the quantity Cg / Fcg carry anyway.
+// With the Identity preconditioner that IS ||r||, and the native drivers evaluate it as such; with
+// another preconditioner the solvers refuse it (their drivers evaluate ResidualNorm).
+template <typename V = double>
+class ImplicitResidualNorm : public CriterionFactory, public builder_base<ImplicitResidualNorm<V>> {
+public:
+    static ImplicitResidualNorm build() { return {}; }
+    ImplicitResidualNorm& with_reduction_factor(V f) { factor_ = f; return *this; }
+    ImplicitResidualNorm& with_baseline(mode m) { baseline_ = m; return *this; }
+    void contribute(criterion_settings& s) const override { s.reduction_factor = factor_; s.baseline = baseline_; s.implicit = true; }
+private:
+    V factor_{static_cast<V>(1e-15)};
+    mode baseline_{mode::rhs_norm};
+};
+// stop::Combined (include/ginkgo/core/stop/combined.hpp): stops when ANY of its criteria does,
+// which is how the drivers treat a list of criteria anyway (Iteration is asked first)
+class Combined : public CriterionFactory, public builder_base<Combined> {
+public:
+    static Combined build() { return {}; }
+    template <typename... Criteria>
+    Combined& with_criteria(Criteria&&... c)
+    {
+        criteria_ = {std::shared_ptr<const CriterionFactory>(std::forward<Criteria>(c))...};
+        return *this;
+    }
+    Combined& with_criteria(std::vector<std::shared_ptr<const CriterionFactory>> c) { criteria_ = std::move(c); return *this; }
+    void contribute(criterion_settings& s) const override { for (const auto& c : criteria_) if (c) c->contribute(s); }
+private:
+    std::vector<std::shared_ptr<const CriterionFactory>> criteria_;
+};
+// stop::combine (combined.hpp:130-160)
+template <typename FactoryContainer>
+std::shared_ptr<const CriterionFactory> combine(FactoryContainer&& factories)
+{
+    if (factories.size() == 1) return factories[0];
+    auto exec = std::shared_ptr<const Executor>();
+    return Combined::build().with_criteria(std::vector<std::shared_ptr<const CriterionFactory>>(factories.begin(), factories.end())).on(exec);
+}
 }  // namespace stop
 
 namespace detail {
@@ -1357,6 +1431,26 @@ private:
 };
 
 namespace preconditioner {
+// include/ginkgo/core/preconditioner/jacobi.hpp:62-167
+template <typename IndexType>
+struct block_interleaved_storage_scheme {
+    block_interleaved_storage_scheme() = default;
+    block_interleaved_storage_scheme(IndexType block_offset_, IndexType group_offset_, uint32 group_power_)
+        : block_offset{block_offset_}, group_offset{group_offset_}, group_power{group_power_} {}
+    IndexType block_offset{};
+    IndexType group_offset{};
+    uint32 group_power{};
+    IndexType get_group_size() const noexcept { return IndexType{1} << group_power; }
+    size_type compute_storage_space(size_type num_blocks) const noexcept
+    {
+        return (num_blocks + 1 == size_type{0}) ? size_type{0} : ((num_blocks + get_group_size() - 1) / get_group_size()) * group_offset;
+    }
+    IndexType get_group_offset(IndexType block_id) const noexcept { return group_offset * (block_id >> group_power); }
+    IndexType get_block_offset(IndexType block_id) const noexcept { return block_offset * (block_id & (get_group_size() - 1)); }
+    IndexType get_global_block_offset(IndexType block_id) const noexcept { return get_group_offset(block_id) + get_block_offset(block_id); }
+    IndexType get_stride() const noexcept { return block_offset << group_power; }
+};
+
 template <typename V = double, typename I = int32>
 class Jacobi : public LinOp, public Transposable {
 public:
@@ -1368,6 +1462,13 @@ public:
         Factory& with_storage_optimization(precision_reduction p) { storage_.assign(1, p); adaptive_ = true; return *this; }
         Factory& with_storage_optimization(const std::vector<precision_reduction>& p) { storage_ = p; adaptive_ = !p.empty(); return *this; }
         Factory& with_accuracy(double a) { accuracy_ = a; return *this; }
+        // jacobi.hpp:338-349: 0 = the executor's default = the wavefront size (64 on HIP), the only
+        // stride the kernels of this backend lay the blocks out for
+        Factory& with_max_block_stride(uint32 s)
+        {
+            if (s != 0 && s != 64) GKO_NOT_SUPPORTED("max_block_stride: 0 or 64 (the HIP wavefront size)");
+            return *this;
+        }
         std::shared_ptr<Factory> on(std::shared_ptr<const Executor> exec) const { auto f = std::make_shared<Factory>(*this); f->exec_ = std::move(exec); return f; }
         std::unique_ptr<Jacobi> generate(std::shared_ptr<const LinOp> A) const
         {
@@ -1392,6 +1493,16 @@ public:
         return out;
     }
     std::vector<double> get_conditioning() const { return conditioning_.to_host(); }
+    // jacobi.hpp:557-609: the scheme of max_block_stride = 64
+    block_interleaved_storage_scheme<I> get_storage_scheme() const
+    {
+        int64_t o[4] = {};
+        GKOMI_CALL(gkomi_jacobi_storage_scheme(static_cast<int>(max_block_size_), o));
+        return {static_cast<I>(o[0]), static_cast<I>(o[1]), static_cast<uint32>(o[2])};
+    }
+    const V* get_blocks() const noexcept { return blocks_.get_const_data(); }
+    size_type get_num_stored_elements() const noexcept { return blocks_.get_num_elems(); }
+    const I* get_const_block_pointers() const noexcept { return block_ptrs_.get_const_data(); }
     // Jacobi::transpose (core/preconditioner/jacobi.cpp): same blocks structure,
     // every stored block transposed in its storage precision (jacobi::transpose_jacobi)
     std::unique_ptr<LinOp> transpose() const override
@@ -1494,6 +1605,9 @@ public:
         stop::criterion_settings s;
         for (const auto& c : criteria_) c->contribute(s);
         if (s.reduction_factor < 0) s.reduction_factor = 0.0;  // Iteration only
+        if (s.implicit && (precond_ || precond_factory_)) {
+            GKO_NOT_SUPPORTED("ImplicitResidualNorm with a preconditioner: the native drivers evaluate ResidualNorm (identical without one)");
+        }
         return s;
     }
     std::vector<std::shared_ptr<const stop::CriterionFactory>> criteria_;
@@ -1875,12 +1989,52 @@ public:
     };
     static Factory build() { return Factory{}; }
 protected:
-    Trs(std::shared_ptr<const Executor> exec, bool unit, std::shared_ptr<const LinOp> A) : LinOp(exec, A->get_size()), unit_(unit), A_(std::move(A)), ws_(exec, gkomi_trs_workspace_bytes()) {}
+public:
+    // what generate() found: dependency levels of the factor and whether the level-scheduled solve is used
+    int64_t get_num_levels() const noexcept { return nlevels_; }
+    bool uses_level_schedule() const noexcept { return planned_; }
+    // a solve that gave up (spin bound) left NaNs in x; sticky until the next generate
+    bool has_overrun() const
+    {
+        int flag = 0;
+        if (planned_) GKOMI_CALL(gkomi_trs_plan_check_overrun(nullptr, plan_.get_const_data(), &flag));
+        else GKOMI_CALL(gkomi_trs_check_overrun(nullptr, ws_.get_const_data(), &flag));
+        return flag != 0;
+    }
+protected:
+    // LowerTrs / UpperTrs::generate (core/solver/lower_trs.cpp generate -> lower_trs::generate): the
+    // dependency-level analysis of the factor, kept for every apply (the reference's SolveStruct)
+    Trs(std::shared_ptr<const Executor> exec, bool unit, std::shared_ptr<const LinOp> A)
+        : LinOp(exec, A->get_size()), unit_(unit), A_(std::move(A)), ws_(exec, gkomi_trs_workspace_bytes()), plan_(exec)
+    {
+        if (!exec_->is_device()) return;
+        ws_.fill(0);
+        auto csr = as<const matrix::Csr<V, I>>(A_.get());
+        const int64_t n = static_cast<int64_t>(size_[0]);
+        array<char> symbolic(exec_, gkomi_trs_symbolic_workspace_bytes(n));
+        int64_t out[4] = {};
+        GKOMI_CALL(gkomi_trs_analyse_symbolic_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), Lower ? 1 : 0, symbolic.get_data(),
+                                                  symbolic.get_num_elems(), out));
+        nslices_ = out[0]; entries_ = out[1]; nlevels_ = out[2]; max_deps_ = out[3];
+        // wide levels: level-scheduled; chains and narrow bands: the analysis-free kernel's in-workgroup hand-offs
+        planned_ = n > 0 && n >= 64 * std::max<int64_t>(nlevels_, 1);
+        if (planned_) {
+            plan_.resize_and_reset(gkomi_trs_plan_bytes(nslices_, entries_));
+            GKOMI_CALL(gkomi_trs_analyse_numeric_f64_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(), Lower ? 1 : 0,
+                                                         symbolic.get_const_data(), nslices_, entries_, nlevels_, plan_.get_data(), plan_.get_num_elems()));
+            GKOMI_CALL(gkomi_synchronize(nullptr));  // `symbolic` goes out of scope
+        }
+    }
     void apply_impl(const LinOp* b, LinOp* x) const override
     {
         ::gko::detail::require_device(exec_, "trs::solve");
         auto csr = as<const matrix::Csr<V, I>>(A_.get());
         auto db = matrix::detail_fmt::dense(b); auto dx = matrix::detail_fmt::dense(x);
+        if (planned_) {
+            GKOMI_CALL(gkomi_trs_solve_plan_f64(nullptr, size_[0], db->cols(), const_cast<char*>(plan_.get_const_data()), nslices_, entries_, max_deps_, unit_ ? 1 : 0,
+                                                db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride()));
+            return;
+        }
         auto fn = Lower ? gkomi_lower_trs_solve_f64_i32 : gkomi_upper_trs_solve_f64_i32;
         GKOMI_CALL(fn(nullptr, size_[0], db->cols(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(), unit_ ? 1 : 0, db->get_const_values(), db->get_stride(),
                       dx->get_values(), dx->get_stride(), const_cast<char*>(ws_.get_const_data()), ws_.get_num_elems()));
@@ -1896,6 +2050,9 @@ protected:
     bool unit_;
     std::shared_ptr<const LinOp> A_;
     array<char> ws_;
+    array<char> plan_;
+    int64_t nslices_{0}, entries_{0}, nlevels_{0}, max_deps_{-1};
+    bool planned_{false};
 };
 template <typename V = double, typename I = int32>
 using LowerTrs = Trs<true, V, I>;

@@ -1,0 +1,65 @@
+// hip/solver/lower_trs_kernels.hip.cpp (upper_trs: the same with lower = 0):
+// should_perform_transpose / generate / solve (core/solver/lower_trs_kernels.hpp).
+// generate = the dependency-level analysis (the hipsparseXcsrsv2_analysis of
+// hip/solver/common_trs_kernels.hip.hpp:61-253), kept in the SolveStruct; solve = the
+// level-scheduled kernel, or the analysis-free one for factors whose levels are narrow.
+#include "../gkomi_bindings.hpp"
+
+namespace gko {
+namespace kernels {
+namespace hip {
+namespace lower_trs {
+
+struct gkomi_solve_struct : solver::SolveStruct {
+    array<char> symbolic, plan, workspace;
+    int64_t nslices{0}, entries{0}, nlevels{0}, max_deps{-1};
+    bool planned{false};
+    explicit gkomi_solve_struct(std::shared_ptr<const Executor> exec) : symbolic(exec), plan(exec), workspace(exec) {}
+};
+
+void should_perform_transpose(std::shared_ptr<const HipExecutor> exec, bool& do_transpose) { do_transpose = false; }
+
+void generate(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double, int32>* matrix,
+              std::shared_ptr<solver::SolveStruct>& solve_struct, bool unit_diag, const solver::trisolve_algorithm algorithm,
+              const size_type num_rhs)
+{
+    auto st = std::make_shared<gkomi_solve_struct>(exec);
+    const int64_t n = static_cast<int64_t>(matrix->get_size()[0]);
+    st->workspace.resize_and_reset(gkomi_trs_workspace_bytes());
+    st->workspace.fill(0);  // the analysis-free kernel's ticket and its sticky give-up flag
+    st->symbolic.resize_and_reset(gkomi_trs_symbolic_workspace_bytes(n));
+    int64_t out[4] = {};
+    GKOMI_CALL(gkomi_trs_analyse_symbolic_i32(GKOMI_NULL_STREAM, n, matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(), /*lower=*/1,
+                                              st->symbolic.get_data(), st->symbolic.get_num_elems(), out));
+    st->nslices = out[0]; st->entries = out[1]; st->nlevels = out[2]; st->max_deps = out[3];
+    // wide levels: the level-scheduled solve; chains and narrow bands: the in-workgroup hand-offs of the other kernel
+    st->planned = n >= 64 * (st->nlevels > 0 ? st->nlevels : 1);
+    if (st->planned) {
+        st->plan.resize_and_reset(gkomi_trs_plan_bytes(st->nslices, st->entries));
+        GKOMI_CALL(gkomi_trs_analyse_numeric_f64_i32(GKOMI_NULL_STREAM, n, matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(),
+                                                     matrix->get_const_values(), 1, st->symbolic.get_const_data(), st->nslices, st->entries,
+                                                     st->nlevels, st->plan.get_data(), st->plan.get_num_elems()));
+    }
+    solve_struct = st;
+}
+
+void solve(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double, int32>* matrix, const solver::SolveStruct* solve_struct,
+           bool unit_diag, const solver::trisolve_algorithm algorithm, matrix::Dense<double>* trans_b, matrix::Dense<double>* trans_x,
+           const matrix::Dense<double>* b, matrix::Dense<double>* x)
+{
+    auto st = const_cast<gkomi_solve_struct*>(dynamic_cast<const gkomi_solve_struct*>(solve_struct));
+    const int64_t n = static_cast<int64_t>(matrix->get_size()[0]);
+    if (st != nullptr && st->planned) {
+        GKOMI_CALL(gkomi_trs_solve_plan_f64(GKOMI_NULL_STREAM, n, b->get_size()[1], st->plan.get_data(), st->nslices, st->entries, st->max_deps,
+                                            unit_diag, b->get_const_values(), b->get_stride(), x->get_values(), x->get_stride()));
+    } else {
+        GKOMI_CALL(gkomi_lower_trs_solve_f64_i32(GKOMI_NULL_STREAM, n, b->get_size()[1], matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(),
+                                                 matrix->get_const_values(), unit_diag, b->get_const_values(), b->get_stride(), x->get_values(),
+                                                 x->get_stride(), st->workspace.get_data(), st->workspace.get_num_elems()));
+    }
+}
+
+}  // namespace lower_trs
+}  // namespace hip
+}  // namespace kernels
+}  // namespace gko

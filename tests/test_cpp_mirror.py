@@ -154,3 +154,42 @@ def test_distributed_solver_example_on_hip_one_rank(bins, oracle):
     ite = oracle.ref_cg_solve(n, rp, ci, v, b, xe, 20 * n, 1e-8, 2, None, 0)
     assert abs(int(kv["Iterations"]) - ite) <= 2
     assert abs(float(kv["Solution norm"]) - np.linalg.norm(xe)) <= 1e-6 * np.linalg.norm(xe)
+
+
+SHIMS = ["matrix/csr_kernels", "matrix/dense_kernels", "solver/cg_kernels", "stop/residual_norm_kernels",
+         "preconditioner/jacobi_kernels", "solver/lower_trs_kernels", "solver/upper_trs_kernels"]
+
+
+def _build_shims(tmp_path):
+    objs = []
+    for f in SHIMS:
+        obj = tmp_path / (f.replace("/", "_") + ".o")
+        r = subprocess.run(["g++", "-std=c++14", "-Wall", "-Wno-unused-parameter", f"-I{ROOT}/include", f"-I{PKG}/include",
+                            "-include", os.path.join(ROOT, "shims", "test", "prelude_mirror.hpp"), "-c",
+                            os.path.join(ROOT, "shims", "hip", f + ".hip.cpp"), "-o", str(obj)], capture_output=True, text=True)
+        assert r.returncode == 0, f + "\n" + r.stderr
+        objs.append(str(obj))
+    return objs
+
+
+def test_shims_compile_against_the_mirror(tmp_path):
+    """shims/hip/*.hip.cpp = the bodies a maintainer drops into hip/ (INTEGRATION.md), kept compilable:
+    they use the accessor names of the reference's classes, which the mirror carries too."""
+    objs = _build_shims(tmp_path)
+    exe = tmp_path / "shim_smoke"
+    r = subprocess.run(["g++", "-std=c++14", f"-I{ROOT}/include", f"-I{PKG}/include", f"-I{ROOT}/shims/test",
+                        os.path.join(ROOT, "shims", "test", "shim_smoke.cpp")] + objs +
+                       ["-o", str(exe), f"-L{PKG}/lib", "-lgkomi", f"-Wl,-rpath,{PKG}/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_shims_run_on_the_device(tmp_path):
+    objs = _build_shims(tmp_path)
+    exe = tmp_path / "shim_smoke"
+    r = subprocess.run(["g++", "-std=c++14", f"-I{ROOT}/include", f"-I{PKG}/include", f"-I{ROOT}/shims/test",
+                        os.path.join(ROOT, "shims", "test", "shim_smoke.cpp")] + objs +
+                       ["-o", str(exe), f"-L{PKG}/lib", "-lgkomi", f"-Wl,-rpath,{PKG}/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout + run.stderr
