@@ -235,19 +235,6 @@ __device__ __forceinline__ double add_products(double sum, const double* prod, i
     return sum;
 }
 
-// c[i] = v, written through to memory at once when WT (agent-scope store): the
-// 8 B per row then leave the L2 while the kernel still streams, not in the
-// write-back at its end
-template <bool WT>
-__device__ __forceinline__ void store_result(double* p, double v)
-{
-    if (WT) {
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        *p = v;
-    }
-}
-
 // ---- nonzero-split stream kernel (needs srow) ---------------------------------
 //
 // The stream kernel above cannot issue a single streaming load before
@@ -266,7 +253,7 @@ __device__ __forceinline__ void store_result(double* p, double v)
 // col_idxs are requested before vals: vector-memory results return in order,
 // so the gathers of b start while the values are still in flight.
 template <int Block, int Tile, int MaxOver, bool Advanced, bool Swizzle,
-          bool Dot = false, bool NT = false, bool ColsFirst = true, bool WT = false>
+          bool Dot = false, bool NT = false, bool ColsFirst = true>
 __global__ __launch_bounds__(Block) void csr_split_kernel(
     int nrows, int nnz, const int32_t* __restrict__ row_ptrs,
     const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
@@ -422,8 +409,10 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = row_begin + tid + i * Block;
-        if (row < row_end) {
-            double sum = Advanced ? c0[i] * beta : 0.0;
+        const bool active = row < row_end;
+        double sum = 0.0;
+        if (active) {
+            sum = Advanced ? c0[i] * beta : 0.0;
             const int hi = rb[i] - t0;
             sum = add_products(sum, prod, ra[i] - t0, min(hi, Tile + over), Tile + MaxOver);
             // a row longer than the caller's hint promised: finish it from memory
@@ -431,12 +420,12 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
                 const double val = Advanced ? alpha * vals[t0 + k] : vals[t0 + k];
                 sum += val * b[col_idxs[t0 + k] * b_stride];
             }
-            store_result<WT>(c + row * c_stride, sum);
             if (Dot) {
                 pq += w[row * w_stride] * sum;
                 qq += sum * sum;
             }
         }
+        if (active) c[row * c_stride] = sum;
     }
     for (int row = row_begin + tid + 2 * Block; row < row_end; row += Block) {
         double sum = Advanced ? c[row * c_stride] * beta : 0.0;
@@ -447,7 +436,7 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
             const double val = Advanced ? alpha * vals[t0 + k] : vals[t0 + k];
             sum += val * b[col_idxs[t0 + k] * b_stride];
         }
-        store_result<WT>(c + row * c_stride, sum);
+        c[row * c_stride] = sum;
         if (Dot) {
             pq += w[row * w_stride] * sum;
             qq += sum * sum;
@@ -851,7 +840,7 @@ int launch_vector(hipStream_t stream, int nrows, int nrhs,
     return check_launch();
 }
 
-template <int Block, int Tile, bool NT, bool WT>
+template <int Block, int Tile, bool NT>
 int launch_split(hipStream_t stream, bool swizzle, int nrows, int nnz,
                  const int32_t* row_ptrs, const int32_t* col_idxs,
                  const double* vals, const double* b, int64_t b_stride,
@@ -865,7 +854,7 @@ int launch_split(hipStream_t stream, bool swizzle, int nrows, int nnz,
     dim3 grid(swz ? per * num_xcd : ntiles, 1);
 #define GKOMI_LAUNCH(ADV, SWZ)                                                 \
     hipLaunchKernelGGL(                                                        \
-        (csr_split_kernel<Block, Tile, MaxOver, ADV, SWZ, false, NT, true, WT>), \
+        (csr_split_kernel<Block, Tile, MaxOver, ADV, SWZ, false, NT, true>), \
         grid, dim3(Block), 0, stream, nrows, nnz, row_ptrs, col_idxs, vals, b, \
         b_stride, c, c_stride, alpha, beta, srow, ntiles, per, over)
     if (alpha != nullptr) {
@@ -1083,13 +1072,13 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
 #define GKOMI_SPLIT_ARGS                                                            \
     stream, !no_swizzle, n, z, row_ptrs, col_idxs, vals, b + j, b_stride, c + j,    \
         c_stride, alpha, beta, srow, over
-            // variant bits: 2 = nontemporal streams, 4 = write-through stores of c
+            // variant bit 2: nontemporal streams.  (Write-through stores of c, 8 or 16 bytes wide, were
+            // measured and dropped: 17.2 vs 16.6 us cold, profiles/r02_tune_split.log.)
 #define GKOMI_SPLIT_TILE(BLOCK, TILE)                                               \
-    switch ((variant >> 1) & 3) {                                                   \
-    case 0: err = launch_split<BLOCK, TILE, false, false>(GKOMI_SPLIT_ARGS); break; \
-    case 1: err = launch_split<BLOCK, TILE, true, false>(GKOMI_SPLIT_ARGS); break;  \
-    case 2: err = launch_split<BLOCK, TILE, false, true>(GKOMI_SPLIT_ARGS); break;  \
-    default: err = launch_split<BLOCK, TILE, true, true>(GKOMI_SPLIT_ARGS); break;  \
+    if (variant & 2) {                                                              \
+        err = launch_split<BLOCK, TILE, true>(GKOMI_SPLIT_ARGS);                    \
+    } else {                                                                        \
+        err = launch_split<BLOCK, TILE, false>(GKOMI_SPLIT_ARGS);                   \
     }
             if (srow_tile == 1536) {
                 GKOMI_SPLIT_TILE(256, 1536)

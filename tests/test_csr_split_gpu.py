@@ -15,7 +15,7 @@ from test_csr_spmv_gpu import _oracle_apply
 pytestmark = pytest.mark.gpu
 SPLIT = 4
 TILES = [1024, 1536, 2048]
-VARIANTS = {"plain": 0, "nt": 2, "wt": 4, "nt_wt": 6, "noswz": 1 << 8}
+VARIANTS = {"plain": 0, "nt": 2, "noswz": 1 << 8, "nt_noswz": (1 << 8) | 2}
 
 
 def strat(variant):
@@ -88,7 +88,7 @@ def test_short_random_rows_with_empty_rows(gk, oracle, tile, seed):
     srow, _ = make_srow(gk, A, tile)
     check_srow(srow, rp, A.nnz, tile)
     expect = _oracle_apply(oracle, nrows, rp, ci, v, b)
-    for variant in ("plain", "nt_wt", "noswz"):
+    for variant in ("plain", "nt", "nt_noswz"):
         got = host(csr_apply_srow(gk, A, dev(b), srow, tile, strategy=strat(variant)))
         assert np.array_equal(got, expect), variant
     # automatic strategy with srow takes the same kernel

@@ -58,9 +58,9 @@ variants = {"stream_v0(256,1,2048)": STREAM, "v1(256,2,4096)": STREAM | (1 << 8)
             "v9_noswz": STREAM | (9 << 8) | (1 << 16), "v11_noswz": STREAM | (11 << 8) | (1 << 16),
             "v14(256,1,1536,nt)": STREAM | (14 << 8), "v14_noswz": STREAM | (14 << 8) | (1 << 16)}
 SPLIT = 4
-# nonzero-split kernel over srow: (tile, variant bits: 2 = nontemporal, 4 = write-through stores, 256 = no XCD chunking)
+# nonzero-split kernel over srow: (tile, variant bits: 2 = nontemporal, 256 = no XCD chunking)
 for tile in (1024, 1536, 2048):
-    for name, bits in (("", 0), ("_nt", 2), ("_wt", 4), ("_nt_wt", 6), ("_noswz", 256), ("_nt_noswz", 258), ("_nt_wt_noswz", 262)):
+    for name, bits in (("", 0), ("_nt", 2), ("_noswz", 256), ("_nt_noswz", 258)):
         variants[f"split{tile}{name}"] = (SPLIT | ((bits & 0xff) << 8) | ((bits >> 8) << 16), tile)
 if os.environ.get("TUNE_ONLY"):
     variants = {k: v for k, v in variants.items() if any(t in k for t in os.environ["TUNE_ONLY"].split(","))}
