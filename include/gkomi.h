@@ -74,6 +74,13 @@ int gkomi_raw_alloc(size_t num_bytes, void** out_ptr);
 int gkomi_raw_free(void* ptr);
 int gkomi_raw_copy(void* dst, const void* src, size_t num_bytes, int kind);
 
+/* Profiler ranges around an operation: what HipExecutor::run does with the logger events
+ * operation_launched / operation_completed (include/ginkgo/core/base/executor.hpp:1153-1158),
+ * as roctx ranges (rocprofv3 --marker-trace).  roctx is opened at run time; no-ops without it. */
+int64_t gkomi_roctx_available(void);
+int gkomi_roctx_push(const char* name);
+int gkomi_roctx_pop(void);
+
 /* ---- CSR SpMV (core/matrix/csr_kernels.hpp:58-75) ----------------------- */
 
 /* Kernel selection, the role of Csr::strategy_type / srow

@@ -79,3 +79,48 @@ extern "C" int gkomi_raw_copy(void* dst, const void* src, size_t num_bytes, int 
     }
     return static_cast<int>(hipMemcpy(dst, src, num_bytes, k));
 }
+
+
+// ---- profiler ranges: the operation_launched / operation_completed pair the reference's
+// HipExecutor::run fires around every kernel (include/ginkgo/core/base/executor.hpp:1153-1158),
+// as roctx ranges that rocprofv3 --marker-trace shows.  roctx is opened at run time; without it
+// the calls are no-ops.
+#include <dlfcn.h>
+
+namespace {
+struct roctx_api {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+};
+roctx_api& roctx()
+{
+    static roctx_api a;
+    if (!a.tried) {
+        a.tried = true;
+        const char* names[] = {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"};
+        for (const char* n : names) {
+            if (void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+                a.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                a.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (a.push != nullptr && a.pop != nullptr) break;
+            }
+        }
+    }
+    return a;
+}
+}  // namespace
+
+extern "C" int64_t gkomi_roctx_available(void) { return roctx().push != nullptr && roctx().pop != nullptr ? 1 : 0; }
+
+extern "C" int gkomi_roctx_push(const char* name)
+{
+    if (roctx().push != nullptr && name != nullptr) roctx().push(name);
+    return GKOMI_SUCCESS;
+}
+
+extern "C" int gkomi_roctx_pop(void)
+{
+    if (roctx().pop != nullptr) roctx().pop();
+    return GKOMI_SUCCESS;
+}

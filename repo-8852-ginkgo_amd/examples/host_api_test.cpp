@@ -96,6 +96,38 @@ int main()
         auto A5 = gko::read_binary<csr>(fin, ref);
         CHECK(A5->get_num_stored_elements() == 1 && A5->get_const_row_ptrs()[1] == 0 && A5->get_const_values()[0] == 2.5);
     }
+    {
+        // log::Logger on an executor: operation_launched / completed around every C-ABI operation
+        // (executor.hpp:1153-1158); stop::Combined; the distributed Partition (host metadata)
+        struct counter : gko::log::Logger {
+            mutable int launched = 0, completed = 0;
+            mutable std::string last;
+            void on_operation_launched(const gko::Executor*, const char* op) const override { ++launched; last = op; }
+            void on_operation_completed(const gko::Executor*, const char*) const override { ++completed; }
+        };
+        auto logger = std::make_shared<counter>();
+        ref->add_logger(logger);
+        using part = gko::experimental::distributed::Partition<gko::int32, gko::int64>;
+        auto p = part::build_from_global_size_uniform(ref, 3, 10);
+        CHECK(logger->launched == 3 && logger->completed == 3);
+        CHECK(logger->last == "gkomi_partition_build_starting_indices");
+        ref->remove_logger(logger.get());
+        auto p2 = part::build_from_global_size_uniform(ref, 2, 7);
+        CHECK(logger->launched == 3);
+        CHECK(p->get_num_parts() == 3 && p->get_size() == 10);
+        CHECK(p->get_range_bounds()[0] == 0 && p->get_range_bounds()[1] == 4 && p->get_range_bounds()[2] == 7 && p->get_range_bounds()[3] == 10);
+        CHECK(p->get_part_size(0) == 4 && p->get_part_size(2) == 3 && p2->get_part_size(1) == 3);
+        gko::stop::criterion_settings st;
+        gko::stop::Combined::build()
+            .with_criteria(gko::stop::Iteration::build().with_max_iters(17u).on(ref),
+                           gko::stop::ImplicitResidualNorm<double>::build().with_reduction_factor(1e-7).on(ref))
+            .on(ref)
+            ->contribute(st);
+        CHECK(st.max_iters == 17 && st.reduction_factor == 1e-7 && st.implicit);
+        gko::preconditioner::block_interleaved_storage_scheme<gko::int32> sch{32, 64, 1};   // max_bs 32 at stride 64
+        CHECK(sch.get_group_size() == 2 && sch.get_stride() == 64 && sch.compute_storage_space(5) == 3 * 64);
+        CHECK(sch.get_global_block_offset(3) == 64 + 32);
+    }
     std::cout << "host api ok\n";
     return 0;
 }

@@ -29,6 +29,7 @@
 #include <cstdint>
 #include <cstring>
 #include <fstream>
+#include <cstdlib>
 #include <functional>
 #include <initializer_list>
 #include <iomanip>
@@ -102,7 +103,69 @@ inline void check(int code, const char* file, int line, const char* call)
     throw Error(file, line, msg);
 }
 }  // namespace detail
-#define GKOMI_CALL(expr) ::gko::detail::check((expr), __FILE__, __LINE__, #expr)
+
+class Executor;
+// ---- logging hook (include/ginkgo/core/log/logger.hpp: operation_launched / operation_completed,
+// fired by Executor::run around every kernel, executor.hpp:1153-1158).  Here every C-ABI call of
+// the mirror is such an operation; its name is the entry point.  Loggers are attached with
+// Executor::add_logger like in the reference; GKOMI_ROCTX=1 additionally brackets every operation
+// with a roctx range for rocprofv3 --marker-trace.
+namespace log {
+class Logger {
+public:
+    virtual ~Logger() = default;
+    virtual void on_operation_launched(const Executor*, const char* /*operation*/) const {}
+    virtual void on_operation_completed(const Executor*, const char* /*operation*/) const {}
+};
+}  // namespace log
+
+namespace detail {
+struct logger_registry {
+    std::vector<std::pair<const Executor*, std::shared_ptr<const log::Logger>>> loggers;
+    bool roctx{false};
+    logger_registry()
+    {
+        const char* v = std::getenv("GKOMI_ROCTX");
+        roctx = v != nullptr && v[0] == '1' && gkomi_roctx_available();
+    }
+    bool active() const { return roctx || !loggers.empty(); }
+};
+inline logger_registry& registry()
+{
+    static logger_registry r;
+    return r;
+}
+// "gkomi_csr_spmv_f64_i32(nullptr, ...)" -> "gkomi_csr_spmv_f64_i32"
+inline std::string operation_name(const char* call)
+{
+    std::string s(call);
+    const auto p = s.find('(');
+    return p == std::string::npos ? s : s.substr(0, p);
+}
+struct operation_scope {
+    explicit operation_scope(const char* call)
+    {
+        if (!registry().active()) return;
+        name_ = operation_name(call);
+        if (registry().roctx) gkomi_roctx_push(name_.c_str());
+        for (const auto& l : registry().loggers) l.second->on_operation_launched(l.first, name_.c_str());
+        armed_ = true;
+    }
+    ~operation_scope()
+    {
+        if (!armed_) return;
+        for (const auto& l : registry().loggers) l.second->on_operation_completed(l.first, name_.c_str());
+        if (registry().roctx) gkomi_roctx_pop();
+    }
+    std::string name_;
+    bool armed_{false};
+};
+}  // namespace detail
+#define GKOMI_CALL(expr)                                                   \
+    do {                                                                   \
+        ::gko::detail::operation_scope gkomi_scope_(#expr);                \
+        ::gko::detail::check((expr), __FILE__, __LINE__, #expr);           \
+    } while (0)
 
 // ---- dim / version ------------------------------------------------------------
 template <size_type N = 2>
@@ -162,6 +225,14 @@ public:
         T out{};
         this->get_master()->copy_from(this, 1, ptr, &out);
         return out;
+    }
+    // log::EnableLogging (include/ginkgo/core/log/logger.hpp:560-620)
+    void add_logger(std::shared_ptr<const log::Logger> logger) const { detail::registry().loggers.emplace_back(this, std::move(logger)); }
+    void remove_logger(const log::Logger* logger) const
+    {
+        auto& v = detail::registry().loggers;
+        v.erase(std::remove_if(v.begin(), v.end(), [&](const std::pair<const Executor*, std::shared_ptr<const log::Logger>>& e) {
+                    return e.first == this && e.second.get() == logger; }), v.end());
     }
 protected:
     virtual void* raw_alloc(size_type bytes) const = 0;

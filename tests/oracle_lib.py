@@ -14,7 +14,9 @@ import numpy as np
 
 REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(REPO_ROOT, "oracle")
-LIB = os.path.join(ORACLE_DIR, "libgko_oracle.so")
+# GKO_ORACLE_LIB: another build of the same sources (tools/sanitize_cpu.sh points it at the
+# AddressSanitizer / UBSan build)
+LIB = os.environ.get("GKO_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libgko_oracle.so")
 
 _SCALARS = {
     "i64": ctypes.c_int64, "i32": ctypes.c_int32, "u8": ctypes.c_uint8,
@@ -26,6 +28,8 @@ _NP = {"i64": np.int64, "i32": np.int32, "u8": np.uint8, "double": np.float64,
 
 
 def build(force=False):
+    if os.environ.get("GKO_ORACLE_LIB"):
+        return LIB
     srcs = glob.glob(os.path.join(ORACLE_DIR, "*.c")) + glob.glob(os.path.join(ORACLE_DIR, "*.h"))
     if force or not os.path.exists(LIB) or any(
             os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
