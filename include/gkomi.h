@@ -284,6 +284,47 @@ int gkomi_coo_spmv2_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
                             const int32_t* col_idxs, const double* vals,
                             const double* b, int64_t b_stride, double* c,
                             int64_t c_stride, const double* alpha);
+/* The same four kernels for a COO matrix whose row_idxs are non-decreasing
+ * (what Coo::read and every conversion to Coo produce; the reference's HIP
+ * kernel, common/cuda_hip/matrix/coo_kernels.hpp.inc:57-222, is tuned for this
+ * order too) -- no atomics, no fill / scale launch, bit-wise reproducible:
+ *   1 <= max_row_nnz_hint <= 64 (the caller vouches that no row has more
+ *     nonzeros): one launch; each tile also reads the 64 nonzeros in front of
+ *     it and stores every row that ends inside it, summed from its first
+ *     nonzero in the reference's order (c = A b is bit-identical to
+ *     reference/matrix/coo_kernels.cpp:63-71 for every row);
+ *   any other hint (-1: unknown): rows inside one tile get a plain store, rows
+ *     cut by a tile boundary are finished by a second small launch from the
+ *     partial sums in `workspace`.
+ * gkomi_coo_analyse_rows_i32 (blocking) supplies both preconditions:
+ * *host_sorted = 1 when row_idxs is non-decreasing, *host_max_row_nnz = the
+ * longest run of equal row indices, capped at 65 (may be NULL).  Unsorted input
+ * must use the entries above.  A hint that was too small is recorded in the
+ * workspace (sticky) and read back by gkomi_coo_sorted_check (blocking; the
+ * result of such a call is wrong).
+ * workspace: gkomi_coo_sorted_workspace_bytes(nnz, nrhs) bytes; the carry
+ * slots need not be kept between calls.  GKOMI_ENOTSUPPORTED when vals is not
+ * 16-B or the index arrays are not 8-B aligned (the entries above take any
+ * alignment). */
+size_t gkomi_coo_sorted_workspace_bytes(int64_t nnz, int64_t nrhs);
+int gkomi_coo_analyse_rows_i32(gkomi_stream_t s, int64_t nnz,
+                               const int32_t* row_idxs, void* workspace,
+                               size_t workspace_bytes, int* host_sorted,
+                               int64_t* host_max_row_nnz);
+int gkomi_coo_sorted_check(gkomi_stream_t s, const void* workspace,
+                           int* host_flag);
+int gkomi_coo_spmv_sorted_f64_i32(
+    gkomi_stream_t s, int64_t nrows, int64_t ncols, int64_t nrhs, int64_t nnz,
+    const int32_t* row_idxs, const int32_t* col_idxs, const double* vals,
+    const double* b, int64_t b_stride, double* c, int64_t c_stride,
+    const double* alpha, const double* beta, int64_t max_row_nnz_hint,
+    void* workspace, size_t workspace_bytes);
+int gkomi_coo_spmv2_sorted_f64_i32(
+    gkomi_stream_t s, int64_t nrows, int64_t ncols, int64_t nrhs, int64_t nnz,
+    const int32_t* row_idxs, const int32_t* col_idxs, const double* vals,
+    const double* b, int64_t b_stride, double* c, int64_t c_stride,
+    const double* alpha, int64_t max_row_nnz_hint, void* workspace,
+    size_t workspace_bytes);
 /* Hybrid::apply_impl: ELL apply then COO apply2 */
 int gkomi_hybrid_spmv_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
                               int64_t nrhs, int64_t ell_num_stored_per_row,
@@ -1009,8 +1050,13 @@ int gkomi_hybrid_matrix_apply_cb(void* ctx, gkomi_stream_t s, int64_t nrhs,
                                  double* c, int64_t c_stride);
 /* The solver drivers with the system matrix behind a callback (config 4 of
  * BASELINE.json runs GMRES on ELL / SELL-P).  Same loops, same arguments as the
- * CSR entry points; CG runs the reference kernel sequence (the fused path is
- * CSR-only). */
+ * CSR entry points; gkomi_cg_solve_op_f64 runs the reference kernel sequence,
+ * gkomi_cg_solve_fused_op_f64 (one right-hand side) the fused loop of
+ * gkomi_cg_solve_f64_i32's mode 1.  Every *_fused_op_* driver recognises
+ * gkomi_{csr,ell,sellp}_matrix_apply_cb + its record and runs that format's
+ * SpMV with the dot-product epilogue (3 launches per CG iteration; iterates
+ * bit-identical across the three formats); any other callback is followed by
+ * a separate partials kernel. */
 int gkomi_cg_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
                           gkomi_matrix_apply_fn matrix, void* matrix_ctx,
                           gkomi_apply_fn precond, void* precond_ctx,
@@ -1018,6 +1064,12 @@ int gkomi_cg_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
                           double reduction_factor, int baseline,
                           void* workspace, size_t workspace_bytes,
                           double* host_info);
+int gkomi_cg_solve_fused_op_f64(
+    gkomi_stream_t s, int64_t n, gkomi_matrix_apply_fn matrix, void* matrix_ctx,
+    gkomi_apply_fn precond, void* precond_ctx, const double* b, double* x,
+    int64_t max_iters, double reduction_factor, int baseline,
+    int64_t check_every, void* workspace, size_t workspace_bytes,
+    double* host_info);
 int gkomi_gmres_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
                              gkomi_matrix_apply_fn matrix, void* matrix_ctx,
                              gkomi_apply_fn precond, void* precond_ctx,

@@ -88,11 +88,7 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
                   double reduction_factor, int baseline, int mode, int check_every, void* workspace,
                   size_t workspace_bytes, double* host_info)
 {
-    const int64_t nnz = A.nnz;
-    const int32_t* row_ptrs = A.row_ptrs;
-    const int32_t* col_idxs = A.col_idxs;
-    const double* vals = A.vals;
-    if (mode == 1 && (!A.is_csr() || n == 0)) mode = 0;  // the fused path needs the CSR arrays (and rows)
+    if (mode == 1 && n == 0) mode = 0;  // the fused path needs rows
     if (n < 0 || nrhs <= 0 || max_iters < 0) return GKOMI_EINVAL;
     if (baseline < 0 || baseline > 2 || (mode != 0 && mode != 1)) return GKOMI_EINVAL;
     if (mode == 1 && nrhs != 1) return GKOMI_ENOTSUPPORTED;
@@ -181,12 +177,12 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
         double* part_b = reinterpret_cast<double*>(ws + l.part_b);
         double* part_c = reinterpret_cast<double*>(ws + l.part_c);
         const int g = vec_grid(n);
-        const int nb = csr_spmv_dot_num_partials(static_cast<int>(n));
-        const bool swizzle = csr_auto_swizzle(n, nnz);
-        const bool aligned = reinterpret_cast<uintptr_t>(vals) % 16 == 0 &&
-                             reinterpret_cast<uintptr_t>(col_idxs) % 8 == 0 &&
-                             reinterpret_cast<uintptr_t>(x) % 16 == 0;
-        if (!aligned) return GKOMI_ENOTSUPPORTED;
+        // q = A p with the p.q partials in the same launch for CSR / ELL /
+        // SELL-P; any other operator: its apply, then a partials kernel
+        const spmv_dot_plan spmv(A);
+        const int nb = spmv.fused() ? spmv.num_partials : g;
+        if (A.is_csr() && !spmv.fused()) return GKOMI_ENOTSUPPORTED;  // misaligned CSR arrays
+        if (reinterpret_cast<uintptr_t>(x) % 16 != 0) return GKOMI_ENOTSUPPORTED;
         cg_scalars polled{};  // per call: concurrent solves on other streams / threads do not share it
         if (check_every < 1) check_every = 1;
         hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(1), 0, stream, scal, orig_tau,
@@ -207,8 +203,14 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
                 hipLaunchKernelGGL(cg_fused_step1_kernel, dim3(g), dim3(fblock), 0, stream, n, p, zz,
                                    part_a, g, tau_part, g, scal, it,
                                    static_cast<long long>(max_iters), reduction_factor);
-                GKOMI_TRY(csr_spmv_dot_launch(stream, static_cast<int>(n), nnz, row_ptrs, col_idxs,
-                                              vals, p, q, part_c, &scal->status, swizzle));
+                if (spmv.fused()) {
+                    GKOMI_TRY(spmv.launch(stream, p, q, part_c, &scal->status));
+                } else {
+                    GKOMI_TRY(A.apply(s, 1, nullptr, p, nullptr, q));
+                    hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, p, q,
+                                       static_cast<const cg_scalars*>(scal), part_c,
+                                       static_cast<double*>(nullptr));
+                }
                 hipLaunchKernelGGL(cg_fused_step2_kernel, dim3(g), dim3(fblock), 0, stream, n, x, r, p,
                                    q, part_c, nb, scal, it, precond == nullptr ? part_a : part_b);
                 if (precond != nullptr) {
@@ -258,6 +260,22 @@ extern "C" int gkomi_cg_solve_f64_i32(
                          make_csr_sysmat(n, nnz, row_ptrs, col_idxs, vals, spmv_strategy, max_row_nnz_hint),
                          precond, precond_ctx, b, x, max_iters, reduction_factor, baseline, mode,
                          check_every, workspace, workspace_bytes, host_info);
+}
+
+// the system matrix behind a callback, fused (single rhs): three launches per
+// iteration for ELL / SELL-P / CSR behind the library's callbacks (SpMV + dot
+// epilogue), apply + 3 for any other operator
+extern "C" int gkomi_cg_solve_fused_op_f64(gkomi_stream_t s, int64_t n, gkomi_matrix_apply_fn matrix,
+                                           void* matrix_ctx, gkomi_apply_fn precond, void* precond_ctx,
+                                           const double* b, double* x, int64_t max_iters,
+                                           double reduction_factor, int baseline, int64_t check_every,
+                                           void* workspace, size_t workspace_bytes, double* host_info)
+{
+    if (matrix == nullptr) return GKOMI_EINVAL;
+    return cg_solve_impl(s, n, 1, make_op_sysmat(n, matrix, matrix_ctx), precond, precond_ctx, b, x,
+                         max_iters, reduction_factor, baseline, 1,
+                         static_cast<int>(check_every < 1 ? 1 : (check_every > 1 << 20 ? 1 << 20 : check_every)),
+                         workspace, workspace_bytes, host_info);
 }
 
 // the system matrix behind a callback: the reference kernel sequence (mode 0)

@@ -10,31 +10,52 @@
 // Algorithmic bytes: ELL 12*stride*K + 8*ncols + 8*nrows; SELL-P
 // 12*slice_size*total_cols + 16*num_slices + 8*ncols + 8*nrows.
 //
-// COO: 16 B/nonzero streamed with 8-/16-B per-lane loads into an LDS tile of
-// products + row ids; the thread that owns the first element of a row segment
-// adds the segment left to right and issues ONE fp64 atomic per segment.  For
-// row-sorted input every row that lies inside one tile is summed exactly in
-// the reference's order (coo_kernels.cpp:92-131); rows cut by a tile boundary
-// get two atomics (commutative: still deterministic); only rows spread over
-// three or more tiles depend on arrival order.
+// COO (any order of the entries): 16 B/nonzero streamed with 8-/16-B per-lane
+// loads into an LDS tile of products + row ids; one thread per row segment adds
+// it left to right and issues ONE fp64 atomic per segment.  For row-sorted
+// input every row that lies inside one tile is summed exactly in the
+// reference's order (coo_kernels.cpp:92-131); rows cut by a tile boundary get
+// two atomics (commutative: still deterministic); only rows spread over three
+// or more tiles depend on arrival order.  The tile kernel lives in
+// coo_spmv.hip (with the atomic-free entries for sorted matrices); the kernel
+// in this file is the round-1 version, kept for arrays that are not 16-/8-B
+// aligned.
 #include "common.hpp"
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <cstdlib>
+
 namespace gkomi {
+// coo_spmv.hip: c += alpha A b with the tile read once per group of columns
+int coo_tile_atomic_launch(hipStream_t s, int64_t nrows, int64_t ncols, int64_t nrhs, int64_t nnz, const int32_t* rows,
+                           const int32_t* cols, const double* vals, const double* b, int64_t b_stride,
+                           double* c, int64_t c_stride, const double* alpha);
 namespace {
 
 constexpr int block = 256;
 constexpr int wave_size = 64;
 
-template <bool Advanced>
+// Dot = true (single column, plain apply) adds the epilogue of the fused
+// Krylov drivers: dot_partial[block] = sum over the block's rows of
+// w(row) * c(row) (w = b unless dot_w is given), on request also of c(row)^2,
+// and nothing at all once *stop_status says the solve has stopped.  Same
+// row -> thread map and block sum as the CSR kernel's epilogue
+// (csr_spmv.hip), so the partials -- and with them the iterates of a fused
+// solve -- are bit-identical across CSR / ELL / SELL-P.
+template <bool Advanced, bool Dot = false>
 __global__ __launch_bounds__(block) void ell_spmv_kernel(
     int64_t nrows, int64_t num_stored, int64_t stride,
     const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
     const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
     int64_t c_stride, const double* __restrict__ alpha_p,
-    const double* __restrict__ beta_p)
+    const double* __restrict__ beta_p, double* __restrict__ dot_partial = nullptr,
+    const uint8_t* __restrict__ stop_status = nullptr,
+    const double* __restrict__ dot_w = nullptr, double* __restrict__ dot_partial2 = nullptr)
 {
+    if (Dot && status_has_stopped(stop_status[0])) return;
+    double pq = 0.0, qq = 0.0;
+    const double* w = Dot && dot_w != nullptr ? dot_w : b;
     b += blockIdx.y;
     c += blockIdx.y;
     double alpha = 1.0, beta = 0.0;
@@ -78,18 +99,37 @@ __global__ __launch_bounds__(block) void ell_spmv_kernel(
             }
         }
         c[row * c_stride] = result;
+        if (Dot) {
+            pq += w[row] * result;
+            qq += result * result;
+        }
+    }
+    if (Dot) {
+        __shared__ double red[block / wave_size];
+        const double total = block_reduce_sum<block>(pq, red);
+        if (threadIdx.x == 0) dot_partial[blockIdx.x] = total;
+        if (dot_partial2 != nullptr) {
+            __syncthreads();
+            const double total2 = block_reduce_sum<block>(qq, red);
+            if (threadIdx.x == 0) dot_partial2[blockIdx.x] = total2;
+        }
     }
 }
 
-template <bool Advanced>
+template <bool Advanced, bool Dot = false>
 __global__ __launch_bounds__(block) void sellp_spmv_kernel(
     int64_t nrows, int64_t slice_size, const uint64_t* __restrict__ slice_sets,
     const uint64_t* __restrict__ slice_lengths,
     const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
     const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
     int64_t c_stride, const double* __restrict__ alpha_p,
-    const double* __restrict__ beta_p)
+    const double* __restrict__ beta_p, double* __restrict__ dot_partial = nullptr,
+    const uint8_t* __restrict__ stop_status = nullptr,
+    const double* __restrict__ dot_w = nullptr, double* __restrict__ dot_partial2 = nullptr)
 {
+    if (Dot && status_has_stopped(stop_status[0])) return;
+    double pq = 0.0, qq = 0.0;
+    const double* w = Dot && dot_w != nullptr ? dot_w : b;
     b += blockIdx.y;
     c += blockIdx.y;
     double alpha = 1.0, beta = 0.0;
@@ -136,6 +176,20 @@ __global__ __launch_bounds__(block) void sellp_spmv_kernel(
             }
         }
         c[row * c_stride] = result;
+        if (Dot) {
+            pq += w[row] * result;
+            qq += result * result;
+        }
+    }
+    if (Dot) {
+        __shared__ double red[block / wave_size];
+        const double total = block_reduce_sum<block>(pq, red);
+        if (threadIdx.x == 0) dot_partial[blockIdx.x] = total;
+        if (dot_partial2 != nullptr) {
+            __syncthreads();
+            const double total2 = block_reduce_sum<block>(qq, red);
+            if (threadIdx.x == 0) dot_partial2[blockIdx.x] = total2;
+        }
     }
 }
 
@@ -415,7 +469,7 @@ inline bool aligned_to(const void* p, size_t a)
     return reinterpret_cast<uintptr_t>(p) % a == 0;
 }
 
-int coo_launch(hipStream_t s, int64_t nrhs, int64_t nnz, const int32_t* rows,
+int coo_launch(hipStream_t s, int64_t nrows, int64_t ncols, int64_t nrhs, int64_t nnz, const int32_t* rows,
                const int32_t* cols, const double* vals, const double* b,
                int64_t b_stride, double* c, int64_t c_stride,
                const double* alpha)
@@ -423,6 +477,15 @@ int coo_launch(hipStream_t s, int64_t nrhs, int64_t nnz, const int32_t* rows,
     if (nnz == 0 || nrhs == 0) return GKOMI_SUCCESS;
     const int64_t nblocks = ceildiv(nnz, coo_tile);
     if (nblocks > INT32_MAX) return GKOMI_ENOTSUPPORTED;
+    static const bool old1 = std::getenv("GKOMI_COO_OLD1") != nullptr;  // tuning hook: the round-1 kernel
+    if (nrhs >= 2 || !old1) {
+        // the tile kernel of coo_spmv.hip (21.3 vs 25.1 us on P2 for one column; the
+        // tile once per 2 columns for more); it wants aligned arrays, the kernel
+        // above takes the rest
+        const int err = coo_tile_atomic_launch(s, nrows, ncols, nrhs, nnz, rows, cols, vals, b, b_stride, c,
+                                               c_stride, alpha);
+        if (err != GKOMI_ENOTSUPPORTED) return err;
+    }
     dim3 grid(static_cast<unsigned>(nblocks), static_cast<unsigned>(nrhs));
     const bool vec = aligned_to(vals, 16) && aligned_to(rows, 8) && aligned_to(cols, 8);
 #define GKOMI_COO(SC, VE)                                                     \
@@ -523,8 +586,8 @@ extern "C" int gkomi_coo_spmv2_f64_i32(
     if (nrhs > 65535) return GKOMI_ENOTSUPPORTED;
     if (nrows == 0 || nrhs == 0) return GKOMI_SUCCESS;
     if (b_stride < nrhs || c_stride < nrhs) return GKOMI_EINVAL;
-    return coo_launch(to_stream(s), nrhs, nnz, row_idxs, col_idxs, vals, b, b_stride, c, c_stride,
-                      alpha);
+    return coo_launch(to_stream(s), nrows, ncols, nrhs, nnz, row_idxs, col_idxs, vals, b, b_stride, c,
+                      c_stride, alpha);
 }
 
 extern "C" int gkomi_coo_spmv_f64_i32(
@@ -564,3 +627,50 @@ extern "C" int gkomi_hybrid_spmv_f64_i32(
     return gkomi_coo_spmv2_f64_i32(s, nrows, ncols, nrhs, coo_nnz, coo_row_idxs, coo_col_idxs,
                                    coo_vals, b, b_stride, c, c_stride, alpha);
 }
+
+namespace gkomi {
+
+// The SpMV + dot epilogue for a system matrix behind the library's own ELL /
+// SELL-P callbacks (the fused drivers of cg_solver.hip / krylov.hip): the
+// number of partials one launch writes, or 0 when `op` is some other operator
+// and the driver has to follow A.apply with a separate partials kernel.
+int op_spmv_dot_num_partials(gkomi_matrix_apply_fn op, const void* ctx)
+{
+    int64_t nrows = 0;
+    if (op == &gkomi_ell_matrix_apply_cb) {
+        const auto* m = static_cast<const gkomi_ell_ctx*>(ctx);
+        if (m->nrows != m->ncols || m->stride < m->nrows) return 0;
+        nrows = m->nrows;
+    } else if (op == &gkomi_sellp_matrix_apply_cb) {
+        const auto* m = static_cast<const gkomi_sellp_ctx*>(ctx);
+        if (m->nrows != m->ncols || m->slice_size <= 0) return 0;
+        nrows = m->nrows;
+    } else {
+        return 0;
+    }
+    if (nrows <= 0 || ceildiv(nrows, block) > (int64_t{1} << 20)) return 0;
+    return static_cast<int>(ceildiv(nrows, block));
+}
+
+int op_spmv_dot_launch(hipStream_t stream, gkomi_matrix_apply_fn op, const void* ctx,
+                       const double* in, double* out, double* partial,
+                       const uint8_t* stop_status, const double* dot_w, double* partial2)
+{
+    const int g = op_spmv_dot_num_partials(op, ctx);
+    if (g <= 0) return GKOMI_ENOTSUPPORTED;
+    if (op == &gkomi_ell_matrix_apply_cb) {
+        const auto* m = static_cast<const gkomi_ell_ctx*>(ctx);
+        hipLaunchKernelGGL((ell_spmv_kernel<false, true>), dim3(g), dim3(block), 0, stream, m->nrows,
+                           m->num_stored_per_row, m->stride, m->col_idxs, m->vals, in, int64_t{1}, out,
+                           int64_t{1}, nullptr, nullptr, partial, stop_status, dot_w, partial2);
+    } else {
+        const auto* m = static_cast<const gkomi_sellp_ctx*>(ctx);
+        hipLaunchKernelGGL((sellp_spmv_kernel<false, true>), dim3(g), dim3(block), 0, stream, m->nrows,
+                           m->slice_size, m->slice_sets, m->slice_lengths, m->col_idxs, m->vals, in,
+                           int64_t{1}, out, int64_t{1}, nullptr, nullptr, partial, stop_status, dot_w,
+                           partial2);
+    }
+    return check_launch();
+}
+
+}  // namespace gkomi

@@ -56,4 +56,56 @@ inline sysmat make_op_sysmat(int64_t n, gkomi_matrix_apply_fn op, void* ctx)
     return A;
 }
 
+// ELL / SELL-P behind the library's own callbacks (formats.hip): partials per
+// launch of the SpMV + dot epilogue, 0 for any other operator
+int op_spmv_dot_num_partials(gkomi_matrix_apply_fn op, const void* ctx);
+int op_spmv_dot_launch(hipStream_t stream, gkomi_matrix_apply_fn op, const void* ctx,
+                       const double* in, double* out, double* partial,
+                       const uint8_t* stop_status, const double* dot_w, double* partial2);
+
+// How a fused single-rhs driver gets out = A in together with the per-block
+// partials of w . out (w = in unless given) and, on request, of out . out in
+// ONE launch: the CSR stream kernel's epilogue, the ELL / SELL-P kernels'
+// epilogue, or not at all (num_partials == 0: any other operator -- the driver
+// follows A.apply with its own partials kernel).  A CSR matrix behind
+// gkomi_csr_matrix_apply_cb counts as CSR.
+struct spmv_dot_plan {
+    int num_partials = 0;
+    bool csr = false, swizzle = false;
+    sysmat A;
+    explicit spmv_dot_plan(const sysmat& A_) : A(A_)
+    {
+        if (!A.is_csr() && A.op == &gkomi_csr_matrix_apply_cb && A.ctx != nullptr) {
+            const auto* m = static_cast<const gkomi_csr_ctx*>(A.ctx);
+            if (m->nrows == A.n && m->ncols == A.n) {
+                A = make_csr_sysmat(A.n, m->nnz, m->row_ptrs, m->col_idxs, m->vals,
+                                    static_cast<int>(m->strategy), m->max_row_nnz_hint);
+            }
+        }
+        if (A.n <= 0 || A.n > INT32_MAX) return;
+        if (A.is_csr()) {
+            if (reinterpret_cast<uintptr_t>(A.vals) % 16 != 0 ||
+                reinterpret_cast<uintptr_t>(A.col_idxs) % 8 != 0) {
+                return;
+            }
+            csr = true;
+            swizzle = csr_auto_swizzle(A.n, A.nnz);
+            num_partials = csr_spmv_dot_num_partials(static_cast<int>(A.n));
+        } else if (A.ctx != nullptr) {
+            num_partials = op_spmv_dot_num_partials(A.op, A.ctx);
+        }
+    }
+    bool fused() const { return num_partials > 0; }
+    int launch(hipStream_t stream, const double* in, double* out, double* partial,
+               const uint8_t* stop_status, const double* dot_w = nullptr,
+               double* partial2 = nullptr) const
+    {
+        if (csr) {
+            return csr_spmv_dot_launch(stream, static_cast<int>(A.n), A.nnz, A.row_ptrs, A.col_idxs,
+                                       A.vals, in, out, partial, stop_status, swizzle, dot_w, partial2);
+        }
+        return op_spmv_dot_launch(stream, A.op, A.ctx, in, out, partial, stop_status, dot_w, partial2);
+    }
+};
+
 }  // namespace gkomi

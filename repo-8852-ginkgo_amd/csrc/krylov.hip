@@ -1123,10 +1123,10 @@ int bicgstab_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_appl
     if (gl > fused_max_parts) gl = fused_max_parts;
     if (gl < 1) gl = 1;
     const int g = static_cast<int>(gl);
-    const bool csr_epilogue = A.is_csr() && n > 0 && reinterpret_cast<uintptr_t>(A.vals) % 16 == 0 &&
-                              reinterpret_cast<uintptr_t>(A.col_idxs) % 8 == 0;
-    const int nb = csr_epilogue ? csr_spmv_dot_num_partials(static_cast<int>(n)) : g;
-    const bool swizzle = csr_auto_swizzle(n, A.nnz);
+    // the dots in the SpMV's epilogue for CSR / ELL / SELL-P (internal.hpp)
+    const spmv_dot_plan spmv(A);
+    const bool csr_epilogue = spmv.fused();
+    const int nb = csr_epilogue ? spmv.num_partials : g;
     if (precond == nullptr) {  // Identity: y = p, z = s without the copies
         y = p;
         z = sv;
@@ -1138,8 +1138,7 @@ int bicgstab_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_appl
     // q = A in, partials of w.q (and q.q) -- in the SpMV epilogue when A is CSR
     auto spmv_dots = [&](const double* in, double* out, const double* w, double* pw, double* pq) {
         if (csr_epilogue) {
-            return csr_spmv_dot_launch(stream, static_cast<int>(n), A.nnz, A.row_ptrs, A.col_idxs,
-                                       A.vals, in, out, pw, &scal->status, swizzle, w, pq);
+            return spmv.launch(stream, in, out, pw, &scal->status, w, pq);
         }
         GKOMI_TRY(A.apply(s, 1, nullptr, in, nullptr, out));
         hipLaunchKernelGGL(fused_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, w, out,
@@ -1497,10 +1496,10 @@ int fcg_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn 
     if (gl > fused_max_parts) gl = fused_max_parts;
     if (gl < 1) gl = 1;
     const int g = static_cast<int>(gl);
-    const bool csr_epilogue = A.is_csr() && n > 0 && reinterpret_cast<uintptr_t>(A.vals) % 16 == 0 &&
-                              reinterpret_cast<uintptr_t>(A.col_idxs) % 8 == 0;
-    const int nb = csr_epilogue ? csr_spmv_dot_num_partials(static_cast<int>(n)) : g;
-    const bool swizzle = csr_auto_swizzle(n, A.nnz);
+    // the dots in the SpMV's epilogue for CSR / ELL / SELL-P (internal.hpp)
+    const spmv_dot_plan spmv(A);
+    const bool csr_epilogue = spmv.fused();
+    const int nb = csr_epilogue ? spmv.num_partials : g;
     const bool identity = precond == nullptr;
     if (identity) z = r;
     hipLaunchKernelGGL(fcg_fused_init_kernel, dim3(1), dim3(1), 0, stream, scal, c.orig_tau);
@@ -1521,8 +1520,7 @@ int fcg_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn 
                 break;
             }
             if (csr_epilogue) {
-                GKOMI_TRY(csr_spmv_dot_launch(stream, static_cast<int>(n), A.nnz, A.row_ptrs, A.col_idxs, A.vals,
-                                              p, q, part_beta, &scal->status, swizzle));
+                GKOMI_TRY(spmv.launch(stream, p, q, part_beta, &scal->status));
             } else {
                 GKOMI_TRY(A.apply(s, 1, nullptr, p, nullptr, q));
                 // only p.q is wanted: the other two sums land in scratch
@@ -1859,10 +1857,10 @@ int cgs_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn 
     if (gl > fused_max_parts) gl = fused_max_parts;
     if (gl < 1) gl = 1;
     const int g = static_cast<int>(gl);
-    const bool csr_epilogue = A.is_csr() && n > 0 && reinterpret_cast<uintptr_t>(A.vals) % 16 == 0 &&
-                              reinterpret_cast<uintptr_t>(A.col_idxs) % 8 == 0;
-    const int nb = csr_epilogue ? csr_spmv_dot_num_partials(static_cast<int>(n)) : g;
-    const bool swizzle = csr_auto_swizzle(n, A.nnz);
+    // the dots in the SpMV's epilogue for CSR / ELL / SELL-P (internal.hpp)
+    const spmv_dot_plan spmv(A);
+    const bool csr_epilogue = spmv.fused();
+    const int nb = csr_epilogue ? spmv.num_partials : g;
     const bool identity = precond == nullptr;
     hipLaunchKernelGGL(cgs_fused_init_kernel, dim3(1), dim3(1), 0, stream, scal, c.orig_tau);
     // partials of r.r_tld and r.r (the third sum is scratch)
@@ -1887,8 +1885,7 @@ int cgs_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn 
                 mp = t;
             }
             if (csr_epilogue) {
-                GKOMI_TRY(csr_spmv_dot_launch(stream, static_cast<int>(n), A.nnz, A.row_ptrs, A.col_idxs, A.vals,
-                                              mp, v_hat, part_gamma, &scal->status, swizzle, r_tld));
+                GKOMI_TRY(spmv.launch(stream, mp, v_hat, part_gamma, &scal->status, r_tld));
             } else {
                 GKOMI_TRY(A.apply(s, 1, nullptr, mp, nullptr, v_hat));
                 hipLaunchKernelGGL(fused_dot3_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r_tld, v_hat,

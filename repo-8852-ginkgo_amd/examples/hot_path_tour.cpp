@@ -63,6 +63,10 @@ int main()
         A->convert_to(coo.get());
         coo->apply(x.get(), y2.get());
         std::cout << "coo_diff " << diff_norm(exec, y.get(), y2.get()) << "\n";
+        // converted from CSR: sorted by row -> the atomic-free kernels; apply2 adds on top
+        coo->apply2(x.get(), y2.get());
+        y2->scale(gko::initialize<vec>({0.5}, exec).get());
+        std::cout << "coo_sorted " << coo->is_sorted_by_row() << " coo_apply2_diff " << diff_norm(exec, y.get(), y2.get()) << "\n";
         auto hyb = gko::matrix::Hybrid<double, int>::create(exec, std::make_shared<gko::matrix::Hybrid<double, int>::column_limit>(3));
         A->convert_to(hyb.get());
         hyb->apply(x.get(), y2.get());

@@ -143,11 +143,51 @@ class Coo:
                      self.vals.data_ptr())
         return MatrixCallback(self.gk, "gkomi_coo_matrix_apply_cb", ctx, self)
 
-    def apply(self, b, x, alpha=None, beta=None):
+    def _sorted_workspace(self, nrhs):
+        """workspace of the atomic-free kernels when row_idxs is sorted (analysed once), else None"""
+        gk = self.gk
+        nb = gk.coo_sorted_workspace_bytes(self.nnz, nrhs)
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < nb:
+            ws = self._ws = torch.empty(max(nb, 16), dtype=U8, device=self.vals.device)
+        if getattr(self, "_sorted", None) is None:
+            flag, longest = ctypes.c_int(0), ctypes.c_int64(0)
+            gk.coo_analyse_rows_i32(_stream(self.vals), self.nnz, self.row_idxs, ws, ws.numel(), ctypes.addressof(flag),
+                                    ctypes.addressof(longest))
+            aligned = self.vals.data_ptr() % 16 == 0 and self.row_idxs.data_ptr() % 8 == 0 and \
+                self.col_idxs.data_ptr() % 8 == 0
+            self._sorted = bool(flag.value) and aligned
+            self.max_row_nnz = int(longest.value)   # capped at 65
+        return ws if self._sorted else None
+
+    def apply(self, b, x, alpha=None, beta=None, sorted_rows=None, hint=None):
+        """sorted_rows: None = use the atomic-free kernels when the rows are sorted, False = never;
+        hint: max_row_nnz_hint of the sorted entry (default: what the analysis found)"""
         dv = self.vals.device
+        ws = self._sorted_workspace(b.shape[1]) if sorted_rows is not False else None
+        if ws is not None:
+            self.gk.coo_spmv_sorted_f64_i32(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.nnz,
+                                            self.row_idxs, self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0),
+                                            _scalar(dv, alpha), _scalar(dv, beta),
+                                            self.max_row_nnz if hint is None else hint, ws, ws.numel())
+            return x
         self.gk.coo_spmv_f64_i32(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.nnz, self.row_idxs,
                                  self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0), _scalar(dv, alpha),
                                  _scalar(dv, beta))
+        return x
+
+    def apply2(self, b, x, alpha=None, sorted_rows=None, hint=None):
+        """x += [alpha] A b (Coo::apply2)"""
+        dv = self.vals.device
+        ws = self._sorted_workspace(b.shape[1]) if sorted_rows is not False else None
+        if ws is not None:
+            self.gk.coo_spmv2_sorted_f64_i32(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.nnz,
+                                             self.row_idxs, self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0),
+                                             _scalar(dv, alpha), self.max_row_nnz if hint is None else hint, ws,
+                                             ws.numel())
+            return x
+        self.gk.coo_spmv2_f64_i32(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.nnz, self.row_idxs,
+                                  self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0), _scalar(dv, alpha))
         return x
 
 

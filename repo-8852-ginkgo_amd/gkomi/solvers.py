@@ -144,7 +144,13 @@ def solve_op(gk, solver, matrix, b, x=None, max_iters=1000, reduction=1e-10, bas
     stream = torch.cuda.current_stream().cuda_stream
     fn = precond.fn if precond is not None else None
     ctx = precond.ctx_ptr if precond is not None else None
-    if solver == "cg":
+    if solver == "cg" and fused:
+        assert nrhs == 1
+        nbytes = gk.cg_workspace_bytes(n, 1)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+        gk.cg_solve_fused_op_f64(stream, n, cb.fn, cb.ctx_ptr, fn, ctx, b2, x2, max_iters, reduction,
+                                 BASELINES[baseline], check_every, ws, nbytes, info)
+    elif solver == "cg":
         nbytes = gk.cg_workspace_bytes(n, nrhs)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
         gk.cg_solve_op_f64(stream, n, nrhs, cb.fn, cb.ctx_ptr, fn, ctx, b2, x2, max_iters, reduction, BASELINES[baseline],

@@ -1002,36 +1002,74 @@ public:
     const V* get_const_values() const noexcept { return values_.get_const_data(); }
     I* get_col_idxs() noexcept { return col_idxs_.get_data(); }
     const I* get_const_col_idxs() const noexcept { return col_idxs_.get_const_data(); }
-    I* get_row_idxs() noexcept { return row_idxs_.get_data(); }
+    // handing out writable row indices forgets what is known about their order
+    I* get_row_idxs() noexcept { sorted_state_ = -1; return row_idxs_.get_data(); }
     const I* get_const_row_idxs() const noexcept { return row_idxs_.get_const_data(); }
     size_type get_num_stored_elements() const noexcept { return values_.get_num_elems(); }
-    void resize(const dim<2>& size, size_type nnz) { values_.resize_and_reset(nnz); col_idxs_.resize_and_reset(nnz); row_idxs_.resize_and_reset(nnz); set_size(size); }
+    void resize(const dim<2>& size, size_type nnz) { values_.resize_and_reset(nnz); col_idxs_.resize_and_reset(nnz); row_idxs_.resize_and_reset(nnz); set_size(size); sorted_state_ = -1; }
+    // row indices non-decreasing (checked on the device once per set of indices):
+    // apply / apply2 then run the atomic-free kernels of csrc/coo_spmv.hip
+    bool is_sorted_by_row() const { return sorted_workspace(1) != nullptr; }
     // x += A b  (Coo::apply2, include/ginkgo/core/matrix/coo.hpp)
     void apply2(const LinOp* b, LinOp* x) const { validate(b, x); run2(nullptr, b, x); }
     void apply2(const LinOp* alpha, const LinOp* b, LinOp* x) const { validate(b, x); run2(alpha, b, x); }
 protected:
-    Coo(std::shared_ptr<const Executor> exec, const dim<2>& size, size_type nnz) : LinOp(exec, size), values_(exec, nnz), col_idxs_(exec, nnz), row_idxs_(exec, nnz) {}
+    Coo(std::shared_ptr<const Executor> exec, const dim<2>& size, size_type nnz) : LinOp(exec, size), values_(exec, nnz), col_idxs_(exec, nnz), row_idxs_(exec, nnz), sorted_ws_(exec) {}
+    // workspace of the sorted kernels, or nullptr when the rows are not sorted (or misaligned)
+    void* sorted_workspace(size_type nrhs) const
+    {
+        if (!exec_->is_device() || sorted_state_ == 0) return nullptr;
+        const size_type nnz = get_num_stored_elements();
+        const size_type need = std::max<size_type>(gkomi_coo_sorted_workspace_bytes(nnz, nrhs), 16);
+        if (sorted_ws_.get_num_elems() < need) sorted_ws_.resize_and_reset(need);
+        if (sorted_state_ < 0) {
+            int flag = 0;
+            int64_t longest = 0;
+            GKOMI_CALL(gkomi_coo_analyse_rows_i32(nullptr, nnz, get_const_row_idxs(), sorted_ws_.get_data(), sorted_ws_.get_num_elems(), &flag, &longest));
+            max_row_nnz_ = longest;  // capped at 65: rows of up to 64 nonzeros take the one-launch kernel
+            const bool aligned = reinterpret_cast<std::uintptr_t>(get_const_values()) % 16 == 0 && reinterpret_cast<std::uintptr_t>(get_const_row_idxs()) % 8 == 0 &&
+                                 reinterpret_cast<std::uintptr_t>(get_const_col_idxs()) % 8 == 0;
+            sorted_state_ = flag && aligned ? 1 : 0;
+        }
+        return sorted_state_ == 1 ? sorted_ws_.get_data() : nullptr;
+    }
     void run2(const LinOp* alpha, const LinOp* b, LinOp* x) const
     {
         detail::require_device(exec_, "coo::spmv2");
         auto db = detail_fmt::dense(b); auto dx = detail_fmt::dense(x);
+        auto al = alpha ? detail_fmt::dense(alpha)->get_const_values() : nullptr;
+        if (void* ws = sorted_workspace(db->cols())) {
+            GKOMI_CALL(gkomi_coo_spmv2_sorted_f64_i32(nullptr, size_[0], size_[1], db->cols(), get_num_stored_elements(), get_const_row_idxs(), get_const_col_idxs(),
+                                                      get_const_values(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(), al, max_row_nnz_, ws,
+                                                      sorted_ws_.get_num_elems()));
+            return;
+        }
         GKOMI_CALL(gkomi_coo_spmv2_f64_i32(nullptr, size_[0], size_[1], db->cols(), get_num_stored_elements(), get_const_row_idxs(), get_const_col_idxs(),
-                                           get_const_values(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(),
-                                           alpha ? detail_fmt::dense(alpha)->get_const_values() : nullptr));
+                                           get_const_values(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(), al));
     }
     void run(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const
     {
         detail::require_device(exec_, "coo::spmv");
         auto db = detail_fmt::dense(b); auto dx = detail_fmt::dense(x);
+        auto al = alpha ? detail_fmt::dense(alpha)->get_const_values() : nullptr;
+        auto be = beta ? detail_fmt::dense(beta)->get_const_values() : nullptr;
+        if (void* ws = sorted_workspace(db->cols())) {
+            GKOMI_CALL(gkomi_coo_spmv_sorted_f64_i32(nullptr, size_[0], size_[1], db->cols(), get_num_stored_elements(), get_const_row_idxs(), get_const_col_idxs(),
+                                                     get_const_values(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(), al, be, max_row_nnz_, ws,
+                                                     sorted_ws_.get_num_elems()));
+            return;
+        }
         GKOMI_CALL(gkomi_coo_spmv_f64_i32(nullptr, size_[0], size_[1], db->cols(), get_num_stored_elements(), get_const_row_idxs(), get_const_col_idxs(),
-                                          get_const_values(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(),
-                                          alpha ? detail_fmt::dense(alpha)->get_const_values() : nullptr, beta ? detail_fmt::dense(beta)->get_const_values() : nullptr));
+                                          get_const_values(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(), al, be));
     }
     void apply_impl(const LinOp* b, LinOp* x) const override { run(nullptr, b, nullptr, x); }
     void apply_impl(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const override { run(alpha, b, beta, x); }
     array<V> values_;
     array<I> col_idxs_;
     array<I> row_idxs_;
+    mutable int sorted_state_{-1};   // -1 unknown, 0 not sorted, 1 sorted
+    mutable int64_t max_row_nnz_{-1};
+    mutable array<char> sorted_ws_;
 };
 
 template <typename V = double, typename I = int32>
@@ -1475,6 +1513,43 @@ struct matrix_callback {
         return 0;
     }
 };
+// The system matrix of a solver as (gkomi_matrix_apply_fn, context): Ell and
+// Sellp go by the library's own callbacks + records, which the fused drivers
+// recognise (SpMV with the dot-product epilogue, csrc/formats.hip); every other
+// LinOp goes through matrix_callback.
+struct system_callback {
+    matrix_callback generic;
+    gkomi_ell_ctx ell{};
+    gkomi_sellp_ctx sellp{};
+    gkomi_matrix_apply_fn fn;
+    void* ctx;
+    system_callback(const LinOp* A, std::shared_ptr<const Executor> exec, size_type n)
+        : generic{A, std::move(exec), n}, fn(&matrix_callback::call), ctx(&generic)
+    {
+        if (auto e = dynamic_cast<const matrix::Ell<double, int32>*>(A)) {
+            ell.nrows = static_cast<int64_t>(e->get_size()[0]);
+            ell.ncols = static_cast<int64_t>(e->get_size()[1]);
+            ell.num_stored_per_row = static_cast<int64_t>(e->get_num_stored_elements_per_row());
+            ell.stride = static_cast<int64_t>(e->get_stride());
+            ell.col_idxs = e->get_const_col_idxs();
+            ell.vals = e->get_const_values();
+            fn = &gkomi_ell_matrix_apply_cb;
+            ctx = &ell;
+        } else if (auto sp = dynamic_cast<const matrix::Sellp<double, int32>*>(A)) {
+            sellp.nrows = static_cast<int64_t>(sp->get_size()[0]);
+            sellp.ncols = static_cast<int64_t>(sp->get_size()[1]);
+            sellp.slice_size = static_cast<int64_t>(sp->get_slice_size());
+            sellp.slice_sets = reinterpret_cast<const uint64_t*>(sp->get_const_slice_sets());
+            sellp.slice_lengths = reinterpret_cast<const uint64_t*>(sp->get_const_slice_lengths());
+            sellp.col_idxs = sp->get_const_col_idxs();
+            sellp.vals = sp->get_const_values();
+            fn = &gkomi_sellp_matrix_apply_cb;
+            ctx = &sellp;
+        }
+    }
+    system_callback(const system_callback&) = delete;
+    system_callback& operator=(const system_callback&) = delete;
+};
 }  // namespace detail
 
 // include/ginkgo/core/base/lin_op.hpp:433-455 (real values: conj_transpose == transpose)
@@ -1728,9 +1803,14 @@ protected:
                                               csr->get_strategy()->get_code(), csr->get_max_row_nnz(), pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
                                               settings_.reduction_factor, detail::baseline_code(settings_.baseline), nrhs == 1 ? 1 : 0, 8, ws.get_data(), ws.get_num_elems(), info.data()));
         } else {  // any other format: the system matrix as a callback
-            ::gko::detail::matrix_callback mcb{A_.get(), exec_, static_cast<size_type>(n)};
-            GKOMI_CALL(gkomi_cg_solve_op_f64(nullptr, n, nrhs, &::gko::detail::matrix_callback::call, &mcb, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
-                                             settings_.reduction_factor, detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
+            ::gko::detail::system_callback mcb(A_.get(), exec_, static_cast<size_type>(n));
+            if (nrhs == 1) {  // the fused loop; Ell / Sellp with the dot in the SpMV's epilogue
+                GKOMI_CALL(gkomi_cg_solve_fused_op_f64(nullptr, n, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
+                                                       settings_.reduction_factor, detail::baseline_code(settings_.baseline), 8, ws.get_data(), ws.get_num_elems(), info.data()));
+            } else {
+                GKOMI_CALL(gkomi_cg_solve_op_f64(nullptr, n, nrhs, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
+                                                 settings_.reduction_factor, detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
+            }
         }
         last_iters_ = static_cast<int64_t>(info[0]);
         last_converged_ = info[1] != 0.0;
@@ -1790,8 +1870,8 @@ protected:
                               csr->get_strategy()->get_code(), csr->get_max_row_nnz(), pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
                               settings_.reduction_factor, baseline_code(settings_.baseline), 8, ws.get_data(), ws.get_num_elems(), info.data()));
         } else {
-            ::gko::detail::matrix_callback mcb{A_.get(), exec_, static_cast<size_type>(n)};
-            GKOMI_CALL(OpDriver(nullptr, n, nrhs, &::gko::detail::matrix_callback::call, &mcb, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
+            ::gko::detail::system_callback mcb(A_.get(), exec_, static_cast<size_type>(n));
+            GKOMI_CALL(OpDriver(nullptr, n, nrhs, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
                                 settings_.reduction_factor, baseline_code(settings_.baseline), 8, ws.get_data(), ws.get_num_elems(), info.data()));
         }
         last_iters_ = static_cast<int64_t>(info[0]);
@@ -2021,8 +2101,8 @@ protected:
                                                  csr->get_strategy()->get_code(), csr->get_max_row_nnz(), pfn, pctx, db->get_const_values(), dx->get_values(), krylov_dim_,
                                                  settings_.max_iters, settings_.reduction_factor, detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
         } else {
-            ::gko::detail::matrix_callback mcb{A_.get(), exec_, static_cast<size_type>(n)};
-            GKOMI_CALL(gkomi_gmres_solve_op_f64(nullptr, n, nrhs, &::gko::detail::matrix_callback::call, &mcb, pfn, pctx, db->get_const_values(), dx->get_values(), krylov_dim_,
+            ::gko::detail::system_callback mcb(A_.get(), exec_, static_cast<size_type>(n));
+            GKOMI_CALL(gkomi_gmres_solve_op_f64(nullptr, n, nrhs, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), krylov_dim_,
                                                 settings_.max_iters, settings_.reduction_factor, detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
         }
         last_iters_ = static_cast<int64_t>(info[0]);

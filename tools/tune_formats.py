@@ -82,6 +82,16 @@ report("sellp(64)", lambda: gk.sellp_spmv_f64_i32(s, n, n, 1, 64, sets, lens, sc
 rows = torch.zeros(nnz, dtype=torch.int32, device="cuda")
 gk.convert_ptrs_to_idxs_i32(s, rpd, n, rows)
 report("coo (fill + spmv2)", lambda: gk.coo_spmv_f64_i32(s, n, n, 1, nnz, rows, cid, vd, x, 1, y, 1, None, None), 16 * nnz + 24 * n)
+cws_bytes = gk.coo_sorted_workspace_bytes(nnz, 8)
+cws = torch.empty(cws_bytes, dtype=torch.uint8, device="cuda")
+report("coo sorted, carries (any row length)", lambda: gk.coo_spmv_sorted_f64_i32(s, n, n, 1, nnz, rows, cid, vd, x, 1, y, 1, None, None, -1, cws, cws_bytes), 16 * nnz + 16 * n)
+report("coo sorted, halo (rows <= 64)", lambda: gk.coo_spmv_sorted_f64_i32(s, n, n, 1, nnz, rows, cid, vd, x, 1, y, 1, None, None, 5, cws, cws_bytes), 16 * nnz + 16 * n)
+for k_rhs in (4, 8):
+    xb = d(np.sin(0.01 * np.arange(n * k_rhs)).reshape(n, k_rhs))
+    yb = torch.empty((n, k_rhs), dtype=torch.float64, device="cuda")
+    report(f"coo {k_rhs} rhs (fill + tile atomics)", lambda: gk.coo_spmv_f64_i32(s, n, n, k_rhs, nnz, rows, cid, vd, xb, k_rhs, yb, k_rhs, None, None), 16 * nnz + 24 * n * k_rhs)
+    report(f"coo {k_rhs} rhs sorted, carries", lambda: gk.coo_spmv_sorted_f64_i32(s, n, n, k_rhs, nnz, rows, cid, vd, xb, k_rhs, yb, k_rhs, None, None, -1, cws, cws_bytes), 16 * nnz + 16 * n * k_rhs)
+    report(f"coo {k_rhs} rhs sorted, halo", lambda: gk.coo_spmv_sorted_f64_i32(s, n, n, k_rhs, nnz, rows, cid, vd, xb, k_rhs, yb, k_rhs, None, None, 5, cws, cws_bytes), 16 * nnz + 16 * n * k_rhs)
 # several right-hand sides: one pass over the matrix per 4 columns vs one per column
 for k_rhs in (2, 4, 8):
     xb = d(np.sin(0.01 * np.arange(n * k_rhs)).reshape(n, k_rhs))

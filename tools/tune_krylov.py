@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-iteration time of the Krylov drivers on the 1M-row problems: BiCGSTAB
 reference sequence vs the fused 6-launch driver, FCG, CGS, CG (fused) for
-comparison.  Usage: python tools/tune_krylov.py [grid]"""
+comparison; `formats` as second argument: the fused drivers on CSR / ELL /
+SELL-P / COO system matrices.  Usage: python tools/tune_krylov.py [grid] [fused|formats]"""
 import os
 import sys
 import time
@@ -49,6 +50,27 @@ for name in ("poisson2d", "convection3d"):
     bv = b[:, 0].contiguous()
     print(f"{name}: n={n} nnz={len(v)}")
     kw = dict(max_iters=5000, reduction=1e-10)
+    if len(sys.argv) > 2 and sys.argv[2] == "formats":
+        from gkomi import formats
+        A = formats.Csr(gk, n, n, rpd, cid, vd)
+        spmv_x = d(sv.reshape(n, 1)); spmv_y = torch.zeros_like(spmv_x)
+        for fmt in ("csr", "ell", "sellp", "coo"):
+            M = A if fmt == "csr" else A.to(fmt)
+            for _ in range(3):
+                M.apply(spmv_x, spmv_y)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                M.apply(spmv_x, spmv_y)
+            e1.record(); torch.cuda.synchronize()
+            print(f"  {fmt:6s} spmv (warm) {e0.elapsed_time(e1) * 20:7.1f} us")
+            solvers_here = ("cg", "fcg", "bicgstab", "cgs") if name == "poisson2d" else ("bicgstab", "cgs")
+            for sol in solvers_here:
+                if sol == "cg":
+                    timed(f"{fmt:6s} cg reference sequence (op)", lambda: solvers.solve_op(gk, "cg", M, bv, **kw))
+                timed(f"{fmt:6s} {sol} fused (op)", lambda: solvers.solve_op(gk, sol, M, bv, fused=True, check_every=16, **kw))
+        timed("csr    cg fused (CSR entry)", lambda: solvers.cg_solve(gk, n, rpd, cid, vd, b, mode=1, check_every=16, **kw))
+        continue
     if len(sys.argv) > 2 and sys.argv[2] == "fused":   # for rocprofv3: only the fused driver
         timed("bicgstab fused, check_every 32", lambda: solvers.krylov_solve(gk, "bicgstab", n, rpd, cid, vd, bv, check_every=32, fused=True, **kw))
         continue
