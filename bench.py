@@ -41,6 +41,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, MI355X_MICROARCH.md "HBM3E peak BW"
 GRID = 1000            # P2: 1000 x 1000 grid
+T_START = time.perf_counter()
 TRIALS = 3
 GKOMI_CSR_STREAMING = 1 << 24
 
@@ -84,6 +85,7 @@ def cpu_baseline_child(seconds):
     """Reference omp/ CSR SpMV + CG (oracle port, omp/matrix/csr_kernels.cpp:76-99,
     core/solver/cg.cpp:107-193 on omp kernels) on this host's cores, first-touch
     placed; prints one JSON line."""
+    allowed, share = len(os.sched_getaffinity(0)), cpu_share()   # before the OpenMP runtime binds this thread
     import matgen
     import oracle_lib
     orc = oracle_lib.load()
@@ -114,7 +116,8 @@ def cpu_baseline_child(seconds):
         if os.path.isdir("/sys/devices/system/node") else 1
     out = {"value": round(2.0 * nnz * reps / el / 1e9, 3), "unit": "GFLOP/s",
            "cores": int(orc.omp_bench_threads()), "threads": int(orc.omp_bench_threads()),
-           "host_cpus": os.cpu_count(), "cpus_allowed": len(os.sched_getaffinity(0)), "numa_nodes": numa, "kind": "port",
+           "host_cpus": os.cpu_count(), "cpus_allowed": allowed, "cpu_share": share,
+           "numa_nodes": numa, "kind": "port",
            "omp_num_threads": os.environ.get("OMP_NUM_THREADS", ""),
            "omp_proc_bind": os.environ.get("OMP_PROC_BIND", ""), "omp_places": os.environ.get("OMP_PLACES", ""),
            "sample": f"{reps} x omp csr::spmv on the same 1M-row 5-pt Poisson matrix ({el:.1f} s), "
@@ -127,12 +130,31 @@ def cpu_baseline_child(seconds):
     print(json.dumps(out))
 
 
+def cpu_share():
+    """CPUs this process may really use: the affinity mask capped by the cgroup's CPU quota
+    (the GPU box shows 256 CPUs in the mask and a quota of 16: 256 OpenMP threads on that
+    quota spend their time being throttled -- the first version of this leg did just that)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def progress(msg):
+    sys.stderr.write(f"[bench {time.perf_counter() - T_START:7.1f}s] {msg}\n")
+    sys.stderr.flush()
+
+
 def cpu_baseline(seconds):
-    """The omp/ path on every CPU this process may use, in child processes (the OpenMP runtime
-    fixes its binding when it starts): unbound, OMP_PROC_BIND=true and
-    OMP_PROC_BIND=true + OMP_PLACES=cores; the fastest SpMV is the headline, all are reported."""
+    """The omp/ path on the CPUs this process may use (cpu_share), in child processes (the
+    OpenMP runtime fixes its binding when it starts): unbound, OMP_PROC_BIND=true
+    and OMP_PROC_BIND=true + OMP_PLACES=cores; the fastest SpMV is the headline, all are reported."""
     runs = {}
-    ncpu = str(len(os.sched_getaffinity(0)))
+    ncpu = str(cpu_share())
     for name, env in (("unbound", {"OMP_PROC_BIND": "false"}), ("bound", {"OMP_PROC_BIND": "true"}),
                       ("bound_cores", {"OMP_PROC_BIND": "true", "OMP_PLACES": "cores"})):
         e = {k: v for k, v in os.environ.items() if not k.startswith("OMP_") and not k.startswith("GOMP_")}
@@ -140,8 +162,9 @@ def cpu_baseline(seconds):
         e["OMP_NUM_THREADS"] = ncpu
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-seconds", str(seconds)],
-                               env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                               env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
             runs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+            progress(f"cpu baseline {name}: {runs[name]['value']} GFLOP/s with {runs[name]['threads']} threads")
         except Exception as ex:  # noqa: BLE001 - reported in the line
             runs[name] = {"error": repr(ex)[:200]}
     good = {k: v for k, v in runs.items() if "value" in v}
@@ -242,6 +265,7 @@ def main():
     out = {}
     if not distributed:
         # ---------------- N = 1: P2, configs[1] ----------------
+        progress("P2: building the 1M-row matrix, 8 copies")
         n, rp, ci, v = matgen.poisson_2d_5pt(GRID)
         nnz = int(rp[-1])
         x_host = np.sin(0.01 * np.arange(n)).reshape(n, 1)
@@ -261,6 +285,7 @@ def main():
 
         step_cold = lambda i: launch(copies[i % ncopies], cold_strategy)
         step_warm = lambda i: launch(copies[0], 0)
+        progress("P2: timing the cold SpMV")
         for i in range(args.warmup):
             step_cold(i)
         (wall, ev), regions = timed_region(step_cold, args.steps)
@@ -315,6 +340,7 @@ def main():
             gk.csr_spmv_f64_i32(stream, nn, nn, 1, nz, a[0], a[1], a[2], sb, 1, b, 1, None, None, 0, hint)
             return sb, b
 
+        progress("P2: CG solves")
         if not args.no_cg:
             c = copies[0]
             sb, b = sinus_system(n, c, nnz, 5)
@@ -337,6 +363,7 @@ def main():
         got_p2 = copies[0][4].cpu().numpy().copy()
 
         if not args.no_p3:
+            progress(f"P3: building the {args.p3_grid}^3 matrix")
             # the one-GPU anchor of the strong-scaling curve: BASELINE config 5's matrix on one GPU
             del copies[1:]
             g = args.p3_grid
@@ -373,6 +400,7 @@ def main():
             del a3, x3, y3, srow3
 
         if not args.no_cpu_baseline:
+            progress("CPU baseline (3 child processes)")
             base = cpu_baseline(args.cpu_seconds)
             out["cpu_baseline"] = base
             # end-of-run parity check of what was timed, against the oracle (reference/ SpMV)
@@ -392,6 +420,8 @@ def main():
         rows, cols, vals = gd.poisson3d_rows(g, lo, hi)
         nnz_local = len(vals)
         nnz_global = 7 * n_global - 6 * g * g
+        if rank == 0:
+            progress(f"P3 {g}^3 over {world} ranks: building the distributed matrix")
         M = gd.Matrix(gd.GpuOps(gk, device)).read_distributed(rows, cols, vals, part)
         del rows, cols, vals
         n_loc = M.num_local_rows
@@ -441,6 +471,8 @@ def main():
             (A.apply(comm, sd, b) if A is not None else M.apply(sd, b))
             torch.cuda.synchronize()
 
+            if rank == 0:
+                progress("distributed CG solves")
             def solve(rhs):
                 xs = torch.zeros((n_loc, 1), dtype=torch.float64, device=device)
                 if A is not None:
@@ -480,6 +512,7 @@ def main():
             comm.close()
 
     if rank == 0:
+        progress("done")
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:

@@ -1072,8 +1072,9 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
 #define GKOMI_SPLIT_ARGS                                                            \
     stream, !no_swizzle, n, z, row_ptrs, col_idxs, vals, b + j, b_stride, c + j,    \
         c_stride, alpha, beta, srow, over
-            // variant bit 2: nontemporal streams.  (Write-through stores of c, 8 or 16 bytes wide, were
-            // measured and dropped: 17.2 vs 16.6 us cold, profiles/r02_tune_split.log.)
+            // variant bit 2: nontemporal streams.  (Write-through stores of c, 8 or 16 bytes wide, and
+            // nontemporal stores of c were measured and dropped: 17.2 / 16.9 vs 16.6 us cold,
+            // profiles/r02_tune_split.log, r02_tune_ntstore.log.)
 #define GKOMI_SPLIT_TILE(BLOCK, TILE)                                               \
     if (variant & 2) {                                                              \
         err = launch_split<BLOCK, TILE, true>(GKOMI_SPLIT_ARGS);                    \
