@@ -688,7 +688,10 @@ int gkomi_csr_transpose_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
  *         the device, the device stops updating at the iteration the
  *         criterion fires (same iteration count and iterates as mode 0 up to
  *         reduction order) and the host polls the status every `check_every`
- *         iterations.
+ *         iterations.  It moves 16 B per lane through x and the workspace
+ *         vectors: when x or workspace is not 16-B aligned (hipMalloc gives
+ *         256 B) the call runs mode 0 instead; CSR arrays may have any
+ *         alignment (aligned ones get the SpMV + dot-product epilogue).
  * host_info (may be NULL): [0] iterations, [1] converged (1) / iteration
  * limit (0), then per rhs j: [2+2j] final ||r||_2 (recurrence residual),
  * [3+2j] baseline norm.  Needs 2 + 2 nrhs doubles.

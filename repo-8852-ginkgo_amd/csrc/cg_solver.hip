@@ -89,6 +89,12 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
                   size_t workspace_bytes, double* host_info)
 {
     if (mode == 1 && n == 0) mode = 0;  // the fused path needs rows
+    // the fused kernels move 16 B per lane through x and the workspace vectors: anything else
+    // (a view at an odd offset) takes the reference sequence, like the other fused drivers
+    if (mode == 1 && nrhs == 1 &&
+        (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(workspace) % 16 != 0)) {
+        mode = 0;
+    }
     if (n < 0 || nrhs <= 0 || max_iters < 0) return GKOMI_EINVAL;
     if (baseline < 0 || baseline > 2 || (mode != 0 && mode != 1)) return GKOMI_EINVAL;
     if (mode == 1 && nrhs != 1) return GKOMI_ENOTSUPPORTED;
@@ -181,8 +187,7 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
         // SELL-P; any other operator: its apply, then a partials kernel
         const spmv_dot_plan spmv(A);
         const int nb = spmv.fused() ? spmv.num_partials : g;
-        if (A.is_csr() && !spmv.fused()) return GKOMI_ENOTSUPPORTED;  // misaligned CSR arrays
-        if (reinterpret_cast<uintptr_t>(x) % 16 != 0) return GKOMI_ENOTSUPPORTED;
+        // (misaligned CSR arrays: spmv.fused() is false, apply + partials kernel like any operator)
         cg_scalars polled{};  // per call: concurrent solves on other streams / threads do not share it
         if (check_every < 1) check_every = 1;
         hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(1), 0, stream, scal, orig_tau,

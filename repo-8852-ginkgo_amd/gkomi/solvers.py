@@ -10,6 +10,17 @@ APPLY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctyp
 BASELINES = {"rhs_norm": 0, "initial_resnorm": 1, "absolute": 2}
 
 
+def _check_precond(precond, nrhs):
+    """The native preconditioner contexts carry the column count of the vectors they
+    are applied to (it is also their stride): a context generated for another count
+    would read the n x nrhs row-major vectors as n x ctx.nrhs."""
+    ctx = getattr(precond, "ctx", None)
+    have = getattr(ctx, "nrhs", None)
+    if have is not None and int(have) != int(nrhs):
+        raise ValueError(f"preconditioner generated for nrhs = {int(have)}, applied to {int(nrhs)} right-hand sides: "
+                         f"pass nrhs={int(nrhs)} to its generate call")
+
+
 def cg_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reduction=1e-10,
              baseline="rhs_norm", mode=1, check_every=16, strategy=0, max_row_nnz=-1,
              precond=None, precond_ctx=None):
@@ -20,6 +31,7 @@ def cg_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reducti
     Returns dict(x, iterations, converged, residual_norm, baseline_norm, rel_residual)."""
     b2 = b.reshape(n, -1) if n > 0 else b.reshape(0, b.shape[1] if b.dim() > 1 else 1)
     nrhs = b2.shape[1]
+    _check_precond(precond, nrhs)
     if mode == 1 and nrhs != 1:
         mode = 0
     if x is None:
@@ -54,6 +66,7 @@ def krylov_solve(gk, solver, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1
     assert solver in ("bicgstab", "fcg", "cgs")
     b2 = b.reshape(n, -1) if n > 0 else b.reshape(0, b.shape[1] if b.dim() > 1 else 1)
     nrhs = b2.shape[1]
+    _check_precond(precond, nrhs)
     if x is None:
         x = torch.zeros_like(b2)
     x2 = x.reshape(n, nrhs)
@@ -86,6 +99,7 @@ def bicg_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, max_iters=1000, reduc
     transposed preconditioner (pass the same object for a symmetric one)."""
     b2 = b.reshape(n, -1) if n > 0 else b.reshape(0, b.shape[1] if b.dim() > 1 else 1)
     nrhs = b2.shape[1]
+    _check_precond(precond, nrhs)
     if x is None:
         x = torch.zeros_like(b2)
     x2 = x.reshape(n, nrhs)
@@ -112,6 +126,7 @@ def ir_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, relaxation_factor=1.0, 
     Preconditioner-like object whose apply approximates A^-1."""
     b2 = b.reshape(n, -1) if n > 0 else b.reshape(0, b.shape[1] if b.dim() > 1 else 1)
     nrhs = b2.shape[1]
+    _check_precond(inner, nrhs)
     if x is None:
         x = torch.zeros_like(b2)
     x2 = x.reshape(n, nrhs)
@@ -136,6 +151,7 @@ def solve_op(gk, solver, matrix, b, x=None, max_iters=1000, reduction=1e-10, bas
     n = matrix.nrows
     b2 = b.reshape(n, -1) if n > 0 else b.reshape(0, b.shape[1] if b.dim() > 1 else 1)
     nrhs = b2.shape[1]
+    _check_precond(precond, nrhs)
     if x is None:
         x = torch.zeros_like(b2)
     x2 = x.reshape(n, nrhs)
@@ -344,6 +360,7 @@ def gmres_solve(gk, n, row_ptrs, col_idxs, vals, b, x=None, krylov_dim=100, max_
     precond: None or a Preconditioner."""
     b2 = b.reshape(n, -1) if n > 0 else b.reshape(0, b.shape[1] if b.dim() > 1 else 1)
     nrhs = b2.shape[1]
+    _check_precond(precond, nrhs)
     if x is None:
         x = torch.zeros_like(b2)
     x2 = x.reshape(n, nrhs)

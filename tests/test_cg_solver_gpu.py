@@ -134,3 +134,37 @@ def test_workspace_too_small(gk):
         gk.cg_solve_f64_i32(None, n, 1, int(rp[-1]), dev(rp), dev(ci), dev(v), 0, -1, None, None, b,
                             torch.zeros_like(b), 10, 1e-6, 0, 0, 1, ws, 16, info)
     assert e.value.code == -4
+
+
+def test_fused_mode_on_views_at_odd_offsets(gk, oracle):
+    """Cg on Dense views / offset arrays (the reference works on any alignment): x 8 bytes
+    off a 16-B boundary runs the reference sequence instead of mode 1; CSR value / column
+    arrays at odd offsets keep the fused loop (SpMV through the generic apply + a partials
+    kernel).  Same iteration count and solution either way."""
+    n, rp, ci, v = matgen.poisson_2d_5pt(37, 41)
+    b = np.sin(0.1 * np.arange(n))
+    xe = np.zeros(n)
+    it = oracle.ref_cg_solve(n, rp, ci, v, b, xe, 2000, 1e-10, 0, None, 0)
+    pad_v = torch.zeros(len(v) + 1, dtype=torch.float64, device="cuda:0")
+    pad_c = torch.zeros(len(ci) + 1, dtype=torch.int32, device="cuda:0")
+    pad_v[1:] = dev(v)
+    pad_c[1:] = dev(ci)
+    xbuf = torch.zeros(n + 1, dtype=torch.float64, device="cuda:0")
+    for vals, cols, x in ((pad_v[1:], pad_c[1:], None), (dev(v), dev(ci), xbuf[1:]), (pad_v[1:], pad_c[1:], xbuf[1:])):
+        if x is not None:
+            x.zero_()
+            assert x.data_ptr() % 16 == 8
+        res = solvers.cg_solve(gk, n, dev(rp), cols, vals, dev(b), x=x, max_iters=2000, reduction=1e-10, mode=1)
+        assert res["converged"] and abs(res["iterations"] - it) <= 1
+        assert matgen.rel_err(host(res["x"]), xe) <= 1e-8
+
+
+def test_preconditioner_generated_for_another_column_count_is_refused(gk):
+    n, rp, ci, v = matgen.poisson_2d_5pt(10, 10)
+    pc = solvers.jacobi_generate(gk, n, dev(rp), dev(ci), dev(v), max_block_size=4)      # nrhs = 1
+    b = dev(np.ones((n, 3)))
+    with pytest.raises(ValueError, match="nrhs"):
+        solvers.cg_solve(gk, n, dev(rp), dev(ci), dev(v), b, precond=pc, mode=0)
+    pc3 = solvers.jacobi_generate(gk, n, dev(rp), dev(ci), dev(v), max_block_size=4, nrhs=3)
+    res = solvers.cg_solve(gk, n, dev(rp), dev(ci), dev(v), b, precond=pc3, mode=0, max_iters=500, reduction=1e-10)
+    assert res["converged"]
