@@ -22,7 +22,11 @@
 // HBM traffic per iteration (n rows, Identity): K1 3n, K2 matrix + 2n (+n
 // for p in the epilogue, L2-resident), K3 6n values -- vs 18n + matrix in the
 // reference's accounting (core/solver/cg.cpp:148-156).
-#include "cg_fused.hpp"
+#include "cg_persistent.hpp"
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 
 namespace gkomi {
 namespace {
@@ -30,7 +34,7 @@ namespace {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct workspace_layout {
-    size_t r, z, p, q, scalars, part_a, part_b, part_c, red, small, total;
+    size_t r, z, p, q, scalars, part_a, part_b, part_c, red, small, pcg_ctl, pcg_slots, total;
 };
 
 workspace_layout make_layout(int64_t n, int64_t nrhs)
@@ -51,6 +55,9 @@ workspace_layout make_layout(int64_t n, int64_t nrhs)
     // mode 0 scalars: alpha-free set {prev_rho, rho, beta, tau, orig_tau, one, neg_one} x nrhs,
     // then stop_status[nrhs] and 2 flag bytes
     l.small = off; off += align_up(sizeof(double) * 8 * static_cast<size_t>(nrhs) + nrhs + 16, 256);
+    // the persistent single-launch solve: its control word and two banks of one slot per workgroup
+    l.pcg_ctl = off; off += align_up(sizeof(pcg_control), 256);
+    l.pcg_slots = off; off += align_up(sizeof(pcg_slot) * 2 * (max_parts + pcg_copies) * pcg_max_stride, 256);
     l.total = off;
     return l;
 }
@@ -60,6 +67,17 @@ workspace_layout make_layout(int64_t n, int64_t nrhs)
         int err_ = (expr);       \
         if (err_) return err_;   \
     } while (0)
+
+std::atomic<int64_t> pcg_solves{0};  // solves finished by the single-launch kernel (diagnostics, tests)
+
+// number of CUs of the current device (the persistent solve runs one workgroup on each), 0 = unknown
+int device_cu_count()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
+}
 
 int identity_or_precond(gkomi_apply_fn precond, void* ctx, gkomi_stream_t s,
                         int64_t n, int64_t nrhs, const double* r, double* z)
@@ -75,6 +93,8 @@ int identity_or_precond(gkomi_apply_fn precond, void* ctx, gkomi_stream_t s,
 }  // namespace gkomi
 
 using namespace gkomi;
+
+extern "C" int64_t gkomi_cg_persistent_solves(void) { return pcg_solves.load(); }
 
 extern "C" size_t gkomi_cg_workspace_bytes(int64_t n, int64_t nrhs)
 {
@@ -193,6 +213,125 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
         hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(1), 0, stream, scal, orig_tau,
                            baseline == 2 ? 1 : 0);
         GKOMI_TRY(check_launch());
+        // The whole solve in one launch (cg_persistent.hpp) when the vectors AND the matrix fit the
+        // register files: Identity preconditioner, aligned CSR, rows of at most 7 nonzeros (the
+        // caller's max_row_nnz_hint says so; the kernel checks), one workgroup per CU.
+        // GKOMI_CG_PERSISTENT=0 turns it off, =2 also takes matrices that do not fit (they stream
+        // from memory every iteration: 33 vs 34.8 us per iteration on P2, not worth the rendezvous).
+        static const int persistent_mode = [] {
+            const char* e = std::getenv("GKOMI_CG_PERSISTENT");
+            return e == nullptr ? 1 : std::atoi(e);
+        }();
+        static const int cus = device_cu_count();
+        // one persistent solve at a time per process: two of them would wait for each other's CUs
+        static std::atomic_flag pcg_busy = ATOMIC_FLAG_INIT;
+        bool solved = false;
+        const int64_t pcg_chunk = cus > 0 ? ceildiv(n, cus) : 0;
+        const int64_t pcg_hint = spmv.A.hint;  // (a CSR matrix behind its callback carries its own)
+        const bool pcg_fits_matrix =
+            pcg_hint >= 1 && pcg_hint <= 7 && ceildiv(pcg_chunk, 512) <= (pcg_hint <= 5 ? 8 : 4);
+        const bool pcg_fits_vectors = ceildiv(pcg_chunk, pcg_block) <= pcg_max_rows_per_thread;
+        if (persistent_mode >= 1 && precond == nullptr && spmv.csr && cus >= 8 && cus <= max_parts &&
+            n >= 64 * static_cast<int64_t>(cus) && (pcg_fits_matrix || (persistent_mode >= 2 && pcg_fits_vectors)) &&
+            !pcg_busy.test_and_set()) {
+            struct release_guard {
+                std::atomic_flag& f;
+                ~release_guard() { f.clear(); }
+            } release{pcg_busy};
+            const sysmat& M = spmv.A;
+            pcg_control* ctl = reinterpret_cast<pcg_control*>(ws + l.pcg_ctl);
+            pcg_slot* slots = reinterpret_cast<pcg_slot*>(ws + l.pcg_slots);
+            const int chunk = static_cast<int>(ceildiv(n, cus));
+            const int rows_per_thread = static_cast<int>(ceildiv(chunk, pcg_block));
+            const long long max_polls = 1ll << 22;
+            static const int stride = [] {
+                const char* e = std::getenv("GKOMI_PCG_STRIDE");  // slot spacing in 16-B units (tuning)
+                const int v = e != nullptr ? std::atoi(e) : pcg_default_stride;
+                return v >= 1 && v <= pcg_max_stride ? v : pcg_default_stride;
+            }();
+            static const bool resident_on = [] {
+                const char* e = std::getenv("GKOMI_PCG_RESIDENT");
+                return e == nullptr || e[0] != '0';
+            }();
+            static const int nap = [] {
+                const char* e = std::getenv("GKOMI_PCG_NAP");
+                const int v = e != nullptr ? std::atoi(e) : 1;
+                return v >= 0 && v <= 64 ? v : 1;
+            }();
+            hipLaunchKernelGGL(pcg_clear_kernel, dim3(1), dim3(256), 0, stream, slots, stride, 2 * (cus + pcg_copies), ctl);
+#define GKOMI_PCG(R, KR, BLOCK)                                                                        \
+    hipLaunchKernelGGL((cg_persistent_kernel<R, KR, BLOCK>), dim3(cus), dim3(BLOCK), 0, stream,        \
+                       static_cast<int>(n), chunk, M.row_ptrs, M.col_idxs, M.vals, x, r, p, q, slots,  \
+                       stride, nap, ctl, scal, static_cast<long long>(max_iters), reduction_factor,    \
+                       max_polls)
+            // rows of at most 5 nonzeros, up to 8 rows per thread of a 512-thread workgroup (256
+            // registers each): the matrix stays in registers
+            const int rows_per_thread_512 = static_cast<int>(ceildiv(chunk, 512));
+            // (7 nonzeros x 8 rows does not fit the 256 registers: up to 4 rows per thread there)
+            const bool resident = pcg_fits_matrix && resident_on;
+            if (resident && M.hint <= 5) {
+                if (rows_per_thread_512 <= 2) {
+                    GKOMI_PCG(2, 5, 512);
+                } else if (rows_per_thread_512 <= 4) {
+                    GKOMI_PCG(4, 5, 512);
+                } else {
+                    GKOMI_PCG(8, 5, 512);
+                }
+            } else if (resident) {
+                if (rows_per_thread_512 <= 2) {
+                    GKOMI_PCG(2, 7, 512);
+                } else {
+                    GKOMI_PCG(4, 7, 512);
+                }
+            } else if (rows_per_thread <= 1) {
+                GKOMI_PCG(1, 0, 1024);
+            } else if (rows_per_thread <= 2) {
+                GKOMI_PCG(2, 0, 1024);
+            } else if (rows_per_thread <= 4) {
+                GKOMI_PCG(4, 0, 1024);
+            } else {
+                GKOMI_PCG(8, 0, 1024);
+            }
+#undef GKOMI_PCG
+            GKOMI_TRY(check_launch());
+            pcg_control hctl{};
+            GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&hctl, ctl, sizeof(pcg_control), hipMemcpyDeviceToHost, stream)));
+            GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&polled, scal, sizeof(cg_scalars), hipMemcpyDeviceToHost, stream)));
+            GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
+#ifdef GKOMI_PCG_PROFILE
+            fprintf(stderr, "pcg phases (us per iteration, workgroup 0): meet rho %.2f | p + barrier %.2f | inv %.2f | "
+                            "spmv %.2f | meet pq %.2f | update %.2f over %lld iterations\n",
+                    hctl.ticks[0] * 0.01 / (polled.stop_iter + 1), hctl.ticks[1] * 0.01 / (polled.stop_iter + 1),
+                    hctl.ticks[2] * 0.01 / (polled.stop_iter + 1), hctl.ticks[3] * 0.01 / (polled.stop_iter + 1),
+                    hctl.ticks[4] * 0.01 / (polled.stop_iter + 1), hctl.ticks[5] * 0.01 / (polled.stop_iter + 1),
+                    polled.stop_iter);
+#endif
+            if (hctl.overrun == 0 && (polled.status & GKOMI_STATUS_ID_MASK)) {
+                solved = true;
+                pcg_solves.fetch_add(1);
+                iterations = polled.stop_iter;
+                converged = (polled.status & GKOMI_STATUS_CONVERGED) ? 1 : 0;
+                if (host_info != nullptr) {
+                    host_info[2] = polled.tau;
+                    host_info[3] = polled.orig_tau;
+                }
+            } else {
+                // a meeting timed out (workgroups not resident together?): x is a valid guess, start over
+                // from r = b - A x with the three-launch iteration
+                GKOMI_TRY(gkomi_dense_copy_f64(s, n, 1, b, 1, r, 1));
+                GKOMI_TRY(A.apply(s, 1, neg_one, x, one, r));
+                GKOMI_TRY(gkomi_dense_fill_f64(s, n, 1, p, 1, 0.0));
+                hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(1), 0, stream, scal, orig_tau,
+                                   baseline == 2 ? 1 : 0);
+            }
+        }
+        if (solved) {
+            if (host_info != nullptr) {
+                host_info[0] = static_cast<double>(iterations);
+                host_info[1] = static_cast<double>(converged);
+            }
+            return precond_status(precond, precond_ctx, s);
+        }
         // partials of r.z (and r.r) for the first check
         const double* zz = precond == nullptr ? r : z;
         if (precond != nullptr) GKOMI_TRY(precond(precond_ctx, s, r, z));

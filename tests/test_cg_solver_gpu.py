@@ -168,3 +168,84 @@ def test_preconditioner_generated_for_another_column_count_is_refused(gk):
     pc3 = solvers.jacobi_generate(gk, n, dev(rp), dev(ci), dev(v), max_block_size=4, nrhs=3)
     res = solvers.cg_solve(gk, n, dev(rp), dev(ci), dev(v), b, precond=pc3, mode=0, max_iters=500, reduction=1e-10)
     assert res["converged"]
+
+
+# ---- the single-launch ("persistent") CG: vectors and matrix in the register files ----------
+def _persistent_solve(gk, n, rp, ci, v, b, hint, **kw):
+    before = gk.cg_persistent_solves()
+    res = solvers.cg_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), mode=1, max_row_nnz=hint, **kw)
+    return res, gk.cg_persistent_solves() - before
+
+
+@pytest.mark.parametrize("grid", [(300, 270), (600, 500), (1000, 1000)], ids=["2_rows_per_thread", "4", "8"])
+def test_persistent_cg_poisson_like_the_oracle(gk, oracle, grid):
+    """mode 1 with max_row_nnz_hint = 5 on >= 16 k rows: the whole solve is one launch.  Same
+    iteration (the partial sums are grouped per workgroup instead of per 1024 rows: +-1 at most),
+    same solution as the oracle's loop, and the same bits on every run (no atomics anywhere)."""
+    n, rp, ci, v = matgen.poisson_2d_5pt(*grid)
+    s = np.sin(np.arange(n, dtype=np.float64))
+    b = np.zeros((n, 1))
+    oracle.ref_csr_spmv(n, 1, rp, ci, v, (s / np.linalg.norm(s)).reshape(n, 1), 1, b, 1)
+    xe = np.zeros(n)
+    it = oracle.ref_cg_solve(n, rp, ci, v, b[:, 0].copy(), xe, 5000, 1e-10, 0, None, 0)
+    res, took = _persistent_solve(gk, n, rp, ci, v, b[:, 0].copy(), 5, max_iters=5000, reduction=1e-10)
+    assert took == 1, "the persistent kernel did not run (or gave up)"
+    assert res["converged"] and abs(res["iterations"] - it) <= 1
+    assert matgen.rel_err(host(res["x"]), xe) <= 1e-7
+    again, took = _persistent_solve(gk, n, rp, ci, v, b[:, 0].copy(), 5, max_iters=5000, reduction=1e-10)
+    assert took == 1 and again["iterations"] == res["iterations"]
+    assert host(again["x"]).tobytes() == host(res["x"]).tobytes()
+    # the three-launch iteration (no hint) agrees to rounding
+    plain = solvers.cg_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b[:, 0].copy()), mode=1, max_iters=5000,
+                             reduction=1e-10)
+    assert abs(plain["iterations"] - res["iterations"]) <= 1
+    assert matgen.rel_err(host(plain["x"]), host(res["x"])) <= 1e-8
+
+
+@pytest.mark.parametrize("g3", [48, 80], ids=["2_rows_per_thread", "4"])
+def test_persistent_cg_seven_point_stencil(gk, oracle, g3):
+    n, rp, ci, v = matgen.poisson_3d_7pt(g3)
+    b = np.cos(0.01 * np.arange(n))
+    xe = np.zeros(n)
+    it = oracle.ref_cg_solve(n, rp, ci, v, b.copy(), xe, 3000, 1e-9, 0, None, 0)
+    res, took = _persistent_solve(gk, n, rp, ci, v, b, 7, max_iters=3000, reduction=1e-9)
+    assert took == 1 and res["converged"] and abs(res["iterations"] - it) <= 1
+    assert matgen.rel_err(host(res["x"]), xe) <= 1e-7
+
+
+def test_persistent_cg_stops_like_the_other_paths(gk, oracle):
+    n, rp, ci, v = matgen.poisson_2d_5pt(200, 150)
+    b = np.ones(n)
+    # iteration limit: exactly max_iters iterations, not converged
+    res, took = _persistent_solve(gk, n, rp, ci, v, b, 5, max_iters=7, reduction=1e-30)
+    assert took == 1 and res["iterations"] == 7 and not res["converged"]
+    xe = np.zeros(n)
+    oracle.ref_cg_solve(n, rp, ci, v, b.copy(), xe, 7, 1e-30, 0, None, 0)
+    assert matgen.rel_err(host(res["x"]), xe) <= 1e-12
+    # nonzero initial guess, every baseline
+    rng = np.random.default_rng(0)
+    x0 = rng.standard_normal(n)
+    for name, code in (("rhs_norm", 0), ("initial_resnorm", 1), ("absolute", 2)):
+        xe = x0.copy()
+        it = oracle.ref_cg_solve(n, rp, ci, v, b.copy(), xe, 2000, 1e-8, code, None, 0)
+        before = gk.cg_persistent_solves()
+        res = solvers.cg_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), x=dev(x0.copy()), mode=1, max_row_nnz=5,
+                               max_iters=2000, reduction=1e-8, baseline=name)
+        assert gk.cg_persistent_solves() == before + 1
+        assert abs(res["iterations"] - it) <= 1 and matgen.rel_err(host(res["x"]), xe) <= 1e-6, name
+    # already converged: zero iterations, x untouched
+    res, took = _persistent_solve(gk, n, rp, ci, v, np.zeros(n) + 1e-300, 5, max_iters=10, reduction=1e-3,
+                                  baseline="absolute")
+    assert took == 1 and res["iterations"] == 0 and res["converged"] and not host(res["x"]).any()
+
+
+def test_persistent_cg_with_a_hint_that_is_too_small_falls_back(gk, oracle):
+    """rows of 7 nonzeros announced as 5: the kernel (which keeps 5 per row) notices before its
+    first iteration and the three-launch iteration does the solve."""
+    n, rp, ci, v = matgen.poisson_3d_7pt(40)
+    b = np.sin(0.1 * np.arange(n))
+    xe = np.zeros(n)
+    it = oracle.ref_cg_solve(n, rp, ci, v, b.copy(), xe, 2000, 1e-10, 0, None, 0)
+    res, took = _persistent_solve(gk, n, rp, ci, v, b, 5, max_iters=2000, reduction=1e-10)
+    assert took == 0 and res["converged"] and abs(res["iterations"] - it) <= 1
+    assert matgen.rel_err(host(res["x"]), xe) <= 1e-8

@@ -70,6 +70,8 @@ for name in ("poisson2d", "convection3d"):
                     timed(f"{fmt:6s} cg reference sequence (op)", lambda: solvers.solve_op(gk, "cg", M, bv, **kw))
                 timed(f"{fmt:6s} {sol} fused (op)", lambda: solvers.solve_op(gk, sol, M, bv, fused=True, check_every=16, **kw))
         timed("csr    cg fused (CSR entry)", lambda: solvers.cg_solve(gk, n, rpd, cid, vd, b, mode=1, check_every=16, **kw))
+        timed("csr    cg fused (CSR entry, max_row_nnz hint)", lambda: solvers.cg_solve(
+            gk, n, rpd, cid, vd, b, mode=1, check_every=16, max_row_nnz=A.max_row_nnz(), **kw))
         continue
     if len(sys.argv) > 2 and sys.argv[2] == "fused":   # for rocprofv3: only the fused driver
         timed("bicgstab fused, check_every 32", lambda: solvers.krylov_solve(gk, "bicgstab", n, rpd, cid, vd, bv, check_every=32, fused=True, **kw))
