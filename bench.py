@@ -319,14 +319,18 @@ def main():
 
         import gkomi.solvers as solvers
 
-        def timed_cg(nn, a, rhs, check_every=32):
-            solvers.cg_solve(gk, nn, a[0], a[1], a[2], rhs, max_iters=50000, reduction=1e-10, check_every=check_every)
+        def timed_cg(nn, a, rhs, check_every=32, hint=-1):
+            """hint = the matrix's longest row (Csr keeps it, like srow): with it the driver may run
+            the whole solve in one launch (rows <= 7 nonzeros, <= ~1M rows); -1 = three launches
+            per iteration"""
+            solvers.cg_solve(gk, nn, a[0], a[1], a[2], rhs, max_iters=50000, reduction=1e-10, check_every=check_every,
+                             max_row_nnz=hint)
             runs = []
             for _ in range(3):  # best of 3 whole solves (the same host stalls), all of them reported
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 res = solvers.cg_solve(gk, nn, a[0], a[1], a[2], rhs, max_iters=50000, reduction=1e-10,
-                                       check_every=check_every)
+                                       check_every=check_every, max_row_nnz=hint)
                 torch.cuda.synchronize()
                 runs.append((time.perf_counter() - t0, res))
             el, res = min(runs, key=lambda r: r[0])
@@ -345,20 +349,31 @@ def main():
             c = copies[0]
             sb, b = sinus_system(n, c, nnz, 5)
             cg_bytes = 11 * 8 * n + (12 * nnz + 4 * (n + 1))  # per iteration: 11 n values + matrix
-            res, el, all_s = timed_cg(n, c, b)
+            before = gk.cg_persistent_solves()
+            res, el, all_s = timed_cg(n, c, b, hint=5)
+            single_launch = gk.cg_persistent_solves() > before
+            res3, el3, all_s3 = timed_cg(n, c, b)
             out["cg"] = {"metric": "CG iters/sec to 1e-10 (fused driver, Identity preconditioner, sinus rhs "
                                    "b = A s/|s|, benchmark/solver default)",
+                         "driver": ("single launch: x, r, p and the matrix (rows <= 5 nonzeros) stay in the register "
+                                    "files, three device-wide meetings per iteration (csrc/cg_persistent.hpp)")
+                         if single_launch else "three launches per iteration",
+                         "three_launch_driver": {"iterations": res3["iterations"], "seconds": round(el3, 5),
+                                                 "all_seconds": all_s3,
+                                                 "iters_per_sec": round(res3["iterations"] / el3, 1)},
                          "iterations": res["iterations"], "seconds": round(el, 5), "timing": "best of 3 solves",
                          "all_seconds": all_s, "iters_per_sec": round(res["iterations"] / el, 1),
-                         "achieved_gbs": round(cg_bytes * res["iterations"] / el / 1e9, 1),
+                         # the byte model (11 n values + matrix per iteration) belongs to the three-launch
+                         # iteration; the single-launch one moves 2 n values (p out, p gathered) per iteration
+                         "achieved_gbs": None if single_launch else round(cg_bytes * res["iterations"] / el / 1e9, 1),
+                         "three_launch_achieved_gbs": round(cg_bytes * res3["iterations"] / el3 / 1e9, 1),
                          "final_residual_norm_rel": res["rel_residual"],
                          "solution_rel_err": float(torch.linalg.norm(res["x"] - sb) / torch.linalg.norm(sb)),
                          "converged": bool(res["converged"])}
             ones = torch.ones((n, 1), dtype=torch.float64, device=device)
-            res, el, all_s = timed_cg(n, c, ones)
+            res, el, all_s = timed_cg(n, c, ones, hint=5)
             out["cg_rhs_ones"] = {"iterations": res["iterations"], "seconds": round(el, 5), "all_seconds": all_s,
                                   "iters_per_sec": round(res["iterations"] / el, 1),
-                                  "achieved_gbs": round(cg_bytes * res["iterations"] / el / 1e9, 1),
                                   "final_residual_norm_rel": res["rel_residual"], "converged": bool(res["converged"])}
         got_p2 = copies[0][4].cpu().numpy().copy()
 

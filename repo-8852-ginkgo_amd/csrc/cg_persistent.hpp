@@ -182,7 +182,8 @@ __device__ __forceinline__ bool pcg_barrier(pcg_slot* slots, int stride, int nap
 // SpMV is R*K gathers of p per thread and the row sums in storage order.  A row
 // longer than K raises ctl->overrun before the first iteration (the driver
 // falls back).  K = 0: the matrix streams from memory through LDS tiles.
-template <int R, int K, int Block>
+// XL: x lives in LDS instead of registers (7 nonzeros x 8 rows per thread leave no room for it)
+template <int R, int K, int Block, bool XL = false>
 __global__ __launch_bounds__(Block) void cg_persistent_kernel(
     int n, int chunk, const int32_t* __restrict__ row_ptrs, const int32_t* __restrict__ col_idxs,
     const double* __restrict__ vals, double* __restrict__ x, double* __restrict__ r, double* pbuf0,
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
     __shared__ __attribute__((aligned(16))) double prod[K > 0 ? 2 : (Block * pcg_items)];
     // K > 0: byte offsets of the rows' columns (5 x 4 x 1024 x 4 B = 80 KB), thread-minor: no bank conflicts
     __shared__ unsigned int lcol[K > 0 ? K * R * Block : 1];
+    __shared__ double lx[XL ? R * Block : 1];
     __shared__ double smem[Block / wave_size];
     const int nwg = gridDim.x;
     const int tid = threadIdx.x;
@@ -204,17 +206,26 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
     const int nz1 = row_ptrs[b1];
     const int nnz_total = row_ptrs[n];
     int ra[R], rb[R];
-    double xr[R], rr[R], pr[R], qr[R];
+    double xr[XL ? 1 : R], rr[R], pr[R], qr[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int row = b0 + k * Block + tid;
         ra[k] = rb[k] = nz1;
-        xr[k] = rr[k] = 0.0;
+        rr[k] = 0.0;
+        if (XL) {
+            lx[k * Block + tid] = 0.0;
+        } else {
+            xr[k] = 0.0;
+        }
         pr[k] = 0.0;  // cg::initialize: p = 0
         if (row < b1) {
             ra[k] = row_ptrs[row];
             rb[k] = row_ptrs[row + 1];
-            xr[k] = x[row];
+            if (XL) {
+                lx[k * Block + tid] = x[row];
+            } else {
+                xr[k] = x[row];
+            }
             rr[k] = r[row];
         }
     }
@@ -379,7 +390,11 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
             const double alpha = rho / pq;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                xr[k] += alpha * pr[k];
+                if (XL) {
+                    lx[k * Block + tid] += alpha * pr[k];
+                } else {
+                    xr[k] += alpha * pr[k];
+                }
                 rr[k] -= alpha * qr[k];
             }
         }
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
     for (int k = 0; k < R; ++k) {
         const int row = b0 + k * Block + tid;
         if (row < b1) {
-            x[row] = xr[k];
+            x[row] = XL ? lx[k * Block + tid] : xr[k];
             r[row] = rr[k];
         }
     }

@@ -229,7 +229,7 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
         const int64_t pcg_chunk = cus > 0 ? ceildiv(n, cus) : 0;
         const int64_t pcg_hint = spmv.A.hint;  // (a CSR matrix behind its callback carries its own)
         const bool pcg_fits_matrix =
-            pcg_hint >= 1 && pcg_hint <= 7 && ceildiv(pcg_chunk, 512) <= (pcg_hint <= 5 ? 8 : 4);
+            pcg_hint >= 1 && pcg_hint <= 7 && ceildiv(pcg_chunk, 512) <= 8;
         const bool pcg_fits_vectors = ceildiv(pcg_chunk, pcg_block) <= pcg_max_rows_per_thread;
         if (persistent_mode >= 1 && precond == nullptr && spmv.csr && cus >= 8 && cus <= max_parts &&
             n >= 64 * static_cast<int64_t>(cus) && (pcg_fits_matrix || (persistent_mode >= 2 && pcg_fits_vectors)) &&
@@ -260,14 +260,13 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
             }();
             hipLaunchKernelGGL(pcg_clear_kernel, dim3(1), dim3(256), 0, stream, slots, stride, 2 * (cus + pcg_copies), ctl);
 #define GKOMI_PCG(R, KR, BLOCK)                                                                        \
-    hipLaunchKernelGGL((cg_persistent_kernel<R, KR, BLOCK>), dim3(cus), dim3(BLOCK), 0, stream,        \
+    hipLaunchKernelGGL((cg_persistent_kernel<R, KR, BLOCK, (KR == 7 && R == 8)>), dim3(cus), dim3(BLOCK), 0, stream, \
                        static_cast<int>(n), chunk, M.row_ptrs, M.col_idxs, M.vals, x, r, p, q, slots,  \
                        stride, nap, ctl, scal, static_cast<long long>(max_iters), reduction_factor,    \
                        max_polls)
             // rows of at most 5 nonzeros, up to 8 rows per thread of a 512-thread workgroup (256
             // registers each): the matrix stays in registers
             const int rows_per_thread_512 = static_cast<int>(ceildiv(chunk, 512));
-            // (7 nonzeros x 8 rows does not fit the 256 registers: up to 4 rows per thread there)
             const bool resident = pcg_fits_matrix && resident_on;
             if (resident && M.hint <= 5) {
                 if (rows_per_thread_512 <= 2) {
@@ -280,8 +279,10 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
             } else if (resident) {
                 if (rows_per_thread_512 <= 2) {
                     GKOMI_PCG(2, 7, 512);
-                } else {
+                } else if (rows_per_thread_512 <= 4) {
                     GKOMI_PCG(4, 7, 512);
+                } else {
+                    GKOMI_PCG(8, 7, 512);  // x in LDS: 7 nonzeros x 8 rows of values fill the registers
                 }
             } else if (rows_per_thread <= 1) {
                 GKOMI_PCG(1, 0, 1024);

@@ -202,7 +202,7 @@ def test_persistent_cg_poisson_like_the_oracle(gk, oracle, grid):
     assert matgen.rel_err(host(plain["x"]), host(res["x"])) <= 1e-8
 
 
-@pytest.mark.parametrize("g3", [48, 80], ids=["2_rows_per_thread", "4"])
+@pytest.mark.parametrize("g3", [48, 80, 100], ids=["2_rows_per_thread", "4", "8_x_in_lds"])
 def test_persistent_cg_seven_point_stencil(gk, oracle, g3):
     n, rp, ci, v = matgen.poisson_3d_7pt(g3)
     b = np.cos(0.01 * np.arange(n))
