@@ -104,16 +104,40 @@ __device__ __forceinline__ bool pcg_fetch(const pcg_slot* slot, long long meetin
 
 constexpr int pcg_copies = 32;  // copies of the total the workgroups read it from (8 readers each)
 
-// Every workgroup's `mine`, added in slot order by workgroup 0, which hands the
-// total back through pcg_copies slots: two memory hand-offs per meeting, 256 +
-// 255 polls in flight instead of 256 x 256 on 256 cache lines (3.9 us per
-// meeting when every workgroup gathered all partials itself).  The total is
-// computed once: every workgroup continues with the same bits.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for
+// every outstanding global load of the wave (vmcnt(0)) -- exactly what must NOT
+// happen while a prefetch for the next step is in flight behind a meeting.
+__device__ __forceinline__ void pcg_sync_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// smem: Block / 64 + 1 doubles.  The sum of v over the workgroup, identical in every thread
+// (one value per wave through LDS, added in wave order).
+template <int Block>
+__device__ __forceinline__ double pcg_block_sum(double v, double* smem)
+{
+    v = wave_reduce_sum(v);
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
+    pcg_sync_lds();
+    double total = 0.0;
+#pragma unroll
+    for (int w = 0; w < Block / wave_size; ++w) total += smem[w];
+    pcg_sync_lds();  // smem is free again
+    return total;
+}
+
+// Every workgroup's `mine` (thread 0's argument), added in slot order by workgroup 0, which
+// hands the total back through pcg_copies slots: two memory hand-offs per meeting, 256 + 255
+// polls in flight instead of 256 x 256 on 256 cache lines (3.9 us per meeting when every
+// workgroup gathered all partials itself).  The total is computed once: every workgroup
+// continues with the same bits.  smem: Block / 64 + 1 doubles.
 template <int Block>
 __device__ __forceinline__ bool pcg_meet(pcg_slot* slots, int stride, int nap, int nwg, long long meeting,
                                          double mine, double* smem, pcg_control* ctl, long long max_polls,
                                          double* total)
 {
+    constexpr int nwaves = Block / wave_size;
     // per parity: nwg slots of partials, then pcg_copies slots of the total
     pcg_slot* bank = slots + (meeting & 1) * static_cast<int64_t>(nwg + pcg_copies) * stride;
     pcg_slot* back = bank + static_cast<int64_t>(nwg) * stride;
@@ -132,33 +156,38 @@ __device__ __forceinline__ bool pcg_meet(pcg_slot* slots, int stride, int nap, i
         }
         return true;
     };
+    if (threadIdx.x == 0) smem[nwaves] = 1.0;  // "nobody gave up"
+    pcg_sync_lds();
     double sum = 0.0;
     if (blockIdx.x == 0) {
+        // nwg <= 1024: thread t holds workgroup t's partial; one sum per wave goes through LDS and
+        // every thread adds them in wave order
         double part = 0.0;
         if (static_cast<int>(threadIdx.x) < nwg) ok = wait_for(bank + threadIdx.x * stride, &part);
-        if (!__syncthreads_and(ok ? 1 : 0)) {
-            if (threadIdx.x == 0) __hip_atomic_store(&ctl->overrun, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-        // nwg <= 1024: thread t holds workgroup t's partial; after the reduction smem holds one
-        // sum per wave, which every thread adds in the same order
-        (void)block_reduce_sum<Block>(part, smem);
+        if (!ok) smem[nwaves] = 0.0;
+        part = wave_reduce_sum(part);
+        if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = part;
+        pcg_sync_lds();
 #pragma unroll
-        for (int w = 0; w < Block / wave_size; ++w) sum += smem[w];
-        if (threadIdx.x < pcg_copies) pcg_publish(back + threadIdx.x * stride, sum, meeting);
+        for (int w = 0; w < nwaves; ++w) sum += smem[w];
+        ok = smem[nwaves] != 0.0;
+        if (ok && threadIdx.x < pcg_copies) pcg_publish(back + threadIdx.x * stride, sum, meeting);
     } else {
         if (threadIdx.x == 0) {
             ok = wait_for(back + (blockIdx.x % pcg_copies) * stride, &sum);
             smem[0] = sum;
+            if (!ok) smem[nwaves] = 0.0;
         }
-        if (!__syncthreads_and(ok ? 1 : 0)) {
-            if (threadIdx.x == 0) __hip_atomic_store(&ctl->overrun, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
+        pcg_sync_lds();
         sum = smem[0];
+        ok = smem[nwaves] != 0.0;
+    }
+    pcg_sync_lds();  // smem is free again
+    if (!ok) {
+        if (threadIdx.x == 0) __hip_atomic_store(&ctl->overrun, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
     }
     *total = sum;
-    __syncthreads();  // smem is free again
     return true;
 }
 
@@ -169,7 +198,7 @@ __device__ __forceinline__ bool pcg_barrier(pcg_slot* slots, int stride, int nap
 {
     // every wave's write-through stores are acknowledged before the workgroup's slot goes out
     __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
+    pcg_sync_lds();
     double unused;
     return pcg_meet<Block>(slots, stride, nap, nwg, meeting, 0.0, smem, ctl, max_polls, &unused);
 }
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
     // K > 0: byte offsets of the rows' columns (5 x 4 x 1024 x 4 B = 80 KB), thread-minor: no bank conflicts
     __shared__ unsigned int lcol[K > 0 ? K * R * Block : 1];
     __shared__ double lx[XL ? R * Block : 1];
-    __shared__ double smem[Block / wave_size];
+    __shared__ double smem[Block / wave_size + 1];
     const int nwg = gridDim.x;
     const int tid = threadIdx.x;
     const int b0 = min(static_cast<int>(blockIdx.x) * chunk, n);
@@ -266,9 +295,7 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) acc += rr[k] * rr[k];
-        __syncthreads();
-        const double mine = block_reduce_sum<Block>(acc, smem);
-        __syncthreads();
+        const double mine = pcg_block_sum<Block>(acc, smem);
         if (!pcg_meet<Block>(slots, stride, nap, nwg, ++meeting, mine, smem, ctl, max_polls, &rho)) {
             broken = true;
             break;
@@ -378,8 +405,7 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
         acc = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) acc += pr[k] * qr[k];
-        const double mine_pq = block_reduce_sum<Block>(acc, smem);
-        __syncthreads();
+        const double mine_pq = pcg_block_sum<Block>(acc, smem);
         double pq = 0.0;
         if (!pcg_meet<Block>(slots, stride, nap, nwg, ++meeting, mine_pq, smem, ctl, max_polls, &pq)) {
             broken = true;

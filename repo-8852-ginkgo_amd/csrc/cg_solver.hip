@@ -70,15 +70,6 @@ workspace_layout make_layout(int64_t n, int64_t nrhs)
 
 std::atomic<int64_t> pcg_solves{0};  // solves finished by the single-launch kernel (diagnostics, tests)
 
-// number of CUs of the current device (the persistent solve runs one workgroup on each), 0 = unknown
-int device_cu_count()
-{
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return cus;
-}
-
 int identity_or_precond(gkomi_apply_fn precond, void* ctx, gkomi_stream_t s,
                         int64_t n, int64_t nrhs, const double* r, double* z)
 {
@@ -223,8 +214,6 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
             return e == nullptr ? 1 : std::atoi(e);
         }();
         static const int cus = device_cu_count();
-        // one persistent solve at a time per process: two of them would wait for each other's CUs
-        static std::atomic_flag pcg_busy = ATOMIC_FLAG_INIT;
         bool solved = false;
         const int64_t pcg_chunk = cus > 0 ? ceildiv(n, cus) : 0;
         const int64_t pcg_hint = spmv.A.hint;  // (a CSR matrix behind its callback carries its own)
@@ -233,11 +222,10 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
         const bool pcg_fits_vectors = ceildiv(pcg_chunk, pcg_block) <= pcg_max_rows_per_thread;
         if (persistent_mode >= 1 && precond == nullptr && spmv.csr && cus >= 8 && cus <= max_parts &&
             n >= 64 * static_cast<int64_t>(cus) && (pcg_fits_matrix || (persistent_mode >= 2 && pcg_fits_vectors)) &&
-            !pcg_busy.test_and_set()) {
+            persistent_try_acquire()) {  // one persistent solve at a time per process
             struct release_guard {
-                std::atomic_flag& f;
-                ~release_guard() { f.clear(); }
-            } release{pcg_busy};
+                ~release_guard() { persistent_release(); }
+            } release;
             const sysmat& M = spmv.A;
             pcg_control* ctl = reinterpret_cast<pcg_control*>(ws + l.pcg_ctl);
             pcg_slot* slots = reinterpret_cast<pcg_slot*>(ws + l.pcg_slots);

@@ -9,9 +9,10 @@
 // one Hessenberg column, triangular solve) run one thread per right-hand
 // side exactly like the reference loops -> bit-identical given equal inputs.
 // HBM: step k moves (5k+8) n values (core/solver/gmres.cpp:217-222).
-#include "internal.hpp"
+#include "cg_persistent.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <utility>
 
 namespace gkomi {
@@ -54,7 +55,47 @@ __global__ __launch_bounds__(block) void gmres_restart_kernel(
     }
 }
 
-// one thread per right-hand side; the loop body is the reference's
+// the reference's loop body for right-hand side i (common_gmres_kernels.cpp hessenberg_qr)
+__device__ __forceinline__ void hessenberg_qr_column(
+    int64_t i, int64_t nrhs, double* __restrict__ gsin, double* __restrict__ gcos,
+    double* __restrict__ residual_norm, double* __restrict__ rnc, double* __restrict__ hess,
+    int64_t h_stride, int64_t iter, uint64_t* __restrict__ final_iter_nums,
+    const uint8_t* __restrict__ stop_status)
+{
+    if (status_has_stopped(stop_status[i])) return;
+    final_iter_nums[i]++;
+    for (int64_t j = 0; j < iter; ++j) {
+        const double c = gcos[j * nrhs + i], s = gsin[j * nrhs + i];
+        const double h0 = hess[j * h_stride + i], h1 = hess[(j + 1) * h_stride + i];
+        const double temp = c * h0 + s * h1;
+        hess[(j + 1) * h_stride + i] = -s * h0 + c * h1;
+        hess[j * h_stride + i] = temp;
+    }
+    const double this_h = hess[iter * h_stride + i];
+    const double next_h = hess[(iter + 1) * h_stride + i];
+    double c, s;
+    if (this_h == 0.0) {
+        c = 0.0;
+        s = 1.0;
+    } else {
+        const double scale = fabs(this_h) + fabs(next_h);
+        const double hyp = scale * sqrt(fabs(this_h / scale) * fabs(this_h / scale) +
+                                        fabs(next_h / scale) * fabs(next_h / scale));
+        c = this_h / hyp;
+        s = next_h / hyp;
+    }
+    gcos[iter * nrhs + i] = c;
+    gsin[iter * nrhs + i] = s;
+    hess[iter * h_stride + i] = c * this_h + s * next_h;
+    hess[(iter + 1) * h_stride + i] = 0.0;
+    const double r = rnc[iter * nrhs + i];
+    const double next_r = -s * r;
+    rnc[(iter + 1) * nrhs + i] = next_r;
+    rnc[iter * nrhs + i] = c * r;
+    residual_norm[i] = fabs(next_r);
+}
+
+// one thread per right-hand side
 __global__ __launch_bounds__(block) void gmres_hessenberg_qr_kernel(
     int64_t nrhs, double* __restrict__ gsin, double* __restrict__ gcos,
     double* __restrict__ residual_norm, double* __restrict__ rnc, double* __restrict__ hess,
@@ -63,37 +104,8 @@ __global__ __launch_bounds__(block) void gmres_hessenberg_qr_kernel(
 {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; i < nrhs;
          i += static_cast<int64_t>(gridDim.x) * block) {
-        if (status_has_stopped(stop_status[i])) continue;
-        final_iter_nums[i]++;
-        for (int64_t j = 0; j < iter; ++j) {
-            const double c = gcos[j * nrhs + i], s = gsin[j * nrhs + i];
-            const double h0 = hess[j * h_stride + i], h1 = hess[(j + 1) * h_stride + i];
-            const double temp = c * h0 + s * h1;
-            hess[(j + 1) * h_stride + i] = -s * h0 + c * h1;
-            hess[j * h_stride + i] = temp;
-        }
-        const double this_h = hess[iter * h_stride + i];
-        const double next_h = hess[(iter + 1) * h_stride + i];
-        double c, s;
-        if (this_h == 0.0) {
-            c = 0.0;
-            s = 1.0;
-        } else {
-            const double scale = fabs(this_h) + fabs(next_h);
-            const double hyp = scale * sqrt(fabs(this_h / scale) * fabs(this_h / scale) +
-                                            fabs(next_h / scale) * fabs(next_h / scale));
-            c = this_h / hyp;
-            s = next_h / hyp;
-        }
-        gcos[iter * nrhs + i] = c;
-        gsin[iter * nrhs + i] = s;
-        hess[iter * h_stride + i] = c * this_h + s * next_h;
-        hess[(iter + 1) * h_stride + i] = 0.0;
-        const double r = rnc[iter * nrhs + i];
-        const double next_r = -s * r;
-        rnc[(iter + 1) * nrhs + i] = next_r;
-        rnc[iter * nrhs + i] = c * r;
-        residual_norm[i] = fabs(next_r);
+        hessenberg_qr_column(i, nrhs, gsin, gcos, residual_norm, rnc, hess, h_stride, iter, final_iter_nums,
+                             stop_status);
     }
 }
 
@@ -168,7 +180,7 @@ constexpr int arnoldi_max_blocks = 1024;
 
 // deterministic sum of `count` partials by the whole workgroup; the total is
 // identical in every thread of every workgroup
-__device__ double sum_partials(const double* __restrict__ partials, int count, double* smem)
+__device__ double arnoldi_sum_partials(const double* __restrict__ partials, int count, double* smem)
 {
     double acc = 0.0;
     for (int i = threadIdx.x; i < count; i += arnoldi_block) acc += partials[i];
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_step_kernel(
     }
     double h = 0.0;
     if (prev != nullptr) {
-        h = sum_partials(partial_in, count_in, smem);
+        h = arnoldi_sum_partials(partial_in, count_in, smem);
         if (blockIdx.x == 0 && threadIdx.x == 0) *h_prev_out = h;
     }
     double a0 = 0.0, a1 = 0.0;
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_scale_kernel(
     const int64_t i0 = blockIdx.x * static_cast<int64_t>(arnoldi_block) + threadIdx.x;
     double2 v0 = make_double2(0.0, 0.0);
     if (i0 < n2) v0 = ld2(next, i0);
-    const double hn = sqrt(sum_partials(partial_in, count_in, smem));
+    const double hn = sqrt(arnoldi_sum_partials(partial_in, count_in, smem));
     if (blockIdx.x == 0 && threadIdx.x == 0) *hn_out = hn;
     double2* next2 = reinterpret_cast<double2*>(next);
     if (i0 < n2) next2[i0] = make_double2(v0.x / hn, v0.y / hn);
@@ -336,12 +348,121 @@ __global__ __launch_bounds__(arnoldi_block) void gmres_arnoldi_scale_scalar_kern
     }
 }
 
-// first iteration at which every column had stopped (-1 until then): the
-// criterion runs on the device at every iteration, the host looks every
-// `gmres_check_every` iterations and before every restart
+// ---- one launch per Arnoldi step instead of one per basis vector ----------------
+// The modified Gram-Schmidt sweep of iteration k needs k + 2 device-wide sums, one
+// after the other (h_i = v_i . w can only start when w has lost its v_{i-1}
+// component).  With a launch per sum that is k + 2 kernel boundaries and w
+// re-read and re-written every time (4 n values per basis vector).  Here one
+// workgroup per CU keeps its part of w in registers for the whole sweep, streams
+// each basis vector once (the next one is already in flight while the
+// workgroups meet) and the sums travel through the meetings of
+// cg_persistent.hpp: n values per basis vector and ~3 us per sum.
+// Same operations in the same order as the reference's loop
+// (core/solver/gmres.cpp:300-319); the partial sums are grouped per workgroup.
+// A meeting that times out leaves next_k untouched (w is written at the very
+// end) and raises ctl->overrun: the driver sees it at its next poll.
 struct gmres_stop_record {
     long long iter;
 };
+
+// what follows the sweep in the reference's iteration, done by one thread of workgroup 0 instead
+// of three more launches: the Givens update of the new Hessenberg column, then -- for the NEXT
+// iteration, which the driver would open with it -- the ResidualNorm criterion and the record
+// of the first iteration at which the solve had stopped
+struct gmres_iteration_tail {
+    double* gsin;
+    double* gcos;
+    double* residual_norm;
+    double* rnc;
+    uint64_t* final_iter_nums;
+    uint8_t* stop_status;
+    const double* orig_tau;
+    double goal;
+    uint8_t* flags;
+    gmres_stop_record* record;
+    long long next_iter;
+    int restart_iter;
+};
+
+template <int R>
+__global__ __launch_bounds__(pcg_block) void gmres_arnoldi_persistent_kernel(
+    int n, int chunk, double* __restrict__ next_k, const double* __restrict__ kb, int steps,
+    double* __restrict__ hess_iter, int64_t h_stride, pcg_slot* slots, int stride, int nap, pcg_control* ctl,
+    long long meeting, long long max_polls, gmres_iteration_tail tail)
+{
+    __shared__ double smem[pcg_block / wave_size + 1];
+    if (__hip_atomic_load(&ctl->overrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    const int nwg = gridDim.x;
+    const int tid = threadIdx.x;
+    const int b0 = min(static_cast<int>(blockIdx.x) * chunk, n);
+    const int b1 = min(b0 + chunk, n);
+    double w[R], v[R], vn[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int row = b0 + k * pcg_block + tid;
+        w[k] = row < b1 ? next_k[row] : 0.0;
+        v[k] = row < b1 ? kb[row] : 0.0;
+        vn[k] = 0.0;
+    }
+    for (int i = 0; i < steps; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) acc += w[k] * v[k];
+        if (i + 1 < steps) {  // the next basis vector travels while the workgroups meet
+            const double* nxt = kb + static_cast<int64_t>(n) * (i + 1);
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int row = b0 + k * pcg_block + tid;
+                vn[k] = row < b1 ? nxt[row] : 0.0;
+            }
+        }
+        const double mine = pcg_block_sum<pcg_block>(acc, smem);
+        double h = 0.0;
+        if (!pcg_meet<pcg_block>(slots, stride, nap, nwg, ++meeting, mine, smem, ctl, max_polls, &h)) return;
+        if (blockIdx.x == 0 && tid == 0) hess_iter[i * h_stride] = h;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            w[k] -= h * v[k];
+            v[k] = vn[k];
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) acc += w[k] * w[k];
+    const double mine = pcg_block_sum<pcg_block>(acc, smem);
+    double hn2 = 0.0;
+    if (!pcg_meet<pcg_block>(slots, stride, nap, nwg, ++meeting, mine, smem, ctl, max_polls, &hn2)) return;
+    const double hn = sqrt(hn2);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int row = b0 + k * pcg_block + tid;
+        if (row < b1) next_k[row] = w[k] / hn;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        hess_iter[steps * h_stride] = hn;
+        hessenberg_qr_column(0, 1, tail.gsin, tail.gcos, tail.residual_norm, tail.rnc, hess_iter, h_stride,
+                             tail.restart_iter, tail.final_iter_nums, tail.stop_status);
+        // stop::ResidualNorm on the updated estimate (residual_norm_kernel<false> of stop.hip, one column,
+        // not finalized) and gmres_record_stop_kernel
+        uint8_t st = tail.stop_status[0];
+        uint8_t one_changed = 0;
+        if (tail.residual_norm[0] < tail.goal * tail.orig_tau[0]) {
+            if (!status_has_stopped(st)) {
+                st |= GKOMI_STATUS_CONVERGED | 2;  // id_residual
+                tail.stop_status[0] = st;
+            }
+            one_changed = 1;
+        }
+        const uint8_t all = status_has_stopped(st) ? 1 : 0;
+        tail.flags[0] = all;
+        tail.flags[1] = one_changed;
+        if (all && tail.record->iter < 0) tail.record->iter = tail.next_iter;
+    }
+}
+
+// first iteration at which every column had stopped (-1 until then): the
+// criterion runs on the device at every iteration, the host looks every
+// `gmres_check_every` iterations and before every restart
 constexpr int64_t gmres_check_every = 4;
 
 __global__ void gmres_record_stop_kernel(const uint8_t* __restrict__ flags, long long iter,
@@ -351,7 +472,8 @@ __global__ void gmres_record_stop_kernel(const uint8_t* __restrict__ flags, long
 }
 
 struct gmres_layout {
-    size_t residual, pv, before, after, kb, hess, gsin, gcos, rnc, y, small, fin, red, partials, total;
+    size_t residual, pv, before, after, kb, hess, gsin, gcos, rnc, y, small, fin, red, partials, pcg_ctl, pcg_slots,
+        total;
 };
 
 gmres_layout make_layout(int64_t n, int64_t nrhs, int64_t d)
@@ -374,6 +496,8 @@ gmres_layout make_layout(int64_t n, int64_t nrhs, int64_t d)
     l.fin = off; off += align_up(sizeof(uint64_t) * static_cast<size_t>(nrhs), 256);
     l.red = off; off += align_up(gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8, 256);
     l.partials = off; off += align_up(sizeof(double) * 2 * arnoldi_max_blocks, 256);
+    l.pcg_ctl = off; off += align_up(sizeof(pcg_control), 256);
+    l.pcg_slots = off; off += align_up(sizeof(pcg_slot) * 2 * (max_parts + pcg_copies) * pcg_default_stride, 256);
     l.total = off;
     return l;
 }
@@ -477,7 +601,7 @@ namespace {
 int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
                      void* precond_ctx, const double* b, double* x, int64_t krylov_dim,
                      int64_t max_iters, double reduction_factor, int baseline, void* workspace,
-                     size_t workspace_bytes, double* host_info)
+                     size_t workspace_bytes, double* host_info, bool allow_persistent = true)
 {
     if (n < 0 || nrhs <= 0 || krylov_dim <= 0 || max_iters < 0) return GKOMI_EINVAL;
     if (baseline < 0 || baseline > 2) return GKOMI_EINVAL;
@@ -548,9 +672,36 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A,
     GKOMI_TRY(static_cast<int>(hipMemcpyAsync(record, &host_record, sizeof(host_record), hipMemcpyHostToDevice, stream)));
     GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
     int64_t unpolled = 0;
+    // one launch per Arnoldi step (gmres_arnoldi_persistent_kernel) when w fits the register files
+    static const bool persistent_on = [] {
+        const char* e = std::getenv("GKOMI_GMRES_PERSISTENT");
+        return e == nullptr || e[0] != '0';
+    }();
+    static const int cus = device_cu_count();
+    pcg_control* pctl = reinterpret_cast<pcg_control*>(ws + l.pcg_ctl);
+    pcg_slot* pslots = reinterpret_cast<pcg_slot*>(ws + l.pcg_slots);
+    const int pchunk = cus > 0 ? static_cast<int>(ceildiv(n, cus)) : 0;
+    const int prows = static_cast<int>(ceildiv(pchunk, pcg_block));
+    bool persistent = allow_persistent && persistent_on && nrhs == 1 && cus >= 8 && cus <= max_parts &&
+                      n >= 64 * static_cast<int64_t>(cus) && n <= INT32_MAX && prows <= pcg_max_rows_per_thread &&
+                      persistent_try_acquire();
+    struct release_guard {
+        bool held;
+        ~release_guard() { if (held) persistent_release(); }
+    } release{persistent};
+    long long meeting = 0;
+    bool criterion_done = false;
+    pcg_control host_ctl{};
+    if (persistent) {
+        hipLaunchKernelGGL(pcg_clear_kernel, dim3(1), dim3(256), 0, stream, pslots, pcg_default_stride,
+                           2 * (cus + pcg_copies), pctl);
+    }
     auto poll = [&]() -> int {
         unpolled = 0;
         GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&host_record, record, sizeof(host_record), hipMemcpyDeviceToHost, stream)));
+        if (persistent) {
+            GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&host_ctl, pctl, sizeof(unsigned int), hipMemcpyDeviceToHost, stream)));
+        }
         return static_cast<int>(hipStreamSynchronize(stream));
     };
     while (true) {
@@ -566,10 +717,15 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A,
             }
             stop = true;
         } else {
-            // the criterion gets residual_norm directly (gmres.cpp:240-246), not finalized
-            GKOMI_TRY(gkomi_residual_norm_f64(s, nrhs, residual_norm, orig_tau, reduction_factor,
-                                              id_residual, 0, stop_status, dev_flags, nullptr));
-            hipLaunchKernelGGL(gmres_record_stop_kernel, dim3(1), dim3(1), 0, stream, dev_flags, total_iter, record);
+            // the criterion gets residual_norm directly (gmres.cpp:240-246), not finalized; the
+            // single-launch Arnoldi step of the iteration before has already evaluated it
+            if (!criterion_done) {
+                GKOMI_TRY(gkomi_residual_norm_f64(s, nrhs, residual_norm, orig_tau, reduction_factor,
+                                                  id_residual, 0, stop_status, dev_flags, nullptr));
+                hipLaunchKernelGGL(gmres_record_stop_kernel, dim3(1), dim3(1), 0, stream, dev_flags, total_iter,
+                                   record);
+            }
+            criterion_done = false;
             if (++unpolled >= gmres_check_every || restart_iter == krylov_dim) {
                 GKOMI_TRY(poll());
                 if (host_record.iter >= 0) {
@@ -587,10 +743,46 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A,
         }
         double* this_k = kb + n * nrhs * restart_iter;
         double* next_k = kb + n * nrhs * (restart_iter + 1);
-        GKOMI_TRY(apply_precond(this_k, pv));
+        // Identity preconditioner: matrix::Identity::apply copies this_k -- the SpMV reads it in place
+        if (precond != nullptr) GKOMI_TRY(apply_precond(this_k, pv));
         double* hess_iter = hess + nrhs * restart_iter;
-        GKOMI_TRY(A.apply(s, nrhs, nullptr, pv, nullptr, next_k));
-        if (nrhs == 1 && n > 0) {
+        GKOMI_TRY(A.apply(s, nrhs, nullptr, precond != nullptr ? pv : this_k, nullptr, next_k));
+        if (persistent && host_ctl.overrun != 0) {
+            // a meeting timed out some iterations ago (workgroups not resident together?): x holds
+            // the solution of the last restart -- solve again from there, one launch per sum
+            release.held = false;
+            persistent_release();
+            const int err = gmres_solve_impl(s, n, nrhs, A, precond, precond_ctx, b, x, krylov_dim,
+                                             std::max<int64_t>(max_iters - total_iter, 0), reduction_factor,
+                                             baseline, workspace, workspace_bytes, host_info, false);
+            if (host_info != nullptr) host_info[0] += static_cast<double>(total_iter);
+            return err;
+        }
+        if (persistent) {
+            const int steps = static_cast<int>(restart_iter + 1);
+            const gmres_iteration_tail tail{gsin, gcos, residual_norm, rnc, final_iter_nums, stop_status, orig_tau,
+                                            reduction_factor, dev_flags, record, total_iter + 1,
+                                            static_cast<int>(restart_iter)};
+#define GKOMI_ARN(R)                                                                                  \
+    hipLaunchKernelGGL(gmres_arnoldi_persistent_kernel<R>, dim3(cus), dim3(pcg_block), 0, stream,     \
+                       static_cast<int>(n), pchunk, next_k, kb, steps, hess_iter, h_stride, pslots,   \
+                       pcg_default_stride, 1, pctl, meeting, 1ll << 22, tail)
+            if (prows <= 1) {
+                GKOMI_ARN(1);
+            } else if (prows <= 2) {
+                GKOMI_ARN(2);
+            } else if (prows <= 4) {
+                GKOMI_ARN(4);
+            } else {
+                GKOMI_ARN(8);
+            }
+#undef GKOMI_ARN
+            meeting += steps + 1;
+            criterion_done = true;
+            GKOMI_TRY(check_launch());
+            restart_iter++;
+            continue;  // the Givens update is part of the launch
+        } else if (nrhs == 1 && n > 0) {
             // fused modified Gram-Schmidt: one pass over next_k per basis vector
             const int blocks = static_cast<int>(
                 std::min<int64_t>(arnoldi_max_blocks, std::max<int64_t>(1, ceildiv(n / 2 + 1, arnoldi_block))));

@@ -13,6 +13,12 @@ int csr_spmv_dot_launch(hipStream_t stream, int nrows, int64_t nnz,
 int csr_spmv_dot_num_partials(int nrows);
 bool csr_auto_swizzle(int64_t nrows, int64_t nnz);
 
+// One single-launch ("persistent") solver kernel at a time per process: two of them would each
+// hold some CUs and wait for the rest (runtime.hip).  try_acquire is non-blocking.
+bool persistent_try_acquire();
+void persistent_release();
+int device_cu_count();  // CUs of the current device, 0 = unknown
+
 // end-of-solve health check of a preconditioner callback (blocking): 0 or an error such as
 // GKOMI_ETRS_OVERRUN when one of the ILU's triangular solves gave up (precond.hip)
 int precond_status(gkomi_apply_fn precond, void* ctx, gkomi_stream_t s);

@@ -3,6 +3,8 @@
 // set_gpu_property / populate_exec_info, synchronize, error strings).
 #include "common.hpp"
 
+#include <atomic>
+
 extern "C" const char* gkomi_version(void) { return "gkomi 0.1.0 (gfx950)"; }
 
 extern "C" int gkomi_get_num_devices(int* count)
@@ -124,3 +126,20 @@ extern "C" int gkomi_roctx_pop(void)
     if (roctx().pop != nullptr) roctx().pop();
     return GKOMI_SUCCESS;
 }
+
+namespace gkomi {
+namespace {
+std::atomic_flag persistent_busy = ATOMIC_FLAG_INIT;
+}
+
+bool persistent_try_acquire() { return !persistent_busy.test_and_set(); }
+void persistent_release() { persistent_busy.clear(); }
+
+int device_cu_count()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
+}
+}  // namespace gkomi

@@ -115,6 +115,32 @@ def test_gmres_matches_oracle_nonsymmetric(gk, oracle, krylov_dim):
     assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(b)
 
 
+@pytest.mark.parametrize("g3,krylov_dim", [(27, 30), (45, 10), (64, 30)], ids=["19683_odd", "91125_odd", "262144"])
+def test_gmres_single_launch_arnoldi_matches_oracle(gk, oracle, g3, krylov_dim):
+    """n >= 64 * #CU: the modified Gram-Schmidt sweep, the Givens update and the criterion of an
+    iteration are ONE launch (gmres_arnoldi_persistent_kernel): same iteration count as the
+    oracle's loop (+-1: the sums are grouped per workgroup), same solution, restarts included,
+    odd n included."""
+    n, rp, ci, v = convection_diffusion_3d(g3)
+    b = np.cos(0.3 * np.arange(n))
+    xe = np.zeros(n)
+    it = oracle.ref_gmres_solve(n, rp, ci, v, None, None, b, xe, krylov_dim, 3000, 1e-10, 0, np.zeros(1))
+    res = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), krylov_dim=krylov_dim, max_iters=3000,
+                              reduction=1e-10)
+    assert res["converged"] and abs(res["iterations"] - it) <= 1
+    assert matgen.rel_err(host(res["x"]), xe) <= 1e-6
+    r = b.copy().reshape(n, 1)
+    oracle.ref_csr_advanced_spmv(n, 1, -1.0, rp, ci, v, host(res["x"]).reshape(n, 1), 1, 1.0, r, 1)
+    assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(b)
+    again = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), krylov_dim=krylov_dim, max_iters=3000,
+                                reduction=1e-10)
+    assert again["iterations"] == res["iterations"] and host(again["x"]).tobytes() == host(res["x"]).tobytes()
+    # iteration limit in the middle of a restart cycle
+    cut = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), krylov_dim=krylov_dim, max_iters=krylov_dim + 3,
+                              reduction=1e-30)
+    assert cut["iterations"] == krylov_dim + 3 and not cut["converged"]
+
+
 def test_gmres_odd_number_of_rows(gk, oracle):
     # n odd: every second Krylov basis vector is only 8-byte aligned (the fused
     # Arnoldi kernels then run their 8-byte variant)
