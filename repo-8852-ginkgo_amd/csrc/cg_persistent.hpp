@@ -209,15 +209,16 @@ __device__ __forceinline__ bool pcg_barrier(pcg_slot* slots, int stride, int nap
 // column indices in registers for the whole solve (1M rows x 5 nonzeros = 60 MB in
 // the 128 MB of register files): an iteration then reads no matrix at all, the
 // SpMV is R*K gathers of p per thread and the row sums in storage order.  A row
-// longer than K raises ctl->overrun before the first iteration (the driver
-// falls back).  K = 0: the matrix streams from memory through LDS tiles.
+// longer than K makes every workgroup leave before anything is changed (the
+// driver falls back).  The rows come from CSR arrays or, ell_stored > 0, from ELL
+// arrays.  K = 0: the matrix streams from memory through LDS tiles.
 // XL: x lives in LDS instead of registers (7 nonzeros x 8 rows per thread leave no room for it)
 template <int R, int K, int Block, bool XL = false>
 __global__ __launch_bounds__(Block) void cg_persistent_kernel(
     int n, int chunk, const int32_t* __restrict__ row_ptrs, const int32_t* __restrict__ col_idxs,
     const double* __restrict__ vals, double* __restrict__ x, double* __restrict__ r, double* pbuf0,
     double* pbuf1, pcg_slot* slots, int stride, int nap, pcg_control* ctl, cg_scalars* scal,
-    long long max_iters, double goal, long long max_polls)
+    long long max_iters, double goal, long long max_polls, int ell_stored, int64_t ell_stride)
 {
     typedef double nt_double2 __attribute__((ext_vector_type(2)));
     typedef int nt_int2 __attribute__((ext_vector_type(2)));
@@ -231,9 +232,12 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
     const int tid = threadIdx.x;
     const int b0 = min(static_cast<int>(blockIdx.x) * chunk, n);
     const int b1 = min(b0 + chunk, n);
-    const int nz0 = row_ptrs[b0];
-    const int nz1 = row_ptrs[b1];
-    const int nnz_total = row_ptrs[n];
+    // ell_stored > 0 (K > 0 only): col_idxs / vals are ELL arrays (entry e of row r at r + e * ell_stride,
+    // column -1 = padding), row_ptrs is not read
+    const bool ell = K > 0 && ell_stored > 0;
+    const int nz0 = ell ? 0 : row_ptrs[b0];
+    const int nz1 = ell ? 0 : row_ptrs[b1];
+    const int nnz_total = ell ? 0 : row_ptrs[n];
     int ra[R], rb[R];
     double xr[XL ? 1 : R], rr[R], pr[R], qr[R];
 #pragma unroll
@@ -248,8 +252,10 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
         }
         pr[k] = 0.0;  // cg::initialize: p = 0
         if (row < b1) {
-            ra[k] = row_ptrs[row];
-            rb[k] = row_ptrs[row + 1];
+            if (!ell) {
+                ra[k] = row_ptrs[row];
+                rb[k] = row_ptrs[row + 1];
+            }
             if (XL) {
                 lx[k * Block + tid] = x[row];
             } else {
@@ -261,28 +267,51 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
     // K > 0: the rows of this thread, in registers
     constexpr int KK = K > 0 ? K : 1;
     double mv[R][KK];
-    int len[R];
+    unsigned int present[R];  // bit e: entry e of the row exists (CSR: the first len; ELL: not padding)
     if (K > 0) {
-        bool fits = n <= (1 << 28);
+        bool fits = n <= (1 << 28) && (!ell || ell_stored <= K);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            len[k] = rb[k] - ra[k];
-            fits &= len[k] <= K;
+            const int row = b0 + k * Block + tid;
+            const int len = rb[k] - ra[k];
+            fits &= ell || len <= K;
+            present[k] = 0;
 #pragma unroll
             for (int e = 0; e < KK; ++e) {
-                const bool have = e < len[k];
-                mv[k][e] = have ? vals[ra[k] + e] : 0.0;
+                bool have = false;
+                double val = 0.0;
+                int col = 0;
+                if (ell) {
+                    if (row < b1 && e < ell_stored) {
+                        col = col_idxs[row + e * ell_stride];
+                        val = vals[row + e * ell_stride];
+                        have = col != -1;
+                    }
+                } else if (e < len) {
+                    col = col_idxs[ra[k] + e];
+                    val = vals[ra[k] + e];
+                    have = true;
+                }
+                mv[k][e] = have ? val : 0.0;
+                present[k] |= have ? (1u << e) : 0u;
                 // byte offset of p(col): the gather is base (scalar) + one 32-bit register
-                lcol[(e * R + k) * Block + tid] = have ? static_cast<unsigned int>(col_idxs[ra[k] + e]) * 8u : 0u;
+                lcol[(e * R + k) * Block + tid] = have ? static_cast<unsigned int>(col) * 8u : 0u;
             }
         }
-        if (!__syncthreads_and(fits ? 1 : 0)) {
-            if (tid == 0) __hip_atomic_store(&ctl->overrun, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // everybody learns whether every row fits before anything is changed: a meeting of its own
+        double misfits = 0.0;
+        const double mine = pcg_block_sum<Block>(fits ? 0.0 : 1.0, smem);
+        if (!pcg_meet<Block>(slots, stride, nap, gridDim.x, 1, mine, smem, ctl, max_polls, &misfits)) return;
+        if (misfits != 0.0) {
+            if (blockIdx.x == 0 && tid == 0) {
+                __hip_atomic_store(&ctl->overrun, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;  // x and r untouched: the driver runs the three-launch iteration
         }
     }
     const double orig = scal->orig_tau;
     double prev = scal->rho[1];  // 1.0 (reference cg::initialize)
-    long long meeting = 0;
+    long long meeting = K > 0 ? 1 : 0;
     long long it = 0;
     uint8_t st = 0;
     double rho = 0.0, tau = 0.0;
@@ -351,7 +380,7 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
 #pragma unroll
                     for (int e = 0; e < KK; ++e) {
                         // storage order; entries past the row's end are skipped, not added as zeros
-                        acc_row = e < len[k0 + g] ? acc_row + mv[k0 + g][e] * pv[g][e] : acc_row;
+                        acc_row = (present[k0 + g] >> e) & 1u ? acc_row + mv[k0 + g][e] * pv[g][e] : acc_row;
                     }
                     qr[k0 + g] = acc_row;
                 }

@@ -216,17 +216,30 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
         static const int cus = device_cu_count();
         bool solved = false;
         const int64_t pcg_chunk = cus > 0 ? ceildiv(n, cus) : 0;
-        const int64_t pcg_hint = spmv.A.hint;  // (a CSR matrix behind its callback carries its own)
+        // an ELL system matrix behind the library's callback: its rows go into the registers just the same
+        const gkomi_ell_ctx* ell = !A.is_csr() && A.op == &gkomi_ell_matrix_apply_cb && A.ctx != nullptr
+                                       ? static_cast<const gkomi_ell_ctx*>(A.ctx)
+                                       : nullptr;
+        if (ell != nullptr && (ell->nrows != n || ell->ncols != n || ell->stride < n)) ell = nullptr;
+        const int64_t pcg_hint = ell != nullptr ? ell->num_stored_per_row
+                                                : spmv.A.hint;  // (a CSR matrix behind its callback carries its own)
         const bool pcg_fits_matrix =
             pcg_hint >= 1 && pcg_hint <= 7 && ceildiv(pcg_chunk, 512) <= 8;
         const bool pcg_fits_vectors = ceildiv(pcg_chunk, pcg_block) <= pcg_max_rows_per_thread;
-        if (persistent_mode >= 1 && precond == nullptr && spmv.csr && cus >= 8 && cus <= max_parts &&
-            n >= 64 * static_cast<int64_t>(cus) && (pcg_fits_matrix || (persistent_mode >= 2 && pcg_fits_vectors)) &&
+        if (persistent_mode >= 1 && precond == nullptr && (spmv.csr || ell != nullptr) && cus >= 8 &&
+            cus <= max_parts &&
+            n >= 64 * static_cast<int64_t>(cus) &&
+            (pcg_fits_matrix || (persistent_mode >= 2 && pcg_fits_vectors && ell == nullptr)) &&
             persistent_try_acquire()) {  // one persistent solve at a time per process
             struct release_guard {
                 ~release_guard() { persistent_release(); }
             } release;
             const sysmat& M = spmv.A;
+            const int32_t* m_row_ptrs = ell != nullptr ? nullptr : M.row_ptrs;
+            const int32_t* m_col_idxs = ell != nullptr ? ell->col_idxs : M.col_idxs;
+            const double* m_vals = ell != nullptr ? ell->vals : M.vals;
+            const int ell_stored = ell != nullptr ? static_cast<int>(ell->num_stored_per_row) : 0;
+            const int64_t ell_stride = ell != nullptr ? ell->stride : 0;
             pcg_control* ctl = reinterpret_cast<pcg_control*>(ws + l.pcg_ctl);
             pcg_slot* slots = reinterpret_cast<pcg_slot*>(ws + l.pcg_slots);
             const int chunk = static_cast<int>(ceildiv(n, cus));
@@ -249,14 +262,14 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
             hipLaunchKernelGGL(pcg_clear_kernel, dim3(1), dim3(256), 0, stream, slots, stride, 2 * (cus + pcg_copies), ctl);
 #define GKOMI_PCG(R, KR, BLOCK)                                                                        \
     hipLaunchKernelGGL((cg_persistent_kernel<R, KR, BLOCK, (KR == 7 && R == 8)>), dim3(cus), dim3(BLOCK), 0, stream, \
-                       static_cast<int>(n), chunk, M.row_ptrs, M.col_idxs, M.vals, x, r, p, q, slots,  \
+                       static_cast<int>(n), chunk, m_row_ptrs, m_col_idxs, m_vals, x, r, p, q, slots,  \
                        stride, nap, ctl, scal, static_cast<long long>(max_iters), reduction_factor,    \
-                       max_polls)
+                       max_polls, ell_stored, ell_stride)
             // rows of at most 5 nonzeros, up to 8 rows per thread of a 512-thread workgroup (256
             // registers each): the matrix stays in registers
             const int rows_per_thread_512 = static_cast<int>(ceildiv(chunk, 512));
             const bool resident = pcg_fits_matrix && resident_on;
-            if (resident && M.hint <= 5) {
+            if (resident && pcg_hint <= 5) {
                 if (rows_per_thread_512 <= 2) {
                     GKOMI_PCG(2, 5, 512);
                 } else if (rows_per_thread_512 <= 4) {

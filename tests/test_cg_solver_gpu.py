@@ -249,3 +249,22 @@ def test_persistent_cg_with_a_hint_that_is_too_small_falls_back(gk, oracle):
     res, took = _persistent_solve(gk, n, rp, ci, v, b, 5, max_iters=2000, reduction=1e-10)
     assert took == 0 and res["converged"] and abs(res["iterations"] - it) <= 1
     assert matgen.rel_err(host(res["x"]), xe) <= 1e-8
+
+
+def test_persistent_cg_on_an_ell_system_matrix(gk, oracle):
+    """Ell behind the library's callback: same single launch (the rows are loaded from the ELL
+    arrays, padding skipped), same bits as the CSR solve -- the arithmetic is the same."""
+    from gkomi import formats
+    n, rp, ci, v = matgen.poisson_2d_5pt(300, 270)
+    A = formats.Csr.from_host(gk, n, n, rp, ci, v)
+    E = A.to("ell")
+    b = dev(np.sin(0.1 * np.arange(n)))
+    before = gk.cg_persistent_solves()
+    r_csr = solvers.solve_op(gk, "cg", A, b, max_iters=3000, reduction=1e-10, fused=True)
+    r_ell = solvers.solve_op(gk, "cg", E, b, max_iters=3000, reduction=1e-10, fused=True)
+    assert gk.cg_persistent_solves() == before + 2
+    assert r_ell["converged"] and r_ell["iterations"] == r_csr["iterations"]
+    assert host(r_ell["x"]).tobytes() == host(r_csr["x"]).tobytes()
+    xe = np.zeros(n)
+    it = oracle.ref_cg_solve(n, rp, ci, v, host(b), xe, 3000, 1e-10, 0, None, 0)
+    assert abs(r_ell["iterations"] - it) <= 1 and matgen.rel_err(host(r_ell["x"]), xe) <= 1e-7
