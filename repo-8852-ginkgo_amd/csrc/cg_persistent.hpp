@@ -320,6 +320,12 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
     unsigned long long stamp_ = wall_clock64();
 #endif
     while (true) {
+        // Forget what this CU's L1 and this XCD's L2 know of the p buffer of this iteration: its
+        // lines date from the gathers two iterations ago.  Nobody gathers between here and meeting
+        // 2 (every workgroup has left the SpMV of the iteration before: it published p.q), so the
+        // invalidate may run now, off the critical path, instead of between meeting 2 and the gathers.
+        // (The last wave issues it: the waves that poll in meeting 1 would wait for it.)
+        if (tid >= Block - wave_size) asm volatile("buffer_inv sc1" ::: "memory");
         // 1. rho = r.r (z = r), the criterion, the new search direction
         double acc = 0.0;
 #pragma unroll
@@ -348,14 +354,12 @@ __global__ __launch_bounds__(Block) void cg_persistent_kernel(
             // written through to memory: the other XCDs gather it after the meeting
             if (row < b1) __hip_atomic_store(pbuf + row, pr[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // 2. everybody's p is in memory; forget what this XCD's L2 knew of the buffer two iterations ago
+        // 2. everybody's p is in memory
         if (!pcg_barrier<Block>(slots, stride, nap, nwg, ++meeting, smem, ctl, max_polls)) {
             broken = true;
             break;
         }
         PCG_STAMP(1);
-        if (tid < wave_size) asm volatile("buffer_inv sc1" ::: "memory");
-        __syncthreads();
         PCG_STAMP(2);
 #pragma unroll
         for (int k = 0; k < R; ++k) qr[k] = 0.0;
