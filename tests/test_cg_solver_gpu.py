@@ -268,3 +268,41 @@ def test_persistent_cg_on_an_ell_system_matrix(gk, oracle):
     xe = np.zeros(n)
     it = oracle.ref_cg_solve(n, rp, ci, v, host(b), xe, 3000, 1e-10, 0, None, 0)
     assert abs(r_ell["iterations"] - it) <= 1 and matgen.rel_err(host(r_ell["x"]), xe) <= 1e-7
+
+
+def test_persistent_cg_rows_of_mixed_length(gk, oracle):
+    """A shifted graph Laplacian with 1..7 entries per row (rows without neighbours included), rows
+    of unsorted columns: the register-resident rows keep storage order and skip what a row lacks."""
+    rng = np.random.default_rng(12)
+    n = 70001
+    deg = rng.integers(0, 4, size=n)          # partners drawn per row; the symmetric closure gives <= 6
+    src = np.repeat(np.arange(n), deg)
+    dst = (src + rng.integers(1, 400, size=len(src))) % n
+    keep = src != dst
+    a, b_ = np.concatenate([src[keep], dst[keep]]), np.concatenate([dst[keep], src[keep]])
+    pairs = np.unique(np.stack([a, b_], 1), axis=0)
+    counts = np.bincount(pairs[:, 0], minlength=n)
+    ok = counts[pairs[:, 0]] <= 6
+    # drop edges of over-full rows symmetrically until every row has at most 6 neighbours
+    while not ok.all():
+        bad_rows = set(np.flatnonzero(counts > 6).tolist())
+        mask = np.array([(p in bad_rows) or (q in bad_rows) for p, q in pairs])
+        drop = mask & (rng.random(len(pairs)) < 0.5)
+        dropset = set(map(tuple, pairs[drop])) | set(map(tuple, pairs[drop][:, ::-1]))
+        pairs = np.array([pq for pq in map(tuple, pairs) if pq not in dropset])
+        counts = np.bincount(pairs[:, 0], minlength=n)
+        ok = counts[pairs[:, 0]] <= 6
+    rows = np.concatenate([pairs[:, 0], np.arange(n)])
+    cols = np.concatenate([pairs[:, 1], np.arange(n)])
+    vals = np.concatenate([-np.ones(len(pairs)), counts + 0.5])
+    order = np.lexsort((rng.random(len(rows)), rows))       # rows grouped, columns in random order
+    rp = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows, minlength=n), out=rp[1:])
+    ci, v = cols[order].astype(np.int32), vals[order]
+    assert np.diff(rp).max() <= 7 and np.diff(rp).min() == 1
+    b = np.cos(0.01 * np.arange(n))
+    xe = np.zeros(n)
+    it = oracle.ref_cg_solve(n, rp, ci, v, b.copy(), xe, 3000, 1e-10, 0, None, 0)
+    res, took = _persistent_solve(gk, n, rp, ci, v, b, int(np.diff(rp).max()), max_iters=3000, reduction=1e-10)
+    assert took == 1 and res["converged"] and abs(res["iterations"] - it) <= 1
+    assert matgen.rel_err(host(res["x"]), xe) <= 1e-8
