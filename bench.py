@@ -257,7 +257,7 @@ def main():
                 "all_us_per_step": [round(u, 3) for u in us]}
 
     def make_srow(rp_d, n, nnz):
-        tile = int(gk.csr_srow_tile())
+        tile = int(gk.csr_srow_tile_for(nnz))
         t = torch.empty(int(gk.csr_srow_entries(nnz, tile)), dtype=torch.int32, device=device)
         gk.csr_make_srow_i32(stream, n, nnz, rp_d, tile, t, t.numel())
         return t, tile

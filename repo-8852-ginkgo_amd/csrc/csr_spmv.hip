@@ -926,6 +926,9 @@ bool csr_auto_swizzle(int64_t nrows, int64_t nnz)
 
 extern "C" int64_t gkomi_csr_srow_tile(void) { return 1536; }
 
+// 12 B per nonzero: beyond ~20 M nonzeros the matrix alone fills the 256 MiB Infinity Cache
+extern "C" int64_t gkomi_csr_srow_tile_for(int64_t nnz) { return nnz > 20000000 ? 2048 : 1536; }
+
 extern "C" int64_t gkomi_csr_srow_entries(int64_t nnz, int64_t tile)
 {
     if (nnz < 0 || tile <= 0) return 0;

@@ -442,7 +442,7 @@ class NativeMatrix:
         gk.dist_nonlocal_rows_i32(s, n_loc, nl_rp, self.nl_row_idxs, self.nl_row_ptrs, ws, nb, ctypes.addressof(cnt))
         self.nl_rows = int(cnt.value)
         # srow of the local block (Csr::make_srow)
-        tile = int(gk.csr_srow_tile())
+        tile = int(gk.csr_srow_tile_for(l_nnz))
         self.max_row_nnz = -1
         if n_loc > 0:
             mx = ops.empty(1, torch.int32)

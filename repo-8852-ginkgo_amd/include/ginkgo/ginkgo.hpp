@@ -972,7 +972,7 @@ public:
             GKOMI_CALL(gkomi_csr_max_row_nnz_i32(nullptr, size_[0], get_const_row_ptrs(), mx.get_data()));
             max_row_nnz_ = exec_->copy_val_to_host(mx.get_const_data());
         }
-        srow_tile_ = gkomi_csr_srow_tile();
+        srow_tile_ = gkomi_csr_srow_tile_for(static_cast<int64_t>(get_num_stored_elements()));
         if (nnz >= 2) {
             srow_ = array<I>(exec_, static_cast<size_type>(gkomi_csr_srow_entries(nnz, srow_tile_)));
             GKOMI_CALL(gkomi_csr_make_srow_i32(nullptr, size_[0], nnz, get_const_row_ptrs(), srow_tile_, srow_.get_data(),

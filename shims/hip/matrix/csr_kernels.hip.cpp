@@ -27,7 +27,7 @@ void spmv(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double, int
         GKOMI_NULL_STREAM, a->get_size()[0], a->get_size()[1], b->get_size()[1], a->get_num_stored_elements(),
         a->get_const_row_ptrs(), a->get_const_col_idxs(), a->get_const_values(), b->get_const_values(),
         b->get_stride(), c->get_values(), c->get_stride(), nullptr, nullptr, strategy_code(a),
-        /*max_row_nnz_hint=*/-1, a->get_num_srow_elements() ? a->get_const_srow() : nullptr, gkomi_csr_srow_tile()));
+        /*max_row_nnz_hint=*/-1, a->get_num_srow_elements() ? a->get_const_srow() : nullptr, gkomi_csr_srow_tile_for(static_cast<int64_t>(a->get_num_stored_elements()))));
 }
 
 void advanced_spmv(std::shared_ptr<const HipExecutor> exec, const matrix::Dense<double>* alpha,
@@ -38,7 +38,7 @@ void advanced_spmv(std::shared_ptr<const HipExecutor> exec, const matrix::Dense<
         GKOMI_NULL_STREAM, a->get_size()[0], a->get_size()[1], b->get_size()[1], a->get_num_stored_elements(),
         a->get_const_row_ptrs(), a->get_const_col_idxs(), a->get_const_values(), b->get_const_values(),
         b->get_stride(), c->get_values(), c->get_stride(), alpha->get_const_values(), beta->get_const_values(),
-        strategy_code(a), -1, a->get_num_srow_elements() ? a->get_const_srow() : nullptr, gkomi_csr_srow_tile()));
+        strategy_code(a), -1, a->get_num_srow_elements() ? a->get_const_srow() : nullptr, gkomi_csr_srow_tile_for(static_cast<int64_t>(a->get_num_stored_elements()))));
 }
 
 }  // namespace csr
