@@ -121,8 +121,8 @@ int gkomi_csr_spmv_f64_i32(gkomi_stream_t stream, int64_t nrows, int64_t ncols,
  * nonzeros.  Built once per matrix (whenever row_ptrs changes) into a caller-owned
  * device int32 array of gkomi_csr_srow_entries(nnz, tile) entries;
  * gkomi_csr_srow_tile_for(nnz) is the tile the kernels are tuned for at that size
- * (1536 while the matrix can be Infinity-Cache resident, 2048 for matrices that
- * stream from HBM: 301 vs 309 us on the 256^3 7-point matrix;
+ * (1536 while the matrix can be Infinity-Cache resident, 2048 / 3072 for matrices
+ * that stream from HBM: 300 vs 309 us on the 256^3 7-point matrix;
  * gkomi_csr_srow_tile() = the former).  One small launch, no synchronisation. */
 int64_t gkomi_csr_srow_tile(void);
 int64_t gkomi_csr_srow_tile_for(int64_t nnz);

@@ -927,7 +927,13 @@ bool csr_auto_swizzle(int64_t nrows, int64_t nnz)
 extern "C" int64_t gkomi_csr_srow_tile(void) { return 1536; }
 
 // 12 B per nonzero: beyond ~20 M nonzeros the matrix alone fills the 256 MiB Infinity Cache
-extern "C" int64_t gkomi_csr_srow_tile_for(int64_t nnz) { return nnz > 20000000 ? 2048 : 1536; }
+// and the larger the stream, the larger the tile that pays: 2048 from there, 3072 beyond ~60 M
+// (256^3 7-point, 117 M nonzeros: 309 / 300 / 313 us with tiles of 2048 / 3072 / 4096; 160^3, 28.5 M:
+// ~80 us with all of them -- tools/p3_probe.py)
+extern "C" int64_t gkomi_csr_srow_tile_for(int64_t nnz)
+{
+    return nnz > 60000000 ? 3072 : (nnz > 20000000 ? 2048 : 1536);
+}
 
 extern "C" int64_t gkomi_csr_srow_entries(int64_t nnz, int64_t tile)
 {
@@ -994,7 +1000,7 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
                          (reinterpret_cast<uintptr_t>(col_idxs) % 8 == 0);
     const bool split_ok = srow != nullptr && aligned && nnz >= 2 &&
                           nnz <= INT32_MAX - 2 * srow_tile - 1024 &&
-                          (srow_tile == 1024 || srow_tile == 1536 || srow_tile == 2048);
+                          (srow_tile == 1024 || srow_tile == 1536 || srow_tile == 2048 || srow_tile == 3072);
     if (kind == GKOMI_CSR_SPLIT && !split_ok) return srow == nullptr ? GKOMI_EINVAL : GKOMI_ENOTSUPPORTED;
     if (kind == GKOMI_CSR_AUTO) {
         // the role of Csr::automatical (csr.hpp:526-705): short rows stream
@@ -1088,6 +1094,8 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
                 GKOMI_SPLIT_TILE(256, 1536)
             } else if (srow_tile == 1024) {
                 GKOMI_SPLIT_TILE(256, 1024)
+            } else if (srow_tile == 3072) {
+                GKOMI_SPLIT_TILE(256, 3072)
             } else {
                 GKOMI_SPLIT_TILE(256, 2048)
             }

@@ -14,7 +14,7 @@ from test_csr_spmv_gpu import _oracle_apply
 
 pytestmark = pytest.mark.gpu
 SPLIT = 4
-TILES = [1024, 1536, 2048]
+TILES = [1024, 1536, 2048, 3072]
 VARIANTS = {"plain": 0, "nt": 2, "noswz": 1 << 8, "nt_noswz": (1 << 8) | 2}
 
 
