@@ -845,13 +845,15 @@ int launch_split(hipStream_t stream, bool swizzle, int nrows, int nnz,
                  const int32_t* row_ptrs, const int32_t* col_idxs,
                  const double* vals, const double* b, int64_t b_stride,
                  double* c, int64_t c_stride, const double* alpha,
-                 const double* beta, const int32_t* srow, int over)
+                 const double* beta, const int32_t* srow, int over, int chunk = 0)
 {
     constexpr int MaxOver = split_max_over;
     const int ntiles = nnz / Tile + 1;
-    const int per = static_cast<int>(ceildiv(ntiles, num_xcd));
+    int per = static_cast<int>(ceildiv(ntiles, num_xcd));
+    if (chunk > 0 && chunk < per) per = chunk;  // XCD k takes `chunk` consecutive tiles of every 8 * chunk
     const bool swz = swizzle && ntiles >= 2 * num_xcd;
-    dim3 grid(swz ? per * num_xcd : ntiles, 1);
+    const int groups = static_cast<int>(ceildiv(ntiles, per * num_xcd));
+    dim3 grid(swz ? groups * per * num_xcd : ntiles, 1);
 #define GKOMI_LAUNCH(ADV, SWZ)                                                 \
     hipLaunchKernelGGL(                                                        \
         (csr_split_kernel<Block, Tile, MaxOver, ADV, SWZ, false, NT, true>), \
@@ -1080,7 +1082,7 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
             int err = GKOMI_EINVAL;
 #define GKOMI_SPLIT_ARGS                                                            \
     stream, !no_swizzle, n, z, row_ptrs, col_idxs, vals, b + j, b_stride, c + j,    \
-        c_stride, alpha, beta, srow, over
+        c_stride, alpha, beta, srow, over, chunk
             // variant bit 2: nontemporal streams.  (Write-through stores of c, 8 or 16 bytes wide, and
             // nontemporal stores of c were measured and dropped: 17.2 / 16.9 vs 16.6 us cold,
             // profiles/r02_tune_split.log, r02_tune_ntstore.log.)

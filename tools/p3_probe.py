@@ -25,11 +25,12 @@ def run(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 print(f"{g}^3: n={n} nnz={nnz} bytes={bytes_}")
-for tile in (1536, 2048, 3072):
+for tile in (2048, 3072):
     cnt = int(gk.csr_srow_entries(nnz, tile)); srow = torch.empty(cnt, dtype=torch.int32, device="cuda")
     gk.csr_make_srow_i32(s, n, nnz, rpd, tile, srow, cnt)
-    for name, bits in (("noswz", 256), ("noswz nt", 258)):
-        st = SPLIT | ((bits & 0xff) << 8) | ((bits >> 8) << 16)
+    for name, bits, code in (("noswz nt", 258, 0), ("swz nt", 2, 0), ("chunk 1 nt", 2, 1), ("chunk 4 nt", 2, 3),
+                             ("chunk 16 nt", 2, 5), ("chunk 64 nt", 2, 7), ("chunk 256 nt", 2, 9)):
+        st = SPLIT | ((bits & 0xff) << 8) | ((bits >> 8) << 16) | (code << 17)
         t = run(lambda: gk.csr_spmv_srow_f64_i32(s, n, n, 1, nnz, rpd, cid, vd, x, 1, y, 1, None, None, st, 7, srow, tile))
         print(f"split tile {tile} {name:9s}: {t:8.1f} us {bytes_/t/1e3:7.0f} GB/s {bytes_/t/1e3/8000:.3f}")
 t = run(lambda: gk.csr_spmv_f64_i32(s, n, n, 1, nnz, rpd, cid, vd, x, 1, y, 1, None, None, 0, 7))
