@@ -141,6 +141,9 @@ __device__ __forceinline__ bool pcg_meet(pcg_slot* slots, int stride, int nap, i
     // per parity: nwg slots of partials, then pcg_copies slots of the total
     pcg_slot* bank = slots + (meeting & 1) * static_cast<int64_t>(nwg + pcg_copies) * stride;
     pcg_slot* back = bank + static_cast<int64_t>(nwg) * stride;
+#ifdef GKOMI_PCG_PROFILE
+    const unsigned long long m0_ = wall_clock64();
+#endif
     if (threadIdx.x == 0) pcg_publish(bank + blockIdx.x * stride, mine, meeting);
     bool ok = true;
     auto wait_for = [&](const pcg_slot* slot, double* v) {
@@ -164,6 +167,10 @@ __device__ __forceinline__ bool pcg_meet(pcg_slot* slots, int stride, int nap, i
         // every thread adds them in wave order
         double part = 0.0;
         if (static_cast<int>(threadIdx.x) < nwg) ok = wait_for(bank + threadIdx.x * stride, &part);
+#ifdef GKOMI_PCG_PROFILE
+        if (threadIdx.x == 0) ctl->pad2_[0] += wall_clock64() - m0_;                 // own slot seen (store -> load round trip)
+        if (threadIdx.x == nwg - 1) ctl->pad2_[1] += wall_clock64() - m0_;           // last workgroup's slot seen
+#endif
         if (!ok) smem[nwaves] = 0.0;
         part = wave_reduce_sum(part);
         if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = part;
@@ -172,9 +179,16 @@ __device__ __forceinline__ bool pcg_meet(pcg_slot* slots, int stride, int nap, i
         for (int w = 0; w < nwaves; ++w) sum += smem[w];
         ok = smem[nwaves] != 0.0;
         if (ok && threadIdx.x < pcg_copies) pcg_publish(back + threadIdx.x * stride, sum, meeting);
+#ifdef GKOMI_PCG_PROFILE
+        if (threadIdx.x == 0) ctl->pad2_[2] += wall_clock64() - m0_;                 // total published
+#endif
     } else {
         if (threadIdx.x == 0) {
             ok = wait_for(back + (blockIdx.x % pcg_copies) * stride, &sum);
+#ifdef GKOMI_PCG_PROFILE
+            if (blockIdx.x == 101) ctl->pad2_[3] += wall_clock64() - m0_;            // workgroup 101: total received
+            if (blockIdx.x == 101) ctl->pad2_[4] += 1;
+#endif
             smem[0] = sum;
             if (!ok) smem[nwaves] = 0.0;
         }
@@ -488,6 +502,7 @@ __global__ void pcg_clear_kernel(pcg_slot* slots, int stride, int count, pcg_con
     }
     if (threadIdx.x == 0) ctl->overrun = 0;
     if (threadIdx.x < 8) ctl->ticks[threadIdx.x] = 0;
+    if (threadIdx.x < 16) ctl->pad2_[threadIdx.x] = 0;
 }
 
 }  // namespace

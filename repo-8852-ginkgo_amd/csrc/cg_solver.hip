@@ -307,6 +307,10 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
                     hctl.ticks[2] * 0.01 / (polled.stop_iter + 1), hctl.ticks[3] * 0.01 / (polled.stop_iter + 1),
                     hctl.ticks[4] * 0.01 / (polled.stop_iter + 1), hctl.ticks[5] * 0.01 / (polled.stop_iter + 1),
                     polled.stop_iter);
+            fprintf(stderr, "pcg meeting (us, mean over %llu meetings): own slot seen %.2f | last slot seen %.2f | total "
+                            "published %.2f | workgroup 101 has the total %.2f\n",
+                    hctl.pad2_[4], hctl.pad2_[0] * 0.01 / hctl.pad2_[4], hctl.pad2_[1] * 0.01 / hctl.pad2_[4],
+                    hctl.pad2_[2] * 0.01 / hctl.pad2_[4], hctl.pad2_[3] * 0.01 / hctl.pad2_[4]);
 #endif
             if (hctl.overrun == 0 && (polled.status & GKOMI_STATUS_ID_MASK)) {
                 solved = true;
