@@ -94,6 +94,147 @@ extern "C" size_t gkomi_cg_workspace_bytes(int64_t n, int64_t nrhs)
 }
 
 namespace {
+// The whole solve in one launch (cg_persistent.hpp) when the vectors AND the matrix fit the
+// register files.  Returns 1 when the solve is finished (*result = the final scalars), 0 when the
+// path does not apply or gave up (state restored for the three-launch iteration: r = b - A x from
+// whatever x the kernel left, p = 0, scalars re-initialised), -(1000 + code) on a HIP / library error.
+#define PCG_TRY(expr)                        \
+    do {                                     \
+        const int err_ = (expr);             \
+        if (err_) return -(1000 + err_);     \
+    } while (0)
+int persistent_cg(gkomi_stream_t s, int64_t n, const sysmat& A, const spmv_dot_plan& spmv, gkomi_apply_fn precond,
+                  const double* b, double* x, double* r, double* p, double* q, const double* one,
+                  const double* neg_one, const double* orig_tau, int baseline, int64_t max_iters,
+                  double reduction_factor, cg_scalars* scal, void* ctl_mem, void* slot_mem, cg_scalars* result)
+{
+    hipStream_t stream = to_stream(s);
+    cg_scalars polled{};
+    // The whole solve in one launch (cg_persistent.hpp) when the vectors AND the matrix fit the
+    // register files: Identity preconditioner, aligned CSR, rows of at most 7 nonzeros (the
+    // caller's max_row_nnz_hint says so; the kernel checks), one workgroup per CU.
+    // GKOMI_CG_PERSISTENT=0 turns it off, =2 also takes matrices that do not fit (they stream
+    // from memory every iteration: 33 vs 34.8 us per iteration on P2, not worth the rendezvous).
+    static const int persistent_mode = [] {
+        const char* e = std::getenv("GKOMI_CG_PERSISTENT");
+        return e == nullptr ? 1 : std::atoi(e);
+    }();
+    static const int cus = device_cu_count();
+    const int64_t pcg_chunk = cus > 0 ? ceildiv(n, cus) : 0;
+    // an ELL system matrix behind the library's callback: its rows go into the registers just the same
+    const gkomi_ell_ctx* ell = !A.is_csr() && A.op == &gkomi_ell_matrix_apply_cb && A.ctx != nullptr
+                                   ? static_cast<const gkomi_ell_ctx*>(A.ctx)
+                                   : nullptr;
+    if (ell != nullptr && (ell->nrows != n || ell->ncols != n || ell->stride < n)) ell = nullptr;
+    const int64_t pcg_hint = ell != nullptr ? ell->num_stored_per_row
+                                            : spmv.A.hint;  // (a CSR matrix behind its callback carries its own)
+    const bool pcg_fits_matrix =
+        pcg_hint >= 1 && pcg_hint <= 7 && ceildiv(pcg_chunk, 512) <= 8;
+    const bool pcg_fits_vectors = ceildiv(pcg_chunk, pcg_block) <= pcg_max_rows_per_thread;
+    if (persistent_mode >= 1 && precond == nullptr && (spmv.csr || ell != nullptr) && cus >= 8 &&
+        cus <= max_parts &&
+        n >= 64 * static_cast<int64_t>(cus) &&
+        (pcg_fits_matrix || (persistent_mode >= 2 && pcg_fits_vectors && ell == nullptr)) &&
+        persistent_try_acquire()) {  // one persistent solve at a time per process
+        struct release_guard {
+            ~release_guard() { persistent_release(); }
+        } release;
+        const sysmat& M = spmv.A;
+        const int32_t* m_row_ptrs = ell != nullptr ? nullptr : M.row_ptrs;
+        const int32_t* m_col_idxs = ell != nullptr ? ell->col_idxs : M.col_idxs;
+        const double* m_vals = ell != nullptr ? ell->vals : M.vals;
+        const int ell_stored = ell != nullptr ? static_cast<int>(ell->num_stored_per_row) : 0;
+        const int64_t ell_stride = ell != nullptr ? ell->stride : 0;
+        pcg_control* ctl = static_cast<pcg_control*>(ctl_mem);
+        pcg_slot* slots = static_cast<pcg_slot*>(slot_mem);
+        const int chunk = static_cast<int>(ceildiv(n, cus));
+        const int rows_per_thread = static_cast<int>(ceildiv(chunk, pcg_block));
+        const long long max_polls = 1ll << 22;
+        static const int stride = [] {
+            const char* e = std::getenv("GKOMI_PCG_STRIDE");  // slot spacing in 16-B units (tuning)
+            const int v = e != nullptr ? std::atoi(e) : pcg_default_stride;
+            return v >= 1 && v <= pcg_max_stride ? v : pcg_default_stride;
+        }();
+        static const bool resident_on = [] {
+            const char* e = std::getenv("GKOMI_PCG_RESIDENT");
+            return e == nullptr || e[0] != '0';
+        }();
+        static const int nap = [] {
+            const char* e = std::getenv("GKOMI_PCG_NAP");
+            const int v = e != nullptr ? std::atoi(e) : 1;
+            return v >= 0 && v <= 64 ? v : 1;
+        }();
+        hipLaunchKernelGGL(pcg_clear_kernel, dim3(1), dim3(256), 0, stream, slots, stride, 2 * (cus + pcg_copies), ctl);
+#define GKOMI_PCG(R, KR, BLOCK)                                                                        \
+hipLaunchKernelGGL((cg_persistent_kernel<R, KR, BLOCK, (KR == 7 && R == 8)>), dim3(cus), dim3(BLOCK), 0, stream, \
+                   static_cast<int>(n), chunk, m_row_ptrs, m_col_idxs, m_vals, x, r, p, q, slots,  \
+                   stride, nap, ctl, scal, static_cast<long long>(max_iters), reduction_factor,    \
+                   max_polls, ell_stored, ell_stride)
+        // rows of at most 5 nonzeros, up to 8 rows per thread of a 512-thread workgroup (256
+        // registers each): the matrix stays in registers
+        const int rows_per_thread_512 = static_cast<int>(ceildiv(chunk, 512));
+        const bool resident = pcg_fits_matrix && resident_on;
+        if (resident && pcg_hint <= 5) {
+            if (rows_per_thread_512 <= 2) {
+                GKOMI_PCG(2, 5, 512);
+            } else if (rows_per_thread_512 <= 4) {
+                GKOMI_PCG(4, 5, 512);
+            } else {
+                GKOMI_PCG(8, 5, 512);
+            }
+        } else if (resident) {
+            if (rows_per_thread_512 <= 2) {
+                GKOMI_PCG(2, 7, 512);
+            } else if (rows_per_thread_512 <= 4) {
+                GKOMI_PCG(4, 7, 512);
+            } else {
+                GKOMI_PCG(8, 7, 512);  // x in LDS: 7 nonzeros x 8 rows of values fill the registers
+            }
+        } else if (rows_per_thread <= 1) {
+            GKOMI_PCG(1, 0, 1024);
+        } else if (rows_per_thread <= 2) {
+            GKOMI_PCG(2, 0, 1024);
+        } else if (rows_per_thread <= 4) {
+            GKOMI_PCG(4, 0, 1024);
+        } else {
+            GKOMI_PCG(8, 0, 1024);
+        }
+#undef GKOMI_PCG
+        PCG_TRY(check_launch());
+        pcg_control hctl{};
+        PCG_TRY(static_cast<int>(hipMemcpyAsync(&hctl, ctl, sizeof(pcg_control), hipMemcpyDeviceToHost, stream)));
+        PCG_TRY(static_cast<int>(hipMemcpyAsync(&polled, scal, sizeof(cg_scalars), hipMemcpyDeviceToHost, stream)));
+        PCG_TRY(static_cast<int>(hipStreamSynchronize(stream)));
+#ifdef GKOMI_PCG_PROFILE
+        fprintf(stderr, "pcg phases (us per iteration, workgroup 0): meet rho %.2f | p + barrier %.2f | inv %.2f | "
+                        "spmv %.2f | meet pq %.2f | update %.2f over %lld iterations\n",
+                hctl.ticks[0] * 0.01 / (polled.stop_iter + 1), hctl.ticks[1] * 0.01 / (polled.stop_iter + 1),
+                hctl.ticks[2] * 0.01 / (polled.stop_iter + 1), hctl.ticks[3] * 0.01 / (polled.stop_iter + 1),
+                hctl.ticks[4] * 0.01 / (polled.stop_iter + 1), hctl.ticks[5] * 0.01 / (polled.stop_iter + 1),
+                polled.stop_iter);
+        fprintf(stderr, "pcg meeting (us, mean over %llu meetings): own slot seen %.2f | last slot seen %.2f | total "
+                        "published %.2f | workgroup 101 has the total %.2f\n",
+                hctl.pad2_[4], hctl.pad2_[0] * 0.01 / hctl.pad2_[4], hctl.pad2_[1] * 0.01 / hctl.pad2_[4],
+                hctl.pad2_[2] * 0.01 / hctl.pad2_[4], hctl.pad2_[3] * 0.01 / hctl.pad2_[4]);
+#endif
+        if (hctl.overrun == 0 && (polled.status & GKOMI_STATUS_ID_MASK)) {
+            pcg_solves.fetch_add(1);
+            *result = polled;
+            return 1;
+        } else {
+            // a meeting timed out (workgroups not resident together?): x is a valid guess, start over
+            // from r = b - A x with the three-launch iteration
+            PCG_TRY(gkomi_dense_copy_f64(s, n, 1, b, 1, r, 1));
+            PCG_TRY(A.apply(s, 1, neg_one, x, one, r));
+            PCG_TRY(gkomi_dense_fill_f64(s, n, 1, p, 1, 0.0));
+            hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(1), 0, stream, scal, orig_tau,
+                               baseline == 2 ? 1 : 0);
+        }
+    }
+    return 0;
+}
+#undef PCG_TRY
+
 int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
                   void* precond_ctx, const double* b, double* x, int64_t max_iters,
                   double reduction_factor, int baseline, int mode, int check_every, void* workspace,
@@ -204,139 +345,22 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gk
         hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(1), 0, stream, scal, orig_tau,
                            baseline == 2 ? 1 : 0);
         GKOMI_TRY(check_launch());
-        // The whole solve in one launch (cg_persistent.hpp) when the vectors AND the matrix fit the
-        // register files: Identity preconditioner, aligned CSR, rows of at most 7 nonzeros (the
-        // caller's max_row_nnz_hint says so; the kernel checks), one workgroup per CU.
-        // GKOMI_CG_PERSISTENT=0 turns it off, =2 also takes matrices that do not fit (they stream
-        // from memory every iteration: 33 vs 34.8 us per iteration on P2, not worth the rendezvous).
-        static const int persistent_mode = [] {
-            const char* e = std::getenv("GKOMI_CG_PERSISTENT");
-            return e == nullptr ? 1 : std::atoi(e);
-        }();
-        static const int cus = device_cu_count();
-        bool solved = false;
-        const int64_t pcg_chunk = cus > 0 ? ceildiv(n, cus) : 0;
-        // an ELL system matrix behind the library's callback: its rows go into the registers just the same
-        const gkomi_ell_ctx* ell = !A.is_csr() && A.op == &gkomi_ell_matrix_apply_cb && A.ctx != nullptr
-                                       ? static_cast<const gkomi_ell_ctx*>(A.ctx)
-                                       : nullptr;
-        if (ell != nullptr && (ell->nrows != n || ell->ncols != n || ell->stride < n)) ell = nullptr;
-        const int64_t pcg_hint = ell != nullptr ? ell->num_stored_per_row
-                                                : spmv.A.hint;  // (a CSR matrix behind its callback carries its own)
-        const bool pcg_fits_matrix =
-            pcg_hint >= 1 && pcg_hint <= 7 && ceildiv(pcg_chunk, 512) <= 8;
-        const bool pcg_fits_vectors = ceildiv(pcg_chunk, pcg_block) <= pcg_max_rows_per_thread;
-        if (persistent_mode >= 1 && precond == nullptr && (spmv.csr || ell != nullptr) && cus >= 8 &&
-            cus <= max_parts &&
-            n >= 64 * static_cast<int64_t>(cus) &&
-            (pcg_fits_matrix || (persistent_mode >= 2 && pcg_fits_vectors && ell == nullptr)) &&
-            persistent_try_acquire()) {  // one persistent solve at a time per process
-            struct release_guard {
-                ~release_guard() { persistent_release(); }
-            } release;
-            const sysmat& M = spmv.A;
-            const int32_t* m_row_ptrs = ell != nullptr ? nullptr : M.row_ptrs;
-            const int32_t* m_col_idxs = ell != nullptr ? ell->col_idxs : M.col_idxs;
-            const double* m_vals = ell != nullptr ? ell->vals : M.vals;
-            const int ell_stored = ell != nullptr ? static_cast<int>(ell->num_stored_per_row) : 0;
-            const int64_t ell_stride = ell != nullptr ? ell->stride : 0;
-            pcg_control* ctl = reinterpret_cast<pcg_control*>(ws + l.pcg_ctl);
-            pcg_slot* slots = reinterpret_cast<pcg_slot*>(ws + l.pcg_slots);
-            const int chunk = static_cast<int>(ceildiv(n, cus));
-            const int rows_per_thread = static_cast<int>(ceildiv(chunk, pcg_block));
-            const long long max_polls = 1ll << 22;
-            static const int stride = [] {
-                const char* e = std::getenv("GKOMI_PCG_STRIDE");  // slot spacing in 16-B units (tuning)
-                const int v = e != nullptr ? std::atoi(e) : pcg_default_stride;
-                return v >= 1 && v <= pcg_max_stride ? v : pcg_default_stride;
-            }();
-            static const bool resident_on = [] {
-                const char* e = std::getenv("GKOMI_PCG_RESIDENT");
-                return e == nullptr || e[0] != '0';
-            }();
-            static const int nap = [] {
-                const char* e = std::getenv("GKOMI_PCG_NAP");
-                const int v = e != nullptr ? std::atoi(e) : 1;
-                return v >= 0 && v <= 64 ? v : 1;
-            }();
-            hipLaunchKernelGGL(pcg_clear_kernel, dim3(1), dim3(256), 0, stream, slots, stride, 2 * (cus + pcg_copies), ctl);
-#define GKOMI_PCG(R, KR, BLOCK)                                                                        \
-    hipLaunchKernelGGL((cg_persistent_kernel<R, KR, BLOCK, (KR == 7 && R == 8)>), dim3(cus), dim3(BLOCK), 0, stream, \
-                       static_cast<int>(n), chunk, m_row_ptrs, m_col_idxs, m_vals, x, r, p, q, slots,  \
-                       stride, nap, ctl, scal, static_cast<long long>(max_iters), reduction_factor,    \
-                       max_polls, ell_stored, ell_stride)
-            // rows of at most 5 nonzeros, up to 8 rows per thread of a 512-thread workgroup (256
-            // registers each): the matrix stays in registers
-            const int rows_per_thread_512 = static_cast<int>(ceildiv(chunk, 512));
-            const bool resident = pcg_fits_matrix && resident_on;
-            if (resident && pcg_hint <= 5) {
-                if (rows_per_thread_512 <= 2) {
-                    GKOMI_PCG(2, 5, 512);
-                } else if (rows_per_thread_512 <= 4) {
-                    GKOMI_PCG(4, 5, 512);
-                } else {
-                    GKOMI_PCG(8, 5, 512);
-                }
-            } else if (resident) {
-                if (rows_per_thread_512 <= 2) {
-                    GKOMI_PCG(2, 7, 512);
-                } else if (rows_per_thread_512 <= 4) {
-                    GKOMI_PCG(4, 7, 512);
-                } else {
-                    GKOMI_PCG(8, 7, 512);  // x in LDS: 7 nonzeros x 8 rows of values fill the registers
-                }
-            } else if (rows_per_thread <= 1) {
-                GKOMI_PCG(1, 0, 1024);
-            } else if (rows_per_thread <= 2) {
-                GKOMI_PCG(2, 0, 1024);
-            } else if (rows_per_thread <= 4) {
-                GKOMI_PCG(4, 0, 1024);
-            } else {
-                GKOMI_PCG(8, 0, 1024);
-            }
-#undef GKOMI_PCG
-            GKOMI_TRY(check_launch());
-            pcg_control hctl{};
-            GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&hctl, ctl, sizeof(pcg_control), hipMemcpyDeviceToHost, stream)));
-            GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&polled, scal, sizeof(cg_scalars), hipMemcpyDeviceToHost, stream)));
-            GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
-#ifdef GKOMI_PCG_PROFILE
-            fprintf(stderr, "pcg phases (us per iteration, workgroup 0): meet rho %.2f | p + barrier %.2f | inv %.2f | "
-                            "spmv %.2f | meet pq %.2f | update %.2f over %lld iterations\n",
-                    hctl.ticks[0] * 0.01 / (polled.stop_iter + 1), hctl.ticks[1] * 0.01 / (polled.stop_iter + 1),
-                    hctl.ticks[2] * 0.01 / (polled.stop_iter + 1), hctl.ticks[3] * 0.01 / (polled.stop_iter + 1),
-                    hctl.ticks[4] * 0.01 / (polled.stop_iter + 1), hctl.ticks[5] * 0.01 / (polled.stop_iter + 1),
-                    polled.stop_iter);
-            fprintf(stderr, "pcg meeting (us, mean over %llu meetings): own slot seen %.2f | last slot seen %.2f | total "
-                            "published %.2f | workgroup 101 has the total %.2f\n",
-                    hctl.pad2_[4], hctl.pad2_[0] * 0.01 / hctl.pad2_[4], hctl.pad2_[1] * 0.01 / hctl.pad2_[4],
-                    hctl.pad2_[2] * 0.01 / hctl.pad2_[4], hctl.pad2_[3] * 0.01 / hctl.pad2_[4]);
-#endif
-            if (hctl.overrun == 0 && (polled.status & GKOMI_STATUS_ID_MASK)) {
-                solved = true;
-                pcg_solves.fetch_add(1);
-                iterations = polled.stop_iter;
-                converged = (polled.status & GKOMI_STATUS_CONVERGED) ? 1 : 0;
+        // The whole solve in one launch when vectors and matrix fit the register files (persistent_cg
+        // above); otherwise, or when it gave up, the three-launch iteration below.
+        {
+            const int done = persistent_cg(s, n, A, spmv, precond, b, x, r, p, q, one, neg_one, orig_tau, baseline,
+                                           max_iters, reduction_factor, scal, ws + l.pcg_ctl, ws + l.pcg_slots,
+                                           &polled);
+            if (done < 0) return -done - 1000;
+            if (done == 1) {
                 if (host_info != nullptr) {
+                    host_info[0] = static_cast<double>(polled.stop_iter);
+                    host_info[1] = (polled.status & GKOMI_STATUS_CONVERGED) ? 1.0 : 0.0;
                     host_info[2] = polled.tau;
                     host_info[3] = polled.orig_tau;
                 }
-            } else {
-                // a meeting timed out (workgroups not resident together?): x is a valid guess, start over
-                // from r = b - A x with the three-launch iteration
-                GKOMI_TRY(gkomi_dense_copy_f64(s, n, 1, b, 1, r, 1));
-                GKOMI_TRY(A.apply(s, 1, neg_one, x, one, r));
-                GKOMI_TRY(gkomi_dense_fill_f64(s, n, 1, p, 1, 0.0));
-                hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(1), 0, stream, scal, orig_tau,
-                                   baseline == 2 ? 1 : 0);
+                return precond_status(precond, precond_ctx, s);
             }
-        }
-        if (solved) {
-            if (host_info != nullptr) {
-                host_info[0] = static_cast<double>(iterations);
-                host_info[1] = static_cast<double>(converged);
-            }
-            return precond_status(precond, precond_ctx, s);
         }
         // partials of r.z (and r.r) for the first check
         const double* zz = precond == nullptr ? r : z;
