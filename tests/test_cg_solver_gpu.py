@@ -306,3 +306,41 @@ def test_persistent_cg_rows_of_mixed_length(gk, oracle):
     res, took = _persistent_solve(gk, n, rp, ci, v, b, int(np.diff(rp).max()), max_iters=3000, reduction=1e-10)
     assert took == 1 and res["converged"] and abs(res["iterations"] - it) <= 1
     assert matgen.rel_err(host(res["x"]), xe) <= 1e-8
+
+
+def test_concurrent_solves_share_the_gpu(gk, oracle):
+    """Two host threads, two streams, the same kind of solve at the same time: at most one of them
+    may run the single-launch kernel (its workgroups must all be resident), the other takes the
+    three-launch iteration -- both finish with the right answer."""
+    import threading
+    n, rp, ci, v = matgen.poisson_2d_5pt(400, 400)
+    b = np.sin(0.1 * np.arange(n))
+    xe = np.zeros(n)
+    it = oracle.ref_cg_solve(n, rp, ci, v, b.copy(), xe, 5000, 1e-10, 0, None, 0)
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    results, errors = [None, None], []
+
+    def work(slot):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                bd = dev(b)
+                for _ in range(20):
+                    results[slot] = solvers.cg_solve(gk, n, rpd, cid, vd, bd, mode=1, max_iters=5000, reduction=1e-10,
+                                                     max_row_nnz=5)
+                stream.synchronize()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    before = gk.cg_persistent_solves()
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    took = gk.cg_persistent_solves() - before
+    assert 1 <= took <= 40
+    for r in results:
+        assert r["converged"] and abs(r["iterations"] - it) <= 1
+        assert matgen.rel_err(host(r["x"]), xe) <= 1e-7
