@@ -51,14 +51,14 @@ namespace gkomi {
 namespace {
 
 constexpr int block = 256;
-constexpr int max_nr = 4;
+constexpr int max_nr = 8;
 constexpr int halo_rows = 64;   // longest row the one-launch sorted variant takes
 constexpr int min_tile = 512;
 
 // nonzeros per thread / per workgroup for NR columns per pass (LDS: 8 NR + 4 B per nonzero)
 template <int NR>
 struct tile_shape {
-    static constexpr int items = NR == 1 ? 6 : (NR == 2 ? 4 : 2);
+    static constexpr int items = NR == 1 ? 6 : (NR == 2 ? 4 : 2);  // 8 columns: 2 too (37 KB of LDS)
     static constexpr int tile = block * items;
 };
 
@@ -488,7 +488,7 @@ int launch_tile(hipStream_t s, int groups, const coo_args& a, int64_t col)
     return check_launch();
 }
 
-// columns in passes of 4, 2 and 1 (max_nr: test / tuning hook GKOMI_COO_MAX_NR)
+// columns in passes of 8, 4, 2 and 1 (max_nr: test / tuning hook GKOMI_COO_MAX_NR)
 template <int CMode, int Halo>
 int tile_passes(hipStream_t s, int64_t nrhs, const coo_args& a)
 {
@@ -509,6 +509,7 @@ int tile_passes(hipStream_t s, int64_t nrhs, const coo_args& a)
     // four columns of atomics per segment land in one 32-B sector and serialise
     // (97 us vs 2 x 32 us on P2, profiles/r02_coo.log): pairs at most there
     if (CMode >= 0) {
+        GKOMI_PASS(8)
         GKOMI_PASS(4)
     }
     GKOMI_PASS(2)

@@ -123,7 +123,7 @@ def uncut_rows(nrows, rows):
     the tile sizes in use: 1536 / 1024 / 512 nonzeros for 1 / 2 / 4 columns per pass"""
     nnz = len(rows)
     cut = np.zeros(nrows, dtype=bool)
-    for tile in (TILE, 1024, 512):
+    for tile in (TILE, 1024, 512):   # (8 columns per pass: 512 too)
         for t in range(tile, nnz, tile):
             if rows[t - 1] == rows[t]:
                 cut[rows[t]] = True
@@ -136,7 +136,7 @@ def longest_row(rows):
 
 @pytest.mark.parametrize("variant", ["carries", "halo"])
 @pytest.mark.parametrize("mode", ["spmv", "advanced", "spmv2", "advanced_spmv2"])
-@pytest.mark.parametrize("nrhs", [1, 2, 3, 4, 7])
+@pytest.mark.parametrize("nrhs", [1, 2, 3, 4, 7, 8, 13])
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_sorted_against_the_oracle(gk, oracle, case, nrhs, mode, variant):
     nrows, ncols, rows, ci, v = CASES[case]
