@@ -560,6 +560,57 @@ int gkomi_trs_solve_plan_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
 int gkomi_trs_plan_check_overrun(gkomi_stream_t s, const void* plan,
                                  int* host_flag);
 
+/* ---- the brick plan: a second analysis for factors of grid problems -------------
+ * Same place in the reference (LowerTrs/UpperTrs::generate, common_trs_kernels.hip.hpp:61-253),
+ * same numerical contract (reference/solver/{lower,upper}_trs_kernels.cpp:90-123, bit-identical).
+ * The level plan above pays one memory hand-off per dependency level; factors of stencil
+ * matrices have hundreds to thousands of levels.  This analysis recovers the box grid from the
+ * factor's dependency offsets (a divisor chain 1 | nx | nx ny ...), cuts the rows into bricks of
+ * about `brick_rows` rows (<= 0: chosen) and lets ONE workgroup solve a brick out of LDS, levels
+ * inside a brick costing an LDS round trip.  mode 1: a brick starts when the bricks it depends
+ * on have FINISHED (`threads` = 64 / 128 / 256 compute threads, 0 = from the widest level; x may
+ * alias b).  mode 2 (= 0, default): PIPELINED -- a brick starts at once, a second wave pumps its
+ * inflow from memory into LDS while the one compute wave runs (x pre-filled with a NaN sentinel
+ * is its own ready flag; x must not alias b; `threads` is 64): a brick trails its neighbour by
+ * a brick edge, and the critical path is about the levels of the factor.
+ * The geometry is a guess that is never trusted: the brick graph is built from the actual
+ * entries and must be acyclic, rows may have at most 8 dependencies, a brick with its inflow
+ * must fit LDS -- else GKOMI_ENOTSUPPORTED (*out = NULL) and the caller keeps the level plan.
+ *   create   blocking, host-side symbolic analysis (downloads row_ptrs / col_idxs); the handle
+ *            owns host memory only -> gkomi_trs_bricks_destroy
+ *   info     out[8] = { bricks, brick levels, steps, steps on the critical path of mode 1, LDS
+ *            bytes of the largest brick, dependency slots per row, threads, mode }
+ *   numeric  fills `plan` (device memory, gkomi_trs_bricks_plan_bytes(h) bytes) from the
+ *            factor's values; again whenever the values change.  Blocking.
+ *   solve    x = L^-1 b / U^-1 b from the plan alone; a handle solves on one stream at a time.
+ * A solve whose bounded waits run out writes NaNs, and raises a STICKY flag in the plan
+ * (gkomi_trs_bricks_check_overrun; cleared by the numeric phase). */
+typedef struct gkomi_trs_bricks gkomi_trs_bricks;
+int gkomi_trs_bricks_create_i32(gkomi_stream_t s, int64_t n, const int32_t* row_ptrs,
+                                const int32_t* col_idxs, int lower, int64_t brick_rows,
+                                int threads, int mode, gkomi_trs_bricks** out);
+/* the same analysis from HOST copies of row_ptrs / col_idxs (no device needed), and read-only
+ * views of the handle's host arrays for inspection: which = 0 perm (plan position -> row),
+ * 1 brick_row_begin, 2 brick_step_ptr, 3 step_begin (top bit: the step opens a level),
+ * 4 brick_ext_begin, 5 ext_col, 6 pred_ptr, 7 pred_idx, 8 row -> brick rank, 9 row -> LDS index,
+ * 10 plan position -> index of its first inflow entry */
+int gkomi_trs_bricks_create_host_i32(int64_t n, const int32_t* host_row_ptrs,
+                                     const int32_t* host_col_idxs, int lower,
+                                     int64_t brick_rows, int threads, int mode,
+                                     gkomi_trs_bricks** out);
+int gkomi_trs_bricks_host_array(const gkomi_trs_bricks* h, int which, const int32_t** data,
+                                int64_t* count);
+void gkomi_trs_bricks_destroy(gkomi_trs_bricks* h);
+size_t gkomi_trs_bricks_plan_bytes(const gkomi_trs_bricks* h);
+int gkomi_trs_bricks_info(const gkomi_trs_bricks* h, int64_t* out);
+int gkomi_trs_bricks_numeric_f64_i32(gkomi_stream_t s, gkomi_trs_bricks* h,
+                                     const int32_t* row_ptrs, const int32_t* col_idxs,
+                                     const double* vals, void* plan, size_t plan_bytes);
+int gkomi_trs_bricks_solve_f64(gkomi_stream_t s, gkomi_trs_bricks* h, void* plan,
+                               int64_t nrhs, int unit_diag, const double* b,
+                               int64_t b_stride, double* x, int64_t x_stride);
+int gkomi_trs_bricks_check_overrun(gkomi_stream_t s, const void* plan, int* host_flag);
+
 /* ---- ParILU(0) (core/factorization/par_ilu.cpp:74-163) -------------------- */
 size_t gkomi_factorization_workspace_bytes(int64_t nrows);
 /* factorization::add_diagonal_elements in two phases because the caller owns

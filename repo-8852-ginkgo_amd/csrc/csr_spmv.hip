@@ -908,6 +908,39 @@ int csr_spmv_dot_num_partials(int nrows)
     return static_cast<int>(ceildiv(nrows, 256));
 }
 
+// The same for a matrix with its srow: the nonzero-split kernel with the dot-product epilogue, one
+// partial per tile -- for matrices that stream from HBM (no XCD chunking, nontemporal streams; 300 vs
+// 332 us per SpMV on the 256^3 7-point matrix).  Returns the number of partials, <= 0 when not
+// applicable (the tile must be one the kernel is built for).
+int csr_split_dot_num_partials(int64_t nnz, int64_t tile)
+{
+    if (tile != 2048 && tile != 3072) return 0;
+    return static_cast<int>(nnz / tile + 1);
+}
+
+int csr_split_dot_launch(hipStream_t stream, int nrows, int64_t nnz, const int32_t* row_ptrs,
+                         const int32_t* col_idxs, const double* vals, const double* p, double* q,
+                         double* partial, const uint8_t* stop_status, const int32_t* srow, int64_t tile,
+                         int over)
+{
+    constexpr int Block = 256;
+    const int ntiles = csr_split_dot_num_partials(nnz, tile);
+    if (ntiles <= 0) return GKOMI_ENOTSUPPORTED;
+    const int z = static_cast<int>(nnz);
+#define GKOMI_SPLIT_DOT(TILE)                                                                            \
+    hipLaunchKernelGGL((csr_split_kernel<Block, TILE, split_max_over, false, false, true, true, true>),  \
+                       dim3(ntiles), dim3(Block), 0, stream, nrows, z, row_ptrs, col_idxs, vals, p,      \
+                       int64_t{1}, q, int64_t{1}, nullptr, nullptr, srow, ntiles, 1, over, partial,     \
+                       stop_status, static_cast<const double*>(nullptr), static_cast<double*>(nullptr))
+    if (tile == 2048) {
+        GKOMI_SPLIT_DOT(2048);
+    } else {
+        GKOMI_SPLIT_DOT(3072);
+    }
+#undef GKOMI_SPLIT_DOT
+    return check_launch();
+}
+
 // swizzle heuristic shared by the automatic strategy: XCD-chunked row blocks
 // pay while the matrix is Infinity-Cache resident (measured 13.7 vs 15.1 us
 // warm at 1M rows) and cost ~4 % once it streams from HBM (57.3 vs 59.6 us at

@@ -11,6 +11,12 @@ int csr_spmv_dot_launch(hipStream_t stream, int nrows, int64_t nnz,
                         bool swizzle, const double* dot_w = nullptr,
                         double* partial2 = nullptr);
 int csr_spmv_dot_num_partials(int nrows);
+// the nonzero-split kernel with the dot epilogue, for matrices with an srow that stream from HBM
+int csr_split_dot_num_partials(int64_t nnz, int64_t tile);
+int csr_split_dot_launch(hipStream_t stream, int nrows, int64_t nnz, const int32_t* row_ptrs,
+                         const int32_t* col_idxs, const double* vals, const double* p, double* q,
+                         double* partial, const uint8_t* stop_status, const int32_t* srow, int64_t tile,
+                         int over);
 bool csr_auto_swizzle(int64_t nrows, int64_t nnz);
 
 // One single-launch ("persistent") solver kernel at a time per process: two of them would each

@@ -1,0 +1,1205 @@
+// Sparse triangular solves of STENCIL-SHAPED factors: the brick plan, a second kind of
+// LowerTrs / UpperTrs::generate analysis (hip/solver/common_trs_kernels.hip.hpp:61-253 runs
+// hipsparseXcsrsv2_analysis there).  Numerical contract = reference/solver/lower_trs_kernels.cpp:90-120,
+// upper_trs_kernels.cpp:90-123: per row the subtractions run in storage order, one division.
+//
+// Why a second plan: the level plan of trs_levels.hip pays one MEMORY hand-off per dependency
+// level (~1.7 us: publish, fabric round trip, poll cadence, pass), and the factors of grid
+// problems have hundreds to thousands of levels (7-point 108^3: 322, 5-point 1000^2: 1999).
+// Here the rows are cut into BRICKS -- boxes of the grid the matrix was assembled on -- and a
+// brick is solved by ONE workgroup with the brick's part of x in LDS:
+//   * inside a brick a level costs an LDS round trip + the division (+ an s_barrier when the
+//     workgroup has more than one wave): ~0.15-0.2 us, nothing on the fabric;
+//   * a brick starts when the bricks it depends on have FINISHED (one flag per brick, release /
+//     acquire at agent scope), so a memory hand-off is paid once per brick on the critical
+//     path, not once per level: 19 instead of 322 on the 108^3 factor with 16^3 bricks;
+//   * everything a level needs is in LDS by then: the right-hand side of the brick's rows and
+//     the values of x the brick needs from other bricks are gathered when the brick starts
+//     (all loads in flight together), the stored column indices are LDS indices, and the
+//     factor's entries are prefetched one step ahead -- the loop has no memory wait and no
+//     store (x leaves LDS in one sweep at the end).
+// The grid is not given, it is recovered: the distinct |row - col| of the factor's dependencies
+// must form a divisor chain 1 | s1 | s2 ... (lexicographic numbering of a box grid: 1, nx,
+// nx ny); rows get mixed-radix coordinates from it.  That is a guess about the numbering, never
+// trusted: the brick dependency graph is built from the actual entries and must be acyclic, every
+// row must have at most 8 dependencies, and a brick with its inflow must fit LDS -- otherwise the
+// analysis answers GKOMI_ENOTSUPPORTED and the caller keeps the level plan.  Any factor that
+// passes is solved bit-identically to the reference, whatever its values.
+//
+// Deadlock freedom: bricks are handed out by an atomic ticket in topological order of the
+// brick graph, so the bricks a workgroup waits for belong to workgroups that have started; waits
+// are bounded and a brick that gives up poisons its rows (NaN), marks itself finished (no
+// cascade of timeouts) and raises a STICKY flag.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <new>
+#include <vector>
+
+struct gkomi_trs_bricks {
+    int64_t n = 0;
+    int lower = 1;
+    int width = 0;    // dependency slots per row (ELL width of the plan)
+    int threads = 64; // compute threads of a workgroup of the solve
+    int mode = 2;     // 1: a brick starts when its predecessors have finished; 2: pipelined (inflow pump)
+    int64_t nbricks = 0, nsteps = 0, coarse_levels = 0, critical_steps = 0, lds_bytes_max = 0;
+    int64_t max_brick_steps = 0, nlevels_fine = 0;
+    std::vector<int32_t> perm;             // plan position -> row
+    std::vector<int32_t> inv_local;        // row -> LDS index inside its brick
+    std::vector<int32_t> row_rank;         // row -> rank of its brick (topological order)
+    std::vector<int32_t> ext_row_off;      // plan position -> index of its first inflow entry
+    std::vector<int32_t> brick_row_begin;  // nbricks + 1
+    std::vector<int32_t> brick_step_ptr;   // nbricks + 1
+    std::vector<int32_t> step_begin;       // nsteps + 1; top bit: the step opens a level
+    std::vector<int32_t> brick_ext_begin;  // nbricks + 1
+    std::vector<int32_t> ext_col;          // row whose x an inflow entry needs
+    std::vector<int32_t> pred_ptr, pred_idx;
+    uint32_t epoch = 0;
+    const void* uploaded_to = nullptr;
+};
+
+namespace gkomi {
+namespace {
+
+constexpr int max_width = 8;
+constexpr int max_offsets = 16;
+constexpr int max_dims = 6;
+constexpr int max_preds = 64;
+constexpr int32_t pad_col = INT32_MIN;
+constexpr int32_t level_bit = INT32_MIN;  // top bit of a step_begin entry
+constexpr long long default_max_polls = 1ll << 22;
+constexpr size_t max_lds_bytes = 144 * 1024;  // of 160 KiB per CU
+
+struct brick_header {
+    int64_t n;
+    int64_t nbricks;
+    unsigned int ticket;
+    unsigned int finished;
+    unsigned int overrun;  // sticky: zeroed by the numeric phase, never by a solve
+    int32_t lower;
+};
+static_assert(sizeof(brick_header) <= 256, "the plan header has 256 bytes");
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct brick_layout {
+    size_t perm, diag, rdiag, cols, vals, brick_row_begin, brick_step_ptr, step_begin, brick_ext_begin, ext_col,
+        pred_ptr, pred_idx, done, row_rank, inv_local, ext_row_off, total;
+};
+
+brick_layout make_layout(const gkomi_trs_bricks& h)
+{
+    brick_layout l{};
+    const size_t n = static_cast<size_t>(h.n > 0 ? h.n : 1);
+    const size_t nb = static_cast<size_t>(h.nbricks);
+    auto ints = [](size_t count) { return align_up(sizeof(int32_t) * (count > 0 ? count : 1), 256); };
+    size_t off = 256;
+    l.perm = off; off += ints(n);
+    l.diag = off; off += align_up(sizeof(double) * n, 256);
+    l.rdiag = off; off += align_up(sizeof(double) * n, 256);
+    l.cols = off; off += ints(n * h.width);
+    l.vals = off; off += align_up(sizeof(double) * n * h.width, 256);
+    l.brick_row_begin = off; off += ints(nb + 1);
+    l.brick_step_ptr = off; off += ints(nb + 1);
+    l.step_begin = off; off += ints(h.step_begin.size());
+    l.brick_ext_begin = off; off += ints(nb + 1);
+    l.ext_col = off; off += ints(h.ext_col.size());
+    l.pred_ptr = off; off += ints(nb + 1);
+    l.pred_idx = off; off += ints(h.pred_idx.size());
+    l.done = off; off += ints(nb);
+    l.row_rank = off; off += ints(n);
+    l.inv_local = off; off += ints(n);
+    l.ext_row_off = off; off += ints(n);
+    l.total = off;
+    return l;
+}
+
+// LDS of a brick with R rows, E inflow values, S steps and K dependency slots per row:
+//   x[R + E] | 0.0 | diag[R] | 1 / diag[R] | vals[K R] | cols[K R] | step bounds[S + 4] | rows[R] | inflow rows[E]
+// | inflow needed by step[S + 4]  (the last five: int)
+__host__ __device__ inline size_t brick_lds_bytes(int64_t rows, int64_t inflow, int64_t steps, int width)
+{
+    return sizeof(double) * static_cast<size_t>(rows + inflow + 1 + 2 * rows + width * rows) +
+           sizeof(int32_t) * static_cast<size_t>(width * rows + 2 * (steps + 4) + rows + inflow);
+}
+
+inline bool is_dep(bool lower, int64_t col, int64_t row) { return lower ? col < row : col > row; }
+
+// ---------------------------------------------------------------- analysis (host) ----------
+
+// the whole symbolic analysis; GKOMI_ENOTSUPPORTED = this factor is not for the brick plan
+int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vector<int32_t>& ci,
+            int64_t brick_rows, int threads, int mode)
+{
+    h.mode = mode == 1 ? 1 : 2;
+    if (h.mode == 2) threads = 64;  // one compute wave (+ the pump)
+    const int64_t n = h.n;
+    const bool lower = h.lower != 0;
+    // 1. the distinct dependency offsets and the longest dependency list
+    int64_t offs[max_offsets];
+    int noffs = 0;
+    int width = 0;
+    for (int64_t row = 0; row < n; ++row) {
+        int deps = 0;
+        for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
+            const int64_t col = ci[k];
+            if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
+            ++deps;
+            const int64_t d = lower ? row - col : col - row;
+            int j = 0;
+            while (j < noffs && offs[j] != d) ++j;
+            if (j == noffs) {
+                if (noffs == max_offsets) return GKOMI_ENOTSUPPORTED;
+                offs[noffs++] = d;
+            }
+        }
+        width = std::max(width, deps);
+    }
+    if (noffs == 0 || width > max_width) return GKOMI_ENOTSUPPORTED;
+    std::sort(offs, offs + noffs);
+    // 2. strides of a lexicographic box numbering: a divisor chain
+    int64_t stride[max_dims];
+    int dims = 0;
+    stride[dims++] = 1;
+    for (int j = 0; j < noffs; ++j) {
+        if (offs[j] == stride[dims - 1]) continue;
+        if (offs[j] % stride[dims - 1] != 0 || dims == max_dims) return GKOMI_ENOTSUPPORTED;
+        stride[dims++] = offs[j];
+    }
+    int64_t extent[max_dims];
+    for (int k = 0; k + 1 < dims; ++k) extent[k] = stride[k + 1] / stride[k];
+    extent[dims - 1] = ceildiv(n, stride[dims - 1]);
+    if (brick_rows <= 0) {
+        // pipelined: levels of a brick should fit the one compute wave (8^3, 32^2); else large bricks
+        int wide = 0;
+        for (int k = 0; k < dims; ++k) wide += extent[k] > 1;
+        brick_rows = h.mode == 2 ? (wide >= 3 ? 512 : 1024) : 4096;
+    }
+    // 3. brick edges: about brick_rows rows per brick, near-cubic, an even split of every extent;
+    //    shrunk until a brick with its inflow fits LDS
+    for (int attempt = 0; attempt < 8; ++attempt, brick_rows = std::max<int64_t>(brick_rows / 2, 8)) {
+        int64_t edge[max_dims], nbk[max_dims];
+        {
+            int order[max_dims];
+            for (int k = 0; k < dims; ++k) order[k] = k;
+            std::sort(order, order + dims, [&](int a, int b) { return extent[a] < extent[b]; });
+            double remaining = static_cast<double>(std::max<int64_t>(brick_rows, 1));
+            for (int q = 0; q < dims; ++q) {
+                const int k = order[q];
+                const double want = std::pow(remaining, 1.0 / (dims - q));
+                int64_t e = std::max<int64_t>(1, static_cast<int64_t>(std::llround(want)));
+                e = std::min(e, extent[k]);
+                nbk[k] = ceildiv(extent[k], e);
+                edge[k] = ceildiv(extent[k], nbk[k]);
+                nbk[k] = ceildiv(extent[k], edge[k]);
+                remaining = std::max(1.0, remaining / static_cast<double>(edge[k]));
+            }
+        }
+        int64_t nbricks = 1;
+        for (int k = 0; k < dims; ++k) {
+            nbricks *= nbk[k];
+            if (nbricks > (1 << 24)) return GKOMI_ENOTSUPPORTED;
+        }
+        std::vector<int32_t> brick(static_cast<size_t>(n));
+        for (int64_t row = 0; row < n; ++row) {
+            int64_t id = 0, mul = 1;
+            for (int k = 0; k < dims; ++k) {
+                const int64_t c = k + 1 < dims ? (row / stride[k]) % extent[k] : row / stride[k];
+                id += (c / edge[k]) * mul;
+                mul *= nbk[k];
+            }
+            brick[row] = static_cast<int32_t>(id);
+        }
+        // 4. the brick graph from the actual entries (never from the guessed geometry)
+        std::vector<int32_t> npred(static_cast<size_t>(nbricks), 0);
+        std::vector<int32_t> preds(static_cast<size_t>(nbricks) * max_preds);
+        for (int64_t row = 0; row < n; ++row) {
+            const int32_t mine = brick[row];
+            for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
+                const int64_t col = ci[k];
+                if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
+                const int32_t other = brick[col];
+                if (other == mine) continue;
+                int32_t* list = preds.data() + static_cast<size_t>(mine) * max_preds;
+                int j = 0;
+                while (j < npred[mine] && list[j] != other) ++j;
+                if (j == npred[mine]) {
+                    if (npred[mine] == max_preds) return GKOMI_ENOTSUPPORTED;
+                    list[npred[mine]++] = other;
+                }
+            }
+        }
+        // coarse levels by longest path (Kahn); a cycle = the guessed geometry is wrong
+        std::vector<int32_t> succ_ptr(static_cast<size_t>(nbricks) + 1, 0);
+        for (int64_t b = 0; b < nbricks; ++b) {
+            for (int j = 0; j < npred[b]; ++j) ++succ_ptr[preds[b * max_preds + j] + 1];
+        }
+        for (int64_t b = 0; b < nbricks; ++b) succ_ptr[b + 1] += succ_ptr[b];
+        std::vector<int32_t> succ(static_cast<size_t>(succ_ptr[nbricks]));
+        {
+            std::vector<int32_t> cursor(succ_ptr.begin(), succ_ptr.end() - 1);
+            for (int64_t b = 0; b < nbricks; ++b) {
+                for (int j = 0; j < npred[b]; ++j) succ[cursor[preds[b * max_preds + j]]++] = static_cast<int32_t>(b);
+            }
+        }
+        std::vector<int32_t> coarse(static_cast<size_t>(nbricks), 0), waiting(npred);
+        std::vector<int32_t> topo;
+        topo.reserve(static_cast<size_t>(nbricks));
+        for (int64_t b = 0; b < nbricks; ++b) {
+            if (waiting[b] == 0) topo.push_back(static_cast<int32_t>(b));
+        }
+        for (size_t q = 0; q < topo.size(); ++q) {
+            const int32_t b = topo[q];
+            for (int32_t j = succ_ptr[b]; j < succ_ptr[b + 1]; ++j) {
+                const int32_t t = succ[j];
+                coarse[t] = std::max(coarse[t], coarse[b] + 1);
+                if (--waiting[t] == 0) topo.push_back(t);
+            }
+        }
+        if (static_cast<int64_t>(topo.size()) != nbricks) return GKOMI_ENOTSUPPORTED;
+        // 5. rank = position of a brick in (coarse level, id) order; empty bricks stay (zero rows)
+        int32_t ncoarse = 0;
+        for (int64_t b = 0; b < nbricks; ++b) ncoarse = std::max(ncoarse, coarse[b] + 1);
+        std::vector<int32_t> rank(static_cast<size_t>(nbricks));
+        {
+            std::vector<int32_t> count(static_cast<size_t>(ncoarse) + 1, 0);
+            for (int64_t b = 0; b < nbricks; ++b) ++count[coarse[b] + 1];
+            for (int32_t l = 0; l < ncoarse; ++l) count[l + 1] += count[l];
+            for (int64_t b = 0; b < nbricks; ++b) rank[b] = count[coarse[b]]++;
+        }
+        // 6. level of a row inside its brick (dependencies on other bricks do not count: those
+        //    bricks have finished when this one starts)
+        std::vector<int32_t> fine(static_cast<size_t>(n), 0);
+        std::vector<int32_t> nfine(static_cast<size_t>(nbricks), 0), brick_rows_count(static_cast<size_t>(nbricks), 0),
+            brick_ext(static_cast<size_t>(nbricks), 0);
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t row = lower ? i : n - 1 - i;
+            const int32_t mine = brick[row];
+            int32_t lvl = 0;
+            for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
+                const int64_t col = ci[k];
+                if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
+                if (brick[col] == mine) {
+                    lvl = std::max(lvl, fine[col] + 1);
+                } else {
+                    ++brick_ext[mine];
+                }
+            }
+            fine[row] = lvl;
+            nfine[mine] = std::max(nfine[mine], lvl + 1);
+            ++brick_rows_count[mine];
+        }
+        // LDS of the largest brick: x + inflow, and the brick's part of the factor (see the solve)
+        const int slots = width <= 2 ? 2 : width <= 3 ? 3 : width <= 4 ? 4 : 8;  // the widths the solve is built for
+        int64_t max_lds = 0;
+        for (int64_t b = 0; b < nbricks; ++b) {
+            const int64_t r = brick_rows_count[b];
+            // steps <= levels + rows / threads <= 2 rows + 1
+            max_lds = std::max<int64_t>(max_lds, static_cast<int64_t>(brick_lds_bytes(r, brick_ext[b], 2 * r + 1, slots)));
+        }
+        if (static_cast<size_t>(max_lds) + 256 > max_lds_bytes) {
+            if (brick_rows <= 8) return GKOMI_ENOTSUPPORTED;
+            continue;  // smaller bricks
+        }
+        // 7. plan order: bricks by rank, rows of a brick by level, rows of a level by row index
+        h.nbricks = nbricks;
+        h.coarse_levels = ncoarse;
+        h.width = slots;
+        h.lds_bytes_max = max_lds;
+        h.brick_row_begin.assign(static_cast<size_t>(nbricks) + 1, 0);
+        h.brick_ext_begin.assign(static_cast<size_t>(nbricks) + 1, 0);
+        std::vector<int32_t> level_off(static_cast<size_t>(nbricks) + 1, 0);  // by rank
+        std::vector<int32_t> by_rank(static_cast<size_t>(nbricks));
+        for (int64_t b = 0; b < nbricks; ++b) by_rank[rank[b]] = static_cast<int32_t>(b);
+        for (int64_t r = 0; r < nbricks; ++r) {
+            const int32_t b = by_rank[r];
+            h.brick_row_begin[r + 1] = h.brick_row_begin[r] + brick_rows_count[b];
+            h.brick_ext_begin[r + 1] = h.brick_ext_begin[r] + brick_ext[b];
+            level_off[r + 1] = level_off[r] + nfine[b];
+        }
+        std::vector<int32_t> level_pos(static_cast<size_t>(level_off[nbricks]) + 1, 0);
+        for (int64_t row = 0; row < n; ++row) ++level_pos[level_off[rank[brick[row]]] + fine[row] + 1];
+        for (size_t j = 0; j + 1 < level_pos.size(); ++j) level_pos[j + 1] += level_pos[j];
+        // level_pos[level_off[r] + l] = first plan position of level l of the brick with rank r
+        int max_level_rows = 0;
+        for (size_t j = 0; j + 1 < level_pos.size(); ++j) {
+            max_level_rows = std::max(max_level_rows, level_pos[j + 1] - level_pos[j]);
+        }
+        if (threads <= 0) threads = max_level_rows <= 64 ? 64 : max_level_rows <= 160 ? 128 : 256;
+        h.threads = threads;
+        h.nlevels_fine = level_off[nbricks];
+        // steps: a level in chunks of `threads` rows
+        h.brick_step_ptr.assign(static_cast<size_t>(nbricks) + 1, 0);
+        h.step_begin.clear();
+        for (int64_t r = 0; r < nbricks; ++r) {
+            for (int32_t j = level_off[r]; j < level_off[r + 1]; ++j) {
+                for (int32_t p = level_pos[j]; p < level_pos[j + 1]; p += threads) {
+                    h.step_begin.push_back(p == level_pos[j] ? (p | level_bit) : p);
+                }
+            }
+            h.brick_step_ptr[r + 1] = static_cast<int32_t>(h.step_begin.size());
+        }
+        h.nsteps = static_cast<int64_t>(h.step_begin.size());
+        h.step_begin.push_back(static_cast<int32_t>(n) | level_bit);
+        h.perm.assign(static_cast<size_t>(n), 0);
+        h.inv_local.assign(static_cast<size_t>(n), 0);
+        h.row_rank.assign(static_cast<size_t>(n), 0);
+        {
+            std::vector<int32_t> cursor(level_pos.begin(), level_pos.end() - 1);
+            for (int64_t row = 0; row < n; ++row) {
+                const int32_t r = rank[brick[row]];
+                const int32_t p = cursor[level_off[r] + fine[row]]++;
+                h.perm[p] = static_cast<int32_t>(row);
+                h.inv_local[row] = p - h.brick_row_begin[r];
+                h.row_rank[row] = r;
+            }
+        }
+        // inflow lists in plan order, entries of a row in storage order
+        h.ext_row_off.assign(static_cast<size_t>(n), 0);
+        h.ext_col.clear();
+        h.ext_col.reserve(static_cast<size_t>(h.brick_ext_begin[nbricks]));
+        for (int64_t p = 0; p < n; ++p) {
+            const int64_t row = h.perm[p];
+            h.ext_row_off[p] = static_cast<int32_t>(h.ext_col.size());
+            for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
+                const int64_t col = ci[k];
+                if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
+                if (brick[col] != brick[row]) h.ext_col.push_back(static_cast<int32_t>(col));
+            }
+        }
+        // the bricks a brick waits for, as ranks; critical path in steps
+        h.pred_ptr.assign(static_cast<size_t>(nbricks) + 1, 0);
+        h.pred_idx.clear();
+        std::vector<int64_t> path(static_cast<size_t>(nbricks), 0);
+        h.critical_steps = 0;
+        h.max_brick_steps = 0;
+        for (int64_t r = 0; r < nbricks; ++r) {
+            const int32_t b = by_rank[r];
+            int64_t before = 0;
+            for (int j = 0; j < npred[b]; ++j) {
+                const int32_t pr = rank[preds[static_cast<size_t>(b) * max_preds + j]];
+                h.pred_idx.push_back(pr);
+                before = std::max(before, path[pr]);  // pr < r: already final
+            }
+            h.pred_ptr[r + 1] = static_cast<int32_t>(h.pred_idx.size());
+            const int64_t steps = h.brick_step_ptr[r + 1] - h.brick_step_ptr[r];
+            path[r] = before + steps;
+            h.critical_steps = std::max(h.critical_steps, path[r]);
+            h.max_brick_steps = std::max(h.max_brick_steps, steps);
+        }
+        return GKOMI_SUCCESS;
+    }
+    return GKOMI_ENOTSUPPORTED;
+}
+
+// ---------------------------------------------------------------- numeric phase (device) ----
+
+// ---- x / d without the division's latency -------------------------------------------------
+// The compiler's f64 division is v_div_scale (x2), v_rcp, two Newton steps on the reciprocal,
+// q = n r, e = fma(-d, q, n), v_div_fmas = fma(e, r, q), v_div_fixup: 12 dependent instructions on
+// the critical path of every level.  The reciprocal part depends on d alone -- as long as
+// v_div_scale leaves both operands unscaled, which it does when their exponents are moderate --
+// so the numeric phase runs exactly that part once per row, and the solve finishes with the
+// last three operations: the same instructions on the same operands, hence the same bits as
+// sum / d.  Outside the box (|d| or |sum| not in [2^-383, 2^383), zero, NaN, infinity, subnormal)
+// the solve divides.  tests/test_trs_bricks_gpu.py pins it against the oracle's division over
+// the full exponent range.
+constexpr int safe_exponent_lo = 1023 - 383, safe_exponent_hi = 1023 + 383;  // biased, half-open
+
+__device__ __forceinline__ bool exponent_is_safe(double v)
+{
+    const int e = static_cast<int>((__double_as_longlong(v) >> 52) & 0x7ff);
+    return e >= safe_exponent_lo && e < safe_exponent_hi;
+}
+
+// r as the division computes it for an unscaled denominator; NaN = "divide"
+__device__ __forceinline__ double refined_reciprocal(double d)
+{
+    if (!exponent_is_safe(d)) return __longlong_as_double(0x7ff8000000000000ll);
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
+__device__ __forceinline__ double divide_by_row_diagonal(double sum, double d, double r)
+{
+    if (exponent_is_safe(sum) && r == r) {
+        const double q = sum * r;
+        const double e = __builtin_fma(-d, q, sum);
+        return __builtin_fma(e, r, q);
+    }
+    return sum / d;
+}
+
+// the factor once more in plan order: dependencies only, as LDS indices of the brick (own rows:
+// 0 .. R-1, inflow: R ...), ELL over the whole plan (slot e of position p at e * n + p), the
+// diagonal (last stored occurrence, like the reference's loop) apart
+__global__ __launch_bounds__(256) void trs_brick_fill_kernel(
+    int32_t n, int width, bool lower, const int32_t* __restrict__ row_ptrs, const int32_t* __restrict__ col_idxs,
+    const double* __restrict__ vals, const int32_t* __restrict__ perm, const int32_t* __restrict__ row_rank,
+    const int32_t* __restrict__ inv_local, const int32_t* __restrict__ ext_row_off,
+    const int32_t* __restrict__ brick_row_begin, const int32_t* __restrict__ brick_ext_begin,
+    double* __restrict__ diag, double* __restrict__ rdiag, int32_t* __restrict__ cols,
+    double* __restrict__ pvals)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int row = perm[p];
+    const int rank = row_rank[row];
+    const int rows_here = brick_row_begin[rank + 1] - brick_row_begin[rank];
+    int inflow = ext_row_off[p] - brick_ext_begin[rank];
+    double d = 1.0;
+    int e = 0;
+    for (int k = row_ptrs[row]; k < row_ptrs[row + 1]; ++k) {
+        const int col = col_idxs[k];
+        if (col == row) d = vals[k];
+        if ((lower ? col < row : col > row) && col >= 0 && col < n) {
+            int c;
+            if (row_rank[col] == rank) {
+                c = inv_local[col];
+            } else {
+                c = rows_here + inflow;
+                ++inflow;
+            }
+            if (e < width) {
+                cols[static_cast<int64_t>(e) * n + p] = c;
+                pvals[static_cast<int64_t>(e) * n + p] = vals[k];
+            }
+            ++e;
+        }
+    }
+    diag[p] = d;
+    rdiag[p] = refined_reciprocal(d);
+    for (; e < width; ++e) {
+        cols[static_cast<int64_t>(e) * n + p] = pad_col;
+        pvals[static_cast<int64_t>(e) * n + p] = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------- solve ---------------------
+
+// LDS-only barrier: the prefetch loads of the next step stay in flight (__syncthreads waits
+// for vmcnt(0)); a one-wave workgroup needs the ordering only
+template <int T>
+__device__ __forceinline__ void lds_barrier()
+{
+    if (T > 64) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <int T, int K, bool Unit>
+__global__ __launch_bounds__(T) void trs_brick_solve_kernel(
+    brick_header* hdr, const int32_t* __restrict__ perm, const double* __restrict__ diag,
+    const double* __restrict__ rdiag, const int32_t* __restrict__ cols, const double* __restrict__ pvals,
+    const int32_t* __restrict__ brick_row_begin, const int32_t* __restrict__ brick_step_ptr,
+    const int32_t* __restrict__ step_begin, const int32_t* __restrict__ brick_ext_begin,
+    const int32_t* __restrict__ ext_col, const int32_t* __restrict__ pred_ptr,
+    const int32_t* __restrict__ pred_idx, unsigned int* done, int32_t n, const double* b,
+    int64_t b_stride, double* x, int64_t x_stride, unsigned int epoch, long long max_polls)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ unsigned int s_ticket;
+    __shared__ int s_gave_up;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        s_ticket = atomicAdd(&hdr->ticket, 1u);
+        s_gave_up = 0;
+    }
+    __syncthreads();
+    const int bk = static_cast<int>(s_ticket);
+    const int r0 = brick_row_begin[bk], rows = brick_row_begin[bk + 1] - r0;
+    const int e0 = brick_ext_begin[bk], inflow = brick_ext_begin[bk + 1] - e0;
+    const int s0 = brick_step_ptr[bk], nsteps = brick_step_ptr[bk + 1] - s0;
+    double* lx = lds;                    // right-hand side, then the solution, then the inflow
+    const int zero_cell = rows + inflow; // lx[zero_cell] = 0.0: what an empty dependency slot points at
+    double* ld = lx + zero_cell + 1;     // diagonal
+    double* lr = ld + rows;              // its reciprocal as the division would compute it
+    double* lv = lr + rows;              // values, slot-major
+    int32_t* lc = reinterpret_cast<int32_t*>(lv + static_cast<size_t>(K) * rows);  // LDS indices, slot-major
+    int32_t* ls = lc + static_cast<size_t>(K) * rows;                              // step bounds
+    int32_t* lrow = ls + nsteps + 4;                                               // my rows
+    int32_t* lext = lrow + rows;                                                   // rows my inflow comes from
+    // A. nothing here depends on other bricks, and the brick usually still waits for them: the
+    //    right-hand side of my rows and my part of the factor into LDS, every load in flight
+    for (int i = tid; i < rows; i += T) {
+        const int row = perm[r0 + i];
+        lrow[i] = row;
+        lx[i] = b[row * b_stride];
+        if (!Unit) {
+            ld[i] = diag[r0 + i];
+            lr[i] = rdiag[r0 + i];
+        }
+#pragma unroll
+        for (int e = 0; e < K; ++e) {
+            // an empty slot: value 0.0 (as stored) times the zero cell, sum - (+0.0) = sum bit for bit
+            const int c = cols[static_cast<int64_t>(e) * n + r0 + i];
+            lv[e * rows + i] = pvals[static_cast<int64_t>(e) * n + r0 + i];
+            lc[e * rows + i] = c == pad_col ? zero_cell : c;
+        }
+    }
+    if (tid == 0) lx[zero_cell] = 0.0;
+    for (int i = tid; i < nsteps + 4; i += T) ls[i] = step_begin[s0 + min(i, nsteps)];  // read up to 3 steps ahead
+    for (int j = tid; j < inflow; j += T) lext[j] = ext_col[e0 + j];
+    // B. the bricks I depend on have finished?  (they hold smaller tickets: they have started)
+    {
+        bool gave_up = false;
+        for (int j = pred_ptr[bk] + tid; j < pred_ptr[bk + 1]; j += T) {
+            const unsigned int* flag = done + pred_idx[j];
+            long long polls = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                if (++polls > max_polls) {
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (gave_up) s_gave_up = 1;
+        // no acquire fence (it would invalidate the XCD's L2): the only data of other bricks read
+        // below is x, with agent-scope loads that go to memory, issued after the flags were seen
+    }
+    __syncthreads();
+    const bool poisoned = s_gave_up != 0;
+    if (!poisoned) {
+        // C. what my rows need from other bricks, all loads in flight together
+        for (int j = tid; j < inflow; j += T) {
+            lx[rows + j] = __longlong_as_double(static_cast<long long>(__hip_atomic_load(
+                reinterpret_cast<const unsigned long long*>(x) + static_cast<int64_t>(lext[j]) * x_stride,
+                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        }
+        __syncthreads();
+        // D. level by level, LDS only.  A step = at most T rows of one level.  What a step costs is
+        //    the chain barrier -> x of the dependencies -> subtractions -> division -> write, so
+        //    everything else is kept off it: the factor's entries of the NEXT step are requested
+        //    right behind this step's x reads (LDS answers in order) and the step bounds two steps
+        //    ahead, all of it in registers by the time it is needed.
+        struct step_data {
+            int i;  // my row of the brick, -1 = none
+            bool opens_level;
+            double d, r;
+            int c[K];
+            double v[K];
+        };
+        auto fetch = [&](int s, int first, int next_first, step_data& sd) {
+            sd.i = -1;
+            sd.opens_level = false;
+            if (s >= nsteps) return;
+            const int begin = (first & ~level_bit) - r0;
+            const int end = min((next_first & ~level_bit) - r0, begin + T);
+            sd.opens_level = first < 0;
+            const int i = begin + tid;
+            if (i < end) {
+                sd.i = i;
+                if (!Unit) {
+                    sd.d = ld[i];
+                    sd.r = lr[i];
+                }
+#pragma unroll
+                for (int e = 0; e < K; ++e) {
+                    sd.c[e] = lc[e * rows + i];
+                    sd.v[e] = lv[e * rows + i];
+                }
+            }
+        };
+        // one step: `cur` is complete; `nxt` and the bound three steps on are requested on the way
+        auto step = [&](int s, const step_data& cur, step_data& nxt, int w1, int w2, int& w3) {
+            if (cur.opens_level) lds_barrier<T>();  // the level before is in LDS
+            double xd[K];
+            double sum = 0.0;
+            if (cur.i >= 0) {
+#pragma unroll
+                for (int e = 0; e < K; ++e) xd[e] = lx[cur.c[e]];
+                sum = lx[cur.i];
+            }
+            w3 = ls[s + 3];
+            fetch(s + 1, w1, w2, nxt);
+            if (cur.i >= 0) {
+#pragma unroll
+                for (int e = 0; e < K; ++e) sum -= cur.v[e] * xd[e];
+                lx[cur.i] = Unit ? sum : divide_by_row_diagonal(sum, cur.d, cur.r);
+            }
+        };
+        step_data even, odd;
+        int w1 = ls[1], w2 = ls[2];  // bounds of the steps s + 1, s + 2
+        fetch(0, ls[0], w1, even);
+        for (int s = 0; s < nsteps; s += 2) {
+            int w3, w4;
+            step(s, even, odd, w1, w2, w3);      // requests the bound of step s + 3
+            step(s + 1, odd, even, w2, w3, w4);  // ... s + 4
+            w1 = w3;
+            w2 = w4;
+        }
+    }
+    __syncthreads();
+    // E. the brick leaves LDS in one sweep (write-through: other XCDs read it from memory)
+    for (int i = tid; i < rows; i += T) {
+        const double xr = poisoned ? __longlong_as_double(0x7ff8dead0badbeefll) : lx[i];
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(x) + lrow[i] * x_stride,
+                           static_cast<unsigned long long>(__double_as_longlong(xr)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();  // every wave has waited for its (write-through) stores: x is in memory
+    if (tid == 0) {
+        // a release, although x went out write-through and every wave has counted its stores down: the
+        // count says the XCD's L2 has them, not that they have reached memory, and a relaxed flag
+        // overtook them once in ~10^2 full-size solves (stale x in a brick of another XCD)
+        __hip_atomic_store(done + bk, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (poisoned) atomicExch(&hdr->overrun, 1u);
+        // the last brick to finish re-arms the plan for the next solve (all tickets are taken by then)
+        const unsigned int before = atomicAdd(&hdr->finished, 1u);
+        if (before + 1 == static_cast<unsigned int>(hdr->nbricks)) {
+            hdr->finished = 0;
+            hdr->ticket = 0;
+        }
+    }
+}
+
+
+// ---- pipelined variant ----------------------------------------------------------------------
+// Waiting for whole bricks makes the critical path (bricks on the longest chain) x (levels of a
+// brick): 2-2.6 times the levels of the factor.  Here a brick starts at once and its inflow
+// arrives WHILE it runs: x is pre-filled with a sentinel NaN and doubles as its own ready flag
+// (as in the level plan), every row is written through to memory the moment it is complete, and
+// a second wave of the workgroup -- the pump -- walks the brick's inflow list (it is sorted by
+// the step that needs it), polls x in memory, drops the values into LDS and advances a counter.
+// The compute wave (ONE wave: no barrier in the loop) reads the counter and its dependencies in
+// one LDS round trip per step and repeats the step only if the counter is short.  A brick then
+// trails its neighbour by one brick edge, not by a whole brick: critical path ~ levels of the
+// factor + bricks on the chain x memory latency.  x and b must not alias (x carries the flags).
+constexpr unsigned long long sentinel_bits = 0x7ff8dead0badbeefull;
+constexpr unsigned long long poison_bits = 0x7ff8dead0badf00dull;  // a NaN that is not the sentinel
+
+__global__ __launch_bounds__(256) void trs_brick_prepare_kernel(int64_t n, double* __restrict__ x, int64_t x_stride)
+{
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) {
+        reinterpret_cast<unsigned long long*>(x)[i * x_stride] = sentinel_bits;
+    }
+}
+
+template <int K, bool Unit>
+__global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
+    brick_header* hdr, const int32_t* __restrict__ perm, const double* __restrict__ diag,
+    const double* __restrict__ rdiag, const int32_t* __restrict__ cols, const double* __restrict__ pvals,
+    const int32_t* __restrict__ brick_row_begin, const int32_t* __restrict__ brick_step_ptr,
+    const int32_t* __restrict__ step_begin, const int32_t* __restrict__ brick_ext_begin,
+    const int32_t* __restrict__ ext_col, const int32_t* __restrict__ ext_row_off, int32_t n,
+    const double* __restrict__ b, int64_t b_stride, double* x, int64_t x_stride, long long max_polls)
+{
+    constexpr int T = 64;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ unsigned int s_ticket;
+    __shared__ int s_inflow_ready;  // inflow entries [0, s_inflow_ready) are in LDS; -1: the pump gave up
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        s_ticket = atomicAdd(&hdr->ticket, 1u);
+        s_inflow_ready = 0;
+    }
+    __syncthreads();
+    const int bk = static_cast<int>(s_ticket);
+    const int r0 = brick_row_begin[bk], rows = brick_row_begin[bk + 1] - r0;
+    const int e0 = brick_ext_begin[bk], inflow = brick_ext_begin[bk + 1] - e0;
+    const int s0 = brick_step_ptr[bk], nsteps = brick_step_ptr[bk + 1] - s0;
+    double* lx = lds;
+    const int zero_cell = rows + inflow;
+    double* ld = lx + zero_cell + 1;
+    double* lr = ld + rows;
+    double* lv = lr + rows;
+    int32_t* lc = reinterpret_cast<int32_t*>(lv + static_cast<size_t>(K) * rows);
+    int32_t* ls = lc + static_cast<size_t>(K) * rows;  // step bounds
+    int32_t* lrow = ls + nsteps + 4;
+    int32_t* lext = lrow + rows;
+    int32_t* lneed = lext + inflow;                    // inflow entries step s needs: [0, lneed[s])
+    // A. my part of the factor and of the right-hand side into LDS (both waves)
+    for (int i = tid; i < rows; i += 128) {
+        const int row = perm[r0 + i];
+        lrow[i] = row;
+        lx[i] = b[row * b_stride];
+        if (!Unit) {
+            ld[i] = diag[r0 + i];
+            lr[i] = rdiag[r0 + i];
+        }
+#pragma unroll
+        for (int e = 0; e < K; ++e) {
+            const int c = cols[static_cast<int64_t>(e) * n + r0 + i];
+            lv[e * rows + i] = pvals[static_cast<int64_t>(e) * n + r0 + i];
+            lc[e * rows + i] = c == pad_col ? zero_cell : c;
+        }
+    }
+    for (int i = tid; i < nsteps + 4; i += 128) {
+        const int s = min(i, nsteps);
+        ls[i] = step_begin[s0 + s];
+        // rows of the steps up to and including s end at `end`: their inflow entries come first in the list
+        int need = inflow;
+        if (s < nsteps) {
+            const int begin = step_begin[s0 + s] & ~level_bit;
+            const int end = min(step_begin[s0 + s + 1] & ~level_bit, begin + T);
+            if (end < r0 + rows) need = ext_row_off[end] - e0;
+        }
+        lneed[i] = need;
+    }
+    for (int j = tid; j < inflow; j += 128) lext[j] = ext_col[e0 + j];
+    if (tid == 0) lx[zero_cell] = 0.0;
+    __syncthreads();
+    if (tid >= T) {
+        // ---- the pump: a window of 64 consecutive inflow entries, one per lane; the counter is
+        //      the window's READY PREFIX (an entry that is late does not hold back the ones a
+        //      step needs first), and the window slides by half as soon as its lower half is in
+        const int lane = tid - T;
+        const unsigned long long* xb = reinterpret_cast<const unsigned long long*>(x);
+        auto poll = [&](int j) {
+            return __hip_atomic_load(xb + static_cast<int64_t>(lext[j]) * x_stride, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+        };
+        bool gave_up = false;
+        int base = 0, published = 0;  // entries [0, base + published) are in LDS
+        unsigned long long v = lane < inflow ? poll(lane) : 0ull;
+        long long polls = 0;
+        int nap = 1;
+        while (base + published < inflow) {
+            const int j = base + lane;
+            const bool mine = j < inflow;
+            const unsigned long long late = __ballot(mine && v == sentinel_bits);
+            const int prefix = late == 0ull ? T : __builtin_ctzll(late);
+            if (prefix > published) {
+                if (mine && lane >= published && lane < prefix) lx[rows + j] = __longlong_as_double(static_cast<long long>(v));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the values before the counter
+                if (lane == 0) {
+                    __hip_atomic_store(&s_inflow_ready, min(base + prefix, inflow), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                published = prefix;
+                nap = 1;
+            }
+            if (base + published >= inflow) break;
+            if (published >= T / 2) {  // slide: the upper half moves down, the lanes above it take new entries
+                const unsigned long long moved = __shfl_down(v, T / 2, T);
+                base += T / 2;
+                published -= T / 2;
+                const int nj = base + lane;
+                v = lane < T / 2 ? moved : (nj < inflow ? poll(nj) : 0ull);
+                continue;
+            }
+            if (++polls > max_polls) {
+                gave_up = true;
+                break;
+            }
+            for (int k = 0; k < nap; ++k) __builtin_amdgcn_s_sleep(2);
+            nap = min(nap + 1, 8);  // a brick far behind the front backs off, to ~0.5 us
+            if (mine && v == sentinel_bits) v = poll(j);
+        }
+        if (gave_up && lane == 0) {
+            __hip_atomic_store(&s_inflow_ready, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            atomicExch(&hdr->overrun, 1u);
+        }
+    } else {
+        // ---- the compute wave ----
+        struct step_data {
+            int i;  // my row of the brick, -1 = none
+            int row, need;
+            double d, r;
+            int c[K];
+            double v[K];
+        };
+        auto fetch = [&](int s, int first, int next_first, step_data& sd) {
+            sd.i = -1;
+            sd.need = 0;
+            if (s >= nsteps) return;
+            const int begin = (first & ~level_bit) - r0;
+            const int end = min((next_first & ~level_bit) - r0, begin + T);
+            sd.need = lneed[s];
+            const int i = begin + tid;
+            if (i < end) {
+                sd.i = i;
+                sd.row = lrow[i];
+                if (!Unit) {
+                    sd.d = ld[i];
+                    sd.r = lr[i];
+                }
+#pragma unroll
+                for (int e = 0; e < K; ++e) {
+                    sd.c[e] = lc[e * rows + i];
+                    sd.v[e] = lv[e * rows + i];
+                }
+            }
+        };
+        bool poisoned = false;
+        unsigned long long* xo = reinterpret_cast<unsigned long long*>(x);
+        auto step = [&](int s, const step_data& cur, step_data& nxt, int w1, int w2, int& w3) {
+            if (s >= nsteps) return;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the level before is in LDS (one wave: ordering only)
+            double xd[K];
+            double sum = 0.0;
+            int ready;
+            // counter first, then the dependencies: LDS serves a wave in order, so values read
+            // behind a sufficient counter are the pump's
+            long long spins = 0;
+            while (true) {
+                ready = __hip_atomic_load(&s_inflow_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur.i >= 0) {
+#pragma unroll
+                    for (int e = 0; e < K; ++e) xd[e] = lx[cur.c[e]];
+                    sum = lx[cur.i];
+                }
+                if (ready >= cur.need) break;
+                if (ready < 0 || ++spins > max_polls) {
+                    poisoned = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            w3 = ls[s + 3];
+            fetch(s + 1, w1, w2, nxt);
+            if (cur.i >= 0) {
+#pragma unroll
+                for (int e = 0; e < K; ++e) sum -= cur.v[e] * xd[e];
+                double xr = Unit ? sum : divide_by_row_diagonal(sum, cur.d, cur.r);
+                if (poisoned) xr = __longlong_as_double(static_cast<long long>(poison_bits));
+                if (__double_as_longlong(xr) == static_cast<long long>(sentinel_bits)) {
+                    xr = __longlong_as_double(static_cast<long long>(poison_bits));  // a result must not look unfinished
+                }
+                lx[cur.i] = xr;
+                __hip_atomic_store(xo + cur.row * x_stride, static_cast<unsigned long long>(__double_as_longlong(xr)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+        step_data even, odd;
+        int w1 = ls[1], w2 = ls[2];
+        fetch(0, ls[0], w1, even);
+        for (int s = 0; s < nsteps; s += 2) {
+            int w3 = 0, w4 = 0;
+            step(s, even, odd, w1, w2, w3);
+            step(s + 1, odd, even, w2, w3, w4);
+            w1 = w3;
+            w2 = w4;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int before = atomicAdd(&hdr->finished, 1u);
+        if (before + 1 == static_cast<unsigned int>(hdr->nbricks)) {
+            hdr->finished = 0;
+            hdr->ticket = 0;
+        }
+    }
+}
+
+template <typename T>
+int upload(hipStream_t stream, char* plan, size_t off, const std::vector<T>& v)
+{
+    if (v.empty()) return 0;
+    return static_cast<int>(hipMemcpyAsync(plan + off, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, stream));
+}
+
+}  // namespace
+}  // namespace gkomi
+
+using namespace gkomi;
+
+namespace {
+
+int create_from_host(int64_t n, std::vector<int32_t>& rp, std::vector<int32_t>& ci, int lower, int64_t brick_rows,
+                     int threads, int mode, gkomi_trs_bricks** out)
+{
+    const int64_t nnz = rp[n];
+    for (int64_t i = 0; i < n; ++i) {
+        if (rp[i + 1] < rp[i]) return GKOMI_EINVAL;
+    }
+    if (nnz < 0 || rp[0] != 0 || static_cast<int64_t>(ci.size()) < nnz) return GKOMI_EINVAL;
+    gkomi_trs_bricks* h = new (std::nothrow) gkomi_trs_bricks;
+    if (h == nullptr) return GKOMI_EINVAL;
+    h->n = n;
+    h->lower = lower ? 1 : 0;
+    const int err = analyse(*h, rp, ci, brick_rows, threads, mode);
+    if (err != GKOMI_SUCCESS) {
+        delete h;
+        return err;
+    }
+    *out = h;
+    return GKOMI_SUCCESS;
+}
+
+bool create_args_ok(int64_t n, int threads, int mode, gkomi_trs_bricks** out, int* err)
+{
+    if (out == nullptr) {
+        *err = GKOMI_EINVAL;
+        return false;
+    }
+    *out = nullptr;
+    if (n < 0 || (threads != 0 && threads != 64 && threads != 128 && threads != 256) || mode < 0 || mode > 2) {
+        *err = GKOMI_EINVAL;
+        return false;
+    }
+    if (n < 2 || n > INT32_MAX - 1024) {
+        *err = GKOMI_ENOTSUPPORTED;
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" int gkomi_trs_bricks_create_i32(gkomi_stream_t s, int64_t n, const int32_t* row_ptrs,
+                                           const int32_t* col_idxs, int lower, int64_t brick_rows, int threads,
+                                           int mode, gkomi_trs_bricks** out)
+{
+    int err = 0;
+    if (!create_args_ok(n, threads, mode, out, &err)) return err;
+    if (row_ptrs == nullptr) return GKOMI_EINVAL;
+    hipStream_t stream = to_stream(s);
+    std::vector<int32_t> rp(static_cast<size_t>(n) + 1);
+    err = static_cast<int>(hipMemcpyAsync(rp.data(), row_ptrs, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost, stream));
+    if (err) return err;
+    err = static_cast<int>(hipStreamSynchronize(stream));
+    if (err) return err;
+    const int64_t nnz = rp[n];
+    if (nnz < 0) return GKOMI_EINVAL;
+    std::vector<int32_t> ci(static_cast<size_t>(nnz > 0 ? nnz : 1));
+    if (nnz > 0) {
+        if (col_idxs == nullptr) return GKOMI_EINVAL;
+        err = static_cast<int>(hipMemcpyAsync(ci.data(), col_idxs, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, stream));
+        if (err) return err;
+        err = static_cast<int>(hipStreamSynchronize(stream));
+        if (err) return err;
+    }
+    return create_from_host(n, rp, ci, lower, brick_rows, threads, mode, out);
+}
+
+extern "C" int gkomi_trs_bricks_create_host_i32(int64_t n, const int32_t* host_row_ptrs,
+                                                const int32_t* host_col_idxs, int lower, int64_t brick_rows,
+                                                int threads, int mode, gkomi_trs_bricks** out)
+{
+    int err = 0;
+    if (!create_args_ok(n, threads, mode, out, &err)) return err;
+    if (host_row_ptrs == nullptr) return GKOMI_EINVAL;
+    std::vector<int32_t> rp(host_row_ptrs, host_row_ptrs + n + 1);
+    const int64_t nnz = rp[n];
+    if (nnz < 0 || (nnz > 0 && host_col_idxs == nullptr)) return GKOMI_EINVAL;
+    std::vector<int32_t> ci(host_col_idxs, host_col_idxs + (nnz > 0 ? nnz : 0));
+    return create_from_host(n, rp, ci, lower, brick_rows, threads, mode, out);
+}
+
+extern "C" int gkomi_trs_bricks_host_array(const gkomi_trs_bricks* h, int which, const int32_t** data,
+                                           int64_t* count)
+{
+    if (h == nullptr || data == nullptr || count == nullptr) return GKOMI_EINVAL;
+    const std::vector<int32_t>* v = nullptr;
+    switch (which) {
+    case 0: v = &h->perm; break;
+    case 1: v = &h->brick_row_begin; break;
+    case 2: v = &h->brick_step_ptr; break;
+    case 3: v = &h->step_begin; break;
+    case 4: v = &h->brick_ext_begin; break;
+    case 5: v = &h->ext_col; break;
+    case 6: v = &h->pred_ptr; break;
+    case 7: v = &h->pred_idx; break;
+    case 8: v = &h->row_rank; break;
+    case 9: v = &h->inv_local; break;
+    case 10: v = &h->ext_row_off; break;
+    default: return GKOMI_EINVAL;
+    }
+    *data = v->data();
+    *count = static_cast<int64_t>(v->size());
+    return GKOMI_SUCCESS;
+}
+
+extern "C" void gkomi_trs_bricks_destroy(gkomi_trs_bricks* h) { delete h; }
+
+extern "C" size_t gkomi_trs_bricks_plan_bytes(const gkomi_trs_bricks* h)
+{
+    return h == nullptr ? 0 : make_layout(*h).total;
+}
+
+extern "C" int gkomi_trs_bricks_info(const gkomi_trs_bricks* h, int64_t* out)
+{
+    if (h == nullptr || out == nullptr) return GKOMI_EINVAL;
+    out[0] = h->nbricks;
+    out[1] = h->coarse_levels;
+    out[2] = h->nsteps;
+    out[3] = h->critical_steps;
+    out[4] = h->lds_bytes_max;
+    out[5] = h->width;
+    out[6] = h->threads;
+    out[7] = h->mode;
+    return GKOMI_SUCCESS;
+}
+
+extern "C" int gkomi_trs_bricks_numeric_f64_i32(gkomi_stream_t s, gkomi_trs_bricks* h, const int32_t* row_ptrs,
+                                                const int32_t* col_idxs, const double* vals, void* plan,
+                                                size_t plan_bytes)
+{
+    if (h == nullptr) return GKOMI_EINVAL;
+    const brick_layout l = make_layout(*h);
+    if (plan == nullptr || plan_bytes < l.total) return GKOMI_EWORKSPACE;
+    hipStream_t stream = to_stream(s);
+    char* p = static_cast<char*>(plan);
+    brick_header hd{};
+    hd.n = h->n; hd.nbricks = h->nbricks; hd.ticket = 0; hd.finished = 0; hd.overrun = 0; hd.lower = h->lower;
+    int err = static_cast<int>(hipMemcpyAsync(plan, &hd, sizeof(hd), hipMemcpyHostToDevice, stream));
+    if (err) return err;
+    if (h->uploaded_to != plan) {
+        err = upload(stream, p, l.perm, h->perm);
+        if (!err) err = upload(stream, p, l.brick_row_begin, h->brick_row_begin);
+        if (!err) err = upload(stream, p, l.brick_step_ptr, h->brick_step_ptr);
+        if (!err) err = upload(stream, p, l.step_begin, h->step_begin);
+        if (!err) err = upload(stream, p, l.brick_ext_begin, h->brick_ext_begin);
+        if (!err) err = upload(stream, p, l.ext_col, h->ext_col);
+        if (!err) err = upload(stream, p, l.pred_ptr, h->pred_ptr);
+        if (!err) err = upload(stream, p, l.pred_idx, h->pred_idx);
+        if (!err) err = upload(stream, p, l.row_rank, h->row_rank);
+        if (!err) err = upload(stream, p, l.inv_local, h->inv_local);
+        if (!err) err = upload(stream, p, l.ext_row_off, h->ext_row_off);
+        if (err) return err;
+        h->uploaded_to = plan;
+    }
+    err = static_cast<int>(hipMemsetAsync(p + l.done, 0, sizeof(int32_t) * h->nbricks, stream));
+    if (err) return err;
+    h->epoch = 0;
+    hipLaunchKernelGGL(trs_brick_fill_kernel, dim3(static_cast<unsigned>(ceildiv(h->n, 256))), dim3(256), 0, stream,
+                       static_cast<int32_t>(h->n), h->width, h->lower != 0, row_ptrs, col_idxs, vals,
+                       reinterpret_cast<const int32_t*>(p + l.perm), reinterpret_cast<const int32_t*>(p + l.row_rank),
+                       reinterpret_cast<const int32_t*>(p + l.inv_local),
+                       reinterpret_cast<const int32_t*>(p + l.ext_row_off),
+                       reinterpret_cast<const int32_t*>(p + l.brick_row_begin),
+                       reinterpret_cast<const int32_t*>(p + l.brick_ext_begin), reinterpret_cast<double*>(p + l.diag),
+                       reinterpret_cast<double*>(p + l.rdiag), reinterpret_cast<int32_t*>(p + l.cols), reinterpret_cast<double*>(p + l.vals));
+    err = check_launch();
+    if (err) return err;
+    return static_cast<int>(hipStreamSynchronize(stream));  // the header and the host vectors were sources
+}
+
+namespace {
+
+template <int T, int K, bool Unit>
+int launch_solve(hipStream_t stream, gkomi_trs_bricks* h, char* p, const brick_layout& l, const double* b, int64_t b_stride, double* x, int64_t x_stride, long long max_polls)
+{
+    const size_t lds_bytes = static_cast<size_t>(h->lds_bytes_max > 0 ? h->lds_bytes_max : 16);  // bytes
+    if (lds_bytes > 64 * 1024) {
+        const int err = static_cast<int>(hipFuncSetAttribute(reinterpret_cast<const void*>(&trs_brick_solve_kernel<T, K, Unit>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             static_cast<int>(lds_bytes)));
+        if (err) return err;
+    }
+    ++h->epoch;
+    if (h->epoch == 0) h->epoch = 1;  // 0 = "never finished" (after 2^32 solves a stale flag could match: re-run numeric)
+    hipLaunchKernelGGL((trs_brick_solve_kernel<T, K, Unit>), dim3(static_cast<unsigned>(h->nbricks)), dim3(T), lds_bytes,
+                       stream, reinterpret_cast<brick_header*>(p), reinterpret_cast<const int32_t*>(p + l.perm),
+                       reinterpret_cast<const double*>(p + l.diag), reinterpret_cast<const double*>(p + l.rdiag),
+                       reinterpret_cast<const int32_t*>(p + l.cols),
+                       reinterpret_cast<const double*>(p + l.vals),
+                       reinterpret_cast<const int32_t*>(p + l.brick_row_begin),
+                       reinterpret_cast<const int32_t*>(p + l.brick_step_ptr),
+                       reinterpret_cast<const int32_t*>(p + l.step_begin),
+                       reinterpret_cast<const int32_t*>(p + l.brick_ext_begin),
+                       reinterpret_cast<const int32_t*>(p + l.ext_col), reinterpret_cast<const int32_t*>(p + l.pred_ptr),
+                       reinterpret_cast<const int32_t*>(p + l.pred_idx), reinterpret_cast<unsigned int*>(p + l.done),
+                       static_cast<int32_t>(h->n), b, b_stride, x, x_stride, h->epoch, max_polls);
+    return check_launch();
+}
+
+template <int K, bool Unit>
+int launch_pipelined(hipStream_t stream, gkomi_trs_bricks* h, char* p, const brick_layout& l, const double* b,
+                     int64_t b_stride, double* x, int64_t x_stride, long long max_polls)
+{
+    const size_t lds_bytes = static_cast<size_t>(h->lds_bytes_max > 0 ? h->lds_bytes_max : 16);
+    if (lds_bytes > 64 * 1024) {
+        const int err = static_cast<int>(hipFuncSetAttribute(reinterpret_cast<const void*>(&trs_brick_pipelined_kernel<K, Unit>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             static_cast<int>(lds_bytes)));
+        if (err) return err;
+    }
+    hipLaunchKernelGGL(trs_brick_prepare_kernel, dim3(grid_for(h->n, 256)), dim3(256), 0, stream, h->n, x, x_stride);
+    hipLaunchKernelGGL((trs_brick_pipelined_kernel<K, Unit>), dim3(static_cast<unsigned>(h->nbricks)), dim3(128), lds_bytes,
+                       stream, reinterpret_cast<brick_header*>(p), reinterpret_cast<const int32_t*>(p + l.perm),
+                       reinterpret_cast<const double*>(p + l.diag), reinterpret_cast<const double*>(p + l.rdiag),
+                       reinterpret_cast<const int32_t*>(p + l.cols), reinterpret_cast<const double*>(p + l.vals),
+                       reinterpret_cast<const int32_t*>(p + l.brick_row_begin),
+                       reinterpret_cast<const int32_t*>(p + l.brick_step_ptr),
+                       reinterpret_cast<const int32_t*>(p + l.step_begin),
+                       reinterpret_cast<const int32_t*>(p + l.brick_ext_begin),
+                       reinterpret_cast<const int32_t*>(p + l.ext_col),
+                       reinterpret_cast<const int32_t*>(p + l.ext_row_off), static_cast<int32_t>(h->n), b, b_stride, x,
+                       x_stride, max_polls);
+    return check_launch();
+}
+
+template <bool Unit>
+int launch_pipelined_width(hipStream_t stream, gkomi_trs_bricks* h, char* p, const brick_layout& l, const double* b,
+                           int64_t b_stride, double* x, int64_t x_stride, long long max_polls)
+{
+    if (h->width <= 2) return launch_pipelined<2, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
+    if (h->width <= 3) return launch_pipelined<3, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
+    if (h->width <= 4) return launch_pipelined<4, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
+    return launch_pipelined<8, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
+}
+
+template <int T, bool Unit>
+int launch_solve_width(hipStream_t stream, gkomi_trs_bricks* h, char* p, const brick_layout& l, const double* b,
+                       int64_t b_stride, double* x, int64_t x_stride, long long max_polls)
+{
+    if (h->width <= 2) return launch_solve<T, 2, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
+    if (h->width <= 3) return launch_solve<T, 3, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
+    if (h->width <= 4) return launch_solve<T, 4, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
+    return launch_solve<T, 8, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
+}
+
+template <bool Unit>
+int launch_solve_threads(hipStream_t stream, gkomi_trs_bricks* h, char* p, const brick_layout& l, const double* b,
+                         int64_t b_stride, double* x, int64_t x_stride, long long max_polls)
+{
+    switch (h->threads) {
+    case 64: return launch_solve_width<64, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
+    case 128: return launch_solve_width<128, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
+    default: return launch_solve_width<256, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
+    }
+}
+
+}  // namespace
+
+extern "C" int gkomi_trs_bricks_solve_f64(gkomi_stream_t s, gkomi_trs_bricks* h, void* plan, int64_t nrhs,
+                                          int unit_diag, const double* b, int64_t b_stride, double* x,
+                                          int64_t x_stride)
+{
+    if (h == nullptr || plan == nullptr || nrhs < 0 || b_stride < nrhs || x_stride < nrhs) return GKOMI_EINVAL;
+    if (h->uploaded_to != plan) return GKOMI_EINVAL;  // numeric phase first
+    if (h->mode == 2 && x == b) return GKOMI_EINVAL;  // pipelined: x carries the ready flags
+    if (nrhs == 0) return GKOMI_SUCCESS;
+    const brick_layout l = make_layout(*h);
+    char* p = static_cast<char*>(plan);
+    hipStream_t stream = to_stream(s);
+    const char* env_polls = getenv("GKOMI_TRS_MAX_POLLS");
+    const long long max_polls = env_polls != nullptr && env_polls[0] != 0 ? atoll(env_polls) : default_max_polls;
+    for (int64_t j = 0; j < nrhs; ++j) {
+        int err;
+        if (h->mode == 2) {
+            err = unit_diag != 0
+                      ? launch_pipelined_width<true>(stream, h, p, l, b + j, b_stride, x + j, x_stride, max_polls)
+                      : launch_pipelined_width<false>(stream, h, p, l, b + j, b_stride, x + j, x_stride, max_polls);
+        } else {
+            err = unit_diag != 0
+                      ? launch_solve_threads<true>(stream, h, p, l, b + j, b_stride, x + j, x_stride, max_polls)
+                      : launch_solve_threads<false>(stream, h, p, l, b + j, b_stride, x + j, x_stride, max_polls);
+        }
+        if (err) return err;
+    }
+    return GKOMI_SUCCESS;
+}
+
+extern "C" int gkomi_trs_bricks_check_overrun(gkomi_stream_t s, const void* plan, int* host_flag)
+{
+    if (plan == nullptr || host_flag == nullptr) return GKOMI_EINVAL;
+    brick_header hd{};
+    hipStream_t stream = to_stream(s);
+    int err = static_cast<int>(hipMemcpyAsync(&hd, plan, sizeof(hd), hipMemcpyDeviceToHost, stream));
+    if (err) return err;
+    err = static_cast<int>(hipStreamSynchronize(stream));
+    *host_flag = static_cast<int>(hd.overrun);
+    return err;
+}

@@ -323,6 +323,54 @@ class TrsPlan:
         return bool(flag.value)
 
 
+class TrsBricks:
+    """solver::LowerTrs / UpperTrs after generate() for factors of grid problems: the brick
+    plan (gkomi_trs_bricks_*, csrc/trs_bricks.hip).  Raises GkomiError(GKOMI_ENOTSUPPORTED)
+    when the factor is not stencil-shaped; callers then keep TrsPlan."""
+
+    def __init__(self, gk, n, row_ptrs, col_idxs, vals, lower, brick_rows=0, threads=0, mode=0):
+        self.gk, self.n, self.lower = gk, int(n), bool(lower)
+        self.row_ptrs, self.col_idxs = row_ptrs, col_idxs
+        self.handle = ctypes.c_void_p(0)
+        s = torch.cuda.current_stream().cuda_stream
+        gk.trs_bricks_create_i32(s, n, row_ptrs, col_idxs, int(self.lower), int(brick_rows), int(threads), int(mode),
+                                 ctypes.addressof(self.handle))
+        info = (ctypes.c_int64 * 8)()
+        gk.trs_bricks_info(self.handle.value, ctypes.addressof(info))
+        (self.nbricks, self.coarse_levels, self.nsteps, self.critical_steps, self.lds_bytes, self.width,
+         self.threads, self.mode) = (int(v) for v in info)
+        self.plan_bytes = gk.trs_bricks_plan_bytes(self.handle.value)
+        self.plan = torch.empty(max(self.plan_bytes, 8), dtype=torch.uint8, device=vals.device)
+        self.refresh(vals)
+
+    def estimate_us(self):
+        """critical path of the solve: LDS steps + one memory hand-off per brick level"""
+        return 0.15 * self.critical_steps + 3.0 * self.coarse_levels
+
+    def refresh(self, vals):
+        s = torch.cuda.current_stream().cuda_stream
+        self.vals = vals
+        self.gk.trs_bricks_numeric_f64_i32(s, self.handle.value, self.row_ptrs, self.col_idxs, vals, self.plan,
+                                           self.plan_bytes)
+
+    def solve(self, b, x, unit_diag=False):
+        s = torch.cuda.current_stream().cuda_stream
+        b2, x2 = b.reshape(self.n, -1), x.reshape(self.n, -1)
+        self.gk.trs_bricks_solve_f64(s, self.handle.value, self.plan, b2.shape[1], int(unit_diag), b2, b2.stride(0),
+                                     x2, x2.stride(0))
+        return x
+
+    def overrun(self):
+        flag = ctypes.c_int(0)
+        self.gk.trs_bricks_check_overrun(torch.cuda.current_stream().cuda_stream, self.plan, ctypes.addressof(flag))
+        return bool(flag.value)
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h is not None and h.value:
+            self.gk.trs_bricks_destroy(h.value)
+
+
 # a level must hold this many rows on average for the level-scheduled solve to pay: below it
 # (chains, narrow bands) the analysis-free kernel with its in-workgroup LDS hand-offs is faster
 TRS_PLAN_MIN_ROWS_PER_LEVEL = 64

@@ -1,0 +1,155 @@
+"""GPU parity tests (C ABI) of the brick plan of the triangular solves (csrc/trs_bricks.hip,
+gkomi_trs_bricks_*) against the oracle: bit-exact like every triangular solve here (per row the
+subtractions run in storage order, one division: reference/solver/lower_trs_kernels.cpp:90-120,
+upper_trs_kernels.cpp:90-123).  The analysis itself is covered on the CPU
+(test_trs_bricks_analysis.py)."""
+import numpy as np
+import pytest
+import torch
+
+import gkomi
+import gkomi.solvers as solvers
+import ilu_util
+import matgen
+from gpu_util import dev, host
+from test_trs_bricks_analysis import triangle
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_solve(oracle, n, rp, ci, v, lower, unit, b):
+    e = np.zeros_like(b)
+    (oracle.ref_lower_trs_solve if lower else oracle.ref_upper_trs_solve)(
+        n, b.shape[1], rp, ci, v, int(unit), b.copy(), b.shape[1], e, b.shape[1])
+    return e
+
+
+def brick_solve(gk, n, rp, ci, v, lower, unit, b, brick_rows=0, threads=0, mode=0):
+    bk = solvers.TrsBricks(gk, n, dev(rp), dev(ci), dev(v), lower, brick_rows, threads, mode)
+    x = torch.full(b.shape, 777.0, dtype=torch.float64, device="cuda:0")
+    bk.solve(dev(b), x, unit)
+    assert not bk.overrun()
+    return host(x), bk
+
+
+GRIDS = [
+    ("2d", lambda: matgen.poisson_2d_5pt(70, 45)),
+    ("2d-line", lambda: matgen.poisson_2d_5pt(700, 3)),
+    ("3d", lambda: matgen.poisson_3d_7pt(21, 17, 19)),
+]
+
+
+@pytest.mark.parametrize("lower", [True, False])
+@pytest.mark.parametrize("unit", [False, True])
+@pytest.mark.parametrize("name,make", GRIDS)
+@pytest.mark.parametrize("brick_rows,threads,mode", [(0, 0, 0), (64, 64, 1), (300, 128, 1), (900, 256, 1), (0, 0, 1),
+                                                     (64, 0, 2), (300, 0, 2), (2000, 0, 2)])
+def test_bricks_bitexact_vs_oracle(gk, oracle, name, make, lower, unit, brick_rows, threads, mode):
+    n, rp, ci, v = make()
+    rng = np.random.default_rng(n + brick_rows)
+    v = v * (1.0 + 0.3 * rng.random(len(v)))       # no two rows alike
+    rp, ci, v = triangle(n, rp, ci, v, lower)
+    for nrhs in (1, 3):
+        b = rng.standard_normal((n, nrhs))
+        x, bk = brick_solve(gk, n, rp, ci, v, lower, unit, b, brick_rows, threads, mode)
+        assert bk.nbricks >= 1 and (threads == 0 or bk.threads == threads) and bk.mode == (mode or 2)
+        assert np.array_equal(x, oracle_solve(oracle, n, rp, ci, v, lower, unit, b))
+
+
+def test_bricks_entries_in_any_order_and_other_triangle_ignored(gk, oracle):
+    """a full (not triangular) matrix with shuffled rows: the solve takes the lower / upper part, the
+    subtractions in STORAGE order"""
+    n, rp, ci, v = matgen.poisson_3d_7pt(14)
+    rng = np.random.default_rng(11)
+    ci, v = ci.copy(), v * (1.0 + rng.random(len(v)))
+    for r in range(n):
+        o = rng.permutation(rp[r + 1] - rp[r]) + rp[r]
+        ci[rp[r]:rp[r + 1]], v[rp[r]:rp[r + 1]] = ci[o], v[o]
+    b = rng.standard_normal((n, 1))
+    for lower in (True, False):
+        for mode in (1, 2):
+            x, _ = brick_solve(gk, n, rp, ci, v, lower, False, b, 500, 0, mode)
+            assert np.array_equal(x, oracle_solve(oracle, n, rp, ci, v, lower, False, b))
+
+
+def test_bricks_division_matches_ieee_over_the_exponent_range(gk, oracle):
+    """the solve finishes x = sum / d from a reciprocal prepared by the numeric phase when the
+    exponents are moderate and divides otherwise: both must give the oracle's (IEEE) quotient --
+    values from 2^-1000 to 2^1000, subnormals, zeros, infinities and the edges of the moderate box"""
+    n, rp, ci, v = matgen.poisson_2d_5pt(96, 64)
+    rp, ci, v = triangle(n, rp, ci, v, True)
+    rng = np.random.default_rng(17)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    diag = ci == rows
+    edges = np.array([-1023, -1000, -384, -383, -382, -1, 0, 1, 382, 383, 384, 700])
+    with np.errstate(all="ignore"):
+        for trial in range(4):
+            v2 = v.copy()
+            v2[~diag] = 0.0 if trial == 3 else rng.standard_normal((~diag).sum()) * 2.0 ** rng.integers(-30, 30, (~diag).sum())
+            ex = rng.integers(-1000, 1000, n) if trial < 2 else rng.choice(edges, n)
+            v2[diag] = (1.0 + rng.random(n)) * 2.0 ** ex * rng.choice([-1.0, 1.0], n)
+            eb = rng.integers(-1000, 1000, n) if trial != 1 else rng.choice(edges, n)
+            b = ((1.0 + rng.random(n)) * 2.0 ** eb * rng.choice([-1.0, 1.0], n)).reshape(n, 1)
+            b[rng.integers(0, n, 50), 0] = 0.0
+            b[rng.integers(0, n, 20), 0] = 5e-324
+            b[rng.integers(0, n, 5), 0] = np.inf
+            e = oracle_solve(oracle, n, rp, ci, v2, True, False, b)
+            for mode in (1, 2):
+                x, _ = brick_solve(gk, n, rp, ci, v2, True, False, b, 512, 0, mode)
+                same = (x.view(np.int64) == e.view(np.int64)) | (np.isnan(x) & np.isnan(e))
+                assert same.all(), (trial, mode, np.flatnonzero(~same.ravel())[:5])
+
+
+def test_bricks_refresh_and_repeated_solves(gk, oracle):
+    """new values through the numeric phase alone; the plan re-arms itself after every solve"""
+    n, rp, ci, v = matgen.poisson_3d_7pt(20)
+    f = ilu_util.oracle_par_ilu(oracle, n, rp, ci, v)
+    lrp, lc, lv = f["L"]
+    b = np.cos(0.01 * np.arange(n)).reshape(n, 1)
+    for mode in (1, 2):
+        bk = solvers.TrsBricks(gk, n, dev(lrp), dev(lc), dev(lv), True, 1000, 0, mode)
+        x = torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")
+        e = oracle_solve(oracle, n, lrp, lc, lv, True, False, b)
+        for _ in range(5):
+            x.fill_(3.0)
+            bk.solve(dev(b), x)
+            assert np.array_equal(host(x), e)
+        lv2 = lv * 1.25
+        bk.refresh(dev(lv2))
+        bk.solve(dev(b), x)
+        assert np.array_equal(host(x), oracle_solve(oracle, n, lrp, lc, lv2, True, False, b)) and not bk.overrun()
+
+
+def test_bricks_solve_in_place(gk, oracle):
+    n, rp, ci, v = matgen.poisson_2d_5pt(90)
+    rp, ci, v = triangle(n, rp, ci, v, False)
+    b = np.sin(np.arange(n) * 0.3).reshape(n, 1)
+    bk = solvers.TrsBricks(gk, n, dev(rp), dev(ci), dev(v), False, 700, 0, 1)
+    x = dev(b).clone()
+    bk.solve(x, x)
+    assert np.array_equal(host(x), oracle_solve(oracle, n, rp, ci, v, False, False, b))
+    # the pipelined plan keeps its ready flags in x: aliasing is refused
+    bk2 = solvers.TrsBricks(gk, n, dev(rp), dev(ci), dev(v), False, 700, 0, 2)
+    with pytest.raises(gkomi.GkomiError):
+        bk2.solve(x, x)
+
+
+def test_bricks_not_for_irregular_factors(gk):
+    n, rp, ci, v = matgen.poisson_2d_5pt(40)
+    rp, ci, v = matgen.permute_symmetric(n, rp, ci, v, seed=3)
+    rp, ci, v = triangle(n, rp, ci, v, True)
+    with pytest.raises(gkomi.GkomiError) as e:
+        solvers.TrsBricks(gk, n, dev(rp), dev(ci), dev(v), True)
+    assert "not supported" in str(e.value).lower()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("lower", [True, False])
+def test_bricks_config4_factor_full_size(gk, oracle, lower, mode):
+    """BASELINE config 4's factor shape at full size: 7-point 108^3, ILU(0) pattern"""
+    n, rp, ci, v = matgen.at_like(108)
+    rp, ci, v = triangle(n, rp, ci, v, lower)
+    b = (np.sin(0.001 * np.arange(n)) + 1.1).reshape(n, 1)
+    x, bk = brick_solve(gk, n, rp, ci, v, lower, False, b, 0, 0, mode)
+    assert np.array_equal(x, oracle_solve(oracle, n, rp, ci, v, lower, False, b))
+    assert bk.coarse_levels < 64
