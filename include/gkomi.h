@@ -1248,6 +1248,12 @@ typedef struct gkomi_ilu_ctx {
     int64_t u_nslices;
     int64_t u_entries;
     int64_t u_max_deps;
+    /* factors with a brick plan (gkomi_trs_bricks_*; handle + its device plan after the numeric
+     * phase): when non-NULL the brick solve is used for that factor, before the two above */
+    struct gkomi_trs_bricks* l_bricks;
+    void* l_bricks_plan;
+    struct gkomi_trs_bricks* u_bricks;
+    void* u_bricks_plan;
 } gkomi_ilu_ctx;
 int gkomi_jacobi_apply_cb(void* ctx, gkomi_stream_t s, const double* in,
                           double* out);

@@ -28,14 +28,25 @@ extern "C" int gkomi_ilu_apply_cb(void* ctx_, gkomi_stream_t s, const double* in
 {
     const gkomi_ilu_ctx* c = static_cast<const gkomi_ilu_ctx*>(ctx_);
     if (c == nullptr) return GKOMI_EINVAL;
-    // factors analysed at generate (LowerTrs / UpperTrs::generate): the level-scheduled solves
-    int err = c->l_plan != nullptr
-                  ? gkomi_trs_solve_plan_f64(s, c->n, c->nrhs, c->l_plan, c->l_nslices, c->l_entries,
-                                             c->l_max_deps, c->l_unit_diag, in, c->nrhs, c->intermediate, c->nrhs)
-                  : gkomi_lower_trs_solve_f64_i32(s, c->n, c->nrhs, c->l_row_ptrs, c->l_col_idxs,
-                                                  c->l_vals, c->l_unit_diag, in, c->nrhs, c->intermediate,
-                                                  c->nrhs, c->trs_workspace, c->trs_workspace_bytes);
+    // factors analysed at generate (LowerTrs / UpperTrs::generate): the brick plan where the factor
+    // has one, else the level-scheduled solve, else the analysis-free kernel
+    int err;
+    if (c->l_bricks != nullptr) {
+        err = gkomi_trs_bricks_solve_f64(s, c->l_bricks, c->l_bricks_plan, c->nrhs, c->l_unit_diag, in, c->nrhs,
+                                         c->intermediate, c->nrhs);
+    } else if (c->l_plan != nullptr) {
+        err = gkomi_trs_solve_plan_f64(s, c->n, c->nrhs, c->l_plan, c->l_nslices, c->l_entries, c->l_max_deps,
+                                       c->l_unit_diag, in, c->nrhs, c->intermediate, c->nrhs);
+    } else {
+        err = gkomi_lower_trs_solve_f64_i32(s, c->n, c->nrhs, c->l_row_ptrs, c->l_col_idxs, c->l_vals,
+                                            c->l_unit_diag, in, c->nrhs, c->intermediate, c->nrhs, c->trs_workspace,
+                                            c->trs_workspace_bytes);
+    }
     if (err) return err;
+    if (c->u_bricks != nullptr) {
+        return gkomi_trs_bricks_solve_f64(s, c->u_bricks, c->u_bricks_plan, c->nrhs, 0, c->intermediate, c->nrhs, out,
+                                          c->nrhs);
+    }
     if (c->u_plan != nullptr) {
         return gkomi_trs_solve_plan_f64(s, c->n, c->nrhs, c->u_plan, c->u_nslices, c->u_entries, c->u_max_deps, 0,
                                         c->intermediate, c->nrhs, out, c->nrhs);
@@ -52,7 +63,9 @@ int gkomi::precond_status(gkomi_apply_fn precond, void* ctx_, gkomi_stream_t s)
     if (precond != gkomi_ilu_apply_cb || ctx_ == nullptr) return GKOMI_SUCCESS;
     const gkomi_ilu_ctx* c = static_cast<const gkomi_ilu_ctx*>(ctx_);
     int flag = 0, any = 0;
-    if (c->trs_workspace != nullptr && (c->l_plan == nullptr || c->u_plan == nullptr)) {
+    const bool l_analysed = c->l_plan != nullptr || c->l_bricks != nullptr;
+    const bool u_analysed = c->u_plan != nullptr || c->u_bricks != nullptr;
+    if (c->trs_workspace != nullptr && !(l_analysed && u_analysed)) {
         const int err = gkomi_trs_check_overrun(s, c->trs_workspace, &flag);
         if (err) return err;
         any |= flag;
@@ -60,6 +73,13 @@ int gkomi::precond_status(gkomi_apply_fn precond, void* ctx_, gkomi_stream_t s)
     for (const void* plan : {static_cast<const void*>(c->l_plan), static_cast<const void*>(c->u_plan)}) {
         if (plan == nullptr) continue;
         const int err = gkomi_trs_plan_check_overrun(s, plan, &flag);
+        if (err) return err;
+        any |= flag;
+    }
+    for (const void* plan : {c->l_bricks != nullptr ? static_cast<const void*>(c->l_bricks_plan) : nullptr,
+                             c->u_bricks != nullptr ? static_cast<const void*>(c->u_bricks_plan) : nullptr}) {
+        if (plan == nullptr) continue;
+        const int err = gkomi_trs_bricks_check_overrun(s, plan, &flag);
         if (err) return err;
         any |= flag;
     }

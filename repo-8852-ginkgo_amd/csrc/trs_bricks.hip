@@ -171,12 +171,8 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
     int64_t extent[max_dims];
     for (int k = 0; k + 1 < dims; ++k) extent[k] = stride[k + 1] / stride[k];
     extent[dims - 1] = ceildiv(n, stride[dims - 1]);
-    if (brick_rows <= 0) {
-        // pipelined: levels of a brick should fit the one compute wave (8^3, 32^2); else large bricks
-        int wide = 0;
-        for (int k = 0; k < dims; ++k) wide += extent[k] > 1;
-        brick_rows = h.mode == 2 ? (wide >= 3 ? 512 : 1024) : 4096;
-    }
+    // pipelined: the levels of a brick should about fit the one compute wave (10^3, 32^2); else large bricks
+    if (brick_rows <= 0) brick_rows = h.mode == 2 ? 1024 : 4096;
     // 3. brick edges: about brick_rows rows per brick, near-cubic, an even split of every extent;
     //    shrunk until a brick with its inflow fits LDS
     for (int attempt = 0; attempt < 8; ++attempt, brick_rows = std::max<int64_t>(brick_rows / 2, 8)) {
@@ -428,12 +424,12 @@ __device__ __forceinline__ double refined_reciprocal(double d)
 
 __device__ __forceinline__ double divide_by_row_diagonal(double sum, double d, double r)
 {
-    if (exponent_is_safe(sum) && r == r) {
-        const double q = sum * r;
-        const double e = __builtin_fma(-d, q, sum);
-        return __builtin_fma(e, r, q);
-    }
-    return sum / d;
+    // the quotient first, the question whether it may be used beside it (not in front of it)
+    const double q = sum * r;
+    const double e = __builtin_fma(-d, q, sum);
+    double result = __builtin_fma(e, r, q);
+    if (!(exponent_is_safe(sum) && r == r)) result = sum / d;
+    return result;
 }
 
 // the factor once more in plan order: dependencies only, as LDS indices of the brick (own rows:
@@ -691,7 +687,8 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
     const int32_t* __restrict__ brick_row_begin, const int32_t* __restrict__ brick_step_ptr,
     const int32_t* __restrict__ step_begin, const int32_t* __restrict__ brick_ext_begin,
     const int32_t* __restrict__ ext_col, const int32_t* __restrict__ ext_row_off, int32_t n,
-    const double* __restrict__ b, int64_t b_stride, double* x, int64_t x_stride, long long max_polls)
+    const double* __restrict__ b, int64_t b_stride, double* x, int64_t x_stride, long long max_polls,
+    int nap_max)
 {
     constexpr int T = 64;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -792,7 +789,7 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
                 break;
             }
             for (int k = 0; k < nap; ++k) __builtin_amdgcn_s_sleep(2);
-            nap = min(nap + 1, 8);  // a brick far behind the front backs off, to ~0.5 us
+            nap = min(nap + 1, nap_max);  // a brick far behind the front backs off (8: to ~0.5 us)
             if (mine && v == sentinel_bits) v = poll(j);
         }
         if (gave_up && lane == 0) {
@@ -860,14 +857,11 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
             if (cur.i >= 0) {
 #pragma unroll
                 for (int e = 0; e < K; ++e) sum -= cur.v[e] * xd[e];
-                double xr = Unit ? sum : divide_by_row_diagonal(sum, cur.d, cur.r);
-                if (poisoned) xr = __longlong_as_double(static_cast<long long>(poison_bits));
-                if (__double_as_longlong(xr) == static_cast<long long>(sentinel_bits)) {
-                    xr = __longlong_as_double(static_cast<long long>(poison_bits));  // a result must not look unfinished
-                }
-                lx[cur.i] = xr;
-                __hip_atomic_store(xo + cur.row * x_stride, static_cast<unsigned long long>(__double_as_longlong(xr)),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double xr = Unit ? sum : divide_by_row_diagonal(sum, cur.d, cur.r);
+                lx[cur.i] = xr;  // the next level waits for this; what goes to memory may take two more instructions
+                unsigned long long out = static_cast<unsigned long long>(__double_as_longlong(xr));
+                if (poisoned || out == sentinel_bits) out = poison_bits;  // a result must not look unfinished
+                __hip_atomic_store(xo + cur.row * x_stride, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         };
         step_data even, odd;
@@ -1115,6 +1109,8 @@ int launch_pipelined(hipStream_t stream, gkomi_trs_bricks* h, char* p, const bri
                                                              static_cast<int>(lds_bytes)));
         if (err) return err;
     }
+    const char* env_nap = getenv("GKOMI_TRS_BRICK_NAP");  // tuning knob (tools/trs_bricks_probe.py)
+    const int nap_max = env_nap != nullptr && env_nap[0] != 0 ? std::max(1, atoi(env_nap)) : 8;
     hipLaunchKernelGGL(trs_brick_prepare_kernel, dim3(grid_for(h->n, 256)), dim3(256), 0, stream, h->n, x, x_stride);
     hipLaunchKernelGGL((trs_brick_pipelined_kernel<K, Unit>), dim3(static_cast<unsigned>(h->nbricks)), dim3(128), lds_bytes,
                        stream, reinterpret_cast<brick_header*>(p), reinterpret_cast<const int32_t*>(p + l.perm),
@@ -1126,7 +1122,7 @@ int launch_pipelined(hipStream_t stream, gkomi_trs_bricks* h, char* p, const bri
                        reinterpret_cast<const int32_t*>(p + l.brick_ext_begin),
                        reinterpret_cast<const int32_t*>(p + l.ext_col),
                        reinterpret_cast<const int32_t*>(p + l.ext_row_off), static_cast<int32_t>(h->n), b, b_stride, x,
-                       x_stride, max_polls);
+                       x_stride, max_polls, nap_max);
     return check_launch();
 }
 

@@ -6,6 +6,10 @@ import ctypes
 import numpy as np
 import torch
 
+from ._lib import GkomiError
+
+GKOMI_ENOTSUPPORTED = -2
+
 APPLY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
 BASELINES = {"rhs_norm": 0, "initial_resnorm": 1, "absolute": 2}
 
@@ -211,7 +215,9 @@ class IluCtx(ctypes.Structure):
                 ("l_plan", ctypes.c_void_p), ("l_nslices", ctypes.c_int64), ("l_entries", ctypes.c_int64),
                 ("l_max_deps", ctypes.c_int64),
                 ("u_plan", ctypes.c_void_p), ("u_nslices", ctypes.c_int64), ("u_entries", ctypes.c_int64),
-                ("u_max_deps", ctypes.c_int64)]
+                ("u_max_deps", ctypes.c_int64),
+                ("l_bricks", ctypes.c_void_p), ("l_bricks_plan", ctypes.c_void_p),
+                ("u_bricks", ctypes.c_void_p), ("u_bricks_plan", ctypes.c_void_p)]
 
 
 class Preconditioner:
@@ -376,29 +382,50 @@ class TrsBricks:
 TRS_PLAN_MIN_ROWS_PER_LEVEL = 64
 
 
-def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True):
+# per dependency level of the level plan / per step + per brick on the critical path of a brick plan (us,
+# measured on the 108^3 and 1000^2 factors): what `ilu_from_factors` compares to pick a plan
+TRS_LEVEL_US = 1.7
+TRS_BRICK_STEP_US = 0.3
+
+
+def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True, bricks=True):
     """preconditioner::Ilu over given CSR factors L = (row_ptrs, col_idxs, vals), U likewise.
-    analyse: LowerTrs / UpperTrs::generate -- the dependency-level analysis of both factors; a factor
-    whose levels are wide enough is then solved by the level-scheduled kernel (True / False / "force")."""
+    analyse: LowerTrs / UpperTrs::generate -- the dependency analysis of both factors (True / False / "force");
+    a factor of a grid problem gets the brick plan (bricks=True; csrc/trs_bricks.hip), one whose levels are
+    wide enough the level-scheduled kernel, anything else keeps the analysis-free solve."""
     dv = L[2].device
     inter = torch.zeros((n, nrhs), dtype=torch.float64, device=dv)
     nb = gk.trs_workspace_bytes()
     tws = torch.zeros(nb, dtype=torch.uint8, device=dv)
     plans = [None, None]
+    brick_plans = [None, None]
     if analyse and n > 0:
         for i, (f, lower) in enumerate(((L, True), (U, False))):
             plan = TrsPlan(gk, n, f[0], f[1], f[2], lower)
+            if bricks and plan.nlevels > 16:
+                try:
+                    bk = TrsBricks(gk, n, f[0], f[1], f[2], lower)
+                    # pipelined: about one step per level of the factor
+                    if TRS_BRICK_STEP_US * plan.nlevels + 3.0 * bk.coarse_levels < TRS_LEVEL_US * plan.nlevels:
+                        brick_plans[i] = bk
+                        continue
+                except GkomiError as e:
+                    if e.code != GKOMI_ENOTSUPPORTED:
+                        raise
             if analyse == "force" or n >= TRS_PLAN_MIN_ROWS_PER_LEVEL * max(plan.nlevels, 1):
                 plans[i] = plan
     pl, pu = plans
+    bl, bu = brick_plans
     ctx = IluCtx(n, nrhs, L[0].data_ptr(), L[1].data_ptr(), L[2].data_ptr(), U[0].data_ptr(), U[1].data_ptr(),
                  U[2].data_ptr(), inter.data_ptr(), tws.data_ptr(), nb, int(l_unit_diag), 0,
                  pl.plan.data_ptr() if pl else None, pl.nslices if pl else 0, pl.entries if pl else 0,
                  pl.max_deps if pl else -1,
                  pu.plan.data_ptr() if pu else None, pu.nslices if pu else 0, pu.entries if pu else 0,
-                 pu.max_deps if pu else -1)
-    p = Preconditioner(gk, "gkomi_ilu_apply_cb", ctx, (L, U, inter, tws, pl, pu))
-    p.l_plan, p.u_plan = pl, pu
+                 pu.max_deps if pu else -1,
+                 bl.handle.value if bl else None, bl.plan.data_ptr() if bl else None,
+                 bu.handle.value if bu else None, bu.plan.data_ptr() if bu else None)
+    p = Preconditioner(gk, "gkomi_ilu_apply_cb", ctx, (L, U, inter, tws, pl, pu, bl, bu))
+    p.l_plan, p.u_plan, p.l_bricks, p.u_bricks = pl, pu, bl, bu
     return p
 
 

@@ -2144,11 +2144,14 @@ public:
     // what generate() found: dependency levels of the factor and whether the level-scheduled solve is used
     int64_t get_num_levels() const noexcept { return nlevels_; }
     bool uses_level_schedule() const noexcept { return planned_; }
+    bool uses_brick_plan() const noexcept { return bricks_ != nullptr; }
+    ~Trs() override { gkomi_trs_bricks_destroy(bricks_); }
     // a solve that gave up (spin bound) left NaNs in x; sticky until the next generate
     bool has_overrun() const
     {
         int flag = 0;
-        if (planned_) GKOMI_CALL(gkomi_trs_plan_check_overrun(nullptr, plan_.get_const_data(), &flag));
+        if (bricks_ != nullptr) GKOMI_CALL(gkomi_trs_bricks_check_overrun(nullptr, plan_.get_const_data(), &flag));
+        else if (planned_) GKOMI_CALL(gkomi_trs_plan_check_overrun(nullptr, plan_.get_const_data(), &flag));
         else GKOMI_CALL(gkomi_trs_check_overrun(nullptr, ws_.get_const_data(), &flag));
         return flag != 0;
     }
@@ -2167,6 +2170,24 @@ protected:
         GKOMI_CALL(gkomi_trs_analyse_symbolic_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), Lower ? 1 : 0, symbolic.get_data(),
                                                   symbolic.get_num_elems(), out));
         nslices_ = out[0]; entries_ = out[1]; nlevels_ = out[2]; max_deps_ = out[3];
+        // factors of grid problems (many levels, stencil-shaped): the brick plan -- bricks solved out of LDS,
+        // about one LDS step per level instead of one memory hand-off (csrc/trs_bricks.hip)
+        if (nlevels_ > 16) {
+            const int err = gkomi_trs_bricks_create_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), Lower ? 1 : 0, 0, 0, 0, &bricks_);
+            if (err != GKOMI_SUCCESS && err != GKOMI_ENOTSUPPORTED) GKOMI_CALL(err);
+            if (bricks_ != nullptr) {
+                int64_t info[8] = {};
+                GKOMI_CALL(gkomi_trs_bricks_info(bricks_, info));
+                if (0.3 * nlevels_ + 3.0 * info[1] < 1.7 * nlevels_) {
+                    plan_.resize_and_reset(gkomi_trs_bricks_plan_bytes(bricks_));
+                    GKOMI_CALL(gkomi_trs_bricks_numeric_f64_i32(nullptr, bricks_, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(), plan_.get_data(),
+                                                                plan_.get_num_elems()));
+                    return;
+                }
+                gkomi_trs_bricks_destroy(bricks_);
+                bricks_ = nullptr;
+            }
+        }
         // wide levels: level-scheduled; chains and narrow bands: the analysis-free kernel's in-workgroup hand-offs
         planned_ = n > 0 && n >= 64 * std::max<int64_t>(nlevels_, 1);
         if (planned_) {
@@ -2181,6 +2202,11 @@ protected:
         ::gko::detail::require_device(exec_, "trs::solve");
         auto csr = as<const matrix::Csr<V, I>>(A_.get());
         auto db = matrix::detail_fmt::dense(b); auto dx = matrix::detail_fmt::dense(x);
+        if (bricks_ != nullptr) {
+            GKOMI_CALL(gkomi_trs_bricks_solve_f64(nullptr, bricks_, const_cast<char*>(plan_.get_const_data()), db->cols(), unit_ ? 1 : 0, db->get_const_values(), db->get_stride(),
+                                                  dx->get_values(), dx->get_stride()));
+            return;
+        }
         if (planned_) {
             GKOMI_CALL(gkomi_trs_solve_plan_f64(nullptr, size_[0], db->cols(), const_cast<char*>(plan_.get_const_data()), nslices_, entries_, max_deps_, unit_ ? 1 : 0,
                                                 db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride()));
@@ -2204,6 +2230,7 @@ protected:
     array<char> plan_;
     int64_t nslices_{0}, entries_{0}, nlevels_{0}, max_deps_{-1};
     bool planned_{false};
+    gkomi_trs_bricks* bricks_{nullptr};  // host-side analysis; its device plan lives in plan_
 };
 template <typename V = double, typename I = int32>
 using LowerTrs = Trs<true, V, I>;

@@ -33,7 +33,9 @@ def test_no_torch_types_in_abi():
             assert ctype in ("int", "int32_t", "int64_t", "uint8_t", "uint64_t", "size_t", "double",
                              "float", "void", "gkomi_stream_t", "gkomi_apply_fn", "gkomi_matrix_apply_fn", "char",
                              # plain C records of the ABI itself (pointers and sizes, declared in gkomi.h)
-                             "gkomi_comm", "gkomi_dist_matrix", "gkomi_dist_ctx"), (name, ctype)
+                             "gkomi_comm", "gkomi_dist_matrix", "gkomi_dist_ctx",
+                             # opaque handle (host-side analysis result, like the reference's SolveStruct)
+                             "gkomi_trs_bricks"), (name, ctype)
 
 
 def test_version_and_error_strings(gk):

@@ -358,10 +358,12 @@ def test_trs_overrun_is_sticky_and_surfaces_as_an_error(gk, oracle, monkeypatch,
     ok = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), b, krylov_dim=30, max_iters=200, reduction=1e-10, precond=pre)
     assert ok["converged"]
     monkeypatch.setenv("GKOMI_TRS_MAX_ROUNDS", "1")      # test hook: give up after one look at a dependency
+    monkeypatch.setenv("GKOMI_TRS_MAX_POLLS", "1")       # ... the same for the brick plan
     with pytest.raises(gkomi._lib.GkomiError) as e:
         solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), b, krylov_dim=30, max_iters=20, reduction=1e-10, precond=pre)
     assert e.value.code == -6                            # GKOMI_ETRS_OVERRUN
     monkeypatch.delenv("GKOMI_TRS_MAX_ROUNDS")
+    monkeypatch.delenv("GKOMI_TRS_MAX_POLLS")
     # sticky: a later, healthy solve with the same preconditioner still reports it
     with pytest.raises(gkomi._lib.GkomiError):
         solvers.cg_solve(gk, n, dev(rp), dev(ci), dev(v), b, max_iters=5, reduction=1e-10, precond=pre)

@@ -47,13 +47,19 @@ flag = ctypes.c_int(0); gk.trs_check_overrun(s, tws, ctypes.addressof(flag))
 print(f"AT-like {g3}^3: n={n} nnz={len(v)}  ParILU(5 sweeps) generate {t_gen*1e3:.1f} ms, L nnz {lnnz}, U nnz {unnz}")
 print(f"  lower trs {tl:9.1f} us ({(12*lnnz+20*n)/tl/1e3:6.1f} GB/s)   upper trs {tu:9.1f} us ({(12*unnz+20*n)/tu/1e3:6.1f} GB/s)  overrun={flag.value}")
 pre_plain = solvers.ilu_from_factors(gk, n, L, U, analyse=False)
-t0 = time.perf_counter(); pre = solvers.ilu_from_factors(gk, n, L, U); torch.cuda.synchronize()
+t0 = time.perf_counter(); pre = solvers.ilu_from_factors(gk, n, L, U, bricks=False); torch.cuda.synchronize()
 print(f"  LowerTrs/UpperTrs generate (level analysis of both factors): {1e3*(time.perf_counter()-t0):.1f} ms, "
       f"levels {pre.l_plan.nlevels if pre.l_plan else '-'} / {pre.u_plan.nlevels if pre.u_plan else '-'}")
 if pre.l_plan is not None:
     tl2 = ev_time(lambda: pre.l_plan.solve(b, y)); tu2 = ev_time(lambda: pre.u_plan.solve(y, z))
     print(f"  analysed: lower trs {tl2:9.1f} us   upper trs {tu2:9.1f} us   overrun={int(pre.l_plan.overrun() or pre.u_plan.overrun())}")
-for prec, name in ((None, "none"), (pre_plain, "ParILU (analysis-free trs)"), (pre, "ParILU (analysed trs)")):
+t0 = time.perf_counter(); pre_bk = solvers.ilu_from_factors(gk, n, L, U); torch.cuda.synchronize()
+print(f"  LowerTrs/UpperTrs generate (brick plan where the factor has one): {1e3*(time.perf_counter()-t0):.1f} ms, "
+      f"bricks {pre_bk.l_bricks.nbricks if pre_bk.l_bricks else '-'} / {pre_bk.u_bricks.nbricks if pre_bk.u_bricks else '-'}")
+if pre_bk.l_bricks is not None and pre_bk.u_bricks is not None:
+    tl3 = ev_time(lambda: pre_bk.l_bricks.solve(b, y)); tu3 = ev_time(lambda: pre_bk.u_bricks.solve(y, z))
+    print(f"  brick plan: lower trs {tl3:9.1f} us   upper trs {tu3:9.1f} us   overrun={int(pre_bk.l_bricks.overrun() or pre_bk.u_bricks.overrun())}")
+for prec, name in ((None, "none"), (pre_plain, "ParILU (analysis-free trs)"), (pre, "ParILU (level plan)"), (pre_bk, "ParILU (brick plan)")):
     solvers.gmres_solve(gk, n, rpd, cid, vd, b, krylov_dim=30, max_iters=3000, reduction=1e-10, precond=prec)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     r = solvers.gmres_solve(gk, n, rpd, cid, vd, b, krylov_dim=30, max_iters=3000, reduction=1e-10, precond=prec)
