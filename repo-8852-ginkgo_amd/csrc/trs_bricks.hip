@@ -56,6 +56,7 @@ struct gkomi_trs_bricks {
     std::vector<int32_t> brick_ext_begin;  // nbricks + 1
     std::vector<int32_t> ext_col;          // row whose x an inflow entry needs
     std::vector<int32_t> pred_ptr, pred_idx;
+    std::vector<int64_t> image_off;        // pipelined solve: byte offset of a brick's LDS image, nbricks + 1
     uint32_t epoch = 0;
     const void* uploaded_to = nullptr;
 };
@@ -86,7 +87,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct brick_layout {
     size_t perm, diag, rdiag, cols, vals, brick_row_begin, brick_step_ptr, step_begin, brick_ext_begin, ext_col,
-        pred_ptr, pred_idx, done, row_rank, inv_local, ext_row_off, total;
+        pred_ptr, pred_idx, done, row_rank, inv_local, ext_row_off, stamps, image_off, image, total;
 };
 
 brick_layout make_layout(const gkomi_trs_bricks& h)
@@ -112,8 +113,28 @@ brick_layout make_layout(const gkomi_trs_bricks& h)
     l.row_rank = off; off += ints(n);
     l.inv_local = off; off += ints(n);
     l.ext_row_off = off; off += ints(n);
+    l.stamps = off; off += std::max<size_t>(8 * 1024, 32 * nb);  // tools only: shader-clock stamps
+    l.image_off = off; off += align_up(sizeof(int64_t) * (nb + 1), 256);
+    l.image = off; off += align_up(h.image_off.empty() ? 0 : static_cast<size_t>(h.image_off.back()), 256);
     l.total = off;
     return l;
+}
+
+// bytes of a row's record in the pipelined solve: diag, 1 / diag, K values, K + 3 ints, rounded up to
+// 8 mod 16 -- 64 lanes read the same field of 64 consecutive records, and a stride of 4 m + 2 dwords
+// spreads a 16-lane pass of 8-byte reads over all 32 LDS banks (a 64-byte record: 16-way conflicts)
+__host__ __device__ constexpr int brick_record_bytes(int width)
+{
+    const int need = 28 + 12 * width;
+    return need % 16 <= 8 ? need / 16 * 16 + 8 : need / 16 * 16 + 24;
+}
+
+// the part of a brick's LDS that does not depend on the right-hand side -- records (+ the spare one),
+// {rows, inflow needed} per step (+ 4 beyond the end), the rows the inflow comes from -- is stored
+// ready-made in the plan (its "image") and only copied when the brick starts
+__host__ __device__ constexpr int64_t brick_image_bytes(int64_t rows, int64_t inflow, int64_t steps, int width)
+{
+    return ((rows + 1) * brick_record_bytes(width) + 8 * (steps + 4) + 4 * inflow + 15) / 16 * 16;
 }
 
 // LDS of a brick with R rows, E inflow values, S steps and K dependency slots per row:
@@ -121,8 +142,15 @@ brick_layout make_layout(const gkomi_trs_bricks& h)
 // | inflow needed by step[S + 4]  (the last five: int)
 __host__ __device__ inline size_t brick_lds_bytes(int64_t rows, int64_t inflow, int64_t steps, int width)
 {
-    return sizeof(double) * static_cast<size_t>(rows + inflow + 1 + 2 * rows + width * rows) +
-           sizeof(int32_t) * static_cast<size_t>(width * rows + 2 * (steps + 4) + rows + inflow);
+    // + one spare entry per array: the row a lane without work points at (pipelined solve, which keeps
+    // one record per row: diag, 1 / diag, values, LDS addresses of the dependencies and of the row's
+    // own cell, row index -- (24 + 12 K) bytes rounded up to 8 -- and {rows, inflow needed} per step)
+    const int64_t r1 = rows + 1;
+    const size_t arrays = sizeof(double) * static_cast<size_t>(rows + inflow + 2 + 2 * r1 + width * r1) +
+                          sizeof(int32_t) * static_cast<size_t>(width * r1 + 2 * (steps + 4) + r1 + inflow);
+    const size_t records = (sizeof(double) * static_cast<size_t>(rows + inflow + 2) + 15) / 16 * 16 +
+                           static_cast<size_t>(brick_image_bytes(rows, inflow, steps, width));
+    return arrays > records ? arrays : records;
 }
 
 inline bool is_dep(bool lower, int64_t col, int64_t row) { return lower ? col < row : col > row; }
@@ -295,7 +323,10 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
             // steps <= levels + rows / threads <= 2 rows + 1
             max_lds = std::max<int64_t>(max_lds, static_cast<int64_t>(brick_lds_bytes(r, brick_ext[b], 2 * r + 1, slots)));
         }
-        if (static_cast<size_t>(max_lds) + 256 > max_lds_bytes) {
+        int64_t max_rows = 0;
+        for (int64_t b = 0; b < nbricks; ++b) max_rows = std::max<int64_t>(max_rows, brick_rows_count[b]);
+        // (the pipelined solve gathers a brick's right-hand side 16 rows per lane of its 128)
+        if (static_cast<size_t>(max_lds) + 256 > max_lds_bytes || (h.mode == 2 && max_rows > 2048)) {
             if (brick_rows <= 8) return GKOMI_ENOTSUPPORTED;
             continue;  // smaller bricks
         }
@@ -384,6 +415,12 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
             path[r] = before + steps;
             h.critical_steps = std::max(h.critical_steps, path[r]);
             h.max_brick_steps = std::max(h.max_brick_steps, steps);
+        }
+        h.image_off.assign(h.mode == 2 ? static_cast<size_t>(nbricks) + 1 : 0, 0);
+        for (int64_t r = 0; r < nbricks && h.mode == 2; ++r) {
+            h.image_off[r + 1] = h.image_off[r] + brick_image_bytes(h.brick_row_begin[r + 1] - h.brick_row_begin[r],
+                                                                    h.brick_ext_begin[r + 1] - h.brick_ext_begin[r],
+                                                                    h.brick_step_ptr[r + 1] - h.brick_step_ptr[r], slots);
         }
         return GKOMI_SUCCESS;
     }
@@ -659,6 +696,65 @@ __global__ __launch_bounds__(T) void trs_brick_solve_kernel(
 }
 
 
+// The image of every brick (numeric phase of the pipelined plan): what the solve copies into LDS.
+template <int K>
+__global__ __launch_bounds__(128) void trs_brick_image_kernel(
+    int32_t n, const int32_t* __restrict__ perm, const double* __restrict__ diag, const double* __restrict__ rdiag,
+    const int32_t* __restrict__ cols, const double* __restrict__ pvals, const int32_t* __restrict__ brick_row_begin,
+    const int32_t* __restrict__ brick_step_ptr, const int32_t* __restrict__ step_begin,
+    const int32_t* __restrict__ brick_ext_begin, const int32_t* __restrict__ ext_col,
+    const int32_t* __restrict__ ext_row_off, char* __restrict__ image, const int64_t* __restrict__ image_off)
+{
+    constexpr int T = 64;
+    constexpr int rec_bytes = brick_record_bytes(K);
+    constexpr int off_v = 16, off_ca = 16 + 8 * K, off_xa = 16 + 12 * K, off_row = 20 + 12 * K, off_span = 24 + 12 * K;
+    // the division's fast box as an unsigned test on the biased exponent e of the numerator:
+    // e - box_first < span.  span = box_span for a row whose diagonal is in the box, 0 for one whose
+    // diagonal is not (always the careful path), everything for the spare record (never)
+    constexpr unsigned int box_span = safe_exponent_hi - safe_exponent_lo;
+    const int bk = blockIdx.x, tid = threadIdx.x;
+    const int r0 = brick_row_begin[bk], rows = brick_row_begin[bk + 1] - r0;
+    const int e0 = brick_ext_begin[bk], inflow = brick_ext_begin[bk + 1] - e0;
+    const int s0 = brick_step_ptr[bk], nsteps = brick_step_ptr[bk + 1] - s0;
+    const int zero_cell = rows + inflow, scratch_cell = zero_cell + 1;
+    char* lrec = image + image_off[bk];
+    int2* lstep = reinterpret_cast<int2*>(lrec + static_cast<size_t>(rows + 1) * rec_bytes);
+    int32_t* lext = reinterpret_cast<int32_t*>(lstep + nsteps + 4);
+    for (int i = tid; i <= rows; i += 128) {
+        const bool real = i < rows;
+        const int row = real ? perm[r0 + i] : -1;
+        char* rec = lrec + i * rec_bytes;
+        const double rd = real ? rdiag[r0 + i] : 1.0;
+        *reinterpret_cast<double*>(rec) = real ? diag[r0 + i] : 1.0;
+        *reinterpret_cast<double*>(rec + 8) = rd;
+#pragma unroll
+        for (int e = 0; e < K; ++e) {
+            // an empty slot: value 0.0 (as stored) times the zero cell, sum - (+0.0) = sum bit for bit
+            const int c = real ? cols[static_cast<int64_t>(e) * n + r0 + i] : pad_col;
+            *reinterpret_cast<double*>(rec + off_v + 8 * e) = real ? pvals[static_cast<int64_t>(e) * n + r0 + i] : 0.0;
+            *reinterpret_cast<int32_t*>(rec + off_ca + 4 * e) = 8 * (c == pad_col ? zero_cell : c);
+        }
+        *reinterpret_cast<int32_t*>(rec + off_xa) = 8 * (real ? i : scratch_cell);
+        // the row's byte offset in a contiguous x (the solve multiplies by its stride; it is launched
+        // only if that fits 31 bits); the spare record's is out of any buffer's range: the store is dropped
+        *reinterpret_cast<uint32_t*>(rec + off_row) = real ? static_cast<uint32_t>(row) * 8u : 0xffffffffu;
+        *reinterpret_cast<uint32_t*>(rec + off_span) = !real ? 0xffffffffu : rd == rd ? box_span : 0u;
+    }
+    for (int i = tid; i < nsteps + 4; i += 128) {
+        // steps beyond the last are empty; rows of the steps up to and including s end at `end`:
+        // their inflow entries come first in the list
+        int count = 0, need = inflow;
+        if (i < nsteps) {
+            const int begin = step_begin[s0 + i] & ~level_bit;
+            const int end = min(step_begin[s0 + i + 1] & ~level_bit, begin + T);
+            count = end - begin;
+            if (end < r0 + rows) need = ext_row_off[end] - e0;
+        }
+        lstep[i] = make_int2(count, need);
+    }
+    for (int j = tid; j < inflow; j += 128) lext[j] = ext_col[e0 + j];
+}
+
 // ---- pipelined variant ----------------------------------------------------------------------
 // Waiting for whole bricks makes the critical path (bricks on the longest chain) x (levels of a
 // brick): 2-2.6 times the levels of the factor.  Here a brick starts at once and its inflow
@@ -680,7 +776,7 @@ __global__ __launch_bounds__(256) void trs_brick_prepare_kernel(int64_t n, doubl
     }
 }
 
-template <int K, bool Unit>
+template <int K, bool Unit, bool Stamps = false>
 __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
     brick_header* hdr, const int32_t* __restrict__ perm, const double* __restrict__ diag,
     const double* __restrict__ rdiag, const int32_t* __restrict__ cols, const double* __restrict__ pvals,
@@ -688,7 +784,8 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
     const int32_t* __restrict__ step_begin, const int32_t* __restrict__ brick_ext_begin,
     const int32_t* __restrict__ ext_col, const int32_t* __restrict__ ext_row_off, int32_t n,
     const double* __restrict__ b, int64_t b_stride, double* x, int64_t x_stride, long long max_polls,
-    int nap_max)
+    int nap_max, const char* __restrict__ image, const int64_t* __restrict__ image_off,
+    long long* __restrict__ stamps = nullptr, int stamp_brick = 0)
 {
     constexpr int T = 64;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -701,72 +798,107 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
     }
     __syncthreads();
     const int bk = static_cast<int>(s_ticket);
+    if (Stamps && stamp_brick < 0 && tid == 0) stamps[4 * bk] = wall_clock64();  // started
     const int r0 = brick_row_begin[bk], rows = brick_row_begin[bk + 1] - r0;
     const int e0 = brick_ext_begin[bk], inflow = brick_ext_begin[bk + 1] - e0;
     const int s0 = brick_step_ptr[bk], nsteps = brick_step_ptr[bk + 1] - s0;
+    // LDS: x cells [rows | inflow | 0.0 | scratch] (doubles), then the brick's image (see
+    // trs_brick_image_kernel): one RECORD per row (+ a spare one, the row of a lane without work:
+    // values 0.0 on the zero cell, diagonal 1, result into the scratch cell, a store offset out of
+    // range), {rows, inflow needed} per step, the rows my inflow comes from.
+    // A record holds everything a step needs of its row behind ONE address computation, the LDS
+    // byte addresses of its dependencies' cells ready-made: the compute wave issues every
+    // instruction itself, 4+ cycles each.
+    constexpr int rec_bytes = brick_record_bytes(K);
+    constexpr int off_v = 16, off_ca = 16 + 8 * K, off_xa = 16 + 12 * K, off_row = 20 + 12 * K, off_span = 24 + 12 * K;
+    constexpr unsigned int box_first = safe_exponent_lo;
     double* lx = lds;
-    const int zero_cell = rows + inflow;
-    double* ld = lx + zero_cell + 1;
-    double* lr = ld + rows;
-    double* lv = lr + rows;
-    int32_t* lc = reinterpret_cast<int32_t*>(lv + static_cast<size_t>(K) * rows);
-    int32_t* ls = lc + static_cast<size_t>(K) * rows;  // step bounds
-    int32_t* lrow = ls + nsteps + 4;
-    int32_t* lext = lrow + rows;
-    int32_t* lneed = lext + inflow;                    // inflow entries step s needs: [0, lneed[s])
-    // A. my part of the factor and of the right-hand side into LDS (both waves)
-    for (int i = tid; i < rows; i += 128) {
-        const int row = perm[r0 + i];
-        lrow[i] = row;
-        lx[i] = b[row * b_stride];
-        if (!Unit) {
-            ld[i] = diag[r0 + i];
-            lr[i] = rdiag[r0 + i];
-        }
+    const int zero_cell = rows + inflow, scratch_cell = zero_cell + 1;
+    char* lrec = reinterpret_cast<char*>(lds) + (sizeof(double) * (rows + inflow + 2) + 15) / 16 * 16;
+    int2* lstep = reinterpret_cast<int2*>(lrec + static_cast<size_t>(rows + 1) * rec_bytes);
+    int32_t* lext = reinterpret_cast<int32_t*>(lstep + nsteps + 4);
+    // A. the image: a straight copy, global memory -> LDS without a register in between
+    //    (global_load_lds_dwordx4: 1 KiB per wave and instruction, all of a brick's ~40 per wave in
+    //    flight together).  Gathering the brick from the plan's arrays here took 15 us per brick --
+    //    dependent loads, one row per lane and round trip -- and copying it through registers, eight
+    //    loads in flight per lane, 18 us: brick START-UP, not the levels, was the pace of the solve.
+    {
+        // the right-hand side is a gather behind the permutation (two round trips): its first half goes
+        // out before the image, its second half while the image is on its way (loads return in order)
+        constexpr int gather_max = 16;  // rows <= 128 * 16: every brick that fits LDS
+        int my_row[gather_max];
 #pragma unroll
-        for (int e = 0; e < K; ++e) {
-            const int c = cols[static_cast<int64_t>(e) * n + r0 + i];
-            lv[e * rows + i] = pvals[static_cast<int64_t>(e) * n + r0 + i];
-            lc[e * rows + i] = c == pad_col ? zero_cell : c;
+        for (int u = 0; u < gather_max; ++u) {
+            const int i = tid + 128 * u;
+            my_row[u] = i < rows ? perm[r0 + i] : 0;
         }
-    }
-    for (int i = tid; i < nsteps + 4; i += 128) {
-        const int s = min(i, nsteps);
-        ls[i] = step_begin[s0 + s];
-        // rows of the steps up to and including s end at `end`: their inflow entries come first in the list
-        int need = inflow;
-        if (s < nsteps) {
-            const int begin = step_begin[s0 + s] & ~level_bit;
-            const int end = min(step_begin[s0 + s + 1] & ~level_bit, begin + T);
-            if (end < r0 + rows) need = ext_row_off[end] - e0;
+        const char* src = image + image_off[bk];
+        const int bytes = static_cast<int>(image_off[bk + 1] - image_off[bk]);  // a multiple of 16
+        const int lane16 = (tid & 63) * 16;
+        for (int o = (tid >> 6) * 1024; o < bytes; o += 2048) {
+            if (o + lane16 < bytes) {
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + o + lane16),
+                    (__attribute__((address_space(3))) void*)(lrec + o), 16, 0, 0);
+            }
         }
-        lneed[i] = need;
+        double my_b[gather_max];
+#pragma unroll
+        for (int u = 0; u < gather_max; ++u) my_b[u] = tid + 128 * u < rows ? b[my_row[u] * b_stride] : 0.0;
+#pragma unroll
+        for (int u = 0; u < gather_max; ++u) {
+            if (tid + 128 * u < rows) lx[tid + 128 * u] = my_b[u];
+        }
+        if (tid == 0) {
+            lx[zero_cell] = 0.0;
+            lx[scratch_cell] = 0.0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the image has landed
     }
-    for (int j = tid; j < inflow; j += 128) lext[j] = ext_col[e0 + j];
-    if (tid == 0) lx[zero_cell] = 0.0;
     __syncthreads();
+    if (x_stride != 1) {  // the image holds row * 8: the store offsets of a strided x
+        for (int i = tid; i < rows; i += 128) {
+            uint32_t* off = reinterpret_cast<uint32_t*>(lrec + i * rec_bytes + off_row);
+            *off = static_cast<uint32_t>(*off * x_stride);
+        }
+        __syncthreads();
+    }
     if (tid >= T) {
-        // ---- the pump: a window of 64 consecutive inflow entries, one per lane; the counter is
-        //      the window's READY PREFIX (an entry that is late does not hold back the ones a
-        //      step needs first), and the window slides by half as soon as its lower half is in
+        // ---- the pump: a window of W x 64 consecutive inflow entries, W per lane, all polled together
+        //      (a round trip to memory is ~1 us and a 10^3 brick has 300 entries: 64 per round trip made
+        //      the pump, not the arithmetic, the brick's pace).  The counter is the window's READY
+        //      PREFIX -- an entry that is late does not hold back the ones a step needs first -- and the
+        //      window slides by 64 as soon as its first 64 are in.
+        constexpr int W = 4;
         const int lane = tid - T;
         const unsigned long long* xb = reinterpret_cast<const unsigned long long*>(x);
         auto poll = [&](int j) {
-            return __hip_atomic_load(xb + static_cast<int64_t>(lext[j]) * x_stride, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
+            return j < inflow ? __hip_atomic_load(xb + static_cast<int64_t>(lext[j]) * x_stride, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT)
+                              : 0ull;  // behind the list: "ready"
         };
         bool gave_up = false;
         int base = 0, published = 0;  // entries [0, base + published) are in LDS
-        unsigned long long v = lane < inflow ? poll(lane) : 0ull;
         long long polls = 0;
+        unsigned long long v[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = poll(T * k + lane);
         int nap = 1;
         while (base + published < inflow) {
-            const int j = base + lane;
-            const bool mine = j < inflow;
-            const unsigned long long late = __ballot(mine && v == sentinel_bits);
-            const int prefix = late == 0ull ? T : __builtin_ctzll(late);
+            int prefix = W * T;
+#pragma unroll
+            for (int k = W - 1; k >= 0; --k) {
+                const unsigned long long late = __ballot(v[k] == sentinel_bits);
+                if (late != 0ull) prefix = T * k + __builtin_ctzll(late);
+            }
             if (prefix > published) {
-                if (mine && lane >= published && lane < prefix) lx[rows + j] = __longlong_as_double(static_cast<long long>(v));
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    const int w = T * k + lane;  // my entry of this quarter, counted from `base`
+                    if (w >= published && w < prefix && base + w < inflow) {
+                        lx[rows + base + w] = __longlong_as_double(static_cast<long long>(v[k]));
+                    }
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the values before the counter
                 if (lane == 0) {
                     __hip_atomic_store(&s_inflow_ready, min(base + prefix, inflow), __ATOMIC_RELAXED,
@@ -776,12 +908,12 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
                 nap = 1;
             }
             if (base + published >= inflow) break;
-            if (published >= T / 2) {  // slide: the upper half moves down, the lanes above it take new entries
-                const unsigned long long moved = __shfl_down(v, T / 2, T);
-                base += T / 2;
-                published -= T / 2;
-                const int nj = base + lane;
-                v = lane < T / 2 ? moved : (nj < inflow ? poll(nj) : 0ull);
+            if (published >= T) {  // slide: every quarter moves down, the last one takes new entries
+#pragma unroll
+                for (int k = 0; k + 1 < W; ++k) v[k] = v[k + 1];
+                base += T;
+                published -= T;
+                v[W - 1] = poll(base + T * (W - 1) + lane);
                 continue;
             }
             if (++polls > max_polls) {
@@ -790,7 +922,10 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
             }
             for (int k = 0; k < nap; ++k) __builtin_amdgcn_s_sleep(2);
             nap = min(nap + 1, nap_max);  // a brick far behind the front backs off (8: to ~0.5 us)
-            if (mine && v == sentinel_bits) v = poll(j);
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                if (v[k] == sentinel_bits) v[k] = poll(base + T * k + lane);
+            }
         }
         if (gave_up && lane == 0) {
             __hip_atomic_store(&s_inflow_ready, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -798,83 +933,117 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
         }
     } else {
         // ---- the compute wave ----
+        // What a step costs is the chain result -> dependants -> result: an LDS turnaround (~60
+        // cycles), the subtractions and the division's tail (~9 cycles per dependent f64
+        // instruction) -- plus every instruction the wave issues at all (4+ cycles each) and
+        // every TAKEN branch (~20 cycles; tools/latency_probe.hip, profiles/r02_trs_bricks.md).  So
+        // the loop is straight-line code over ready-made addresses: a lane without a row works on
+        // the spare record, only its two stores are masked, and the rare cases (inflow not in yet,
+        // an operand outside the division's fast box, a NaN that looks like the sentinel) sit
+        // behind wave-uniform branches that are not taken.
         struct step_data {
-            int i;  // my row of the brick, -1 = none
-            int row, need;
             double d, r;
-            int c[K];
             double v[K];
+            int ca[K];          // LDS byte addresses of the dependencies' cells
+            int xa;             // ... of my own cell (the spare record: the scratch cell)
+            unsigned int off;   // byte offset of my row in x (the spare record: out of range)
+            unsigned int span;  // see box_span
+            int need;           // inflow entries this step needs
         };
-        auto fetch = [&](int s, int first, int next_first, step_data& sd) {
-            sd.i = -1;
-            sd.need = 0;
-            if (s >= nsteps) return;
-            const int begin = (first & ~level_bit) - r0;
-            const int end = min((next_first & ~level_bit) - r0, begin + T);
-            sd.need = lneed[s];
-            const int i = begin + tid;
-            if (i < end) {
-                sd.i = i;
-                sd.row = lrow[i];
-                if (!Unit) {
-                    sd.d = ld[i];
-                    sd.r = lr[i];
-                }
+        const char* lxb = reinterpret_cast<const char*>(lx);
+        int begin = 0;  // first row of the step to fetch next
+        auto fetch = [&](int2 st, step_data& sd) {
+            const char* rec = lrec + __umul24(tid < st.x ? begin + tid : rows, rec_bytes);
+            begin += st.x;
+            sd.d = *reinterpret_cast<const double*>(rec);
+            sd.r = *reinterpret_cast<const double*>(rec + 8);
 #pragma unroll
-                for (int e = 0; e < K; ++e) {
-                    sd.c[e] = lc[e * rows + i];
-                    sd.v[e] = lv[e * rows + i];
-                }
+            for (int e = 0; e < K; ++e) {
+                sd.v[e] = *reinterpret_cast<const double*>(rec + off_v + 8 * e);
+                sd.ca[e] = *reinterpret_cast<const int32_t*>(rec + off_ca + 4 * e);
             }
+            sd.xa = *reinterpret_cast<const int32_t*>(rec + off_xa);
+            sd.off = *reinterpret_cast<const uint32_t*>(rec + off_row);
+            sd.span = *reinterpret_cast<const uint32_t*>(rec + off_span);
+            sd.need = st.y;
         };
         bool poisoned = false;
-        unsigned long long* xo = reinterpret_cast<unsigned long long*>(x);
-        auto step = [&](int s, const step_data& cur, step_data& nxt, int w1, int w2, int& w3) {
-            if (s >= nsteps) return;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the level before is in LDS (one wave: ordering only)
+        unsigned int healthy = ~0u;  // 0 once the brick has given up: every step takes the careful path
+        // x as a buffer: a store behind its end is dropped, so the lanes without a row need no branch
+        const __amdgpu_buffer_rsrc_t xbuf = __builtin_amdgcn_make_buffer_rsrc(
+            x, 0, static_cast<int>(((static_cast<int64_t>(n) - 1) * x_stride + 1) * 8), 0x00020000);
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        // A step, measured piece by piece (tools/step_probe.hip, shader clocks): the chain itself -- LDS
+        // turnaround, K multiply-subtracts, the division's tail -- 140; the next step's record +55; and
+        // EVERY conditional branch, taken or not, +35, a v_cmp_f64 + s_or chain more.  So: the step
+        // computes on whatever the inflow cells hold, then asks ONE question -- is the inflow counter
+        // short, is an operand outside the division's fast box (integer test on the exponent), has
+        // the brick given up -- and only the (not taken) branch behind it redoes the step carefully.
+        auto step = [&](int s, const step_data& cur, step_data& nxt, int2 st1, int2& st2) {
             double xd[K];
-            double sum = 0.0;
-            int ready;
-            // counter first, then the dependencies: LDS serves a wave in order, so values read
-            // behind a sufficient counter are the pump's
-            long long spins = 0;
-            while (true) {
-                ready = __hip_atomic_load(&s_inflow_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (cur.i >= 0) {
+            // counter first, then the values: LDS serves a wave in order, so values read behind a
+            // sufficient counter are the pump's
+            int ready = __hip_atomic_load(&s_inflow_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-                    for (int e = 0; e < K; ++e) xd[e] = lx[cur.c[e]];
-                    sum = lx[cur.i];
-                }
-                if (ready >= cur.need) break;
-                if (ready < 0 || ++spins > max_polls) {
-                    poisoned = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            w3 = ls[s + 3];
-            fetch(s + 1, w1, w2, nxt);
-            if (cur.i >= 0) {
+            for (int e = 0; e < K; ++e) xd[e] = *reinterpret_cast<const double*>(lxb + cur.ca[e]);
+            const double rhs = *reinterpret_cast<const double*>(lxb + cur.xa);
+            st2 = lstep[s + 2];
+            fetch(st1, nxt);
+            double sum = rhs;
 #pragma unroll
-                for (int e = 0; e < K; ++e) sum -= cur.v[e] * xd[e];
-                const double xr = Unit ? sum : divide_by_row_diagonal(sum, cur.d, cur.r);
-                lx[cur.i] = xr;  // the next level waits for this; what goes to memory may take two more instructions
-                unsigned long long out = static_cast<unsigned long long>(__double_as_longlong(xr));
-                if (poisoned || out == sentinel_bits) out = poison_bits;  // a result must not look unfinished
-                __hip_atomic_store(xo + cur.row * x_stride, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int e = 0; e < K; ++e) sum -= cur.v[e] * xd[e];
+            double xr = sum;
+            if (!Unit) {
+                // the division's tail on the prepared reciprocal (see divide_by_row_diagonal)
+                const double q = sum * cur.r;
+                const double rem = __builtin_fma(-cur.d, q, sum);
+                xr = __builtin_fma(rem, cur.r, q);
             }
+            // all ones if the inflow is in and the brick has not given up, else 0 (masks, not && / ?: --
+            // those come back as branches)
+            const unsigned int fine = static_cast<unsigned int>((cur.need - 1 - __builtin_amdgcn_readfirstlane(ready)) >> 31) & healthy;
+            const unsigned int exponent = (static_cast<unsigned int>(__double2hiint(sum)) >> 20) & 0x7ffu;
+            if (__builtin_expect(__any(exponent - box_first >= (cur.span & fine)), 0)) {
+                // carefully: wait for the inflow, read again, divide where the fast box does not hold
+                long long spins = 0;
+                while (ready < cur.need && !poisoned) {
+                    if (ready < 0 || ++spins > max_polls) {
+                        poisoned = true;
+                        healthy = 0u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    ready = __hip_atomic_load(&s_inflow_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                sum = rhs;
+#pragma unroll
+                for (int e = 0; e < K; ++e) sum -= cur.v[e] * *reinterpret_cast<const double*>(lxb + cur.ca[e]);
+                xr = Unit ? sum : divide_by_row_diagonal(sum, cur.d, cur.r);
+                if (poisoned || __double_as_longlong(xr) == static_cast<long long>(sentinel_bits)) {
+                    xr = __longlong_as_double(static_cast<long long>(poison_bits));  // a result must not look unfinished
+                }
+            }
+            *reinterpret_cast<double*>(const_cast<char*>(lxb) + cur.xa) = xr;
+            u32x2 out;
+            out.x = static_cast<unsigned int>(__double2loint(xr));
+            out.y = static_cast<unsigned int>(__double2hiint(xr));
+            __builtin_amdgcn_raw_buffer_store_b64(out, xbuf, cur.off, 0, 16);  // 16 = sc1: write-through, agent scope
         };
         step_data even, odd;
-        int w1 = ls[1], w2 = ls[2];
-        fetch(0, ls[0], w1, even);
-        for (int s = 0; s < nsteps; s += 2) {
-            int w3 = 0, w4 = 0;
-            step(s, even, odd, w1, w2, w3);
-            step(s + 1, odd, even, w2, w3, w4);
-            w1 = w3;
-            w2 = w4;
+        int2 sa = lstep[1];  // {rows, inflow needed} of the step after the current one
+        fetch(lstep[0], even);
+        if (Stamps && stamp_brick < 0 && tid == 0) stamps[4 * bk + 1] = wall_clock64();  // in LDS
+        for (int s = 0; s < nsteps; s += 2) {  // an odd count runs one empty step
+            int2 sb, sc;
+            if (Stamps && bk == stamp_brick && tid == 0 && s < 1022) stamps[1 + s / 2] = __builtin_readcyclecounter();
+            step(s, even, odd, sa, sb);
+            if (Stamps && stamp_brick < 0 && tid == 0 && s == 0) stamps[4 * bk + 2] = wall_clock64();  // first step done
+            step(s + 1, odd, even, sb, sc);
+            sa = sc;
         }
+        if (Stamps && stamp_brick < 0 && tid == 0) stamps[4 * bk + 3] = wall_clock64();  // last step done
     }
+    if (Stamps && bk == stamp_brick && tid == 0) stamps[0] = nsteps;
     __syncthreads();
     if (tid == 0) {
         const unsigned int before = atomicAdd(&hdr->finished, 1u);
@@ -1050,6 +1219,7 @@ extern "C" int gkomi_trs_bricks_numeric_f64_i32(gkomi_stream_t s, gkomi_trs_bric
         if (!err) err = upload(stream, p, l.row_rank, h->row_rank);
         if (!err) err = upload(stream, p, l.inv_local, h->inv_local);
         if (!err) err = upload(stream, p, l.ext_row_off, h->ext_row_off);
+        if (!err) err = upload(stream, p, l.image_off, h->image_off);
         if (err) return err;
         h->uploaded_to = plan;
     }
@@ -1066,6 +1236,32 @@ extern "C" int gkomi_trs_bricks_numeric_f64_i32(gkomi_stream_t s, gkomi_trs_bric
                        reinterpret_cast<double*>(p + l.rdiag), reinterpret_cast<int32_t*>(p + l.cols), reinterpret_cast<double*>(p + l.vals));
     err = check_launch();
     if (err) return err;
+    if (h->mode == 2) {
+#define GKOMI_BRICK_IMAGE(K)                                                                                          \
+    hipLaunchKernelGGL((trs_brick_image_kernel<K>), dim3(static_cast<unsigned>(h->nbricks)), dim3(128), 0, stream,     \
+                       static_cast<int32_t>(h->n), reinterpret_cast<const int32_t*>(p + l.perm),                      \
+                       reinterpret_cast<const double*>(p + l.diag), reinterpret_cast<const double*>(p + l.rdiag),    \
+                       reinterpret_cast<const int32_t*>(p + l.cols), reinterpret_cast<const double*>(p + l.vals),    \
+                       reinterpret_cast<const int32_t*>(p + l.brick_row_begin),                                      \
+                       reinterpret_cast<const int32_t*>(p + l.brick_step_ptr),                                       \
+                       reinterpret_cast<const int32_t*>(p + l.step_begin),                                           \
+                       reinterpret_cast<const int32_t*>(p + l.brick_ext_begin),                                      \
+                       reinterpret_cast<const int32_t*>(p + l.ext_col),                                              \
+                       reinterpret_cast<const int32_t*>(p + l.ext_row_off), p + l.image,                             \
+                       reinterpret_cast<const int64_t*>(p + l.image_off))
+        if (h->width <= 2) {
+            GKOMI_BRICK_IMAGE(2);
+        } else if (h->width <= 3) {
+            GKOMI_BRICK_IMAGE(3);
+        } else if (h->width <= 4) {
+            GKOMI_BRICK_IMAGE(4);
+        } else {
+            GKOMI_BRICK_IMAGE(8);
+        }
+#undef GKOMI_BRICK_IMAGE
+        err = check_launch();
+        if (err) return err;
+    }
     return static_cast<int>(hipStreamSynchronize(stream));  // the header and the host vectors were sources
 }
 
@@ -1112,6 +1308,28 @@ int launch_pipelined(hipStream_t stream, gkomi_trs_bricks* h, char* p, const bri
     const char* env_nap = getenv("GKOMI_TRS_BRICK_NAP");  // tuning knob (tools/trs_bricks_probe.py)
     const int nap_max = env_nap != nullptr && env_nap[0] != 0 ? std::max(1, atoi(env_nap)) : 8;
     hipLaunchKernelGGL(trs_brick_prepare_kernel, dim3(grid_for(h->n, 256)), dim3(256), 0, stream, h->n, x, x_stride);
+    const char* env_stamps = getenv("GKOMI_TRS_BRICK_STAMPS");  // tools/trs_bricks_probe.py stamps
+    if (!Unit && env_stamps != nullptr && env_stamps[0] != 0) {
+        if (lds_bytes > 64 * 1024) {
+            const int err = static_cast<int>(hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&trs_brick_pipelined_kernel<K, false, true>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+            if (err) return err;
+        }
+        hipLaunchKernelGGL((trs_brick_pipelined_kernel<K, false, true>), dim3(static_cast<unsigned>(h->nbricks)), dim3(128),
+                           lds_bytes, stream, reinterpret_cast<brick_header*>(p), reinterpret_cast<const int32_t*>(p + l.perm),
+                           reinterpret_cast<const double*>(p + l.diag), reinterpret_cast<const double*>(p + l.rdiag),
+                           reinterpret_cast<const int32_t*>(p + l.cols), reinterpret_cast<const double*>(p + l.vals),
+                           reinterpret_cast<const int32_t*>(p + l.brick_row_begin),
+                           reinterpret_cast<const int32_t*>(p + l.brick_step_ptr),
+                           reinterpret_cast<const int32_t*>(p + l.step_begin),
+                           reinterpret_cast<const int32_t*>(p + l.brick_ext_begin),
+                           reinterpret_cast<const int32_t*>(p + l.ext_col),
+                           reinterpret_cast<const int32_t*>(p + l.ext_row_off), static_cast<int32_t>(h->n), b, b_stride, x,
+                           x_stride, max_polls, nap_max, p + l.image, reinterpret_cast<const int64_t*>(p + l.image_off),
+                           reinterpret_cast<long long*>(p + l.stamps), atoi(env_stamps));
+        return check_launch();
+    }
     hipLaunchKernelGGL((trs_brick_pipelined_kernel<K, Unit>), dim3(static_cast<unsigned>(h->nbricks)), dim3(128), lds_bytes,
                        stream, reinterpret_cast<brick_header*>(p), reinterpret_cast<const int32_t*>(p + l.perm),
                        reinterpret_cast<const double*>(p + l.diag), reinterpret_cast<const double*>(p + l.rdiag),
@@ -1122,7 +1340,7 @@ int launch_pipelined(hipStream_t stream, gkomi_trs_bricks* h, char* p, const bri
                        reinterpret_cast<const int32_t*>(p + l.brick_ext_begin),
                        reinterpret_cast<const int32_t*>(p + l.ext_col),
                        reinterpret_cast<const int32_t*>(p + l.ext_row_off), static_cast<int32_t>(h->n), b, b_stride, x,
-                       x_stride, max_polls, nap_max);
+                       x_stride, max_polls, nap_max, p + l.image, reinterpret_cast<const int64_t*>(p + l.image_off));
     return check_launch();
 }
 
@@ -1166,6 +1384,7 @@ extern "C" int gkomi_trs_bricks_solve_f64(gkomi_stream_t s, gkomi_trs_bricks* h,
     if (h == nullptr || plan == nullptr || nrhs < 0 || b_stride < nrhs || x_stride < nrhs) return GKOMI_EINVAL;
     if (h->uploaded_to != plan) return GKOMI_EINVAL;  // numeric phase first
     if (h->mode == 2 && x == b) return GKOMI_EINVAL;  // pipelined: x carries the ready flags
+    if (h->mode == 2 && h->n * x_stride * 8 > INT32_MAX) return GKOMI_ENOTSUPPORTED;  // records hold 31-bit byte offsets into x
     if (nrhs == 0) return GKOMI_SUCCESS;
     const brick_layout l = make_layout(*h);
     char* p = static_cast<char*>(plan);
@@ -1186,6 +1405,23 @@ extern "C" int gkomi_trs_bricks_solve_f64(gkomi_stream_t s, gkomi_trs_bricks* h,
         if (err) return err;
     }
     return GKOMI_SUCCESS;
+}
+
+// tools only (not in gkomi.h): the stamps a solve under GKOMI_TRS_BRICK_STAMPS=<brick> left, 1024 entries:
+// [0] = steps of that brick, [1 + k] = shader clock at the top of step 2 k
+extern "C" int gkomi_trs_bricks_debug_stamps(gkomi_stream_t s, const gkomi_trs_bricks* h, const void* plan,
+                                             long long* host_out)
+{
+    if (h == nullptr || plan == nullptr || host_out == nullptr) return GKOMI_EINVAL;
+    const brick_layout l = make_layout(*h);
+    hipStream_t stream = to_stream(s);
+    // 8 KiB in the one-brick mode; 32 bytes per brick when every brick stamped (GKOMI_TRS_BRICK_STAMPS=-1)
+    const char* env_stamps = getenv("GKOMI_TRS_BRICK_STAMPS");
+    const size_t bytes = env_stamps != nullptr && atoi(env_stamps) < 0 ? 32 * static_cast<size_t>(h->nbricks) : 8 * 1024;
+    int err = static_cast<int>(hipMemcpyAsync(host_out, static_cast<const char*>(plan) + l.stamps, bytes,
+                                              hipMemcpyDeviceToHost, stream));
+    if (err) return err;
+    return static_cast<int>(hipStreamSynchronize(stream));
 }
 
 extern "C" int gkomi_trs_bricks_check_overrun(gkomi_stream_t s, const void* plan, int* host_flag)

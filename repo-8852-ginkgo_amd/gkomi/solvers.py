@@ -349,9 +349,9 @@ class TrsBricks:
         self.plan = torch.empty(max(self.plan_bytes, 8), dtype=torch.uint8, device=vals.device)
         self.refresh(vals)
 
-    def estimate_us(self):
-        """critical path of the solve: LDS steps + one memory hand-off per brick level"""
-        return 0.15 * self.critical_steps + 3.0 * self.coarse_levels
+    def estimate_us(self, nlevels):
+        """critical path of the pipelined solve: one LDS step per level of the factor + a memory hand-off per brick level"""
+        return TRS_BRICK_STEP_US * nlevels + TRS_BRICK_HOP_US * self.coarse_levels
 
     def refresh(self, vals):
         s = torch.cuda.current_stream().cuda_stream
@@ -382,10 +382,11 @@ class TrsBricks:
 TRS_PLAN_MIN_ROWS_PER_LEVEL = 64
 
 
-# per dependency level of the level plan / per step + per brick on the critical path of a brick plan (us,
-# measured on the 108^3 and 1000^2 factors): what `ilu_from_factors` compares to pick a plan
+# per dependency level of the level plan / per level + per brick level of the pipelined brick plan (us,
+# measured on the 108^3 and 1000^2 factors, profiles/r02_trs_bricks.md): what `ilu_from_factors` compares
 TRS_LEVEL_US = 1.7
-TRS_BRICK_STEP_US = 0.3
+TRS_BRICK_STEP_US = 0.17
+TRS_BRICK_HOP_US = 5.0
 
 
 def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True, bricks=True):
@@ -406,7 +407,7 @@ def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True, brick
                 try:
                     bk = TrsBricks(gk, n, f[0], f[1], f[2], lower)
                     # pipelined: about one step per level of the factor
-                    if TRS_BRICK_STEP_US * plan.nlevels + 3.0 * bk.coarse_levels < TRS_LEVEL_US * plan.nlevels:
+                    if TRS_BRICK_STEP_US * plan.nlevels + TRS_BRICK_HOP_US * bk.coarse_levels < TRS_LEVEL_US * plan.nlevels:
                         brick_plans[i] = bk
                         continue
                 except GkomiError as e:

@@ -2178,7 +2178,7 @@ protected:
             if (bricks_ != nullptr) {
                 int64_t info[8] = {};
                 GKOMI_CALL(gkomi_trs_bricks_info(bricks_, info));
-                if (0.3 * nlevels_ + 3.0 * info[1] < 1.7 * nlevels_) {
+                if (0.17 * nlevels_ + 5.0 * info[1] < 1.7 * nlevels_) {  // us per level / per brick level (profiles/r02_trs_bricks.md) vs the level plan
                     plan_.resize_and_reset(gkomi_trs_bricks_plan_bytes(bricks_));
                     GKOMI_CALL(gkomi_trs_bricks_numeric_f64_i32(nullptr, bricks_, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(), plan_.get_data(),
                                                                 plan_.get_num_elems()));

@@ -52,7 +52,7 @@ def run(name, n, rp, ci, v, sizes, threads_list, psizes):
                 same = bool(torch.equal(x, ref))
                 print(f"   mode {bk.mode} brick_rows {rows:6d} threads {bk.threads:3d}: {t:8.1f} us  identical={same} overrun={int(bk.overrun())}  "
                       f"bricks {bk.nbricks:6d} brick levels {bk.coarse_levels:4d} critical steps {bk.critical_steps:6d} "
-                      f"lds {bk.lds_bytes // 1024:3d} KiB  estimate {bk.estimate_us():7.1f} us  analysis {t_an:6.1f} ms", flush=True)
+                      f"lds {bk.lds_bytes // 1024:3d} KiB  estimate {bk.estimate_us(plan.nlevels):7.1f} us  analysis {t_an:6.1f} ms", flush=True)
 
 
 def sweep(name, n, rp, ci, v, rows_list):
@@ -70,9 +70,77 @@ def sweep(name, n, rp, ci, v, rows_list):
 
 
 what = sys.argv[1] if len(sys.argv) > 1 else "both"
+if what == "timeline":
+    # every brick stamps start / in LDS / first step done / last step done (shader clock): who waits for what
+    import ctypes
+    fn = gk._cdll.gkomi_trs_bricks_debug_stamps
+    fn.argtypes = [ctypes.c_void_p] * 4
+    n, rp, ci, v = matgen.poisson_3d_7pt(108)
+    trp, tci, tv = tri(n, rp, ci, v, True)
+    rpd, cid, vd = d(trp), d(tci), d(tv)
+    b = torch.from_numpy(np.sin(0.1 * np.arange(n)) + 2.0).cuda().reshape(n, 1)
+    x = torch.zeros_like(b)
+    rows = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bk = solvers.TrsBricks(gk, n, rpd, cid, vd, True, rows, 0, 2)
+    os.environ["GKOMI_TRS_BRICK_STAMPS"] = "-1"
+    for _ in range(3): bk.solve(b, x)
+    torch.cuda.synchronize()
+    out = (ctypes.c_longlong * (4 * bk.nbricks))()
+    fn(None, bk.handle.value, bk.plan.data_ptr(), ctypes.addressof(out))
+    t = np.array(out, dtype=np.int64).reshape(-1, 4)
+    us = (t - t[:, 0].min()) / 100.0   # s_memrealtime: 100 MHz, one clock for the whole chip
+    def harr(which):
+        data = ctypes.POINTER(ctypes.c_int32)(); count = ctypes.c_int64(0)
+        gk.trs_bricks_host_array(bk.handle.value, which, ctypes.addressof(data), ctypes.addressof(count))
+        return np.ctypeslib.as_array(data, shape=(count.value,)).copy()
+    pred_ptr, pred_idx = harr(6), harr(7)
+    print(f"bricks {bk.nbricks}, brick levels {bk.coarse_levels}; first start to last end {us[:, 3].max():.1f} us")
+    load, wait, run = us[:, 1] - us[:, 0], us[:, 2] - us[:, 1], us[:, 3] - us[:, 2]
+    # hand-off: my first step done - the latest first-step-done among the bricks I depend on
+    hop = np.array([us[r, 2] - us[pred_idx[pred_ptr[r]:pred_ptr[r + 1]], 2].max() for r in range(bk.nbricks) if pred_ptr[r + 1] > pred_ptr[r]])
+    lead = np.array([us[pred_idx[pred_ptr[r]:pred_ptr[r + 1]], 2].max() - us[r, 1] for r in range(bk.nbricks) if pred_ptr[r + 1] > pred_ptr[r]])
+    print(f"medians [us]: image + rhs into LDS {np.median(load):.1f}, then until the first step is done {np.median(wait):.1f}, the other steps {np.median(run):.1f}")
+    print(f"first step done after the slowest predecessor's first step: median {np.median(hop):.2f} us, 10% {np.percentile(hop, 10):.2f}, 90% {np.percentile(hop, 90):.2f}")
+    print(f"a brick is in LDS before its slowest predecessor's first step is done by: median {np.median(lead):.1f} us, 10% {np.percentile(lead, 10):.1f} (negative = the brick was late)")
+    print(f"resident at once (max over time): {max(int(((us[:, 0] <= tt) & (us[:, 3] >= tt)).sum()) for tt in np.linspace(0, us[:, 3].max(), 400))}")
+    # the critical chain backwards from the last brick to finish
+    r = int(np.argmax(us[:, 3])); chain = []
+    while True:
+        chain.append(r)
+        ps = pred_idx[pred_ptr[r]:pred_ptr[r + 1]]
+        if len(ps) == 0: break
+        r = int(ps[np.argmax(us[ps, 2])])
+    print("critical chain (rank: started, in LDS, first step done, last step done):")
+    for r in chain[::-1][::max(1, len(chain) // 16)]:
+        print(f"  {r:5d}: {us[r, 0]:7.1f} {us[r, 1]:7.1f} {us[r, 2]:7.1f} {us[r, 3]:7.1f}")
+    sys.exit(0)
+if what == "stamps":
+    # shader-clock stamps at the top of every second step of one brick (GKOMI_TRS_BRICK_STAMPS build path)
+    import ctypes
+    fn = gk._cdll.gkomi_trs_bricks_debug_stamps
+    fn.argtypes = [ctypes.c_void_p] * 4
+    for (nx, ny, rows, brick) in ((8, 128, 1024, 0), (32, 3200, 1024, 50), (108, 108 * 108, 1024, 600)):
+        n, rp, ci, v = matgen.poisson_2d_5pt(nx, ny) if ny != 108 * 108 else matgen.poisson_3d_7pt(108)
+        trp, tci, tv = tri(n, rp, ci, v, True)
+        rpd, cid, vd = d(trp), d(tci), d(tv)
+        b = torch.from_numpy(np.sin(0.1 * np.arange(n)) + 2.0).cuda().reshape(n, 1)
+        x = torch.zeros_like(b)
+        bk = solvers.TrsBricks(gk, n, rpd, cid, vd, True, rows, 0, 2)
+        os.environ["GKOMI_TRS_BRICK_STAMPS"] = str(min(brick, bk.nbricks - 1))
+        for _ in range(3): bk.solve(b, x)
+        torch.cuda.synchronize()
+        out = (ctypes.c_longlong * 1024)()
+        fn(None, bk.handle.value, bk.plan.data_ptr(), ctypes.addressof(out))
+        os.environ.pop("GKOMI_TRS_BRICK_STAMPS")
+        ns = int(out[0]); st = np.array(out[1:1 + (ns + 1) // 2], dtype=np.int64)
+        dt = np.diff(st) / 2.0
+        print(f"{nx}x{ny} brick {brick} of {bk.nbricks}: {ns} steps; shader ticks per step: median {np.median(dt):.0f} min {dt.min():.0f} "
+              f"max {dt.max():.0f} mean {dt.mean():.0f}; first 40: {' '.join(str(int(v)) for v in dt[:40])}", flush=True)
+    sys.exit(0)
 if what == "chain":
     # grids that are one chain of bricks: time per level = LDS step + (hand-off latency) / (levels per brick)
-    for (nx, ny, rows) in ((32, 3200, 1024), (64, 1600, 4096), (16, 6400, 256), (1024, 64, 1024)):
+    # the first two are ONE brick each: their difference = 128 levels without any hand-off
+    for (nx, ny, rows) in ((8, 128, 1024), (8, 256, 2048), (32, 3200, 1024), (64, 1600, 4096), (16, 6400, 256), (1024, 64, 1024)):
         n, rp, ci, v = matgen.poisson_2d_5pt(nx, ny)
         trp, tci, tv = tri(n, rp, ci, v, True)
         rpd, cid, vd = d(trp), d(tci), d(tv)
@@ -95,7 +163,7 @@ quick = os.environ.get("TRS_QUICK")
 if what in ("3d", "both"):
     g = int(sys.argv[2]) if len(sys.argv) > 2 else 108
     n, rp, ci, v = matgen.poisson_3d_7pt(g)
-    run(f"7pt {g}^3", n, rp, ci, v, (4096,) if quick else (1728, 4096), (0,), (0,) if quick else (0, 216, 512, 1000, 1728))
+    run(f"7pt {g}^3", n, rp, ci, v, (4096,) if quick else (1728, 4096), (0,), (0,) if quick else (0, 512, 600, 729, 850, 1000, 1331))
 if what in ("2d", "both"):
     g = int(sys.argv[2]) if len(sys.argv) > 2 and what == "2d" else 1000
     n, rp, ci, v = matgen.poisson_2d_5pt(g)
