@@ -35,7 +35,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <new>
+#include <thread>
 #include <vector>
 
 struct gkomi_trs_bricks {
@@ -157,34 +160,98 @@ inline bool is_dep(bool lower, int64_t col, int64_t row) { return lower ? col < 
 
 // ---------------------------------------------------------------- analysis (host) ----------
 
+// f(part, lo, hi) on `parts` contiguous pieces of [0, n), piece boundaries at multiples of `grain`
+template <typename F>
+void in_parallel(int64_t n, int64_t grain, int parts, F f)
+{
+    grain = std::max<int64_t>(grain, 1);
+    const int64_t units = ceildiv(n, grain);
+    parts = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(parts, units)));
+    std::vector<std::thread> pool;
+    pool.reserve(static_cast<size_t>(parts));
+    for (int p = 0; p < parts; ++p) {
+        const int64_t lo = std::min(n, units * p / parts * grain), hi = std::min(n, units * (p + 1) / parts * grain);
+        if (p + 1 == parts) {
+            f(p, lo, hi);  // the caller's thread takes the last piece
+        } else {
+            pool.emplace_back(f, p, lo, hi);
+        }
+    }
+    for (auto& t : pool) t.join();
+}
+
+inline int analysis_threads()
+{
+    const char* v = getenv("GKOMI_ANALYSIS_THREADS");
+    if (v != nullptr && v[0] != 0) return std::max(1, atoi(v));
+    const unsigned hw = std::thread::hardware_concurrency();
+    return static_cast<int>(std::min(8u, std::max(1u, hw)));
+}
+
 // the whole symbolic analysis; GKOMI_ENOTSUPPORTED = this factor is not for the brick plan
 int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vector<int32_t>& ci,
             int64_t brick_rows, int threads, int mode)
 {
     h.mode = mode == 1 ? 1 : 2;
     if (h.mode == 2) threads = 64;  // one compute wave (+ the pump)
+    const bool trace = getenv("GKOMI_ANALYSIS_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  analysis: %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const int64_t n = h.n;
     const bool lower = h.lower != 0;
     // 1. the distinct dependency offsets and the longest dependency list
+    const int nthreads = analysis_threads();
     int64_t offs[max_offsets];
     int noffs = 0;
     int width = 0;
-    for (int64_t row = 0; row < n; ++row) {
-        int deps = 0;
-        for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
-            const int64_t col = ci[k];
-            if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
-            ++deps;
-            const int64_t d = lower ? row - col : col - row;
-            int j = 0;
-            while (j < noffs && offs[j] != d) ++j;
-            if (j == noffs) {
-                if (noffs == max_offsets) return GKOMI_ENOTSUPPORTED;
-                offs[noffs++] = d;
+    {
+        struct partial {
+            int64_t offs[max_offsets];
+            int noffs = 0, width = 0;
+            bool too_many = false;
+        };
+        std::vector<partial> part(static_cast<size_t>(nthreads));
+        in_parallel(n, 4096, nthreads, [&](int t, int64_t lo, int64_t hi) {
+            partial& me = part[t];
+            for (int64_t row = lo; row < hi && !me.too_many; ++row) {
+                int deps = 0;
+                for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
+                    const int64_t col = ci[k];
+                    if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
+                    ++deps;
+                    const int64_t d = lower ? row - col : col - row;
+                    int j = 0;
+                    while (j < me.noffs && me.offs[j] != d) ++j;
+                    if (j == me.noffs) {
+                        if (me.noffs == max_offsets) {
+                            me.too_many = true;
+                            break;
+                        }
+                        me.offs[me.noffs++] = d;
+                    }
+                }
+                me.width = std::max(me.width, deps);
+            }
+        });
+        for (const partial& me : part) {
+            if (me.too_many) return GKOMI_ENOTSUPPORTED;
+            width = std::max(width, me.width);
+            for (int q = 0; q < me.noffs; ++q) {
+                int j = 0;
+                while (j < noffs && offs[j] != me.offs[q]) ++j;
+                if (j == noffs) {
+                    if (noffs == max_offsets) return GKOMI_ENOTSUPPORTED;
+                    offs[noffs++] = me.offs[q];
+                }
             }
         }
-        width = std::max(width, deps);
     }
+    mark("offsets");
     if (noffs == 0 || width > max_width) return GKOMI_ENOTSUPPORTED;
     std::sort(offs, offs + noffs);
     // 2. strides of a lexicographic box numbering: a divisor chain
@@ -226,35 +293,82 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
             nbricks *= nbk[k];
             if (nbricks > (1 << 24)) return GKOMI_ENOTSUPPORTED;
         }
+        // a LAYER = the bricks with one coordinate along the last dimension = a contiguous range of
+        // rows: bricks never straddle layers, so layers are analysed side by side
+        const int64_t layer_rows = edge[dims - 1] * stride[dims - 1];
         std::vector<int32_t> brick(static_cast<size_t>(n));
-        for (int64_t row = 0; row < n; ++row) {
-            int64_t id = 0, mul = 1;
-            for (int k = 0; k < dims; ++k) {
-                const int64_t c = k + 1 < dims ? (row / stride[k]) % extent[k] : row / stride[k];
-                id += (c / edge[k]) * mul;
-                mul *= nbk[k];
+        in_parallel(n, layer_rows, nthreads, [&](int, int64_t lo, int64_t hi) {
+            // coordinates of `lo` by division, then counted up row by row (dimension 0 has stride 1)
+            int64_t c[max_dims], within[max_dims], mul[max_dims], id = 0;
+            for (int k = 0, m = 1; k < dims; ++k) {
+                c[k] = k + 1 < dims ? (lo / stride[k]) % extent[k] : lo / stride[k];
+                within[k] = c[k] % edge[k];
+                mul[k] = m;
+                id += (c[k] / edge[k]) * m;
+                m *= static_cast<int>(nbk[k]);
             }
-            brick[row] = static_cast<int32_t>(id);
-        }
-        // 4. the brick graph from the actual entries (never from the guessed geometry)
-        std::vector<int32_t> npred(static_cast<size_t>(nbricks), 0);
-        std::vector<int32_t> preds(static_cast<size_t>(nbricks) * max_preds);
-        for (int64_t row = 0; row < n; ++row) {
-            const int32_t mine = brick[row];
-            for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
-                const int64_t col = ci[k];
-                if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
-                const int32_t other = brick[col];
-                if (other == mine) continue;
-                int32_t* list = preds.data() + static_cast<size_t>(mine) * max_preds;
-                int j = 0;
-                while (j < npred[mine] && list[j] != other) ++j;
-                if (j == npred[mine]) {
-                    if (npred[mine] == max_preds) return GKOMI_ENOTSUPPORTED;
-                    list[npred[mine]++] = other;
+            for (int64_t row = lo; row < hi; ++row) {
+                brick[row] = static_cast<int32_t>(id);
+                for (int k = 0; k < dims; ++k) {  // row + 1
+                    if (++c[k] < extent[k] || k + 1 == dims) {
+                        if (++within[k] == edge[k]) {
+                            within[k] = 0;
+                            id += mul[k];
+                        }
+                        break;
+                    }
+                    id -= ((c[k] - 1) / edge[k]) * mul[k];  // back to the first brick along k, carry on
+                    c[k] = 0;
+                    within[k] = 0;
                 }
             }
+        });
+        mark("brick of every row");
+        // 4. the brick graph from the actual entries (never from the guessed geometry), and
+        // 6. the level of a row inside its brick (dependencies on other bricks do not count: their
+        //    values are inflow), rows and inflow entries per brick
+        std::vector<int32_t> npred(static_cast<size_t>(nbricks), 0);
+        std::vector<int32_t> preds(static_cast<size_t>(nbricks) * max_preds);
+        std::vector<int32_t> fine(static_cast<size_t>(n), 0);
+        std::vector<int32_t> nfine(static_cast<size_t>(nbricks), 0), brick_rows_count(static_cast<size_t>(nbricks), 0),
+            brick_ext(static_cast<size_t>(nbricks), 0);
+        std::vector<char> failed(static_cast<size_t>(nthreads), 0);
+        std::vector<uint8_t> row_ext(static_cast<size_t>(n), 0);  // inflow entries of a row (<= max_width)
+        in_parallel(n, layer_rows, nthreads, [&](int t, int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) {
+                const int64_t row = lower ? i : hi - 1 - (i - lo);  // in dependency order
+                const int32_t mine = brick[row];
+                int32_t lvl = 0;
+                for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
+                    const int64_t col = ci[k];
+                    if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
+                    const int32_t other = brick[col];
+                    if (other == mine) {
+                        lvl = std::max(lvl, fine[col] + 1);
+                        continue;
+                    }
+                    ++brick_ext[mine];
+                    ++row_ext[row];
+                    int32_t* list = preds.data() + static_cast<size_t>(mine) * max_preds;
+                    int j = 0;
+                    while (j < npred[mine] && list[j] != other) ++j;
+                    if (j == npred[mine]) {
+                        if (npred[mine] == max_preds) {
+                            failed[t] = 1;
+                            return;
+                        }
+                        list[npred[mine]++] = other;
+                    }
+                }
+                fine[row] = lvl;
+                nfine[mine] = std::max(nfine[mine], lvl + 1);
+                ++brick_rows_count[mine];
+            }
+        });
+        for (char f : failed) {
+            if (f) return GKOMI_ENOTSUPPORTED;
         }
+        mark("brick graph + levels in bricks");
         // coarse levels by longest path (Kahn); a cycle = the guessed geometry is wrong
         std::vector<int32_t> succ_ptr(static_cast<size_t>(nbricks) + 1, 0);
         for (int64_t b = 0; b < nbricks; ++b) {
@@ -293,35 +407,13 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
             for (int32_t l = 0; l < ncoarse; ++l) count[l + 1] += count[l];
             for (int64_t b = 0; b < nbricks; ++b) rank[b] = count[coarse[b]]++;
         }
-        // 6. level of a row inside its brick (dependencies on other bricks do not count: those
-        //    bricks have finished when this one starts)
-        std::vector<int32_t> fine(static_cast<size_t>(n), 0);
-        std::vector<int32_t> nfine(static_cast<size_t>(nbricks), 0), brick_rows_count(static_cast<size_t>(nbricks), 0),
-            brick_ext(static_cast<size_t>(nbricks), 0);
-        for (int64_t i = 0; i < n; ++i) {
-            const int64_t row = lower ? i : n - 1 - i;
-            const int32_t mine = brick[row];
-            int32_t lvl = 0;
-            for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
-                const int64_t col = ci[k];
-                if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
-                if (brick[col] == mine) {
-                    lvl = std::max(lvl, fine[col] + 1);
-                } else {
-                    ++brick_ext[mine];
-                }
-            }
-            fine[row] = lvl;
-            nfine[mine] = std::max(nfine[mine], lvl + 1);
-            ++brick_rows_count[mine];
-        }
         // LDS of the largest brick: x + inflow, and the brick's part of the factor (see the solve)
         const int slots = width <= 2 ? 2 : width <= 3 ? 3 : width <= 4 ? 4 : 8;  // the widths the solve is built for
         int64_t max_lds = 0;
         for (int64_t b = 0; b < nbricks; ++b) {
             const int64_t r = brick_rows_count[b];
-            // steps <= levels + rows / threads <= 2 rows + 1
-            max_lds = std::max<int64_t>(max_lds, static_cast<int64_t>(brick_lds_bytes(r, brick_ext[b], 2 * r + 1, slots)));
+            // a level of w rows is ceil(w / threads) steps: steps <= levels + rows / threads (64: the fewest threads)
+            max_lds = std::max<int64_t>(max_lds, static_cast<int64_t>(brick_lds_bytes(r, brick_ext[b], nfine[b] + r / 64 + 1, slots)));
         }
         int64_t max_rows = 0;
         for (int64_t b = 0; b < nbricks; ++b) max_rows = std::max<int64_t>(max_rows, brick_rows_count[b]);
@@ -330,6 +422,7 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
             if (brick_rows <= 8) return GKOMI_ENOTSUPPORTED;
             continue;  // smaller bricks
         }
+        mark("brick levels, sizes");
         // 7. plan order: bricks by rank, rows of a brick by level, rows of a level by row index
         h.nbricks = nbricks;
         h.coarse_levels = ncoarse;
@@ -383,19 +476,30 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
                 h.row_rank[row] = r;
             }
         }
+        mark("plan order, steps");
         // inflow lists in plan order, entries of a row in storage order
         h.ext_row_off.assign(static_cast<size_t>(n), 0);
-        h.ext_col.clear();
-        h.ext_col.reserve(static_cast<size_t>(h.brick_ext_begin[nbricks]));
-        for (int64_t p = 0; p < n; ++p) {
-            const int64_t row = h.perm[p];
-            h.ext_row_off[p] = static_cast<int32_t>(h.ext_col.size());
-            for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
-                const int64_t col = ci[k];
-                if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
-                if (brick[col] != brick[row]) h.ext_col.push_back(static_cast<int32_t>(col));
+        {
+            int32_t running = 0;
+            for (int64_t p = 0; p < n; ++p) {
+                h.ext_row_off[p] = running;
+                running += row_ext[h.perm[p]];
             }
+            h.ext_col.assign(static_cast<size_t>(running), 0);
         }
+        in_parallel(n, 4096, nthreads, [&](int, int64_t lo, int64_t hi) {
+            for (int64_t p = lo; p < hi; ++p) {
+                const int64_t row = h.perm[p];
+                if (row_ext[row] == 0) continue;
+                int32_t at = h.ext_row_off[p];
+                for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
+                    const int64_t col = ci[k];
+                    if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
+                    if (brick[col] != brick[row]) h.ext_col[at++] = static_cast<int32_t>(col);
+                }
+            }
+        });
+        mark("inflow lists");
         // the bricks a brick waits for, as ranks; critical path in steps
         h.pred_ptr.assign(static_cast<size_t>(nbricks) + 1, 0);
         h.pred_idx.clear();
@@ -416,6 +520,7 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
             h.critical_steps = std::max(h.critical_steps, path[r]);
             h.max_brick_steps = std::max(h.max_brick_steps, steps);
         }
+        mark("predecessor lists");
         h.image_off.assign(h.mode == 2 ? static_cast<size_t>(nbricks) + 1 : 0, 0);
         for (int64_t r = 0; r < nbricks && h.mode == 2; ++r) {
             h.image_off[r + 1] = h.image_off[r] + brick_image_bytes(h.brick_row_begin[r + 1] - h.brick_row_begin[r],
