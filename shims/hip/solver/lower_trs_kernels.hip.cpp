@@ -2,7 +2,8 @@
 // should_perform_transpose / generate / solve (core/solver/lower_trs_kernels.hpp).
 // generate = the dependency-level analysis (the hipsparseXcsrsv2_analysis of
 // hip/solver/common_trs_kernels.hip.hpp:61-253), kept in the SolveStruct; solve = the
-// level-scheduled kernel, or the analysis-free one for factors whose levels are narrow.
+// brick plan for factors of grid problems (csrc/trs_bricks.hip), else the level-scheduled kernel,
+// or the analysis-free one for factors whose levels are narrow.
 #include "../gkomi_bindings.hpp"
 
 namespace gko {
@@ -14,7 +15,9 @@ struct gkomi_solve_struct : solver::SolveStruct {
     array<char> symbolic, plan, workspace;
     int64_t nslices{0}, entries{0}, nlevels{0}, max_deps{-1};
     bool planned{false};
+    gkomi_trs_bricks* bricks{nullptr};  // host side of the brick plan; its device plan is `plan`
     explicit gkomi_solve_struct(std::shared_ptr<const Executor> exec) : symbolic(exec), plan(exec), workspace(exec) {}
+    ~gkomi_solve_struct() { gkomi_trs_bricks_destroy(bricks); }
 };
 
 void should_perform_transpose(std::shared_ptr<const HipExecutor> exec, bool& do_transpose) { do_transpose = false; }
@@ -32,6 +35,23 @@ void generate(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double,
     GKOMI_CALL(gkomi_trs_analyse_symbolic_i32(GKOMI_NULL_STREAM, n, matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(), /*lower=*/1,
                                               st->symbolic.get_data(), st->symbolic.get_num_elems(), out));
     st->nslices = out[0]; st->entries = out[1]; st->nlevels = out[2]; st->max_deps = out[3];
+    // many levels on a box grid: bricks solved out of LDS (one LDS step per level, a memory hand-off per brick level)
+    if (st->nlevels > 16) {
+        const int err = gkomi_trs_bricks_create_i32(GKOMI_NULL_STREAM, n, matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(), /*lower=*/1,
+                                                    0, 0, 0, &st->bricks);
+        if (err != GKOMI_SUCCESS && err != GKOMI_ENOTSUPPORTED) GKOMI_CALL(err);
+        int64_t info[8] = {};
+        if (st->bricks != nullptr) GKOMI_CALL(gkomi_trs_bricks_info(st->bricks, info));
+        if (st->bricks != nullptr && 0.17 * st->nlevels + 5.0 * info[1] < 1.7 * st->nlevels) {
+            st->plan.resize_and_reset(gkomi_trs_bricks_plan_bytes(st->bricks));
+            GKOMI_CALL(gkomi_trs_bricks_numeric_f64_i32(GKOMI_NULL_STREAM, st->bricks, matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(),
+                                                        matrix->get_const_values(), st->plan.get_data(), st->plan.get_num_elems()));
+            solve_struct = st;
+            return;
+        }
+        gkomi_trs_bricks_destroy(st->bricks);
+        st->bricks = nullptr;
+    }
     // wide levels: the level-scheduled solve; chains and narrow bands: the in-workgroup hand-offs of the other kernel
     st->planned = n >= 64 * (st->nlevels > 0 ? st->nlevels : 1);
     if (st->planned) {
@@ -49,7 +69,10 @@ void solve(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double, in
 {
     auto st = const_cast<gkomi_solve_struct*>(dynamic_cast<const gkomi_solve_struct*>(solve_struct));
     const int64_t n = static_cast<int64_t>(matrix->get_size()[0]);
-    if (st != nullptr && st->planned) {
+    if (st != nullptr && st->bricks != nullptr) {
+        GKOMI_CALL(gkomi_trs_bricks_solve_f64(GKOMI_NULL_STREAM, st->bricks, st->plan.get_data(), b->get_size()[1], unit_diag, b->get_const_values(),
+                                              b->get_stride(), x->get_values(), x->get_stride()));
+    } else if (st != nullptr && st->planned) {
         GKOMI_CALL(gkomi_trs_solve_plan_f64(GKOMI_NULL_STREAM, n, b->get_size()[1], st->plan.get_data(), st->nslices, st->entries, st->max_deps,
                                             unit_diag, b->get_const_values(), b->get_stride(), x->get_values(), x->get_stride()));
     } else {
