@@ -566,13 +566,15 @@ int gkomi_trs_plan_check_overrun(gkomi_stream_t s, const void* plan,
  * The level plan above pays one memory hand-off per dependency level; factors of stencil
  * matrices have hundreds to thousands of levels.  This analysis recovers the box grid from the
  * factor's dependency offsets (a divisor chain 1 | nx | nx ny ...), cuts the rows into bricks of
- * about `brick_rows` rows (<= 0: chosen) and lets ONE workgroup solve a brick out of LDS, levels
- * inside a brick costing an LDS round trip.  mode 1: a brick starts when the bricks it depends
- * on have FINISHED (`threads` = 64 / 128 / 256 compute threads, 0 = from the widest level; x may
- * alias b).  mode 2 (= 0, default): PIPELINED -- a brick starts at once, a second wave pumps its
- * inflow from memory into LDS while the one compute wave runs (x pre-filled with a NaN sentinel
- * is its own ready flag; x must not alias b; `threads` is 64): a brick trails its neighbour by
- * a brick edge, and the critical path is about the levels of the factor.
+ * about `brick_rows` rows (<= 0: chosen: ~1000) and lets ONE workgroup solve a brick out of LDS, a level
+ * inside a brick costing an LDS round trip (~0.15 us) instead of a hand-off through memory.
+ * mode 2 (= 0, default): PIPELINED -- a brick starts at once, a second wave pumps its inflow from
+ * memory into LDS while the one compute wave runs; x, pre-filled with a NaN sentinel, is its own ready
+ * flag.  A brick trails its neighbour by a brick edge and the critical path is about the levels of the
+ * factor.  `threads` is 64.  (A solve with x aliasing b, or with n * x_stride * 8 beyond 31 bits,
+ * takes the kernel of mode 1 on the same plan.)  mode 1: a brick starts when the bricks it depends
+ * on have FINISHED (`threads` = 64 / 128 / 256 compute threads, 0 = from the widest level; x may alias b;
+ * 2 - 2.6 x the levels of the factor on the critical path).
  * The geometry is a guess that is never trusted: the brick graph is built from the actual
  * entries and must be acyclic, rows may have at most 8 dependencies, a brick with its inflow
  * must fit LDS -- else GKOMI_ENOTSUPPORTED (*out = NULL) and the caller keeps the level plan.
@@ -583,8 +585,9 @@ int gkomi_trs_plan_check_overrun(gkomi_stream_t s, const void* plan,
  *   numeric  fills `plan` (device memory, gkomi_trs_bricks_plan_bytes(h) bytes) from the
  *            factor's values; again whenever the values change.  Blocking.
  *   solve    x = L^-1 b / U^-1 b from the plan alone; a handle solves on one stream at a time.
- * A solve whose bounded waits run out writes NaNs, and raises a STICKY flag in the plan
- * (gkomi_trs_bricks_check_overrun; cleared by the numeric phase). */
+ * A solve whose bounded waits run out (GKOMI_TRS_MAX_POLLS polls, default 2^22) writes NaNs, and raises a
+ * STICKY flag in the plan (gkomi_trs_bricks_check_overrun; cleared by the numeric phase).  The analysis
+ * uses up to 8 host threads (GKOMI_ANALYSIS_THREADS). */
 typedef struct gkomi_trs_bricks gkomi_trs_bricks;
 int gkomi_trs_bricks_create_i32(gkomi_stream_t s, int64_t n, const int32_t* row_ptrs,
                                 const int32_t* col_idxs, int lower, int64_t brick_rows,

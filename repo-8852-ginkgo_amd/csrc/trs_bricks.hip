@@ -1488,8 +1488,9 @@ extern "C" int gkomi_trs_bricks_solve_f64(gkomi_stream_t s, gkomi_trs_bricks* h,
 {
     if (h == nullptr || plan == nullptr || nrhs < 0 || b_stride < nrhs || x_stride < nrhs) return GKOMI_EINVAL;
     if (h->uploaded_to != plan) return GKOMI_EINVAL;  // numeric phase first
-    if (h->mode == 2 && x == b) return GKOMI_EINVAL;  // pipelined: x carries the ready flags
-    if (h->mode == 2 && h->n * x_stride * 8 > INT32_MAX) return GKOMI_ENOTSUPPORTED;  // records hold 31-bit byte offsets into x
+    // the pipelined solve keeps its ready flags in x and 31-bit byte offsets into x in its records: a solve
+    // in place, or on a very wide / very long x, takes the other kernel (every plan has what it needs)
+    const bool pipelined = h->mode == 2 && x != b && h->n * x_stride * 8 <= INT32_MAX;
     if (nrhs == 0) return GKOMI_SUCCESS;
     const brick_layout l = make_layout(*h);
     char* p = static_cast<char*>(plan);
@@ -1498,7 +1499,7 @@ extern "C" int gkomi_trs_bricks_solve_f64(gkomi_stream_t s, gkomi_trs_bricks* h,
     const long long max_polls = env_polls != nullptr && env_polls[0] != 0 ? atoll(env_polls) : default_max_polls;
     for (int64_t j = 0; j < nrhs; ++j) {
         int err;
-        if (h->mode == 2) {
+        if (pipelined) {
             err = unit_diag != 0
                       ? launch_pipelined_width<true>(stream, h, p, l, b + j, b_stride, x + j, x_stride, max_polls)
                       : launch_pipelined_width<false>(stream, h, p, l, b + j, b_stride, x + j, x_stride, max_polls);
