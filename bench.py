@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cg", action="store_true")
     ap.add_argument("--no-p3", action="store_true")
+    ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--p3-grid", type=int, default=256, help="grid of the 3-D problem (256 = BASELINE config 5)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -413,6 +414,55 @@ def main():
                                      "final_residual_norm_rel": res["rel_residual"]}
             out["p3"] = p3
             del a3, x3, y3, srow3
+
+        if not args.no_config4:
+            # BASELINE config 4's shape (GMRES(30) + ParILU on a 1.26M-row 7-point convection-diffusion system):
+            # an extra entry, never allowed to take the headline line down with it
+            try:
+                progress("config 4: GMRES(30) with and without ParILU")
+                import gkomi.solvers as solvers
+                n4, rp4, ci4, v4 = matgen.at_like(108)
+                a4 = [dev(rp4), dev(ci4), dev(v4)]
+                b4 = dev(np.cos(0.3 * np.arange(n4)).reshape(n4, 1))
+                t0 = time.perf_counter()
+                pre4 = solvers.par_ilu_generate(gk, n4, a4[0].clone(), a4[1], a4[2], iterations=5)
+                torch.cuda.synchronize()
+                gen4 = time.perf_counter() - t0
+                c4 = {"workload": f"AT-like 108^3 7-pt convection-diffusion (n={n4}), rhs cos(0.3 i), reduction 1e-10",
+                      "parilu_generate_incl_trs_analysis_ms": round(gen4 * 1e3, 1),
+                      "trs_plan": ["bricks" if p is not None else "levels" for p in (pre4.l_bricks, pre4.u_bricks)]}
+                for name, pc in (("gmres30", None), ("gmres30_parilu", pre4)):
+                    best = None
+                    for _ in range(2):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        r4 = solvers.gmres_solve(gk, n4, a4[0], a4[1], a4[2], b4, krylov_dim=30, max_iters=3000,
+                                                 reduction=1e-10, precond=pc)
+                        torch.cuda.synchronize()
+                        el = time.perf_counter() - t0
+                        best = el if best is None else min(best, el)
+                    c4[name] = {"iterations": r4["iterations"], "ms": round(best * 1e3, 2), "converged": bool(r4["converged"]),
+                                "us_per_iteration": round(best / max(r4["iterations"], 1) * 1e6, 1)}
+                if pre4.l_bricks is not None and pre4.u_bricks is not None:
+                    y4 = torch.zeros_like(b4)
+                    z4 = torch.zeros_like(b4)
+                    for _ in range(3):
+                        pre4.l_bricks.solve(b4, y4)
+                        pre4.u_bricks.solve(y4, z4)
+                    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                    e0.record()
+                    for _ in range(20):
+                        pre4.l_bricks.solve(b4, y4)
+                    e1.record()
+                    for _ in range(20):
+                        pre4.u_bricks.solve(y4, z4)
+                    e2.record()
+                    torch.cuda.synchronize()
+                    c4["trs_us"] = {"lower": round(e0.elapsed_time(e1) * 1e3 / 20, 1), "upper": round(e1.elapsed_time(e2) * 1e3 / 20, 1)}
+                out["config4"] = c4
+                del a4, b4, pre4
+            except Exception as e:  # noqa: BLE001
+                out["config4"] = {"error": repr(e)}
 
         if not args.no_cpu_baseline:
             progress("CPU baseline (3 child processes)")
