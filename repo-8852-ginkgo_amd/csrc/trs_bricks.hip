@@ -116,7 +116,7 @@ brick_layout make_layout(const gkomi_trs_bricks& h)
     l.row_rank = off; off += ints(n);
     l.inv_local = off; off += ints(n);
     l.ext_row_off = off; off += ints(n);
-    l.stamps = off; off += std::max<size_t>(8 * 1024, 32 * nb);  // tools only: shader-clock stamps
+    l.stamps = off; off += std::max<size_t>(8 * 1024, 64 * nb);  // tools only: shader-clock stamps
     l.image_off = off; off += align_up(sizeof(int64_t) * (nb + 1), 256);
     l.image = off; off += align_up(h.image_off.empty() ? 0 : static_cast<size_t>(h.image_off.back()), 256);
     l.total = off;
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
     }
     __syncthreads();
     const int bk = static_cast<int>(s_ticket);
-    if (Stamps && stamp_brick < 0 && tid == 0) stamps[4 * bk] = wall_clock64();  // started
+    if (Stamps && stamp_brick < 0 && tid == 0) stamps[8 * bk] = wall_clock64();  // started
     const int r0 = brick_row_begin[bk], rows = brick_row_begin[bk + 1] - r0;
     const int e0 = brick_ext_begin[bk], inflow = brick_ext_begin[bk + 1] - e0;
     const int s0 = brick_step_ptr[bk], nsteps = brick_step_ptr[bk + 1] - s0;
@@ -1008,6 +1008,7 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
                 if (lane == 0) {
                     __hip_atomic_store(&s_inflow_ready, min(base + prefix, inflow), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (Stamps && stamp_brick < 0 && base == 0 && published == 0) stamps[8 * bk + 4] = wall_clock64();  // first inflow published
                 }
                 published = prefix;
                 nap = 1;
@@ -1137,16 +1138,17 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
         step_data even, odd;
         int2 sa = lstep[1];  // {rows, inflow needed} of the step after the current one
         fetch(lstep[0], even);
-        if (Stamps && stamp_brick < 0 && tid == 0) stamps[4 * bk + 1] = wall_clock64();  // in LDS
+        if (Stamps && stamp_brick < 0 && tid == 0) stamps[8 * bk + 1] = wall_clock64();  // in LDS
         for (int s = 0; s < nsteps; s += 2) {  // an odd count runs one empty step
             int2 sb, sc;
             if (Stamps && bk == stamp_brick && tid == 0 && s < 1022) stamps[1 + s / 2] = __builtin_readcyclecounter();
             step(s, even, odd, sa, sb);
-            if (Stamps && stamp_brick < 0 && tid == 0 && s == 0) stamps[4 * bk + 2] = wall_clock64();  // first step done
+            if (Stamps && stamp_brick < 0 && tid == 0 && s == 0) stamps[8 * bk + 2] = wall_clock64();  // first step done
             step(s + 1, odd, even, sb, sc);
+            if (Stamps && stamp_brick < 0 && tid == 0 && s == 8) stamps[8 * bk + 5] = wall_clock64();  // steps 0..9 done
             sa = sc;
         }
-        if (Stamps && stamp_brick < 0 && tid == 0) stamps[4 * bk + 3] = wall_clock64();  // last step done
+        if (Stamps && stamp_brick < 0 && tid == 0) stamps[8 * bk + 3] = wall_clock64();  // last step done
     }
     if (Stamps && bk == stamp_brick && tid == 0) stamps[0] = nsteps;
     __syncthreads();
@@ -1521,9 +1523,9 @@ extern "C" int gkomi_trs_bricks_debug_stamps(gkomi_stream_t s, const gkomi_trs_b
     if (h == nullptr || plan == nullptr || host_out == nullptr) return GKOMI_EINVAL;
     const brick_layout l = make_layout(*h);
     hipStream_t stream = to_stream(s);
-    // 8 KiB in the one-brick mode; 32 bytes per brick when every brick stamped (GKOMI_TRS_BRICK_STAMPS=-1)
+    // 8 KiB in the one-brick mode; 64 bytes per brick when every brick stamped (GKOMI_TRS_BRICK_STAMPS=-1)
     const char* env_stamps = getenv("GKOMI_TRS_BRICK_STAMPS");
-    const size_t bytes = env_stamps != nullptr && atoi(env_stamps) < 0 ? 32 * static_cast<size_t>(h->nbricks) : 8 * 1024;
+    const size_t bytes = env_stamps != nullptr && atoi(env_stamps) < 0 ? 64 * static_cast<size_t>(h->nbricks) : 8 * 1024;
     int err = static_cast<int>(hipMemcpyAsync(host_out, static_cast<const char*>(plan) + l.stamps, bytes,
                                               hipMemcpyDeviceToHost, stream));
     if (err) return err;

@@ -85,9 +85,9 @@ if what == "timeline":
     os.environ["GKOMI_TRS_BRICK_STAMPS"] = "-1"
     for _ in range(3): bk.solve(b, x)
     torch.cuda.synchronize()
-    out = (ctypes.c_longlong * (4 * bk.nbricks))()
+    out = (ctypes.c_longlong * (8 * bk.nbricks))()
     fn(None, bk.handle.value, bk.plan.data_ptr(), ctypes.addressof(out))
-    t = np.array(out, dtype=np.int64).reshape(-1, 4)
+    t = np.array(out, dtype=np.int64).reshape(-1, 8)
     us = (t - t[:, 0].min()) / 100.0   # s_memrealtime: 100 MHz, one clock for the whole chip
     def harr(which):
         data = ctypes.POINTER(ctypes.c_int32)(); count = ctypes.c_int64(0)
@@ -102,6 +102,12 @@ if what == "timeline":
     print(f"medians [us]: image + rhs into LDS {np.median(load):.1f}, then until the first step is done {np.median(wait):.1f}, the other steps {np.median(run):.1f}")
     print(f"first step done after the slowest predecessor's first step: median {np.median(hop):.2f} us, 10% {np.percentile(hop, 10):.2f}, 90% {np.percentile(hop, 90):.2f}")
     print(f"a brick is in LDS before its slowest predecessor's first step is done by: median {np.median(lead):.1f} us, 10% {np.percentile(lead, 10):.1f} (negative = the brick was late)")
+    # anatomy of a hand-off: the slowest predecessor's steps 0..9 done (its level 9 = what my first row needs, 10^3
+    # bricks) -> my pump publishes its first inflow -> my first step done
+    has = np.array([r for r in range(bk.nbricks) if pred_ptr[r + 1] > pred_ptr[r]])
+    p9 = np.array([us[pred_idx[pred_ptr[r]:pred_ptr[r + 1]], 5].max() for r in has])
+    print(f"hand-off anatomy [us, medians]: predecessor's first step -> its step 9: {np.median(p9 - np.array([us[pred_idx[pred_ptr[r]:pred_ptr[r + 1]], 2].max() for r in has])):.2f}; "
+          f"its step 9 -> my pump's first publication: {np.median(us[has, 4] - p9):.2f}; publication -> my first step done: {np.median(us[has, 2] - us[has, 4]):.2f}")
     print(f"resident at once (max over time): {max(int(((us[:, 0] <= tt) & (us[:, 3] >= tt)).sum()) for tt in np.linspace(0, us[:, 3].max(), 400))}")
     # the critical chain backwards from the last brick to finish
     r = int(np.argmax(us[:, 3])); chain = []
