@@ -268,3 +268,20 @@ def test_brick_analysis_wraparound_band_is_checked_on_the_entries(gk, oracle):
         assert np.array_equal(replay(bk, n, rp, ci, v, True, False, b), e[:, 0])
     finally:
         bk.close()
+
+
+@pytest.mark.parametrize("lower", [True, False])
+def test_brick_analysis_is_the_same_on_any_number_of_host_threads(gk, monkeypatch, lower):
+    """the symbolic analysis runs layer by layer on up to 8 host threads: the plan must not depend on how many"""
+    n, rp, ci, v = matgen.poisson_3d_7pt(23, 19, 29)
+    rp, ci, v = triangle(n, rp, ci, v, lower)
+    plans = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("GKOMI_ANALYSIS_THREADS", threads)
+        bk = Bricks(gk, n, rp, ci, lower, 300, 0, 2)
+        plans.append(([bk.array(i) for i in range(11)], (bk.nbricks, bk.coarse_levels, bk.nsteps, bk.max_lds, bk.width)))
+        bk.close()
+    for arrays, info in plans[1:]:
+        assert info == plans[0][1]
+        for a, b in zip(arrays, plans[0][0]):
+            assert np.array_equal(a, b)
