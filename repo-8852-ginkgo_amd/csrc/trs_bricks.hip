@@ -1107,6 +1107,9 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
             }
             // all ones if the inflow is in and the brick has not given up, else 0 (masks, not && / ?: --
             // those come back as branches)
+            // (the quotient is pinned in front of the question: left alone, the compiler sinks it behind the
+            // branch, into an else of its own with a second branch)
+            asm volatile("" : "+v"(xr));
             const unsigned int fine = static_cast<unsigned int>((cur.need - 1 - __builtin_amdgcn_readfirstlane(ready)) >> 31) & healthy;
             const unsigned int exponent = (static_cast<unsigned int>(__double2hiint(sum)) >> 20) & 0x7ffu;
             if (__builtin_expect(__any(exponent - box_first >= (cur.span & fine)), 0)) {
