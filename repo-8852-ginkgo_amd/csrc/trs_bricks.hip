@@ -33,6 +33,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
@@ -62,6 +63,8 @@ struct gkomi_trs_bricks {
     std::vector<int64_t> image_off;        // pipelined solve: byte offset of a brick's LDS image, nbricks + 1
     uint32_t epoch = 0;
     const void* uploaded_to = nullptr;
+    uint64_t token = 0;  // written into the plan with the index arrays: a later numeric phase skips the upload only
+                         // if the plan still carries it (the caller may have reallocated the same address)
 };
 
 namespace gkomi {
@@ -83,6 +86,7 @@ struct brick_header {
     unsigned int finished;
     unsigned int overrun;  // sticky: zeroed by the numeric phase, never by a solve
     int32_t lower;
+    uint64_t token;  // of the handle whose index arrays this plan holds
 };
 static_assert(sizeof(brick_header) <= 256, "the plan header has 256 bytes");
 
@@ -1314,10 +1318,24 @@ extern "C" int gkomi_trs_bricks_numeric_f64_i32(gkomi_stream_t s, gkomi_trs_bric
     hipStream_t stream = to_stream(s);
     char* p = static_cast<char*>(plan);
     brick_header hd{};
+    int err = 0;
+    bool index_arrays_there = false;
+    if (h->uploaded_to == plan && h->token != 0) {
+        err = static_cast<int>(hipMemcpyAsync(&hd, plan, sizeof(hd), hipMemcpyDeviceToHost, stream));
+        if (!err) err = static_cast<int>(hipStreamSynchronize(stream));
+        if (err) return err;
+        index_arrays_there = hd.token == h->token && hd.n == h->n && hd.nbricks == h->nbricks;
+    }
+    if (!index_arrays_there) {
+        static std::atomic<uint64_t> counter{1};
+        h->token = ((reinterpret_cast<uint64_t>(h) << 16) ^ (counter.fetch_add(1) * 0x9e3779b97f4a7c15ull)) | 1ull;
+    }
+    hd = brick_header{};
     hd.n = h->n; hd.nbricks = h->nbricks; hd.ticket = 0; hd.finished = 0; hd.overrun = 0; hd.lower = h->lower;
-    int err = static_cast<int>(hipMemcpyAsync(plan, &hd, sizeof(hd), hipMemcpyHostToDevice, stream));
+    hd.token = h->token;
+    err = static_cast<int>(hipMemcpyAsync(plan, &hd, sizeof(hd), hipMemcpyHostToDevice, stream));
     if (err) return err;
-    if (h->uploaded_to != plan) {
+    if (!index_arrays_there) {
         err = upload(stream, p, l.perm, h->perm);
         if (!err) err = upload(stream, p, l.brick_row_begin, h->brick_row_begin);
         if (!err) err = upload(stream, p, l.brick_step_ptr, h->brick_step_ptr);

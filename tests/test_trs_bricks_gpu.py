@@ -120,6 +120,24 @@ def test_bricks_refresh_and_repeated_solves(gk, oracle):
         assert np.array_equal(host(x), oracle_solve(oracle, n, lrp, lc, lv2, True, False, b)) and not bk.overrun()
 
 
+def test_bricks_numeric_phase_notices_a_plan_that_lost_its_index_arrays(gk, oracle):
+    """the index arrays are uploaded once per plan buffer; a caller that reuses the address for something else in
+    between (here: zeroes it) must still get a valid plan from the next numeric phase"""
+    n, rp, ci, v = matgen.poisson_2d_5pt(60)
+    rp, ci, v = triangle(n, rp, ci, v, True)
+    b = np.cos(np.arange(n) * 0.2).reshape(n, 1)
+    e = oracle_solve(oracle, n, rp, ci, v, True, False, b)
+    bk = solvers.TrsBricks(gk, n, dev(rp), dev(ci), dev(v), True, 400)
+    x = torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")
+    bk.solve(dev(b), x)
+    assert np.array_equal(host(x), e)
+    bk.plan.zero_()
+    bk.refresh(dev(v))
+    x.fill_(5.0)
+    bk.solve(dev(b), x)
+    assert np.array_equal(host(x), e) and not bk.overrun()
+
+
 def test_bricks_solve_in_place(gk, oracle):
     n, rp, ci, v = matgen.poisson_2d_5pt(90)
     rp, ci, v = triangle(n, rp, ci, v, False)
