@@ -270,8 +270,8 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
     int64_t extent[max_dims];
     for (int k = 0; k + 1 < dims; ++k) extent[k] = stride[k + 1] / stride[k];
     extent[dims - 1] = ceildiv(n, stride[dims - 1]);
-    // pipelined: the levels of a brick should about fit the one compute wave (10^3, 32^2); else large bricks
-    if (brick_rows <= 0) brick_rows = h.mode == 2 ? 1024 : 4096;
+    // pipelined: the levels of a brick should about fit the one compute wave (11^3, 37^2); else large bricks
+    if (brick_rows <= 0) brick_rows = h.mode == 2 ? 1400 : 4096;
     // 3. brick edges: about brick_rows rows per brick, near-cubic, an even split of every extent;
     //    shrunk until a brick with its inflow fits LDS
     for (int attempt = 0; attempt < 8; ++attempt, brick_rows = std::max<int64_t>(brick_rows / 2, 8)) {
@@ -989,9 +989,15 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
         bool gave_up = false;
         int base = 0, published = 0;  // entries [0, base + published) are in LDS
         long long polls = 0;
+        // until the brick's first entry is in, only the first 16 entries of the window are polled: most resident
+        // bricks are far behind the front, and hundreds of pumps gathering 256 lines each raise the hand-off
+        // latency of the few that matter (tools/poll_probe.hip: 1.3 -> 3 us round trip)
+        constexpr int cold_lanes = 16;  // 1 .. 64 measured: +-2 % (profiles/r02_trs_bricks.log)
         unsigned long long v[W];
+        v[0] = lane < cold_lanes ? poll(lane) : (lane < inflow ? sentinel_bits : 0ull);
 #pragma unroll
-        for (int k = 0; k < W; ++k) v[k] = poll(T * k + lane);
+        for (int k = 1; k < W; ++k) v[k] = T * k + lane < inflow ? sentinel_bits : 0ull;
+        bool hot = false;
         int nap = 1;
         while (base + published < inflow) {
             int prefix = W * T;
@@ -1016,6 +1022,7 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
                 }
                 published = prefix;
                 nap = 1;
+                hot = true;
             }
             if (base + published >= inflow) break;
             if (published >= T) {  // slide: every quarter moves down, the last one takes new entries
@@ -1034,7 +1041,7 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
             nap = min(nap + 1, nap_max);  // a brick far behind the front backs off (8: to ~0.5 us)
 #pragma unroll
             for (int k = 0; k < W; ++k) {
-                if (v[k] == sentinel_bits) v[k] = poll(base + T * k + lane);
+                if (v[k] == sentinel_bits && (hot || (k == 0 && lane < cold_lanes))) v[k] = poll(base + T * k + lane);
             }
         }
         if (gave_up && lane == 0) {
