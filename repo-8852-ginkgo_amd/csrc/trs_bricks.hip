@@ -39,6 +39,7 @@
 #include <chrono>
 #include <cstdio>
 #include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -178,7 +179,11 @@ void in_parallel(int64_t n, int64_t grain, int parts, F f)
         if (p + 1 == parts) {
             f(p, lo, hi);  // the caller's thread takes the last piece
         } else {
-            pool.emplace_back(f, p, lo, hi);
+            try {
+                pool.emplace_back(f, p, lo, hi);
+            } catch (const std::system_error&) {
+                f(p, lo, hi);  // no more threads to be had: this piece on the caller's thread, too
+            }
         }
     }
     for (auto& t : pool) t.join();
