@@ -275,13 +275,35 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
     int64_t extent[max_dims];
     for (int k = 0; k + 1 < dims; ++k) extent[k] = stride[k + 1] / stride[k];
     extent[dims - 1] = ceildiv(n, stride[dims - 1]);
-    // pipelined: the levels of a brick should about fit the one compute wave (11^3, 37^2); else large bricks
-    if (brick_rows <= 0) brick_rows = h.mode == 2 ? 1400 : 4096;
+    int active = 0;  // dimensions that are more than one point wide
+    for (int k = 0; k < dims; ++k) active += extent[k] > 1;
+    // pipelined: the levels of a brick should fit the one compute wave (8 x 8 x 27, 37^2); else large bricks
+    if (brick_rows <= 0) brick_rows = h.mode == 2 ? (active >= 3 ? 1728 : 1400) : 4096;
     // 3. brick edges: about brick_rows rows per brick, near-cubic, an even split of every extent;
     //    shrunk until a brick with its inflow fits LDS
     for (int attempt = 0; attempt < 8; ++attempt, brick_rows = std::max<int64_t>(brick_rows / 2, 8)) {
         int64_t edge[max_dims], nbk[max_dims];
-        {
+        if (h.mode == 2 && active >= 3) {
+            // pipelined, three or more dimensions: a level of a box is at most the product of all its edges but
+            // the longest -- keep that within the 64 lanes of the compute wave (8 x 8, 4 x 4 x 4) so that every
+            // level is ONE step, and spend the rows on the last dimension (measured on the 108^3 factor:
+            // 8 x 8 x 27 bricks 167 us, 12^3 181, 10^3 186)
+            const int64_t cross = active == 3 ? 8 : 4;
+            int last = dims - 1;
+            while (extent[last] <= 1) --last;
+            int64_t product = 1;
+            for (int k = 0; k < dims; ++k) {
+                if (k == last) continue;
+                edge[k] = std::min<int64_t>(extent[k], extent[k] > 1 ? cross : 1);
+                product *= edge[k];
+            }
+            edge[last] = std::max<int64_t>(1, std::min<int64_t>(extent[last], brick_rows / product));
+            for (int k = 0; k < dims; ++k) {
+                nbk[k] = ceildiv(extent[k], edge[k]);
+                if (k == last) edge[k] = ceildiv(extent[k], nbk[k]);  // an even split of the long edge
+                nbk[k] = ceildiv(extent[k], edge[k]);
+            }
+        } else {
             int order[max_dims];
             for (int k = 0; k < dims; ++k) order[k] = k;
             std::sort(order, order + dims, [&](int a, int b) { return extent[a] < extent[b]; });
@@ -295,6 +317,15 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
                 edge[k] = ceildiv(extent[k], nbk[k]);
                 nbk[k] = ceildiv(extent[k], edge[k]);
                 remaining = std::max(1.0, remaining / static_cast<double>(edge[k]));
+            }
+        }
+        if (const char* forced = getenv("GKOMI_TRS_BRICK_EDGES")) {  // tuning: "e0,e1,e2" (tools/trs_bricks_probe.py edges)
+            int k = 0;
+            for (const char* q = forced; *q != 0 && k < dims; ++k) {
+                edge[k] = std::max<int64_t>(1, std::min<int64_t>(extent[k], atoll(q)));
+                nbk[k] = ceildiv(extent[k], edge[k]);
+                while (*q != 0 && *q != ',') ++q;
+                if (*q == ',') ++q;
             }
         }
         int64_t nbricks = 1;

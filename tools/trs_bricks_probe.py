@@ -70,6 +70,26 @@ def sweep(name, n, rp, ci, v, rows_list):
 
 
 what = sys.argv[1] if len(sys.argv) > 1 else "both"
+if what == "edges":
+    # brick shapes: cubes against bricks that are long along one axis (every level fits the 64-lane wave)
+    n, rp, ci, v = matgen.poisson_3d_7pt(108)
+    trp, tci, tv = tri(n, rp, ci, v, True)
+    rpd, cid, vd = d(trp), d(tci), d(tv)
+    b = torch.from_numpy(np.sin(0.1 * np.arange(n)) + 2.0).cuda().reshape(n, 1)
+    x = torch.zeros_like(b)
+    ref_plan = solvers.TrsPlan(gk, n, rpd, cid, vd, True); ref = torch.zeros_like(b); ref_plan.solve(b, ref)
+    for edges in ("12,12,12", "10,10,10", "8,8,27", "8,27,8", "27,8,8", "7,9,27", "4,16,27", "16,4,27", "5,12,27", "8,8,13", "8,8,18", "6,10,27", "7,7,36", "6,8,36", "4,8,54", "8,4,54", "8,8,20"):
+        os.environ["GKOMI_TRS_BRICK_EDGES"] = edges
+        try:
+            bk = solvers.TrsBricks(gk, n, rpd, cid, vd, True, 0, 0, 2)
+        except gkomi.GkomiError as e:
+            print(f"edges {edges}: {e}"); continue
+        x.fill_(3.0)
+        t = timed(lambda: bk.solve(b, x))
+        print(f"edges {edges:10s}: {t:8.1f} us  identical={bool(torch.equal(x, ref))} bricks {bk.nbricks:5d} brick levels {bk.coarse_levels:3d} "
+              f"steps {bk.nsteps:6d} lds {bk.lds_bytes // 1024:3d} KiB", flush=True)
+    os.environ.pop("GKOMI_TRS_BRICK_EDGES")
+    sys.exit(0)
 if what == "timeline":
     # every brick stamps start / in LDS / first step done / last step done (shader clock): who waits for what
     import ctypes
