@@ -566,7 +566,7 @@ int gkomi_trs_plan_check_overrun(gkomi_stream_t s, const void* plan,
  * The level plan above pays one memory hand-off per dependency level; factors of stencil
  * matrices have hundreds to thousands of levels.  This analysis recovers the box grid from the
  * factor's dependency offsets (a divisor chain 1 | nx | nx ny ...), cuts the rows into bricks of
- * about `brick_rows` rows (<= 0: chosen: 8 x 8 x 27 / 37 x 37) and lets ONE workgroup solve a brick out of LDS, a level
+ * about `brick_rows` rows (<= 0: chosen: 8 x 8 x 27 / 45 x 45) and lets ONE workgroup solve a brick out of LDS, a level
  * inside a brick costing an LDS round trip (~0.15 us) instead of a hand-off through memory.
  * mode 2 (= 0, default): PIPELINED -- a brick starts at once, a second wave pumps its inflow from
  * memory into LDS while the one compute wave runs; x, pre-filled with a NaN sentinel, is its own ready

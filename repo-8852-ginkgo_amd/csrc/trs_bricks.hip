@@ -277,8 +277,9 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
     extent[dims - 1] = ceildiv(n, stride[dims - 1]);
     int active = 0;  // dimensions that are more than one point wide
     for (int k = 0; k < dims; ++k) active += extent[k] > 1;
-    // pipelined: the levels of a brick should fit the one compute wave (8 x 8 x 27, 37^2); else large bricks
-    if (brick_rows <= 0) brick_rows = h.mode == 2 ? (active >= 3 ? 1728 : 1400) : 4096;
+    // pipelined: the levels of a brick should fit the one compute wave, and a brick about fill a CU's LDS
+    // (8 x 8 x 27, 45^2: fewer bricks = fewer hand-offs); else large bricks
+    if (brick_rows <= 0) brick_rows = h.mode == 2 ? (active >= 3 ? 1728 : 2025) : 4096;
     // 3. brick edges: about brick_rows rows per brick, near-cubic, an even split of every extent;
     //    shrunk until a brick with its inflow fits LDS
     for (int attempt = 0; attempt < 8; ++attempt, brick_rows = std::max<int64_t>(brick_rows / 2, 8)) {

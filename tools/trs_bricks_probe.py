@@ -88,6 +88,22 @@ if what == "edges":
         t = timed(lambda: bk.solve(b, x))
         print(f"edges {edges:10s}: {t:8.1f} us  identical={bool(torch.equal(x, ref))} bricks {bk.nbricks:5d} brick levels {bk.coarse_levels:3d} "
               f"steps {bk.nsteps:6d} lds {bk.lds_bytes // 1024:3d} KiB", flush=True)
+    n, rp, ci, v = matgen.poisson_2d_5pt(1000)
+    trp, tci, tv = tri(n, rp, ci, v, True)
+    rpd, cid, vd = d(trp), d(tci), d(tv)
+    b = torch.from_numpy(np.sin(0.1 * np.arange(n)) + 2.0).cuda().reshape(n, 1)
+    x = torch.zeros_like(b)
+    ref_plan = solvers.TrsPlan(gk, n, rpd, cid, vd, True); ref = torch.zeros_like(b); ref_plan.solve(b, ref)
+    for edges in ("37,37", "32,32", "45,45", "64,31", "31,64", "50,40", "64,16", "16,64", "40,50"):
+        os.environ["GKOMI_TRS_BRICK_EDGES"] = edges
+        try:
+            bk = solvers.TrsBricks(gk, n, rpd, cid, vd, True, 0, 0, 2)
+        except gkomi.GkomiError as e:
+            print(f"2-D edges {edges}: {e}"); continue
+        x.fill_(3.0)
+        t = timed(lambda: bk.solve(b, x))
+        print(f"2-D edges {edges:10s}: {t:8.1f} us  identical={bool(torch.equal(x, ref))} bricks {bk.nbricks:5d} brick levels {bk.coarse_levels:3d} "
+              f"steps {bk.nsteps:6d} lds {bk.lds_bytes // 1024:3d} KiB", flush=True)
     os.environ.pop("GKOMI_TRS_BRICK_EDGES")
     sys.exit(0)
 if what == "timeline":
