@@ -765,6 +765,11 @@ size_t gkomi_cg_workspace_bytes(int64_t n, int64_t nrhs);
  * Everything else -- and a solve whose workgroups could not all be resident --
  * runs the three-launch iteration.  GKOMI_CG_PERSISTENT=0 disables it. */
 int64_t gkomi_cg_persistent_solves(void);
+/* Diagnostics: how many GMRES solves of this process had a meeting of the
+ * single-launch Arnoldi step time out and were finished, from the x of the last
+ * completed restart, by the launch-per-vector kernels.  GKOMI_MEET_MAX_POLLS
+ * (test hook) shortens the wait of the CG and GMRES meetings. */
+int64_t gkomi_gmres_meeting_fallbacks(void);
 int gkomi_cg_solve_f64_i32(gkomi_stream_t s, int64_t n, int64_t nrhs,
                            int64_t nnz, const int32_t* row_ptrs,
                            const int32_t* col_idxs, const double* vals,

@@ -149,7 +149,10 @@ int persistent_cg(gkomi_stream_t s, int64_t n, const sysmat& A, const spmv_dot_p
         pcg_slot* slots = static_cast<pcg_slot*>(slot_mem);
         const int chunk = static_cast<int>(ceildiv(n, cus));
         const int rows_per_thread = static_cast<int>(ceildiv(chunk, pcg_block));
-        const long long max_polls = 1ll << 22;
+        const long long max_polls = [] {
+            const char* e = std::getenv("GKOMI_MEET_MAX_POLLS");  // test hook: how long a meeting waits
+            return e != nullptr && e[0] != 0 ? std::max(1ll, atoll(e)) : 1ll << 22;
+        }();
         static const int stride = [] {
             const char* e = std::getenv("GKOMI_PCG_STRIDE");  // slot spacing in 16-B units (tuning)
             const int v = e != nullptr ? std::atoi(e) : pcg_default_stride;

@@ -11,6 +11,8 @@
 // HBM: step k moves (5k+8) n values (core/solver/gmres.cpp:217-222).
 #include "cg_persistent.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <utility>
@@ -598,6 +600,11 @@ extern "C" size_t gkomi_gmres_workspace_bytes(int64_t n, int64_t nrhs, int64_t k
 }
 
 namespace {
+std::atomic<int64_t> gmres_meeting_fallbacks{0};
+}
+extern "C" int64_t gkomi_gmres_meeting_fallbacks(void) { return gmres_meeting_fallbacks.load(); }
+
+namespace {
 int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
                      void* precond_ctx, const double* b, double* x, int64_t krylov_dim,
                      int64_t max_iters, double reduction_factor, int baseline, void* workspace,
@@ -704,11 +711,33 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A,
         }
         return static_cast<int>(hipStreamSynchronize(stream));
     };
+    // A meeting of the single-launch Arnoldi step timed out (workgroups not resident together?): the
+    // launches since then returned early, so the Hessenberg column, the Givens terms, the residual norms
+    // and the stop record may be stale or unwritten.  Nothing of the current restart cycle is used: x
+    // still holds the solution of the last COMPLETED restart (only update_solution writes x, and every
+    // path to it passes a poll) -- solve again from there with one launch per sum.  Checked right after
+    // every poll, before update_solution and before the stop / max_iters exits.
+    auto solve_again_without_meetings = [&]() -> int {
+        gmres_meeting_fallbacks.fetch_add(1);
+        release.held = false;
+        persistent_release();
+        const long long done = std::max<long long>(total_iter - restart_iter, 0);
+        const int err = gmres_solve_impl(s, n, nrhs, A, precond, precond_ctx, b, x, krylov_dim,
+                                         std::max<int64_t>(max_iters - done, 0), reduction_factor, baseline,
+                                         workspace, workspace_bytes, host_info, false);
+        if (host_info != nullptr) host_info[0] += static_cast<double>(done);
+        return err;
+    };
+    const long long meet_max_polls = [] {
+        const char* e = std::getenv("GKOMI_MEET_MAX_POLLS");  // test hook: how long a meeting waits
+        return e != nullptr && e[0] != 0 ? std::max(1ll, atoll(e)) : 1ll << 22;
+    }();
     while (true) {
         ++total_iter;
         bool stop = false;
         if (total_iter >= max_iters) {
             GKOMI_TRY(poll());  // converged during the iterations not looked at yet?
+            if (persistent && host_ctl.overrun != 0) return solve_again_without_meetings();
             if (host_record.iter >= 0) {
                 converged = 1;
                 total_iter = host_record.iter;
@@ -728,6 +757,7 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A,
             criterion_done = false;
             if (++unpolled >= gmres_check_every || restart_iter == krylov_dim) {
                 GKOMI_TRY(poll());
+                if (persistent && host_ctl.overrun != 0) return solve_again_without_meetings();
                 if (host_record.iter >= 0) {
                     stop = true;
                     converged = 1;
@@ -747,17 +777,6 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A,
         if (precond != nullptr) GKOMI_TRY(apply_precond(this_k, pv));
         double* hess_iter = hess + nrhs * restart_iter;
         GKOMI_TRY(A.apply(s, nrhs, nullptr, precond != nullptr ? pv : this_k, nullptr, next_k));
-        if (persistent && host_ctl.overrun != 0) {
-            // a meeting timed out some iterations ago (workgroups not resident together?): x holds
-            // the solution of the last restart -- solve again from there, one launch per sum
-            release.held = false;
-            persistent_release();
-            const int err = gmres_solve_impl(s, n, nrhs, A, precond, precond_ctx, b, x, krylov_dim,
-                                             std::max<int64_t>(max_iters - total_iter, 0), reduction_factor,
-                                             baseline, workspace, workspace_bytes, host_info, false);
-            if (host_info != nullptr) host_info[0] += static_cast<double>(total_iter);
-            return err;
-        }
         if (persistent) {
             const int steps = static_cast<int>(restart_iter + 1);
             const gmres_iteration_tail tail{gsin, gcos, residual_norm, rnc, final_iter_nums, stop_status, orig_tau,
@@ -766,7 +785,7 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A,
 #define GKOMI_ARN(R)                                                                                  \
     hipLaunchKernelGGL(gmres_arnoldi_persistent_kernel<R>, dim3(cus), dim3(pcg_block), 0, stream,     \
                        static_cast<int>(n), pchunk, next_k, kb, steps, hess_iter, h_stride, pslots,   \
-                       pcg_default_stride, 1, pctl, meeting, 1ll << 22, tail)
+                       pcg_default_stride, 1, pctl, meeting, meet_max_polls, tail)
             if (prows <= 1) {
                 GKOMI_ARN(1);
             } else if (prows <= 2) {

@@ -1200,6 +1200,9 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
             sa = sc;
         }
         if (Stamps && stamp_brick < 0 && tid == 0) stamps[8 * bk + 3] = wall_clock64();  // last step done
+        // the compute wave may run out of patience before the pump does (it spins faster): poison in x
+        // must never leave without the flag
+        if (poisoned && tid == 0) atomicExch(&hdr->overrun, 1u);
     }
     if (Stamps && bk == stamp_brick && tid == 0) stamps[0] = nsteps;
     __syncthreads();

@@ -389,11 +389,13 @@ TRS_BRICK_STEP_US = 0.17
 TRS_BRICK_HOP_US = 5.0
 
 
-def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True, bricks=True):
+def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True, bricks=True, brick_rows=0):
     """preconditioner::Ilu over given CSR factors L = (row_ptrs, col_idxs, vals), U likewise.
     analyse: LowerTrs / UpperTrs::generate -- the dependency analysis of both factors (True / False / "force");
     a factor of a grid problem gets the brick plan (bricks=True; csrc/trs_bricks.hip), one whose levels are
-    wide enough the level-scheduled kernel, anything else keeps the analysis-free solve."""
+    wide enough the level-scheduled kernel, anything else keeps the analysis-free solve.
+    brick_rows: rows per brick of the brick plan (0: the library's default); bricks="force" takes the
+    brick plan whenever the factor admits one, whatever the cost model says."""
     dv = L[2].device
     inter = torch.zeros((n, nrhs), dtype=torch.float64, device=dv)
     nb = gk.trs_workspace_bytes()
@@ -405,9 +407,9 @@ def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True, brick
             plan = TrsPlan(gk, n, f[0], f[1], f[2], lower)
             if bricks and plan.nlevels > 16:
                 try:
-                    bk = TrsBricks(gk, n, f[0], f[1], f[2], lower)
+                    bk = TrsBricks(gk, n, f[0], f[1], f[2], lower, brick_rows=brick_rows)
                     # pipelined: about one step per level of the factor
-                    if TRS_BRICK_STEP_US * plan.nlevels + TRS_BRICK_HOP_US * bk.coarse_levels < TRS_LEVEL_US * plan.nlevels:
+                    if bricks == "force" or TRS_BRICK_STEP_US * plan.nlevels + TRS_BRICK_HOP_US * bk.coarse_levels < TRS_LEVEL_US * plan.nlevels:
                         brick_plans[i] = bk
                         continue
                 except GkomiError as e:

@@ -264,6 +264,25 @@ private:
 
 
 // include/ginkgo/core/distributed/vector.hpp: the local rows of a global vector
+namespace detail {
+// index of the one range that belongs to `rank`; refuses partitions with several ranges per part
+template <typename PartitionType>
+inline size_type own_range(const PartitionType* partition, int rank, const char* what)
+{
+    const size_type nr = partition->get_num_ranges();
+    if (nr != static_cast<size_type>(partition->get_num_parts())) GKO_NOT_SUPPORTED(what);
+    size_type own = nr;
+    for (size_type i = 0; i < nr; ++i) {
+        if (partition->get_part_ids()[i] == rank) {
+            if (own != nr) GKO_NOT_SUPPORTED(what);
+            own = i;
+        }
+    }
+    if (own == nr) GKO_NOT_SUPPORTED(what);
+    return own;
+}
+}  // namespace detail
+
 template <typename ValueType = double>
 class Vector : public LinOp {
 public:
@@ -279,10 +298,10 @@ public:
     void read_distributed(const matrix_data<ValueType, GlobalIndexType>& data, const Partition<int32, GlobalIndexType>* partition)
     {
         const int rank = comm_.rank();
-        const auto lo = partition->get_range_bounds()[rank], hi = partition->get_range_bounds()[rank + 1];
-        if (partition->get_num_ranges() != static_cast<size_type>(partition->get_num_parts())) {
-            GKO_NOT_SUPPORTED("Vector::read_distributed: one contiguous range per part");
-        }
+        // ranges map to parts through part_ids (reference/distributed/partition_kernels.cpp:42-95): this
+        // rank's rows are those of the range whose part id is the rank, not of range number `rank`
+        const auto own = detail::own_range(partition, rank, "Vector::read_distributed: one contiguous range per part");
+        const auto lo = partition->get_range_bounds()[own], hi = partition->get_range_bounds()[own + 1];
         const size_type nloc = static_cast<size_type>(hi - lo), ncols = data.size[1];
         std::vector<ValueType> host(nloc * ncols, ValueType{});
         for (const auto& e : data.nonzeros) {
@@ -367,10 +386,10 @@ public:
     void read_distributed(const matrix_data<ValueType, GlobalIndexType>& data, const Partition<LocalIndexType, GlobalIndexType>* partition)
     {
         const int rank = comm_.rank();
-        const auto lo = partition->get_range_bounds()[rank], hi = partition->get_range_bounds()[rank + 1];
-        if (partition->get_num_ranges() != static_cast<size_type>(partition->get_num_parts())) {
-            GKO_NOT_SUPPORTED("Matrix::read_distributed: one contiguous range per part");
-        }
+        // ranges map to parts through part_ids (reference/distributed/partition_kernels.cpp:42-95): this
+        // rank's rows are those of the range whose part id is the rank, not of range number `rank`
+        const auto own = detail::own_range(partition, rank, "Matrix::read_distributed: one contiguous range per part");
+        const auto lo = partition->get_range_bounds()[own], hi = partition->get_range_bounds()[own + 1];
         staged_.rows.clear(); staged_.cols.clear(); staged_.vals.clear();
         auto sorted = data;
         sorted.ensure_row_major_order();

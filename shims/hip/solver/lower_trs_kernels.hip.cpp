@@ -5,6 +5,7 @@
 // brick plan for factors of grid problems (csrc/trs_bricks.hip), else the level-scheduled kernel,
 // or the analysis-free one for factors whose levels are narrow.
 #include "../gkomi_bindings.hpp"
+#include <cstdlib>
 
 namespace gko {
 namespace kernels {
@@ -15,6 +16,7 @@ struct gkomi_solve_struct : solver::SolveStruct {
     array<char> symbolic, plan, workspace;
     int64_t nslices{0}, entries{0}, nlevels{0}, max_deps{-1};
     bool planned{false};
+    unsigned long long solves{0};  // since generate: when the sticky give-up flag is looked at
     gkomi_trs_bricks* bricks{nullptr};  // host side of the brick plan; its device plan is `plan`
     explicit gkomi_solve_struct(std::shared_ptr<const Executor> exec) : symbolic(exec), plan(exec), workspace(exec) {}
     ~gkomi_solve_struct() { gkomi_trs_bricks_destroy(bricks); }
@@ -68,17 +70,37 @@ void solve(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double, in
            const matrix::Dense<double>* b, matrix::Dense<double>* x)
 {
     auto st = const_cast<gkomi_solve_struct*>(dynamic_cast<const gkomi_solve_struct*>(solve_struct));
+    if (st == nullptr) GKO_NOT_SUPPORTED("solve needs the SolveStruct of this backend's generate()");
     const int64_t n = static_cast<int64_t>(matrix->get_size()[0]);
-    if (st != nullptr && st->bricks != nullptr) {
+    if (st->bricks != nullptr) {
         GKOMI_CALL(gkomi_trs_bricks_solve_f64(GKOMI_NULL_STREAM, st->bricks, st->plan.get_data(), b->get_size()[1], unit_diag, b->get_const_values(),
                                               b->get_stride(), x->get_values(), x->get_stride()));
-    } else if (st != nullptr && st->planned) {
+    } else if (st->planned) {
         GKOMI_CALL(gkomi_trs_solve_plan_f64(GKOMI_NULL_STREAM, n, b->get_size()[1], st->plan.get_data(), st->nslices, st->entries, st->max_deps,
                                             unit_diag, b->get_const_values(), b->get_stride(), x->get_values(), x->get_stride()));
     } else {
         GKOMI_CALL(gkomi_lower_trs_solve_f64_i32(GKOMI_NULL_STREAM, n, b->get_size()[1], matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(),
                                                  matrix->get_const_values(), unit_diag, b->get_const_values(), b->get_stride(), x->get_values(),
                                                  x->get_stride(), st->workspace.get_data(), st->workspace.get_num_elems()));
+    }
+    // A solve whose bounded waits ran out leaves NaNs in x and a STICKY flag (the reference's nan_produced
+    // guard, cuda/solver/common_trs_kernels.cuh:444-449).  Reading it is a blocking 4-byte copy, so it is
+    // looked at after the first solve, then every 256th (GKOMI_TRS_CHECK_EVERY=1: every solve); sticky
+    // means a later look still reports an earlier give-up.
+    static const unsigned long long every = [] {
+        const char* e = std::getenv("GKOMI_TRS_CHECK_EVERY");
+        return e != nullptr && std::atoll(e) > 0 ? static_cast<unsigned long long>(std::atoll(e)) : 256ull;
+    }();
+    if (st->solves++ % every == 0) {
+        int gave_up = 0;
+        if (st->bricks != nullptr) {
+            GKOMI_CALL(gkomi_trs_bricks_check_overrun(GKOMI_NULL_STREAM, st->plan.get_const_data(), &gave_up));
+        } else if (st->planned) {
+            GKOMI_CALL(gkomi_trs_plan_check_overrun(GKOMI_NULL_STREAM, st->plan.get_const_data(), &gave_up));
+        } else {
+            GKOMI_CALL(gkomi_trs_check_overrun(GKOMI_NULL_STREAM, st->workspace.get_const_data(), &gave_up));
+        }
+        if (gave_up != 0) GKOMI_CALL(GKOMI_ETRS_OVERRUN);
     }
 }
 

@@ -239,3 +239,30 @@ def test_cg_with_block_jacobi(gk, oracle, mode, max_bs):
     r = b.copy().reshape(n, 1)
     oracle.ref_csr_advanced_spmv(n, 1, -1.0, rp2, ci2, v2, host(res["x"]).reshape(n, 1), 1, 1.0, r, 1)
     assert np.linalg.norm(r) <= 2e-10 * np.linalg.norm(b) * 10
+
+
+def test_gmres_meeting_timeout_falls_back_before_touching_x(gk, oracle, monkeypatch):
+    """when a meeting of the single-launch Arnoldi step times out, the launches after
+    it return early and leave the Hessenberg column / Givens terms / stop record stale.  The driver
+    now looks at the flag right after every poll -- before update_solution, before the stop and
+    the max_iters exits -- and solves again, from the x of the last completed restart, with the
+    launch-per-vector kernels.  GKOMI_MEET_MAX_POLLS=1 (test hook) makes every meeting time out."""
+    n, rp, ci, v = convection_diffusion_3d(27)
+    b = np.cos(0.3 * np.arange(n))
+    xe = np.zeros(n)
+    it = oracle.ref_gmres_solve(n, rp, ci, v, None, None, b, xe, 30, 3000, 1e-10, 0, np.zeros(1))
+    healthy = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), krylov_dim=30, max_iters=3000, reduction=1e-10)
+    monkeypatch.setenv("GKOMI_MEET_MAX_POLLS", "1")
+    before = gk.gmres_meeting_fallbacks()
+    res = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), krylov_dim=30, max_iters=3000, reduction=1e-10)
+    assert gk.gmres_meeting_fallbacks() == before + 1
+    assert res["converged"] and abs(res["iterations"] - it) <= 1
+    assert np.all(np.isfinite(host(res["x"]))) and matgen.rel_err(host(res["x"]), xe) <= 1e-6
+    assert matgen.rel_err(host(res["x"]), host(healthy["x"])) <= 1e-9
+    # the iteration limit inside the first restart cycle: no garbage in x, no false "converged"
+    cut = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), krylov_dim=30, max_iters=7, reduction=1e-30)
+    assert gk.gmres_meeting_fallbacks() == before + 2
+    assert cut["iterations"] == 7 and not cut["converged"] and np.all(np.isfinite(host(cut["x"])))
+    monkeypatch.delenv("GKOMI_MEET_MAX_POLLS")
+    cut_ok = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), krylov_dim=30, max_iters=7, reduction=1e-30)
+    assert matgen.rel_err(host(cut["x"]), host(cut_ok["x"])) <= 1e-9

@@ -342,18 +342,34 @@ def test_trs_plan_ilu0_apply_and_refresh(gk, oracle):
     assert np.array_equal(host(yd), y2) and not pl.overrun() and not pu.overrun()
 
 
-@pytest.mark.parametrize("analyse", [False, "force"])
+@pytest.mark.parametrize("analyse", [False, "force", "bricks"])
 def test_trs_overrun_is_sticky_and_surfaces_as_an_error(gk, oracle, monkeypatch, analyse):
     """a triangular solve that gives up used to erase its own flag at the next
     solve and no driver looked at it.  Now the flag is sticky and the solver drivers return
-    GKOMI_ETRS_OVERRUN for an Ilu preconditioner whose solves gave up."""
+    GKOMI_ETRS_OVERRUN for an Ilu preconditioner whose solves gave up.
+    The contract is the reference's `nan_produced` guard, cuda/solver/common_trs_kernels.cuh:444-449.
+    Independent of the library's default brick shape: "force" rules the brick plan
+    out (level plan), "bricks" asks for bricks of 256 rows and checks there is a hand-off to give up on."""
     import gkomi
     import gkomi.solvers as solvers
-    n, rp, ci, v = matgen.poisson_2d_5pt(40)
+    n, rp, ci, v = matgen.poisson_2d_5pt(48)
     f = ilu_util.oracle_par_ilu(oracle, n, rp, ci, v)
     L = tuple(dev(a) for a in f["L"])
     U = tuple(dev(a) for a in f["U"])
-    pre = solvers.ilu_from_factors(gk, n, L, U, analyse=analyse)
+
+    def make():
+        if analyse == "bricks":
+            p = solvers.ilu_from_factors(gk, n, L, U, analyse=True, bricks="force", brick_rows=256)
+            assert p.l_bricks is not None and p.u_bricks is not None
+            assert p.l_bricks.nbricks > 1 and p.u_bricks.nbricks > 1   # there is a brick-to-brick hand-off to poll
+            assert p.l_bricks.coarse_levels > 1
+        else:
+            p = solvers.ilu_from_factors(gk, n, L, U, analyse=analyse, bricks=False)
+            assert p.l_bricks is None and p.u_bricks is None
+            assert (p.l_plan is not None) == (analyse == "force")
+        return p
+
+    pre = make()
     b = dev(np.ones(n))
     ok = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), b, krylov_dim=30, max_iters=200, reduction=1e-10, precond=pre)
     assert ok["converged"]
@@ -368,6 +384,24 @@ def test_trs_overrun_is_sticky_and_surfaces_as_an_error(gk, oracle, monkeypatch,
     with pytest.raises(gkomi._lib.GkomiError):
         solvers.cg_solve(gk, n, dev(rp), dev(ci), dev(v), b, max_iters=5, reduction=1e-10, precond=pre)
     # a fresh preconditioner (fresh workspace / plans) is healthy again
-    pre2 = solvers.ilu_from_factors(gk, n, L, U, analyse=analyse)
+    pre2 = make()
     assert solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), b, krylov_dim=30, max_iters=200, reduction=1e-10,
                                precond=pre2)["converged"]
+
+
+def test_trs_single_brick_has_nothing_to_wait_for(gk, oracle, monkeypatch):
+    """The complement of the overrun test: a factor that fits ONE brick has no inflow, so even with
+    the polls cut to one the solve finishes, bit-exact, and raises no flag."""
+    import gkomi.solvers as solvers
+    n, rp, ci, v = matgen.poisson_2d_5pt(24)
+    f = ilu_util.oracle_par_ilu(oracle, n, rp, ci, v)
+    lrp, lc, lv = f["L"]
+    bk = solvers.TrsBricks(gk, n, dev(lrp), dev(lc), dev(lv), True, brick_rows=1024)
+    assert bk.nbricks == 1
+    b = np.sin(0.1 * np.arange(n)).reshape(n, 1)
+    y = np.zeros_like(b)
+    oracle.ref_lower_trs_solve(n, 1, lrp, lc, lv, 0, b, 1, y, 1)
+    monkeypatch.setenv("GKOMI_TRS_MAX_POLLS", "1")
+    yd = torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")
+    bk.solve(dev(b), yd)
+    assert np.array_equal(host(yd), y) and not bk.overrun()
