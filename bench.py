@@ -23,6 +23,16 @@ N > 1  (configs[4], "P3", one process per GPU under torch.distributed): STRONG
        "cg" = row-partitioned CG to 1e-10 without an iteration cap (native fused
        driver, csrc/dist_cg.hip, over its own RCCL communicator).
        GKOMI_BENCH_FORCE_DIST=1 runs that code path with a world of one rank.
+       Without WORLD_SIZE in the environment `--gpus N` starts the N rank processes
+       itself (python -m torch.distributed.run, as child processes, before this
+       process makes any GPU call) and exits with their code; with fewer than N
+       devices it says so and exits 2.
+
+Timing: every timed region is EXACTLY K steps between barrier + synchronize on both
+sides (max over ranks).  The line's `value` is the MEDIAN region of as many regions as it
+takes to cover >= 0.05 s of measured steps (the reference's own floor,
+benchmark/utils/general.hpp:96-117; at least 3, at most 400 regions); best and all-region
+statistics are reported next to it.
 """
 import argparse
 import json
@@ -57,11 +67,11 @@ def traffic_from_profiles():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
-        return None
+        return None, None
     try:
-        return int(json.load(open(files[-1]))["traffic_bytes_per_launch"])
+        return int(json.load(open(files[-1]))["traffic_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def parse():
@@ -76,7 +86,13 @@ def parse():
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--p3-grid", type=int, default=256, help="grid of the 3-D problem (256 = BASELINE config 5)")
+    ap.add_argument("--no-config3", action="store_true")
+    ap.add_argument("--min-region-seconds", type=float, default=0.05,
+                    help="floor on the total length of the timed regions of K steps each (more regions, never more steps)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, initialise the process group, report the rank count, exit (launch rehearsal; "
+                         "GKOMI_BENCH_BACKEND=gloo runs it without GPUs)")
     return ap.parse_args()
 
 
@@ -199,10 +215,68 @@ def time_loop(torch, fn, steps, barrier):
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE: start N rank processes (one per GPU) as CHILDREN of this
+    process -- which has made no GPU call and never will -- and exit with their code.  A process that has
+    touched the GPU must not exec another program on this pool, hence children, never os.exec*."""
+    import socket
+    backend = os.environ.get("GKOMI_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        import torch  # importing torch and counting devices initialises no GPU context
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible on this node: "
+                             f"nothing was started.  Use --gpus {max(have, 1)} or a node with {args.gpus} GPUs.\n")
+            sys.exit(2)
+    with socket.socket() as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    progress(f"starting {args.gpus} ranks: {' '.join(cmd[1:8])} bench.py ...")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def rendezvous_only(args, world, rank, local_rank):
+    """The launch path without the benchmark: process group up, every rank counted, one JSON line."""
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("GKOMI_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        t = torch.ones(1, device=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+        t = torch.ones(1)
+    dist.all_reduce(t)
+    ranks = sorted(int(r) for r in _gather_ranks(dist, rank, world))
+    if rank == 0:
+        print(json.dumps({"rendezvous": int(t.item()), "n_gpus": args.gpus, "world_size": dist.get_world_size(),
+                          "backend": backend, "ranks": ranks}), flush=True)
+    dist.destroy_process_group()
+
+
+def _gather_ranks(dist, rank, world):
+    got = [None] * world
+    dist.all_gather_object(got, rank)
+    return got
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         cpu_baseline_child(args.cpu_seconds)
+        return
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)   # does not return
+    if args.rendezvous_only:
+        rendezvous_only(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),
+                        int(os.environ.get("LOCAL_RANK", "0")))
         return
     import torch
     # stdout carries exactly one JSON line: whatever libraries print on fd 1
@@ -214,6 +288,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or os.environ.get("GKOMI_BENCH_FORCE_DIST") == "1"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -229,7 +307,6 @@ def main():
         barrier = lambda: dist.barrier(device_ids=[local_rank])
     else:
         barrier = lambda: None
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import gkomi
     import matgen
@@ -238,24 +315,31 @@ def main():
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
     def timed_region(step_fn, steps):
-        """TRIALS timed regions of exactly `steps` steps (barrier + synchronize on both sides, max
-        over ranks per region).  The line reports the best region (the box's host stalls a call by
-        ~10 ms every few hundred ms, tools/stall_probe.py) next to the median and all of them."""
+        """Timed regions of EXACTLY `steps` steps each (barrier + synchronize on both sides, max over
+        ranks per region): at least TRIALS of them, and as many more as it takes for the measured steps
+        to cover --min-region-seconds (a 20-step region of an 18-us kernel is 0.4 ms: one host stall --
+        ~10 ms every few hundred ms on this pool, tools/stall_probe.py -- or one clock step decides
+        it).  Returns the MEDIAN region (what the line's value is computed from) and all of them."""
         regions = []
-        for _ in range(TRIALS):
+        budget = max(args.min_region_seconds, 0.0)
+        while len(regions) < TRIALS or (sum(w for w, _ in regions) < budget and len(regions) < 400):
             wall, ev = time_loop(torch, step_fn, steps, barrier)
             if distributed:
                 t = torch.tensor([wall, ev], dtype=torch.float64, device=device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 wall, ev = float(t[0].item()), float(t[1].item())
             regions.append((wall, ev))
-        best = min(regions)
-        return best, regions
+        ordered = sorted(regions)
+        return ordered[(len(ordered) - 1) // 2], regions
 
     def spread(regions, steps):
-        us = [w / steps * 1e6 for w, _ in regions]
-        return {"best_us_per_step": round(min(us), 3), "median_us_per_step": round(statistics.median(us), 3),
-                "all_us_per_step": [round(u, 3) for u in us]}
+        us = sorted(w / steps * 1e6 for w, _ in regions)
+        ev = sorted(e / steps * 1e6 for _, e in regions)
+        q = lambda a, f: round(a[min(len(a) - 1, int(f * len(a)))], 3)
+        return {"regions": len(us), "measured_seconds": round(sum(w for w, _ in regions), 4),
+                "best_us_per_step": round(us[0], 3), "median_us_per_step": round(statistics.median(us), 3),
+                "p90_us_per_step": q(us, 0.9), "worst_us_per_step": round(us[-1], 3),
+                "median_event_us_per_step": round(statistics.median(ev), 3), "best_event_us_per_step": round(ev[0], 3)}
 
     def make_srow(rp_d, n, nnz):
         tile = int(gk.csr_srow_tile_for(nnz))
@@ -294,7 +378,8 @@ def main():
             "metric": "CSR SpMV GFLOP/s (fp64, 1M-row 5-pt Poisson per GPU)",
             "value": round(flops_per_launch * args.steps / wall / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 5),
-            "timing": f"best of {TRIALS} timed regions of {args.steps} steps", "timing_spread": spread(regions, args.steps),
+            "timing": f"median of {len(regions)} timed regions of {args.steps} steps each "
+                      f"(>= {args.min_region_seconds} s of measured steps)", "timing_spread": spread(regions, args.steps),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "benchmark/spmv: CSR fp64/int32 y=Ax on 1000x1000 5-pt Poisson "
                                    "(n=1e6, nnz=4996000), x=sin(0.01 i)",
@@ -305,10 +390,35 @@ def main():
         }
         kern_s = ev / args.steps
         achieved = bytes_per_launch / kern_s / 1e9
+        traffic, traffic_file = traffic_from_profiles()
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(),
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "traffic_source": (f"{traffic_file}: rocprofv3 --pmc passes of this command "
+                                              "(tools/profile.sh), not re-measured in this run") if traffic_file else None,
                            "kernel": "csr_split_kernel", "bytes_per_launch": bytes_per_launch,
                            "us_per_launch": round(kern_s * 1e6, 3)}
+        # the practical ceiling of THIS box for the same bytes: a pure 16-B streaming kernel over the same
+        # rotating copies (no gather, no LDS, no dependent access), best grid of four, same region policy
+        progress("P2: streaming ceiling for the same byte mix")
+        ceiling = {}
+        for blocks in (1024, 2048, 4096, 8192):
+            stepm = lambda i, blocks=blocks: gk.diag_stream_csr_bytes(stream, blocks, n, nnz, copies[i % ncopies][0],
+                                                                      copies[i % ncopies][1], copies[i % ncopies][2],
+                                                                      copies[i % ncopies][3], copies[i % ncopies][4])
+            for i in range(ncopies):
+                stepm(i)
+            (_, mev), mreg = timed_region(stepm, args.steps)
+            ceiling[blocks] = mev / args.steps * 1e6
+        best_blocks = min(ceiling, key=ceiling.get)
+        out["roofline"]["practical_ceiling_us"] = round(ceiling[best_blocks], 3)
+        out["roofline"]["practical_ceiling_gbs"] = round(bytes_per_launch / ceiling[best_blocks] / 1e3, 1)
+        out["roofline"]["frac_of_practical_ceiling"] = round(ceiling[best_blocks] / (kern_s * 1e6), 4)
+        out["roofline"]["practical_ceiling_note"] = (
+            f"gkomi_diag_stream_csr_bytes ({best_blocks} workgroups; all grids: "
+            + ", ".join(f"{b}: {t:.2f} us" for b, t in ceiling.items())
+            + "): the same 79 952 004 B as pure coalesced 16-B streams, cold over the same copies, same run")
+        for c in copies:   # the probe overwrote y
+            launch(c, cold_strategy)
         for i in range(args.warmup):
             step_warm(i)
         (wwall, wev), wregions = timed_region(step_warm, args.steps)
@@ -320,62 +430,78 @@ def main():
 
         import gkomi.solvers as solvers
 
-        def timed_cg(nn, a, rhs, check_every=32, hint=-1):
-            """hint = the matrix's longest row (Csr keeps it, like srow): with it the driver may run
-            the whole solve in one launch (rows <= 7 nonzeros, <= ~1M rows); -1 = three launches
-            per iteration"""
-            solvers.cg_solve(gk, nn, a[0], a[1], a[2], rhs, max_iters=50000, reduction=1e-10, check_every=check_every,
-                             max_row_nnz=hint)
+        import gkomi.formats as formats
+
+        def as_csr(nn, a):
+            """gko::matrix::Csr on the device: carries its srow and its longest row like the C++ mirror's Csr;
+            the solver drivers get it as a gkomi_csr_ctx record -> the nonzero-split kernel (with the
+            dot-product epilogue in the fused iterations), the kernel `value` is measured on"""
+            return formats.Csr(gk, nn, nn, a[0], a[1], a[2])
+
+        def timed_solves(fn):
+            fn()
             runs = []
-            for _ in range(3):  # best of 3 whole solves (the same host stalls), all of them reported
+            for _ in range(3):  # median of 3 whole solves, all of them reported
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                res = solvers.cg_solve(gk, nn, a[0], a[1], a[2], rhs, max_iters=50000, reduction=1e-10,
-                                       check_every=check_every, max_row_nnz=hint)
+                res = fn()
                 torch.cuda.synchronize()
                 runs.append((time.perf_counter() - t0, res))
-            el, res = min(runs, key=lambda r: r[0])
+            runs.sort(key=lambda r: r[0])
+            el, res = runs[1]
             return res, el, [round(r[0], 5) for r in runs]
 
-        def sinus_system(nn, a, nz, hint):
+        def timed_cg(A, rhs, check_every=32, single_launch=True, precond=None):
+            """single_launch=False: gkomi_cg_persistent_enable(0) -- the three-launch iteration (what every
+            system beyond ~1M rows / 7 nonzeros per row, and every preconditioned solve, runs)"""
+            gk.cg_persistent_enable(1 if single_launch else 0)
+            try:
+                return timed_solves(lambda: solvers.solve_op(gk, "cg", A, rhs, max_iters=50000, reduction=1e-10,
+                                                             check_every=check_every, fused=True, precond=precond))
+            finally:
+                gk.cg_persistent_enable(1)
+
+        def sinus_system(A):
+            nn = A.nrows
             s = np.sin(np.arange(nn, dtype=np.float64))
             s /= np.linalg.norm(s)
             sb = dev(s.reshape(nn, 1))
             b = torch.empty((nn, 1), dtype=torch.float64, device=device)
-            gk.csr_spmv_f64_i32(stream, nn, nn, 1, nz, a[0], a[1], a[2], sb, 1, b, 1, None, None, 0, hint)
+            A.apply(sb, b)
             return sb, b
+
+        def cg_entry(res, el, all_s):
+            return {"iterations": res["iterations"], "seconds": round(el, 5), "all_seconds": all_s,
+                    "iters_per_sec": round(res["iterations"] / el, 1), "us_per_iteration": round(el / max(res["iterations"], 1) * 1e6, 2),
+                    "final_residual_norm_rel": res["rel_residual"], "converged": bool(res["converged"])}
 
         progress("P2: CG solves")
         if not args.no_cg:
-            c = copies[0]
-            sb, b = sinus_system(n, c, nnz, 5)
+            A2 = as_csr(n, copies[0])
+            sb, b = sinus_system(A2)
             cg_bytes = 11 * 8 * n + (12 * nnz + 4 * (n + 1))  # per iteration: 11 n values + matrix (DESIGN.md 4.3)
             before = gk.cg_persistent_solves()
-            res, el, all_s = timed_cg(n, c, b, hint=5)
+            res, el, all_s = timed_cg(A2, b)
             single_launch = gk.cg_persistent_solves() > before
-            res3, el3, all_s3 = timed_cg(n, c, b)
+            res3, el3, all_s3 = timed_cg(A2, b, single_launch=False)
             out["cg"] = {"metric": "CG iters/sec to 1e-10 (fused driver, Identity preconditioner, sinus rhs "
                                    "b = A s/|s|, benchmark/solver default)",
                          "driver": ("single launch: x, r, p and the matrix (rows <= 5 nonzeros) stay in the register "
                                     "files, three device-wide meetings per iteration (csrc/cg_persistent.hpp)")
                          if single_launch else "three launches per iteration",
-                         "three_launch_driver": {"iterations": res3["iterations"], "seconds": round(el3, 5),
-                                                 "all_seconds": all_s3,
-                                                 "iters_per_sec": round(res3["iterations"] / el3, 1)},
-                         "iterations": res["iterations"], "seconds": round(el, 5), "timing": "best of 3 solves",
-                         "all_seconds": all_s, "iters_per_sec": round(res["iterations"] / el, 1),
+                         "three_launch_driver": dict(cg_entry(res3, el3, all_s3),
+                                                     spmv_kernel="csr_split_kernel<Dot> over the matrix's srow",
+                                                     achieved_gbs=round(cg_bytes * res3["iterations"] / el3 / 1e9, 1)),
+                         "timing": "median of 3 solves",
                          # the byte model (11 n values + matrix per iteration) belongs to the three-launch
                          # iteration; the single-launch one moves 2 n values (p out, p gathered) per iteration
                          "achieved_gbs": None if single_launch else round(cg_bytes * res["iterations"] / el / 1e9, 1),
-                         "three_launch_achieved_gbs": round(cg_bytes * res3["iterations"] / el3 / 1e9, 1),
-                         "final_residual_norm_rel": res["rel_residual"],
-                         "solution_rel_err": float(torch.linalg.norm(res["x"] - sb) / torch.linalg.norm(sb)),
-                         "converged": bool(res["converged"])}
+                         "solution_rel_err": float(torch.linalg.norm(res["x"] - sb) / torch.linalg.norm(sb))}
+            out["cg"].update(cg_entry(res, el, all_s))
             ones = torch.ones((n, 1), dtype=torch.float64, device=device)
-            res, el, all_s = timed_cg(n, c, ones, hint=5)
-            out["cg_rhs_ones"] = {"iterations": res["iterations"], "seconds": round(el, 5), "all_seconds": all_s,
-                                  "iters_per_sec": round(res["iterations"] / el, 1),
-                                  "final_residual_norm_rel": res["rel_residual"], "converged": bool(res["converged"])}
+            out["cg_rhs_ones"] = cg_entry(*timed_cg(A2, ones))
+            launch(copies[0], cold_strategy)
+            torch.cuda.synchronize()
         got_p2 = copies[0][4].cpu().numpy().copy()
 
         if not args.no_p3:
@@ -402,16 +528,17 @@ def main():
                   "spmv_gbs": round(b3 * steps3 / e3 / 1e9, 1), "spmv_frac_of_8tbs": round(b3 * steps3 / e3 / 1e9 / HBM_PEAK_GBS, 4),
                   "timing_spread": spread(r3, steps3)}
             if not args.no_cg:
-                sb3, bb3 = sinus_system(n3, a3, nnz3, 7)
-                res, el, all_s = timed_cg(n3, a3, bb3)
-                p3["cg"] = {"iterations": res["iterations"], "seconds": round(el, 5), "all_seconds": all_s,
-                            "iters_per_sec": round(res["iterations"] / el, 1), "converged": bool(res["converged"]),
-                            "final_residual_norm_rel": res["rel_residual"],
-                            "solution_rel_err": float(torch.linalg.norm(res["x"] - sb3) / torch.linalg.norm(sb3))}
-                res, el, all_s = timed_cg(n3, a3, torch.ones((n3, 1), dtype=torch.float64, device=device))
-                p3["cg_rhs_ones"] = {"iterations": res["iterations"], "seconds": round(el, 5), "all_seconds": all_s,
-                                     "iters_per_sec": round(res["iterations"] / el, 1), "converged": bool(res["converged"]),
-                                     "final_residual_norm_rel": res["rel_residual"]}
+                A3 = as_csr(n3, a3)
+                sb3, bb3 = sinus_system(A3)
+                res, el, all_s = timed_cg(A3, bb3)
+                # per iteration (three launches): K1 3n + K2 (matrix + 2n) + K3 6n values
+                cg3_bytes = 11 * 8 * n3 + 12 * nnz3 + 4 * (n3 + 1)
+                p3["cg"] = dict(cg_entry(res, el, all_s), achieved_gbs=round(cg3_bytes * res["iterations"] / el / 1e9, 1),
+                                frac_of_8tbs=round(cg3_bytes * res["iterations"] / el / 1e9 / HBM_PEAK_GBS, 4),
+                                bytes_per_iteration=cg3_bytes,
+                                solution_rel_err=float(torch.linalg.norm(res["x"] - sb3) / torch.linalg.norm(sb3)))
+                p3["cg_rhs_ones"] = cg_entry(*timed_cg(A3, torch.ones((n3, 1), dtype=torch.float64, device=device)))
+                del A3
             out["p3"] = p3
             del a3, x3, y3, srow3
 
@@ -423,7 +550,11 @@ def main():
                 import gkomi.solvers as solvers
                 n4, rp4, ci4, v4 = matgen.at_like(108)
                 a4 = [dev(rp4), dev(ci4), dev(v4)]
+                A4 = as_csr(n4, a4)
                 b4 = dev(np.cos(0.3 * np.arange(n4)).reshape(n4, 1))
+                pre4 = solvers.par_ilu_generate(gk, n4, a4[0].clone(), a4[1], a4[2], iterations=5)   # warm-up (first call
+                del pre4                                                                        # pays one-time set-up)
+                torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 pre4 = solvers.par_ilu_generate(gk, n4, a4[0].clone(), a4[1], a4[2], iterations=5)
                 torch.cuda.synchronize()
@@ -436,8 +567,8 @@ def main():
                     for _ in range(2):
                         torch.cuda.synchronize()
                         t0 = time.perf_counter()
-                        r4 = solvers.gmres_solve(gk, n4, a4[0], a4[1], a4[2], b4, krylov_dim=30, max_iters=3000,
-                                                 reduction=1e-10, precond=pc)
+                        r4 = solvers.solve_op(gk, "gmres", A4, b4, krylov_dim=30, max_iters=3000, reduction=1e-10,
+                                              precond=pc)
                         torch.cuda.synchronize()
                         el = time.perf_counter() - t0
                         best = el if best is None else min(best, el)
@@ -460,9 +591,64 @@ def main():
                     torch.cuda.synchronize()
                     c4["trs_us"] = {"lower": round(e0.elapsed_time(e1) * 1e3 / 20, 1), "upper": round(e1.elapsed_time(e2) * 1e3 / 20, 1)}
                 out["config4"] = c4
-                del a4, b4, pre4
+                del a4, b4, pre4, A4
             except Exception as e:  # noqa: BLE001
                 out["config4"] = {"error": repr(e)}
+
+        if not args.no_config3:
+            # BASELINE config 3 (benchmark/solver: CG + block-Jacobi(32) on thermal2, 1.2 M rows) on SURVEY 8(d)'s
+            # stand-ins; what benchmark/solver/solver.cpp:488-534 reports: generate time, apply time, iterations --
+            # plus the apply's roofline (8 x stored block elements + 4 (#blocks + 1) + 16 n bytes)
+            try:
+                import gkomi.solvers as solvers
+                c3 = {"preconditioner": "preconditioner::Jacobi, max_block_size 32 (benchmark default), fp64 blocks",
+                      "rhs": "b = 1, x0 = 0, reduction 1e-10 (rhs_norm)"}
+                for name, gen in (("t2_like_permuted_1108", lambda: matgen.t2_like_permuted(1108)),
+                                  ("diffusion_patch_ordered_1104", lambda: matgen.diffusion_2d_patch_ordered(1104))):
+                    progress(f"config 3: {name}")
+                    n5, rp5, ci5, v5 = gen()
+                    a5 = [dev(rp5), dev(ci5), dev(v5)]
+                    nnz5 = int(rp5[-1])
+                    del rp5, ci5, v5
+                    A5 = as_csr(n5, a5)
+                    solvers.jacobi_generate(gk, n5, a5[0], a5[1], a5[2], max_block_size=32)   # first call: one-time set-up
+                    gens = []
+                    for _ in range(3):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        pre5 = solvers.jacobi_generate(gk, n5, a5[0], a5[1], a5[2], max_block_size=32)
+                        torch.cuda.synchronize()
+                        gens.append(time.perf_counter() - t0)
+                    sizes = torch.diff(pre5.block_ptrs[:pre5.num_blocks + 1]).to(torch.int64)
+                    stored = int(torch.sum(sizes * sizes).item())
+                    jac_bytes = 8 * stored + 4 * (pre5.num_blocks + 1) + 16 * n5
+                    b5 = torch.ones((n5, 1), dtype=torch.float64, device=device)
+                    z5 = torch.empty_like(b5)
+                    stepj = lambda i: pre5.apply(b5, z5)
+                    for i in range(5):
+                        stepj(i)
+                    (_, jev), jreg = timed_region(stepj, 50)
+                    e = {"n": n5, "nnz": nnz5, "num_blocks": pre5.num_blocks,
+                         "stored_block_elements": stored,
+                         "generate_ms": round(statistics.median(gens) * 1e3, 3), "generate_all_ms": [round(g * 1e3, 3) for g in gens],
+                         "apply": {"us": round(jev / 50 * 1e6, 2), "bytes": jac_bytes, "gbs": round(jac_bytes / (jev / 50) / 1e9, 1),
+                                   "frac_of_8tbs": round(jac_bytes / (jev / 50) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "kernel": "jacobi_apply_kernel", "timing_spread": spread(jreg, 50)}}
+                    res, el, all_s = timed_cg(A5, b5, precond=pre5)
+                    e["cg_jacobi"] = dict(cg_entry(res, el, all_s), time_to_1e_10_ms=round(el * 1e3, 2))
+                    gk.cg_persistent_enable(0)   # plain CG on the same footing: three launches per iteration
+                    try:
+                        res, el, all_s = timed_solves(lambda: solvers.solve_op(gk, "cg", A5, b5, max_iters=20000, reduction=1e-10,
+                                                                               check_every=32, fused=True))
+                    finally:
+                        gk.cg_persistent_enable(1)
+                    e["cg_plain"] = dict(cg_entry(res, el, all_s), time_to_1e_10_ms=round(el * 1e3, 2) if res["converged"] else None,
+                                         note=None if res["converged"] else "not converged within 20000 iterations")
+                    c3[name] = e
+                    del a5, A5, pre5, b5, z5
+                out["config3"] = c3
+            except Exception as e:  # noqa: BLE001 - an extra entry, never allowed to take the headline down
+                out["config3"] = {"error": repr(e)}
 
         if not args.no_cpu_baseline:
             progress("CPU baseline (3 child processes)")
@@ -492,9 +678,11 @@ def main():
         n_loc = M.num_local_rows
         driver = "python: torch.distributed collectives (no RCCL handle for the native driver)"
         comm = A = None
+        rccl_ranks = rccl_rank = None
         try:
             comm = gd.RcclComm(gk, device)
             A = gd.NativeMatrix(M)
+            rccl_ranks, rccl_rank = comm.query()
             driver = "native: csrc/dist_cg.hip over its own RCCL communicator"
         except Exception as ex:  # noqa: BLE001 - the portable path takes over, and says so
             driver += f" [{repr(ex)[:120]}]"
@@ -514,13 +702,14 @@ def main():
             "metric": f"distributed CSR SpMV GFLOP/s (fp64, {g}^3 7-pt Poisson, row-partitioned over {world} GPUs)",
             "value": round(2.0 * nnz_global * steps / wall / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world,
             "steps": steps, "warmup": max(3, args.warmup // 4), "ms_per_step": round(wall / steps * 1e3, 5),
-            "timing": f"best of {TRIALS} timed regions of {steps} steps", "timing_spread": spread(regions, steps),
+            "timing": f"median of {len(regions)} timed regions of {steps} steps each", "timing_spread": spread(regions, steps),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"distributed-solver: row-partitioned y=Ax and CG on {g}^3 7-pt Poisson "
                                    f"(n={n_global}, nnz={nnz_global}), {world} contiguous row slabs, RCCL halo exchange",
                        "partition": f"{world} row slabs of {n_global // world} rows; halo "
                                     f"{M.recv_count} doubles in / {M.send_count} out on rank {rank}",
-                       "driver": driver},
+                       "driver": driver, "rccl_ranks": rccl_ranks, "rccl_rank_of_rank0": rccl_rank,
+                       "torch_distributed_world_size": dist.get_world_size()},
             "roofline": {"bound": "hbm", "achieved": round(local_bytes * steps / ev / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(local_bytes * steps / ev / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "distributed apply (rank 0's share: local block + non-local rows)",

@@ -764,7 +764,21 @@ size_t gkomi_cg_workspace_bytes(int64_t n, int64_t nrhs);
  * kernel boundaries (16 vs 31 us per iteration on the 1M-row Poisson matrix).
  * Everything else -- and a solve whose workgroups could not all be resident --
  * runs the three-launch iteration.  GKOMI_CG_PERSISTENT=0 disables it. */
+/* Diagnostics: a pure streaming kernel over the arrays of a CSR SpMV -- reads
+ * vals, col_idxs, row_ptrs and b, writes c (c is OVERWRITTEN with meaningless
+ * values), 16 B per lane, `blocks` workgroups of 256 threads, grid-stride --
+ * i.e. exactly the 12 nnz + 4 (nrows + 1) + 8 nrows + 8 nrows bytes of
+ * SURVEY 8(d) with no gather and no dependent access.  bench.py times it next to
+ * the SpMV as the practical ceiling of the box for that byte mix.  All arrays
+ * 16-byte aligned. */
+int gkomi_diag_stream_csr_bytes(gkomi_stream_t s, int blocks, int64_t nrows,
+                                int64_t nnz, const int32_t* row_ptrs,
+                                const int32_t* col_idxs, const double* vals,
+                                const double* b, double* c);
 int64_t gkomi_cg_persistent_solves(void);
+/* Process-wide switch of the single-launch CG (what GKOMI_CG_PERSISTENT sets at
+ * start-up): 0 = off (every solve runs the three-launch iteration), 1 = on. */
+int gkomi_cg_persistent_enable(int mode);
 /* Diagnostics: how many GMRES solves of this process had a meeting of the
  * single-launch Arnoldi step time out and were finished, from the x of the last
  * completed restart, by the launch-per-vector kernels.  GKOMI_MEET_MAX_POLLS
@@ -989,6 +1003,9 @@ int64_t gkomi_comm_rccl_available(void);
 int gkomi_comm_rccl_unique_id(void* id_out);
 int gkomi_comm_rccl_create(const void* id_in, int rank, int size, gkomi_comm* out);
 int gkomi_comm_rccl_destroy(gkomi_comm* comm);
+/* ncclCommCount / ncclCommUserRank of an RCCL communicator made by
+ * gkomi_comm_rccl_create: what RCCL itself reports (bench.py prints it). */
+int gkomi_comm_rccl_query(const gkomi_comm* comm, int* count, int* user_rank);
 /* thin callers of the two function pointers (for bindings that cannot call through
  * a struct member) */
 int gkomi_comm_allreduce_sum_f64(const gkomi_comm* comm, gkomi_stream_t s,
@@ -1074,6 +1091,11 @@ typedef struct gkomi_csr_ctx {
     const double* vals;
     int64_t strategy;          /* strategy word of gkomi_csr_spmv_f64_i32 */
     int64_t max_row_nnz_hint;
+    /* Csr::srow_ (gkomi_csr_make_srow_i32) and its tile, or NULL / 0.  With it the
+     * solver drivers run the nonzero-split kernel -- the one gkomi_csr_spmv_srow_f64_i32
+     * runs -- also for the SpMV + dot-product launches of their fused iterations. */
+    const int32_t* srow;
+    int64_t srow_tile;
 } gkomi_csr_ctx;
 typedef struct gkomi_ell_ctx {
     int64_t nrows, ncols, num_stored_per_row, stride;

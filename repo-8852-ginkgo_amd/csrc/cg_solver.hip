@@ -47,10 +47,9 @@ workspace_layout make_layout(int64_t n, int64_t nrhs)
     l.p = off; off += vec;
     l.q = off; off += vec;
     l.scalars = off; off += 256;
-    const size_t nb = static_cast<size_t>(csr_spmv_dot_num_partials(static_cast<int>(n)));
     l.part_a = off; off += align_up(sizeof(double) * max_parts, 256);   // r.z / r.r
     l.part_b = off; off += align_up(sizeof(double) * max_parts, 256);   // r.r with a preconditioner
-    l.part_c = off; off += align_up(sizeof(double) * (nb + 1), 256);    // p.q
+    l.part_c = off; off += align_up(sizeof(double) * spmv_dot_partials_room(n), 256);    // p.q (internal.hpp)
     l.red = off; off += align_up(gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8, 256);
     // mode 0 scalars: alpha-free set {prev_rho, rho, beta, tau, orig_tau, one, neg_one} x nrhs,
     // then stop_status[nrhs] and 2 flag bytes
@@ -69,6 +68,11 @@ workspace_layout make_layout(int64_t n, int64_t nrhs)
     } while (0)
 
 std::atomic<int64_t> pcg_solves{0};  // solves finished by the single-launch kernel (diagnostics, tests)
+// GKOMI_CG_PERSISTENT at start-up, gkomi_cg_persistent_enable afterwards
+std::atomic<int> pcg_mode{[] {
+    const char* e = std::getenv("GKOMI_CG_PERSISTENT");
+    return e == nullptr ? 1 : std::atoi(e);
+}()};
 
 int identity_or_precond(gkomi_apply_fn precond, void* ctx, gkomi_stream_t s,
                         int64_t n, int64_t nrhs, const double* r, double* z)
@@ -86,6 +90,12 @@ int identity_or_precond(gkomi_apply_fn precond, void* ctx, gkomi_stream_t s,
 using namespace gkomi;
 
 extern "C" int64_t gkomi_cg_persistent_solves(void) { return pcg_solves.load(); }
+extern "C" int gkomi_cg_persistent_enable(int mode)
+{
+    if (mode < 0 || mode > 2) return GKOMI_EINVAL;
+    pcg_mode.store(mode);
+    return GKOMI_SUCCESS;
+}
 
 extern "C" size_t gkomi_cg_workspace_bytes(int64_t n, int64_t nrhs)
 {
@@ -115,10 +125,7 @@ int persistent_cg(gkomi_stream_t s, int64_t n, const sysmat& A, const spmv_dot_p
     // caller's max_row_nnz_hint says so; the kernel checks), one workgroup per CU.
     // GKOMI_CG_PERSISTENT=0 turns it off, =2 also takes matrices that do not fit (they stream
     // from memory every iteration: 33 vs 34.8 us per iteration on P2, not worth the rendezvous).
-    static const int persistent_mode = [] {
-        const char* e = std::getenv("GKOMI_CG_PERSISTENT");
-        return e == nullptr ? 1 : std::atoi(e);
-    }();
+    const int persistent_mode = pcg_mode.load();
     static const int cus = device_cu_count();
     const int64_t pcg_chunk = cus > 0 ? ceildiv(n, cus) : 0;
     // an ELL system matrix behind the library's callback: its rows go into the registers just the same
@@ -238,11 +245,14 @@ hipLaunchKernelGGL((cg_persistent_kernel<R, KR, BLOCK, (KR == 7 && R == 8)>), di
 }
 #undef PCG_TRY
 
-int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
+int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_, gkomi_apply_fn precond,
                   void* precond_ctx, const double* b, double* x, int64_t max_iters,
                   double reduction_factor, int baseline, int mode, int check_every, void* workspace,
                   size_t workspace_bytes, double* host_info)
 {
+    // what this solve moves between two applies of A decides how A is read (internal.hpp)
+    sysmat A = A_;
+    A.note_working_set(static_cast<int64_t>(sizeof(double)) * n * nrhs * 6);
     if (mode == 1 && n == 0) mode = 0;  // the fused path needs rows
     // the fused kernels move 16 B per lane through x and the workspace vectors: anything else
     // (a view at an odd offset) takes the reference sequence, like the other fused drivers

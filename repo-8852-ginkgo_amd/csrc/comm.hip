@@ -33,6 +33,8 @@ struct rccl_api {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     bool ok = false;
 };
 
@@ -59,6 +61,8 @@ rccl_api& api()
         GKOMI_SYM(GroupStart, "ncclGroupStart");
         GKOMI_SYM(GroupEnd, "ncclGroupEnd");
         GKOMI_SYM(GetErrorString, "ncclGetErrorString");
+        GKOMI_SYM(CommCount, "ncclCommCount");
+        GKOMI_SYM(CommUserRank, "ncclCommUserRank");
 #undef GKOMI_SYM
         a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.Send && a.Recv &&
                a.GroupStart && a.GroupEnd;
@@ -167,6 +171,18 @@ extern "C" int gkomi_comm_rccl_create(const void* id_in, int rank, int size, gko
     out->allreduce_sum_f64 = rccl_allreduce_sum_f64;
     out->alltoallv = rccl_alltoallv;
     return GKOMI_SUCCESS;
+}
+
+// what RCCL itself says about the communicator (not what the launcher said): ranks and this rank
+extern "C" int gkomi_comm_rccl_query(const gkomi_comm* comm, int* count, int* user_rank)
+{
+    if (comm == nullptr || comm->self == nullptr || count == nullptr || user_rank == nullptr) return GKOMI_EINVAL;
+    if (comm->allreduce_sum_f64 != rccl_allreduce_sum_f64) return GKOMI_EINVAL;  // not an RCCL communicator
+    const rccl_api& a = api();
+    if (a.CommCount == nullptr || a.CommUserRank == nullptr) return GKOMI_ENOTSUPPORTED;
+    const rccl_comm* c = static_cast<const rccl_comm*>(comm->self);
+    if (a.CommCount(c->comm, count) != ncclSuccess) return GKOMI_ECOMM;
+    return nccl_code(a.CommUserRank(c->comm, user_rank));
 }
 
 extern "C" int gkomi_comm_rccl_destroy(gkomi_comm* comm)

@@ -880,26 +880,26 @@ int csr_spmv_dot_launch(hipStream_t stream, int nrows, int64_t nnz,
                         const int32_t* row_ptrs, const int32_t* col_idxs,
                         const double* vals, const double* p, double* q,
                         double* partial, const uint8_t* stop_status,
-                        bool swizzle, const double* dot_w, double* partial2)
+                        bool swizzle, const double* dot_w, double* partial2, bool nontemporal)
 {
     constexpr int Block = 256, Tile = 1536;
     const int nblocks = static_cast<int>(ceildiv(nrows, Block));
     const int per = static_cast<int>(ceildiv(nblocks, num_xcd));
     const bool swz = swizzle && nblocks >= 2 * num_xcd;
     dim3 grid(swz ? per * num_xcd : nblocks, 1);
+    // not Infinity-Cache resident (the matrix alone, or the solve's working set: the driver says so):
+    // the matrix streams from HBM every iteration, read it with nontemporal loads (see csr_auto_swizzle)
+    const bool nt = nontemporal || !swizzle;
+#define GKOMI_STREAM_DOT(SWZ, NT)                                                              \
+    hipLaunchKernelGGL((csr_stream_kernel<Block, 1, Tile, false, SWZ, true, NT>), grid, dim3(Block), 0, stream, \
+                       nrows, row_ptrs, col_idxs, vals, p, int64_t{1}, q, int64_t{1}, nullptr, nullptr, nblocks, \
+                       per, partial, stop_status, dot_w, partial2)
     if (swz) {
-        hipLaunchKernelGGL((csr_stream_kernel<Block, 1, Tile, false, true, true>),
-                           grid, dim3(Block), 0, stream, nrows, row_ptrs,
-                           col_idxs, vals, p, int64_t{1}, q, int64_t{1},
-                           nullptr, nullptr, nblocks, per, partial, stop_status, dot_w, partial2);
+        if (nt) GKOMI_STREAM_DOT(true, true); else GKOMI_STREAM_DOT(true, false);
     } else {
-        // not Infinity-Cache resident: the matrix streams from HBM every
-        // iteration, read it with nontemporal loads (see csr_auto_swizzle)
-        hipLaunchKernelGGL((csr_stream_kernel<Block, 1, Tile, false, false, true, true>),
-                           grid, dim3(Block), 0, stream, nrows, row_ptrs,
-                           col_idxs, vals, p, int64_t{1}, q, int64_t{1},
-                           nullptr, nullptr, nblocks, per, partial, stop_status, dot_w, partial2);
+        if (nt) GKOMI_STREAM_DOT(false, true); else GKOMI_STREAM_DOT(false, false);
     }
+#undef GKOMI_STREAM_DOT
     return check_launch();
 }
 
@@ -909,36 +909,93 @@ int csr_spmv_dot_num_partials(int nrows)
 }
 
 // The same for a matrix with its srow: the nonzero-split kernel with the dot-product epilogue, one
-// partial per tile -- for matrices that stream from HBM (no XCD chunking, nontemporal streams; 300 vs
-// 332 us per SpMV on the 256^3 7-point matrix).  Returns the number of partials, <= 0 when not
-// applicable (the tile must be one the kernel is built for).
+// partial per tile (on the 256^3 7-point matrix 300 vs 332 us per SpMV).  XCD chunking and nontemporal
+// streams as the caller decides (spmv_dot_plan: by the size of the matrix and of the solve's working set).
+// Returns the number of partials, <= 0 when not applicable (the tile must be one the kernel is built for).
 int csr_split_dot_num_partials(int64_t nnz, int64_t tile)
 {
-    if (tile != 2048 && tile != 3072) return 0;
+    if (tile != 1536 && tile != 2048 && tile != 3072) return 0;
+    if (nnz < 2 || nnz > INT32_MAX - 2 * tile - 1024) return 0;
     return static_cast<int>(nnz / tile + 1);
+}
+
+namespace {
+template <int Tile>
+int launch_split_dot(hipStream_t stream, int nrows, int nnz, const int32_t* row_ptrs, const int32_t* col_idxs,
+                     const double* vals, const double* p, double* q, double* partial, const uint8_t* stop_status,
+                     const int32_t* srow, int over, bool swizzle, bool nt, const double* dot_w, double* partial2)
+{
+    constexpr int Block = 256;
+    const int ntiles = nnz / Tile + 1;
+    const int per = static_cast<int>(ceildiv(ntiles, num_xcd));
+    const bool swz = swizzle && ntiles >= 2 * num_xcd;
+    dim3 grid(swz ? per * num_xcd : ntiles, 1);
+#define GKOMI_SPLIT_DOT(SWZ, NT)                                                                          \
+    hipLaunchKernelGGL((csr_split_kernel<Block, Tile, split_max_over, false, SWZ, true, NT, true>), grid, \
+                       dim3(Block), 0, stream, nrows, nnz, row_ptrs, col_idxs, vals, p, int64_t{1}, q,    \
+                       int64_t{1}, nullptr, nullptr, srow, ntiles, per, over, partial, stop_status, dot_w, partial2)
+    if (swz) {
+        if (nt) GKOMI_SPLIT_DOT(true, true); else GKOMI_SPLIT_DOT(true, false);
+    } else {
+        if (nt) GKOMI_SPLIT_DOT(false, true); else GKOMI_SPLIT_DOT(false, false);
+    }
+#undef GKOMI_SPLIT_DOT
+    return check_launch();
+}
+
+// out[j] = raw[j * run .. (j + 1) * run) added in index order within a lane's stride, then across the
+// wave's fixed tree: one wave per output, the same bits on every run
+__global__ __launch_bounds__(1024) void compress_partials_kernel(const double* __restrict__ raw, int nraw,
+                                                                  double* __restrict__ out, int nout, int run,
+                                                                  const double* __restrict__ raw2,
+                                                                  double* __restrict__ out2,
+                                                                  const uint8_t* __restrict__ stop_status)
+{
+    if (stop_status != nullptr && status_has_stopped(stop_status[0])) return;
+    const int wave = (blockIdx.x * 1024 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= nout) return;
+    const int lo = wave * run, hi = min(lo + run, nraw);
+    double a = 0.0, b = 0.0;
+    for (int i = lo + lane; i < hi; i += 64) {
+        a += raw[i];
+        if (raw2 != nullptr) b += raw2[i];
+    }
+    a = wave_reduce_sum(a);
+    if (lane == 0) out[wave] = a;
+    if (raw2 != nullptr) {
+        b = wave_reduce_sum(b);
+        if (lane == 0) out2[wave] = b;
+    }
+}
+}  // namespace
+
+int compress_partials_launch(hipStream_t stream, const double* raw, int nraw, double* out, int nout,
+                             const double* raw2, double* out2, const uint8_t* stop_status)
+{
+    if (nraw <= 0 || nout <= 0) return GKOMI_EINVAL;
+    const int run = static_cast<int>(ceildiv(nraw, nout));
+    hipLaunchKernelGGL(compress_partials_kernel, dim3(static_cast<unsigned>(ceildiv(nout, 16))), dim3(1024), 0,
+                       stream, raw, nraw, out, nout, run, raw2, out2, stop_status);
+    return check_launch();
 }
 
 int csr_split_dot_launch(hipStream_t stream, int nrows, int64_t nnz, const int32_t* row_ptrs,
                          const int32_t* col_idxs, const double* vals, const double* p, double* q,
                          double* partial, const uint8_t* stop_status, const int32_t* srow, int64_t tile,
-                         int over)
+                         int over, bool swizzle, bool nontemporal, const double* dot_w, double* partial2)
 {
-    constexpr int Block = 256;
-    const int ntiles = csr_split_dot_num_partials(nnz, tile);
-    if (ntiles <= 0) return GKOMI_ENOTSUPPORTED;
+    if (csr_split_dot_num_partials(nnz, tile) <= 0) return GKOMI_ENOTSUPPORTED;
     const int z = static_cast<int>(nnz);
-#define GKOMI_SPLIT_DOT(TILE)                                                                            \
-    hipLaunchKernelGGL((csr_split_kernel<Block, TILE, split_max_over, false, false, true, true, true>),  \
-                       dim3(ntiles), dim3(Block), 0, stream, nrows, z, row_ptrs, col_idxs, vals, p,      \
-                       int64_t{1}, q, int64_t{1}, nullptr, nullptr, srow, ntiles, 1, over, partial,     \
-                       stop_status, static_cast<const double*>(nullptr), static_cast<double*>(nullptr))
-    if (tile == 2048) {
-        GKOMI_SPLIT_DOT(2048);
-    } else {
-        GKOMI_SPLIT_DOT(3072);
+    if (tile == 1536) {
+        return launch_split_dot<1536>(stream, nrows, z, row_ptrs, col_idxs, vals, p, q, partial, stop_status, srow,
+                                      over, swizzle, nontemporal, dot_w, partial2);
+    } else if (tile == 2048) {
+        return launch_split_dot<2048>(stream, nrows, z, row_ptrs, col_idxs, vals, p, q, partial, stop_status, srow,
+                                      over, swizzle, nontemporal, dot_w, partial2);
     }
-#undef GKOMI_SPLIT_DOT
-    return check_launch();
+    return launch_split_dot<3072>(stream, nrows, z, row_ptrs, col_idxs, vals, p, q, partial, stop_status, srow,
+                                  over, swizzle, nontemporal, dot_w, partial2);
 }
 
 // swizzle heuristic shared by the automatic strategy: XCD-chunked row blocks
@@ -1042,7 +1099,9 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
         // (cut by nonzeros when the matrix carries its srow, by rows otherwise);
         // long rows one sub-wave per row; when a few rows
         // dwarf the average (max > 64 x mean) split by nonzeros instead
-        if (split_ok && r == 1 && max_row_nnz_hint >= 0 && max_row_nnz_hint <= split_max_over + 1) {
+        // (an unknown row length too: a row longer than the 64 nonzeros read behind its tile is
+        // finished from memory by its thread -- correct for any matrix; callers that know better say so)
+        if (split_ok && r == 1 && max_row_nnz_hint <= split_max_over + 1) {
             kind = GKOMI_CSR_SPLIT;
         } else if (max_row_nnz_hint < 0 || max_row_nnz_hint <= 256) {
             kind = GKOMI_CSR_STREAM;

@@ -605,11 +605,14 @@ std::atomic<int64_t> gmres_meeting_fallbacks{0};
 extern "C" int64_t gkomi_gmres_meeting_fallbacks(void) { return gmres_meeting_fallbacks.load(); }
 
 namespace {
-int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
+int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_, gkomi_apply_fn precond,
                      void* precond_ctx, const double* b, double* x, int64_t krylov_dim,
                      int64_t max_iters, double reduction_factor, int baseline, void* workspace,
                      size_t workspace_bytes, double* host_info, bool allow_persistent = true)
 {
+    // what this solve moves between two applies of A decides how A is read (internal.hpp)
+    sysmat A = A_;
+    A.note_working_set(static_cast<int64_t>(sizeof(double)) * n * nrhs * (krylov_dim + 6));
     if (n < 0 || nrhs <= 0 || krylov_dim <= 0 || max_iters < 0) return GKOMI_EINVAL;
     if (baseline < 0 || baseline > 2) return GKOMI_EINVAL;
     const gmres_layout l = make_layout(n, nrhs, krylov_dim);

@@ -9,15 +9,30 @@ int csr_spmv_dot_launch(hipStream_t stream, int nrows, int64_t nnz,
                         const double* vals, const double* p, double* q,
                         double* partial, const uint8_t* stop_status,
                         bool swizzle, const double* dot_w = nullptr,
-                        double* partial2 = nullptr);
+                        double* partial2 = nullptr, bool nontemporal = false);
 int csr_spmv_dot_num_partials(int nrows);
 // the nonzero-split kernel with the dot epilogue, for matrices with an srow that stream from HBM
 int csr_split_dot_num_partials(int64_t nnz, int64_t tile);
 int csr_split_dot_launch(hipStream_t stream, int nrows, int64_t nnz, const int32_t* row_ptrs,
                          const int32_t* col_idxs, const double* vals, const double* p, double* q,
                          double* partial, const uint8_t* stop_status, const int32_t* srow, int64_t tile,
-                         int over);
+                         int over, bool swizzle, bool nontemporal, const double* dot_w = nullptr,
+                         double* partial2 = nullptr);
 bool csr_auto_swizzle(int64_t nrows, int64_t nnz);
+// `raw` partial sums -> at most spmv_dot_max_partials, in place order (each output = the sum of a run of
+// consecutive inputs, added in index order by one wave): what the consumers of a fused driver re-add
+constexpr int spmv_dot_max_partials = 4096;
+int compress_partials_launch(hipStream_t stream, const double* raw, int nraw, double* out, int nout,
+                             const double* raw2, double* out2, const uint8_t* stop_status);
+// room a fused driver keeps for the partials of one SpMV + dot launch (doubles): the row-cut
+// kernel leaves one per 256 rows, the nonzero-split kernel one per tile -- up to n / 64 + 1 (rows of up
+// to ~24 nonzeros on average with the 1536 tile), in front of them the compressed ones
+inline size_t spmv_dot_partials_room(int64_t n)
+{
+    return static_cast<size_t>(spmv_dot_max_partials) + static_cast<size_t>(n / 64 + 2);
+}
+// the Infinity Cache: a solve whose working set between two applies of A is larger reads A nontemporally
+constexpr int64_t infinity_cache_bytes = int64_t{256} << 20;
 
 // One single-launch ("persistent") solver kernel at a time per process: two of them would each
 // hold some CUs and wait for the rest (runtime.hip).  try_acquire is non-blocking.
@@ -38,6 +53,8 @@ struct sysmat {
     const double* vals = nullptr;
     int strategy = 0;
     int64_t hint = -1;
+    const int32_t* srow = nullptr;  // tile start rows of the nonzero-split kernel (Csr::srow_), or none
+    int64_t srow_tile = 0;
     gkomi_matrix_apply_fn op = nullptr;
     void* ctx = nullptr;
     bool is_csr() const { return op == nullptr; }
@@ -46,8 +63,19 @@ struct sysmat {
               const double* beta, double* out) const
     {
         if (op != nullptr) return op(ctx, s, nrhs, alpha, in, nrhs, beta, out, nrhs);
-        return gkomi_csr_spmv_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, in, nrhs, out,
-                                      nrhs, alpha, beta, strategy, hint);
+        return gkomi_csr_spmv_srow_f64_i32(s, n, n, nrhs, nnz, row_ptrs, col_idxs, vals, in, nrhs, out,
+                                           nrhs, alpha, beta, strategy, hint, srow, srow_tile);
+    }
+    int64_t storage_bytes() const { return is_csr() ? 12 * nnz + 4 * (n + 1) : 0; }
+    // What the driver knows and a single apply cannot: between two applies of A the solve moves
+    // `vector_bytes` of vectors besides the matrix.  Beyond the Infinity Cache the matrix will not be
+    // found there at its next use -> nontemporal matrix streams (GKOMI_CSR_STREAMING), which also
+    // leaves the cache to the vectors (not a bench-only flag).
+    void note_working_set(int64_t vector_bytes)
+    {
+        if (is_csr() && (strategy & 0xff) == GKOMI_CSR_AUTO && storage_bytes() + vector_bytes > infinity_cache_bytes) {
+            strategy |= GKOMI_CSR_STREAMING;
+        }
     }
 };
 
@@ -61,9 +89,21 @@ inline sysmat make_csr_sysmat(int64_t n, int64_t nnz, const int32_t* row_ptrs,
     return A;
 }
 
+// a CSR matrix behind the library's own callback is CSR to every driver (its srow, strategy and row
+// statistic travel in the record); anything else stays an operator
 inline sysmat make_op_sysmat(int64_t n, gkomi_matrix_apply_fn op, void* ctx)
 {
     sysmat A;
+    if (op == &gkomi_csr_matrix_apply_cb && ctx != nullptr) {
+        const auto* m = static_cast<const gkomi_csr_ctx*>(ctx);
+        if (m->nrows == n && m->ncols == n) {
+            A = make_csr_sysmat(n, m->nnz, m->row_ptrs, m->col_idxs, m->vals, static_cast<int>(m->strategy),
+                                m->max_row_nnz_hint);
+            A.srow = m->srow;
+            A.srow_tile = m->srow != nullptr ? m->srow_tile : 0;
+            return A;
+        }
+    }
     A.n = n; A.op = op; A.ctx = ctx;
     return A;
 }
@@ -82,41 +122,60 @@ int op_spmv_dot_launch(hipStream_t stream, gkomi_matrix_apply_fn op, const void*
 // follows A.apply with its own partials kernel).  A CSR matrix behind
 // gkomi_csr_matrix_apply_cb counts as CSR.
 struct spmv_dot_plan {
-    int num_partials = 0;
-    bool csr = false, swizzle = false;
+    int num_partials = 0;  // what the consumers re-add (<= spmv_dot_max_partials once compressed)
+    int raw_partials = 0;  // what the launch leaves (behind the compressed ones when there are more)
+    bool csr = false, swizzle = false, split = false, nontemporal = false;
+    int over = 0;
     sysmat A;
     explicit spmv_dot_plan(const sysmat& A_) : A(A_)
     {
-        if (!A.is_csr() && A.op == &gkomi_csr_matrix_apply_cb && A.ctx != nullptr) {
-            const auto* m = static_cast<const gkomi_csr_ctx*>(A.ctx);
-            if (m->nrows == A.n && m->ncols == A.n) {
-                A = make_csr_sysmat(A.n, m->nnz, m->row_ptrs, m->col_idxs, m->vals,
-                                    static_cast<int>(m->strategy), m->max_row_nnz_hint);
-            }
-        }
         if (A.n <= 0 || A.n > INT32_MAX) return;
         if (A.is_csr()) {
             if (reinterpret_cast<uintptr_t>(A.vals) % 16 != 0 ||
                 reinterpret_cast<uintptr_t>(A.col_idxs) % 8 != 0) {
                 return;
             }
+            const int kind = A.strategy & 0xff;
             csr = true;
             swizzle = csr_auto_swizzle(A.n, A.nnz);
-            num_partials = csr_spmv_dot_num_partials(static_cast<int>(A.n));
+            nontemporal = !swizzle || (A.strategy & GKOMI_CSR_STREAMING) != 0;
+            raw_partials = csr_spmv_dot_num_partials(static_cast<int>(A.n));
+            // the matrix carries its srow: cut by nonzeros (rows of up to 65 entries are summed from
+            // the tile; a longer row is finished from memory, so an unknown row length is safe too)
+            const int nsplit = A.srow != nullptr && (kind == GKOMI_CSR_AUTO || kind == GKOMI_CSR_SPLIT) && A.nnz >= 2 && A.hint <= 65
+                                   ? csr_split_dot_num_partials(A.nnz, A.srow_tile)
+                                   : 0;
+            if (nsplit > 0 && static_cast<size_t>(nsplit) + spmv_dot_max_partials <= spmv_dot_partials_room(A.n)) {
+                split = true;
+                raw_partials = nsplit;
+                over = A.hint < 0 ? 64 : (A.hint <= 1 ? 0 : static_cast<int>(A.hint / 2 * 2));
+            }
         } else if (A.ctx != nullptr) {
-            num_partials = op_spmv_dot_num_partials(A.op, A.ctx);
+            raw_partials = op_spmv_dot_num_partials(A.op, A.ctx);
         }
+        num_partials = raw_partials > spmv_dot_max_partials ? spmv_dot_max_partials : raw_partials;
     }
     bool fused() const { return num_partials > 0; }
+    // `partial` (and `partial2`) must hold spmv_dot_partials_room(n) doubles
     int launch(hipStream_t stream, const double* in, double* out, double* partial,
                const uint8_t* stop_status, const double* dot_w = nullptr,
                double* partial2 = nullptr) const
     {
-        if (csr) {
-            return csr_spmv_dot_launch(stream, static_cast<int>(A.n), A.nnz, A.row_ptrs, A.col_idxs,
-                                       A.vals, in, out, partial, stop_status, swizzle, dot_w, partial2);
+        const bool squeeze = raw_partials > num_partials;
+        double* raw = squeeze ? partial + spmv_dot_max_partials : partial;
+        double* raw2 = partial2 != nullptr && squeeze ? partial2 + spmv_dot_max_partials : partial2;
+        int err;
+        if (split) {
+            err = csr_split_dot_launch(stream, static_cast<int>(A.n), A.nnz, A.row_ptrs, A.col_idxs, A.vals, in, out,
+                                       raw, stop_status, A.srow, A.srow_tile, over, swizzle, nontemporal, dot_w, raw2);
+        } else if (csr) {
+            err = csr_spmv_dot_launch(stream, static_cast<int>(A.n), A.nnz, A.row_ptrs, A.col_idxs,
+                                      A.vals, in, out, raw, stop_status, swizzle, dot_w, raw2, nontemporal);
+        } else {
+            err = op_spmv_dot_launch(stream, A.op, A.ctx, in, out, raw, stop_status, dot_w, raw2);
         }
-        return op_spmv_dot_launch(stream, A.op, A.ctx, in, out, partial, stop_status, dot_w, partial2);
+        if (err != 0 || !squeeze) return err;
+        return compress_partials_launch(stream, raw, raw_partials, partial, num_partials, raw2, partial2, stop_status);
     }
 };
 

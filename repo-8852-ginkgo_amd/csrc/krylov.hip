@@ -379,7 +379,7 @@ solver_layout make_solver_layout(int64_t n, int64_t nrhs, int nvec)
     l.red = take(gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8);
     // fused single-rhs drivers: 3 x <=1024 partials of the vector kernels and
     // 3 x one partial per SpMV row block, plus the device scalars
-    l.parts = take(sizeof(double) * (3 * 1024 + 3 * (static_cast<size_t>(n) / 256 + 2)) + 256);
+    l.parts = take(sizeof(double) * (3 * 1024 + 3 * (spmv_dot_partials_room(n))) + 256);
     l.total = off;
     return l;
 }
@@ -741,10 +741,13 @@ extern "C" size_t gkomi_krylov_workspace_bytes(int64_t n, int64_t nrhs)
     auto V = [&](int k) { return reinterpret_cast<double*>(ws + l.vec[k]); }
 
 namespace {
-int bicgstab_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
+int bicgstab_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_, gkomi_apply_fn precond,
     void* precond_ctx, const double* b, double* x, int64_t max_iters, double reduction_factor,
     int baseline, int64_t check_every, void* workspace, size_t workspace_bytes, double* host_info)
 {
+    // what this solve moves between two applies of A decides how A is read (internal.hpp)
+    sysmat A = A_;
+    A.note_working_set(static_cast<int64_t>(sizeof(double)) * n * nrhs * 10);
     GKOMI_DRIVER_PROLOGUE(8);
     double *r = V(0), *z = V(1), *y = V(2), *v = V(3), *sv = V(4), *t = V(5), *p = V(6), *rr = V(7);
     double *alpha = sc, *beta = sc + nrhs, *gamma = sc + 2 * nrhs, *prev_rho = sc + 3 * nrhs,
@@ -1091,11 +1094,14 @@ __global__ __launch_bounds__(fblock) void bicgstab_fused_step3_kernel(
     }
 }
 
-int bicgstab_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn precond,
+int bicgstab_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_apply_fn precond,
                         void* precond_ctx, const double* b, double* x, int64_t max_iters,
                         double reduction_factor, int baseline, int64_t check_every, void* workspace,
                         size_t workspace_bytes, double* host_info)
 {
+    // what this solve moves between two applies of A decides how A is read (internal.hpp)
+    sysmat A = A_;
+    A.note_working_set(static_cast<int64_t>(sizeof(double)) * n * 1 * 10);
     const int64_t nrhs = 1;
     if (n > INT32_MAX - 1024) return GKOMI_ENOTSUPPORTED;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0) {  // the vector kernels move 16 B per lane
@@ -1115,7 +1121,7 @@ int bicgstab_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_appl
     double* part_rho = parts + 32;
     double* part_tau = part_rho + fused_max_parts;
     double* part_ss = part_tau + fused_max_parts;
-    const size_t per_spmv = static_cast<size_t>(n) / 256 + 2;
+    const size_t per_spmv = spmv_dot_partials_room(n);
     double* part_beta = part_ss + fused_max_parts;
     double* part_gamma = part_beta + per_spmv;
     double* part_tt = part_gamma + per_spmv;
@@ -1236,10 +1242,13 @@ extern "C" int gkomi_bicgstab_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t 
 }
 
 namespace {
-int fcg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
+int fcg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_, gkomi_apply_fn precond,
     void* precond_ctx, const double* b, double* x, int64_t max_iters, double reduction_factor,
     int baseline, int64_t check_every, void* workspace, size_t workspace_bytes, double* host_info)
 {
+    // what this solve moves between two applies of A decides how A is read (internal.hpp)
+    sysmat A = A_;
+    A.note_working_set(static_cast<int64_t>(sizeof(double)) * n * nrhs * 7);
     GKOMI_DRIVER_PROLOGUE(5);
     double *r = V(0), *z = V(1), *p = V(2), *q = V(3), *t = V(4);
     double *beta = sc, *prev_rho = sc + nrhs, *rho = sc + 2 * nrhs, *rho_t = sc + 3 * nrhs;
@@ -1467,11 +1476,14 @@ __global__ __launch_bounds__(fblock) void fcg_fused_step2_kernel(
     }
 }
 
-int fcg_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn precond,
+int fcg_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_apply_fn precond,
                    void* precond_ctx, const double* b, double* x, int64_t max_iters,
                    double reduction_factor, int baseline, int64_t check_every, void* workspace,
                    size_t workspace_bytes, double* host_info)
 {
+    // what this solve moves between two applies of A decides how A is read (internal.hpp)
+    sysmat A = A_;
+    A.note_working_set(static_cast<int64_t>(sizeof(double)) * n * 1 * 7);
     const int64_t nrhs = 1;
     if (n > INT32_MAX - 1024) return GKOMI_ENOTSUPPORTED;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0) {
@@ -1491,7 +1503,7 @@ int fcg_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn 
     double* part_rhot = part_rho + fused_max_parts;
     double* part_tau = part_rhot + fused_max_parts;
     double* part_beta = part_tau + fused_max_parts;
-    const size_t per_spmv = static_cast<size_t>(n) / 256 + 2;  // >= g: room for three arrays (layout)
+    const size_t per_spmv = spmv_dot_partials_room(n);  // >= g: room for three arrays (layout)
     int64_t gl = ceildiv(n / 2 + 1, fblock);
     if (gl > fused_max_parts) gl = fused_max_parts;
     if (gl < 1) gl = 1;
@@ -1602,10 +1614,13 @@ extern "C" int gkomi_fcg_solve_op_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
 }
 
 namespace {
-int cgs_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A, gkomi_apply_fn precond,
+int cgs_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_, gkomi_apply_fn precond,
     void* precond_ctx, const double* b, double* x, int64_t max_iters, double reduction_factor,
     int baseline, int64_t check_every, void* workspace, size_t workspace_bytes, double* host_info)
 {
+    // what this solve moves between two applies of A decides how A is read (internal.hpp)
+    sysmat A = A_;
+    A.note_working_set(static_cast<int64_t>(sizeof(double)) * n * nrhs * 11);
     GKOMI_DRIVER_PROLOGUE(8);
     double *r = V(0), *r_tld = V(1), *p = V(2), *q = V(3), *u = V(4), *u_hat = V(5), *v_hat = V(6),
            *t = V(7);
@@ -1828,11 +1843,14 @@ __global__ __launch_bounds__(fblock) void cgs_fused_step3_kernel(
     }
 }
 
-int cgs_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn precond,
+int cgs_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_apply_fn precond,
                    void* precond_ctx, const double* b, double* x, int64_t max_iters,
                    double reduction_factor, int baseline, int64_t check_every, void* workspace,
                    size_t workspace_bytes, double* host_info)
 {
+    // what this solve moves between two applies of A decides how A is read (internal.hpp)
+    sysmat A = A_;
+    A.note_working_set(static_cast<int64_t>(sizeof(double)) * n * 1 * 11);
     const int64_t nrhs = 1;
     if (n > INT32_MAX - 1024) return GKOMI_ENOTSUPPORTED;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0) {
@@ -1852,7 +1870,7 @@ int cgs_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A, gkomi_apply_fn 
     double* part_rho = parts + 32;
     double* part_tau = part_rho + fused_max_parts;
     double* part_gamma = part_tau + 2 * fused_max_parts;
-    const size_t per_spmv = static_cast<size_t>(n) / 256 + 2;
+    const size_t per_spmv = spmv_dot_partials_room(n);
     int64_t gl = ceildiv(n / 2 + 1, fblock);
     if (gl > fused_max_parts) gl = fused_max_parts;
     if (gl < 1) gl = 1;

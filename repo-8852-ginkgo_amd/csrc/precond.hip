@@ -93,9 +93,10 @@ extern "C" int gkomi_csr_matrix_apply_cb(void* ctx_, gkomi_stream_t s, int64_t n
 {
     const gkomi_csr_ctx* m = static_cast<const gkomi_csr_ctx*>(ctx_);
     if (m == nullptr) return GKOMI_EINVAL;
-    return gkomi_csr_spmv_f64_i32(s, m->nrows, m->ncols, nrhs, m->nnz, m->row_ptrs, m->col_idxs,
-                                  m->vals, b, b_stride, c, c_stride, alpha, beta,
-                                  static_cast<int>(m->strategy), m->max_row_nnz_hint);
+    return gkomi_csr_spmv_srow_f64_i32(s, m->nrows, m->ncols, nrhs, m->nnz, m->row_ptrs, m->col_idxs,
+                                       m->vals, b, b_stride, c, c_stride, alpha, beta,
+                                       static_cast<int>(m->strategy), m->max_row_nnz_hint, m->srow,
+                                       m->srow != nullptr ? m->srow_tile : 0);
 }
 
 extern "C" int gkomi_ell_matrix_apply_cb(void* ctx_, gkomi_stream_t s, int64_t nrhs,

@@ -143,3 +143,57 @@ int device_cu_count()
     return cus;
 }
 }  // namespace gkomi
+
+// ---- diagnostics: the practical streaming ceiling for the CSR SpMV byte mix ----
+// A pure streaming kernel that moves exactly SURVEY 8(d)'s bytes of a CSR SpMV (reads 12 B per
+// nonzero + 4 B per row pointer + 8 B per entry of b, writes 8 B per row) with coalesced 16-B
+// loads and nothing else: no gather, no LDS, no dependent round trip.  What it takes is what the
+// memory system of THIS box needs for those bytes at this size -- bench.py times it in the same run,
+// over the same rotating copies, and reports it as roofline.practical_ceiling_us.
+namespace {
+__global__ __launch_bounds__(256) void stream_csr_byte_mix_kernel(int64_t nnz, int64_t nrows,
+                                                                  const double2* __restrict__ vals,
+                                                                  const int4* __restrict__ cols,
+                                                                  const double2* __restrict__ b,
+                                                                  const int4* __restrict__ row_ptrs,
+                                                                  double2* __restrict__ c)
+{
+    const int64_t tid = blockIdx.x * 256ll + threadIdx.x;
+    const int64_t nth = gridDim.x * 256ll;
+    double acc = 0.0;
+    int iacc = 0;
+    for (int64_t i = tid; i < nnz / 2; i += nth) {
+        const double2 v = vals[i];
+        acc += v.x + v.y;
+    }
+    for (int64_t i = tid; i < nnz / 4; i += nth) {
+        const int4 k = cols[i];
+        iacc += k.x + k.y + k.z + k.w;
+    }
+    for (int64_t i = tid; i < nrows / 4; i += nth) {
+        const int4 k = row_ptrs[i];
+        iacc += k.x + k.y + k.z + k.w;
+    }
+    for (int64_t i = tid; i < nrows / 2; i += nth) {
+        const double2 xv = b[i];
+        c[i] = make_double2(xv.x + acc, xv.y + iacc);
+    }
+}
+}  // namespace
+
+extern "C" int gkomi_diag_stream_csr_bytes(gkomi_stream_t s, int blocks, int64_t nrows, int64_t nnz,
+                                           const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
+                                           const double* b, double* c)
+{
+    if (blocks <= 0 || nrows < 0 || nnz < 0) return GKOMI_EINVAL;
+    if (reinterpret_cast<uintptr_t>(vals) % 16 || reinterpret_cast<uintptr_t>(col_idxs) % 16 ||
+        reinterpret_cast<uintptr_t>(row_ptrs) % 16 || reinterpret_cast<uintptr_t>(b) % 16 ||
+        reinterpret_cast<uintptr_t>(c) % 16) {
+        return GKOMI_EINVAL;
+    }
+    hipLaunchKernelGGL(stream_csr_byte_mix_kernel, dim3(blocks), dim3(256), 0, gkomi::to_stream(s), nnz, nrows,
+                       reinterpret_cast<const double2*>(vals), reinterpret_cast<const int4*>(col_idxs),
+                       reinterpret_cast<const double2*>(b), reinterpret_cast<const int4*>(row_ptrs),
+                       reinterpret_cast<double2*>(c));
+    return gkomi::check_launch();
+}

@@ -404,6 +404,12 @@ class RcclComm:
         self.ptr = ctypes.addressof(self.struct)
         self.rank, self.size = rank, world
 
+    def query(self):
+        """(ranks, this rank) as RCCL itself reports them (ncclCommCount / ncclCommUserRank)"""
+        count, me = ctypes.c_int(0), ctypes.c_int(0)
+        self.gk.comm_rccl_query(self.ptr, ctypes.addressof(count), ctypes.addressof(me))
+        return int(count.value), int(me.value)
+
     def close(self):
         if self.struct.self:
             self.gk.comm_rccl_destroy(self.ptr)

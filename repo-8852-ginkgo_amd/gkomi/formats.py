@@ -17,7 +17,8 @@ def _ctx_type(name, fields):
 
 _i64, _ptr = ctypes.c_int64, ctypes.c_void_p
 CsrCtx = _ctx_type("CsrCtx", [("nrows", _i64), ("ncols", _i64), ("nnz", _i64), ("row_ptrs", _ptr), ("col_idxs", _ptr),
-                              ("vals", _ptr), ("strategy", _i64), ("max_row_nnz_hint", _i64)])
+                              ("vals", _ptr), ("strategy", _i64), ("max_row_nnz_hint", _i64), ("srow", _ptr),
+                              ("srow_tile", _i64)])
 EllCtx = _ctx_type("EllCtx", [("nrows", _i64), ("ncols", _i64), ("num_stored_per_row", _i64), ("stride", _i64),
                               ("col_idxs", _ptr), ("vals", _ptr)])
 SellpCtx = _ctx_type("SellpCtx", [("nrows", _i64), ("ncols", _i64), ("slice_size", _i64), ("slice_sets", _ptr),
@@ -50,17 +51,21 @@ def _scalar(dev, x):
 class Csr:
     name = "csr"
 
-    def __init__(self, gk, nrows, ncols, row_ptrs, col_idxs, vals, strategy=0):
+    def __init__(self, gk, nrows, ncols, row_ptrs, col_idxs, vals, strategy=0, split=True):
+        """split=False: no srow -- the matrix is cut by rows (the kernel of a Csr without srow_)"""
         self.gk, self.nrows, self.ncols = gk, int(nrows), int(ncols)
+        self.split = bool(split)
         self.row_ptrs, self.col_idxs, self.vals = row_ptrs, col_idxs, vals
         self.nnz = int(vals.numel())
         self.strategy = strategy
         self._max_row_nnz = None
+        self._srow = None
+        self.srow_tile = 0
 
     @classmethod
-    def from_host(cls, gk, nrows, ncols, row_ptrs, col_idxs, vals, device="cuda:0", strategy=0):
+    def from_host(cls, gk, nrows, ncols, row_ptrs, col_idxs, vals, device="cuda:0", strategy=0, split=True):
         d = lambda a, t: torch.from_numpy(np.ascontiguousarray(a, dtype=t)).to(device)
-        return cls(gk, nrows, ncols, d(row_ptrs, np.int32), d(col_idxs, np.int32), d(vals, np.float64), strategy)
+        return cls(gk, nrows, ncols, d(row_ptrs, np.int32), d(col_idxs, np.int32), d(vals, np.float64), strategy, split)
 
     @classmethod
     def from_triplets(cls, gk, nrows, ncols, rows, cols, vals, sum_duplicates=True, strategy=0):
@@ -93,16 +98,35 @@ class Csr:
             self._max_row_nnz = int(mx.item())
         return self._max_row_nnz
 
+    def srow(self):
+        """Csr::make_srow (csr.hpp:1139-1157): the tile start rows of the nonzero-split kernel, built once"""
+        if not self.split or self.nnz < 2:
+            return None
+        if self._srow is None:
+            gk = self.gk
+            self.srow_tile = int(gk.csr_srow_tile_for(self.nnz))
+            ne = int(gk.csr_srow_entries(self.nnz, self.srow_tile))
+            self._srow = torch.zeros(max(ne, 1), dtype=I32, device=self.vals.device)
+            try:
+                gk.csr_make_srow_i32(_stream(self.vals), self.nrows, self.nnz, self.row_ptrs, self.srow_tile,
+                                     self._srow, ne)
+            except Exception:  # too large for the split kernel: the row-cut kernels serve it
+                self._srow, self.srow_tile = False, 0
+        return self._srow if self._srow is not False else None
+
     def apply(self, b, x, alpha=None, beta=None):
         dv = self.vals.device
-        self.gk.csr_spmv_f64_i32(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.nnz, self.row_ptrs,
-                                 self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0), _scalar(dv, alpha),
-                                 _scalar(dv, beta), self.strategy, self.max_row_nnz())
+        self.gk.csr_spmv_srow_f64_i32(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.nnz, self.row_ptrs,
+                                      self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0), _scalar(dv, alpha),
+                                      _scalar(dv, beta), self.strategy, self.max_row_nnz(), self.srow(),
+                                      self.srow_tile)
         return x
 
     def callback(self):
+        srow = self.srow()
         ctx = CsrCtx(self.nrows, self.ncols, self.nnz, self.row_ptrs.data_ptr(), self.col_idxs.data_ptr(),
-                     self.vals.data_ptr(), self.strategy, self.max_row_nnz())
+                     self.vals.data_ptr(), self.strategy, self.max_row_nnz(),
+                     srow.data_ptr() if srow is not None else None, self.srow_tile)
         return MatrixCallback(self.gk, "gkomi_csr_matrix_apply_cb", ctx, self)
 
     def row_idxs(self):
@@ -120,7 +144,7 @@ class Csr:
             code = self.CSR_STRATEGIES[fmt]
             if code == self.strategy:
                 return self
-            return Csr(self.gk, self.nrows, self.ncols, self.row_ptrs, self.col_idxs, self.vals, code)
+            return Csr(self.gk, self.nrows, self.ncols, self.row_ptrs, self.col_idxs, self.vals, code, self.split)
         return {"coo": Coo, "ell": Ell, "sellp": Sellp, "hybrid": Hybrid}[fmt].from_csr(self, **kw)
 
 

@@ -229,6 +229,13 @@ class Preconditioner:
         self.ctx_ptr = ctypes.addressof(ctx)
         self.keep = keep
 
+    def apply(self, b, x):
+        """x = M^-1 b through the callback itself (what the solver drivers call); b, x: n x nrhs device tensors"""
+        rc = APPLY_FN(self.fn)(self.ctx_ptr, torch.cuda.current_stream().cuda_stream, b.data_ptr(), x.data_ptr())
+        if rc != 0:
+            raise GkomiError("gkomi_apply_fn", rc, "preconditioner apply failed")
+        return x
+
 
 AUTODETECT = 0xff  # gko::precision_reduction::autodetect()
 

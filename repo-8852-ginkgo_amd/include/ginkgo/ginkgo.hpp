@@ -963,6 +963,7 @@ public:
     // kernel, rebuilt whenever row_ptrs may have changed (read / adopt / conversions reset it)
     const I* get_const_srow() const noexcept { return srow_.get_const_data(); }
     size_type get_num_srow_elements() const noexcept { return srow_.get_num_elems(); }
+    int64_t get_srow_tile() const noexcept { return srow_tile_; }
     void make_srow() const
     {
         if (srow_valid_ || !exec_->is_device()) return;
@@ -1519,6 +1520,7 @@ struct matrix_callback {
 // LinOp goes through matrix_callback.
 struct system_callback {
     matrix_callback generic;
+    gkomi_csr_ctx csr{};
     gkomi_ell_ctx ell{};
     gkomi_sellp_ctx sellp{};
     gkomi_matrix_apply_fn fn;
@@ -1526,7 +1528,23 @@ struct system_callback {
     system_callback(const LinOp* A, std::shared_ptr<const Executor> exec, size_type n)
         : generic{A, std::move(exec), n}, fn(&matrix_callback::call), ctx(&generic)
     {
-        if (auto e = dynamic_cast<const matrix::Ell<double, int32>*>(A)) {
+        if (auto c = dynamic_cast<const matrix::Csr<double, int32>*>(A)) {
+            // the matrix travels with its srow and its row statistic: the drivers then run the kernel
+            // Csr::apply runs, also inside their fused SpMV + dot launches
+            c->make_srow();
+            csr.nrows = static_cast<int64_t>(c->get_size()[0]);
+            csr.ncols = static_cast<int64_t>(c->get_size()[1]);
+            csr.nnz = static_cast<int64_t>(c->get_num_stored_elements());
+            csr.row_ptrs = c->get_const_row_ptrs();
+            csr.col_idxs = c->get_const_col_idxs();
+            csr.vals = c->get_const_values();
+            csr.strategy = c->get_strategy()->get_code();
+            csr.max_row_nnz_hint = c->get_max_row_nnz();
+            csr.srow = c->get_num_srow_elements() ? c->get_const_srow() : nullptr;
+            csr.srow_tile = c->get_num_srow_elements() ? c->get_srow_tile() : 0;
+            fn = &gkomi_csr_matrix_apply_cb;
+            ctx = &csr;
+        } else if (auto e = dynamic_cast<const matrix::Ell<double, int32>*>(A)) {
             ell.nrows = static_cast<int64_t>(e->get_size()[0]);
             ell.ncols = static_cast<int64_t>(e->get_size()[1]);
             ell.num_stored_per_row = static_cast<int64_t>(e->get_num_stored_elements_per_row());
@@ -1789,7 +1807,6 @@ protected:
             ds->cg_solve(b, x, settings_, precond_.get(), &last_iters_, &last_converged_);
             return;
         }
-        auto csr = dynamic_cast<const matrix::Csr<V, int32>*>(A_.get());
         auto db = matrix::detail_fmt::dense(b); auto dx = matrix::detail_fmt::dense(x);
         const int64_t n = size_[0], nrhs = db->cols();
         if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
@@ -1798,19 +1815,14 @@ protected:
         ::gko::detail::linop_callback cb{precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
         auto pfn = precond_ ? &::gko::detail::linop_callback::call : nullptr;
         void* pctx = precond_ ? &cb : nullptr;
-        if (csr) {
-            GKOMI_CALL(gkomi_cg_solve_f64_i32(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
-                                              csr->get_strategy()->get_code(), csr->get_max_row_nnz(), pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
-                                              settings_.reduction_factor, detail::baseline_code(settings_.baseline), nrhs == 1 ? 1 : 0, 8, ws.get_data(), ws.get_num_elems(), info.data()));
-        } else {  // any other format: the system matrix as a callback
-            ::gko::detail::system_callback mcb(A_.get(), exec_, static_cast<size_type>(n));
-            if (nrhs == 1) {  // the fused loop; Ell / Sellp with the dot in the SpMV's epilogue
-                GKOMI_CALL(gkomi_cg_solve_fused_op_f64(nullptr, n, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
-                                                       settings_.reduction_factor, detail::baseline_code(settings_.baseline), 8, ws.get_data(), ws.get_num_elems(), info.data()));
-            } else {
-                GKOMI_CALL(gkomi_cg_solve_op_f64(nullptr, n, nrhs, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
-                                                 settings_.reduction_factor, detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
-            }
+        // a Csr system matrix travels as its record (srow, row statistic): detail::system_callback
+        ::gko::detail::system_callback mcb(A_.get(), exec_, static_cast<size_type>(n));
+        if (nrhs == 1) {  // the fused loop; Ell / Sellp with the dot in the SpMV's epilogue
+            GKOMI_CALL(gkomi_cg_solve_fused_op_f64(nullptr, n, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
+                                                   settings_.reduction_factor, detail::baseline_code(settings_.baseline), 8, ws.get_data(), ws.get_num_elems(), info.data()));
+        } else {
+            GKOMI_CALL(gkomi_cg_solve_op_f64(nullptr, n, nrhs, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
+                                             settings_.reduction_factor, detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
         }
         last_iters_ = static_cast<int64_t>(info[0]);
         last_converged_ = info[1] != 0.0;
@@ -1856,7 +1868,6 @@ protected:
     void apply_impl(const LinOp* b, LinOp* x) const override
     {
         ::gko::detail::require_device(exec_, "solver::apply");
-        auto csr = dynamic_cast<const matrix::Csr<double, int32>*>(A_.get());
         auto db = matrix::detail_fmt::dense(b); auto dx = matrix::detail_fmt::dense(x);
         const int64_t n = size_[0], nrhs = db->cols();
         if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
@@ -1865,15 +1876,10 @@ protected:
         ::gko::detail::linop_callback cb{precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
         auto pfn = precond_ ? &::gko::detail::linop_callback::call : nullptr;
         void* pctx = precond_ ? &cb : nullptr;
-        if (csr) {
-            GKOMI_CALL(Driver(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
-                              csr->get_strategy()->get_code(), csr->get_max_row_nnz(), pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
-                              settings_.reduction_factor, baseline_code(settings_.baseline), 8, ws.get_data(), ws.get_num_elems(), info.data()));
-        } else {
-            ::gko::detail::system_callback mcb(A_.get(), exec_, static_cast<size_type>(n));
-            GKOMI_CALL(OpDriver(nullptr, n, nrhs, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
-                                settings_.reduction_factor, baseline_code(settings_.baseline), 8, ws.get_data(), ws.get_num_elems(), info.data()));
-        }
+        // a Csr system matrix travels as its record (srow, row statistic): detail::system_callback
+        ::gko::detail::system_callback mcb(A_.get(), exec_, static_cast<size_type>(n));
+        GKOMI_CALL(OpDriver(nullptr, n, nrhs, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
+                            settings_.reduction_factor, baseline_code(settings_.baseline), 8, ws.get_data(), ws.get_num_elems(), info.data()));
         last_iters_ = static_cast<int64_t>(info[0]);
         last_converged_ = info[1] != 0.0;
     }
@@ -2087,7 +2093,6 @@ protected:
     void apply_impl(const LinOp* b, LinOp* x) const override
     {
         ::gko::detail::require_device(exec_, "gmres::apply");
-        auto csr = dynamic_cast<const matrix::Csr<V, int32>*>(A_.get());
         auto db = matrix::detail_fmt::dense(b); auto dx = matrix::detail_fmt::dense(x);
         const int64_t n = size_[0], nrhs = db->cols();
         if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
@@ -2096,15 +2101,10 @@ protected:
         ::gko::detail::linop_callback cb{precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
         auto pfn = precond_ ? &::gko::detail::linop_callback::call : nullptr;
         void* pctx = precond_ ? &cb : nullptr;
-        if (csr) {
-            GKOMI_CALL(gkomi_gmres_solve_f64_i32(nullptr, n, nrhs, csr->get_num_stored_elements(), csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(),
-                                                 csr->get_strategy()->get_code(), csr->get_max_row_nnz(), pfn, pctx, db->get_const_values(), dx->get_values(), krylov_dim_,
-                                                 settings_.max_iters, settings_.reduction_factor, detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
-        } else {
-            ::gko::detail::system_callback mcb(A_.get(), exec_, static_cast<size_type>(n));
-            GKOMI_CALL(gkomi_gmres_solve_op_f64(nullptr, n, nrhs, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), krylov_dim_,
-                                                settings_.max_iters, settings_.reduction_factor, detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
-        }
+        // a Csr system matrix travels as its record (srow, row statistic): detail::system_callback
+        ::gko::detail::system_callback mcb(A_.get(), exec_, static_cast<size_type>(n));
+        GKOMI_CALL(gkomi_gmres_solve_op_f64(nullptr, n, nrhs, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), krylov_dim_,
+                                            settings_.max_iters, settings_.reduction_factor, detail::baseline_code(settings_.baseline), ws.get_data(), ws.get_num_elems(), info.data()));
         last_iters_ = static_cast<int64_t>(info[0]);
         last_converged_ = info[1] != 0.0;
     }

@@ -268,7 +268,10 @@ def test_fused_drivers_on_every_matrix_format(gk, solver, precond):
     and SELL-P carry the dot-product epilogue in their SpMV (same row -> thread map
     and block sums as the CSR kernel), so the iterates are bit-identical to the
     fused CSR entry point's; CSR behind its callback is the CSR entry point; COO /
-    Hybrid take apply + a partials kernel (different partial sums: rounding)."""
+    Hybrid take apply + a partials kernel (different partial sums: rounding).
+    A Csr that carries its srow ("csr_split": what the C++ mirror's Csr and formats.Csr pass by
+    default) runs the nonzero-split kernel with the dot epilogue: one partial per tile instead of
+    one per 256 rows, so the iterates agree to rounding, not bit for bit."""
     from gkomi import formats
     n, rp, ci, v = matgen.poisson_2d_5pt(37, 41)   # n = 1517: not a multiple of the block
     if solver in ("bicgstab", "cgs"):
@@ -276,9 +279,13 @@ def test_fused_drivers_on_every_matrix_format(gk, solver, precond):
         rows = np.repeat(np.arange(n), np.diff(rp))
         v[ci == rows - 1] -= 0.3
         v[ci == rows] += 0.3
-    A = formats.Csr.from_host(gk, n, n, rp, ci, v)
+    A = formats.Csr.from_host(gk, n, n, rp, ci, v, split=False)
+    S = formats.Csr.from_host(gk, n, n, rp, ci, v)
+    assert S.srow() is not None and A.srow() is None
     xs = np.sin(0.3 * np.arange(n))
     b = A.apply(dev(xs.reshape(n, 1)), torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")).reshape(n)
+    assert host(S.apply(dev(xs.reshape(n, 1)), torch.zeros((n, 1), dtype=torch.float64, device="cuda:0"))).tobytes() == \
+        host(b).tobytes()
     pc = solvers.jacobi_generate(gk, n, A.row_ptrs, A.col_idxs, A.vals, max_block_size=4) if precond else None
     kw = dict(max_iters=2000, reduction=1e-10, precond=pc, check_every=4)
     if solver == "cg":
@@ -286,8 +293,9 @@ def test_fused_drivers_on_every_matrix_format(gk, solver, precond):
     else:
         base = solvers.krylov_solve(gk, solver, n, A.row_ptrs, A.col_idxs, A.vals, b, fused=True, **kw)
     assert base["converged"] and matgen.rel_err(host(base["x"]), xs) < 1e-7
-    for fmt in ("csr", "ell", "sellp", "coo", "hybrid"):
-        M = A if fmt == "csr" else (A.to(fmt, kind=0, num_columns=3) if fmt == "hybrid" else A.to(fmt))
+    for fmt in ("csr", "csr_split", "ell", "sellp", "coo", "hybrid"):
+        M = A if fmt == "csr" else S if fmt == "csr_split" else (
+            A.to(fmt, kind=0, num_columns=3) if fmt == "hybrid" else A.to(fmt))
         res = solvers.solve_op(gk, solver, M, b, fused=True, **kw)
         assert res["converged"] and matgen.rel_err(host(res["x"]), xs) < 1e-7, fmt
         if fmt in ("csr", "ell", "sellp"):
@@ -295,6 +303,8 @@ def test_fused_drivers_on_every_matrix_format(gk, solver, precond):
             assert host(res["x"]).tobytes() == host(base["x"]).tobytes(), fmt
         else:
             assert abs(res["iterations"] - base["iterations"]) <= max(2, base["iterations"] // 10), fmt
+            if fmt == "csr_split":
+                assert matgen.rel_err(host(res["x"]), host(base["x"])) < 1e-8
 
 
 # ---- fused single-rhs BiCGSTAB (6 launches per iteration) ---------------------------

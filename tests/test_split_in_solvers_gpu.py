@@ -1,0 +1,154 @@
+"""the kernel the bench measures (nonzero-split over srow) is the one the
+API and the solver drivers run.  A Csr that carries its srow (gkomi_csr_ctx.srow) gets
+* gkomi_csr_spmv_srow_f64_i32 with the automatic strategy and an UNKNOWN row length (hint -1): the
+  split kernel, bit-exact for any row lengths (rows longer than the over-read finish from memory);
+* the fused CG / FCG / BiCGSTAB / CGS iterations: csr_split_kernel<Dot> (one partial per tile),
+  compressed to <= 4096 partials by one small launch when a launch leaves more;
+* GMRES: the split kernel for every A v.
+Reference semantics: reference/matrix/csr_kernels.cpp:75-128 (SpMV), core/solver/cg.cpp:107-193."""
+import numpy as np
+import pytest
+import torch
+
+import matgen
+from gpu_util import dev, host
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gk():
+    import gkomi
+    return gkomi.lib()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    import oracle_lib
+    return oracle_lib.load()
+
+
+def _random_rows(n, max_len, seed, long_rows=()):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, max_len + 1, size=n)
+    for r, ln in long_rows:
+        lens[r] = ln
+    rp = np.zeros(n + 1, np.int32)
+    rp[1:] = np.cumsum(lens)
+    ci = rng.integers(0, n, size=rp[-1]).astype(np.int32)
+    v = rng.standard_normal(rp[-1])
+    return rp, ci, v
+
+
+@pytest.mark.parametrize("long_rows", [(), ((17, 200), (4000, 3000), (9999, 70))], ids=["short", "long_rows"])
+@pytest.mark.parametrize("hint", [-1, None])
+def test_automatic_strategy_with_srow_and_unknown_row_length_is_bit_exact(gk, oracle, long_rows, hint):
+    """hint -1 is what a binding passes that has no row statistic (shims/hip/matrix/csr_kernels.hip.cpp
+    used to): with an srow the automatic strategy now picks the split kernel anyway."""
+    from gkomi import formats
+    n = 10000
+    rp, ci, v = _random_rows(n, 9, 3, long_rows)
+    A = formats.Csr.from_host(gk, n, n, rp, ci, v)
+    x = np.cos(0.01 * np.arange(n)).reshape(n, 1)
+    e = np.empty((n, 1))
+    oracle.ref_csr_spmv(n, 1, rp, ci, v, x, 1, e, 1)
+    srow = A.srow()
+    assert srow is not None
+    y = torch.full((n, 1), float("nan"), dtype=torch.float64, device="cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    h = -1 if hint == -1 else int(np.max(np.diff(rp)))
+    gk.csr_spmv_srow_f64_i32(s, n, n, 1, int(rp[-1]), A.row_ptrs, A.col_idxs, A.vals, dev(x), 1, y, 1, None, None, 0, h,
+                             srow, A.srow_tile)
+    # a caller that KNOWS of a 3000-entry row among rows of 4.5 gets the load-balanced kernel (atomics:
+    # tolerance parity, like the reference's load_balance); everything else here is the split kernel
+    exact = not (long_rows and hint is None)
+    if not exact:
+        assert matgen.rel_err(host(y), e) < 1e-14
+        return
+    assert np.array_equal(host(y), e)
+    # advanced apply through the same selection
+    y0 = np.sin(0.3 * np.arange(n)).reshape(n, 1)
+    e2 = y0.copy()
+    oracle.ref_csr_advanced_spmv(n, 1, -0.75, rp, ci, v, x, 1, 2.5, e2, 1)
+    yd = dev(y0)
+    gk.csr_spmv_srow_f64_i32(s, n, n, 1, int(rp[-1]), A.row_ptrs, A.col_idxs, A.vals, dev(x), 1, yd, 1,
+                             dev(np.array([-0.75])), dev(np.array([2.5])), 0, h, srow, A.srow_tile)
+    assert np.array_equal(host(yd), e2)
+
+
+@pytest.mark.parametrize("solver", ["cg", "fcg", "bicgstab", "cgs"])
+@pytest.mark.parametrize("grid", [(300, 270), (64, 64, 70)], ids=["5pt_81000", "7pt_286720"])
+def test_fused_drivers_with_srow_agree_with_the_row_cut_kernels(gk, oracle, solver, grid):
+    """Same recurrences, the dot partials grouped per tile instead of per 256 rows: iteration counts within
+    one, solutions to 1e-8, true residual (oracle SpMV) at the tolerance of the solve."""
+    from gkomi import formats, solvers
+    if len(grid) == 2:
+        n, rp, ci, v = matgen.poisson_2d_5pt(*grid)
+    else:
+        n, rp, ci, v = matgen.poisson_3d_7pt(*grid)
+    if solver in ("bicgstab", "cgs"):
+        v = v.copy()
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        v[ci == rows - 1] -= 0.3
+        v[ci == rows] += 0.3
+    A = formats.Csr.from_host(gk, n, n, rp, ci, v, split=False)
+    S = formats.Csr.from_host(gk, n, n, rp, ci, v)
+    b = np.sin(0.1 * np.arange(n)) + 1.0
+    kw = dict(max_iters=4000, reduction=1e-10, fused=True)
+    if solver == "cg":
+        # the single-launch CG would take both solves (Identity preconditioner, short rows): this test
+        # is about the three-launch iteration, so precondition with the scalar Jacobi
+        kw["precond"] = solvers.jacobi_generate(gk, n, A.row_ptrs, A.col_idxs, A.vals, max_block_size=1)
+    base = solvers.solve_op(gk, solver, A, dev(b), **kw)
+    res = solvers.solve_op(gk, solver, S, dev(b), **kw)
+    assert base["converged"] and res["converged"]
+    assert abs(res["iterations"] - base["iterations"]) <= max(1, base["iterations"] // 50)
+    assert matgen.rel_err(host(res["x"]), host(base["x"])) <= 1e-8
+    r = b.copy().reshape(n, 1)
+    oracle.ref_csr_advanced_spmv(n, 1, -1.0, rp, ci, v, host(res["x"]).reshape(n, 1), 1, 1.0, r, 1)
+    assert np.linalg.norm(r) <= 1e-8 * np.linalg.norm(b)
+    again = solvers.solve_op(gk, solver, S, dev(b), **kw)   # deterministic: fixed summation order
+    assert again["iterations"] == res["iterations"] and host(again["x"]).tobytes() == host(res["x"]).tobytes()
+
+
+def test_more_partials_than_the_consumers_re_add_are_compressed(gk, oracle):
+    """7-point 100^3 (1 M rows, 6.94 M nonzeros): the split SpMV + dot launch leaves 4519 partials (> 4096),
+    one small launch adds runs of them in a fixed order before K3 reads them.  With a block-Jacobi
+    preconditioner so that the single-launch CG does not take the solve.  The row-cut path (3907
+    partials, not compressed) is the comparison."""
+    from gkomi import formats, solvers
+    n, rp, ci, v = matgen.poisson_3d_7pt(100)
+    assert int(rp[-1]) // 1536 + 1 > 4096 and (n + 255) // 256 <= 4096
+    A = formats.Csr.from_host(gk, n, n, rp, ci, v, split=False)
+    S = formats.Csr.from_host(gk, n, n, rp, ci, v)
+    pc = solvers.jacobi_generate(gk, n, A.row_ptrs, A.col_idxs, A.vals, max_block_size=1)
+    b = np.sin(0.1 * np.arange(n)) + 1.0
+    kw = dict(max_iters=2000, reduction=1e-10, fused=True, precond=pc)
+    base = solvers.solve_op(gk, "cg", A, dev(b), **kw)
+    res = solvers.solve_op(gk, "cg", S, dev(b), **kw)
+    assert base["converged"] and res["converged"] and abs(res["iterations"] - base["iterations"]) <= 2
+    assert matgen.rel_err(host(res["x"]), host(base["x"])) <= 1e-8
+    r = b.copy().reshape(n, 1)
+    oracle.ref_csr_advanced_spmv(n, 1, -1.0, rp, ci, v, host(res["x"]).reshape(n, 1), 1, 1.0, r, 1)
+    assert np.linalg.norm(r) <= 1e-8 * np.linalg.norm(b)
+    # BiCGSTAB uses both outputs of the epilogue (s.t and t.t): both are compressed
+    resb = solvers.solve_op(gk, "bicgstab", S, dev(b), max_iters=2000, reduction=1e-10, fused=True)
+    baseb = solvers.solve_op(gk, "bicgstab", A, dev(b), max_iters=2000, reduction=1e-10, fused=True)
+    assert resb["converged"] and abs(resb["iterations"] - baseb["iterations"]) <= max(2, baseb["iterations"] // 10)
+    assert matgen.rel_err(host(resb["x"]), host(baseb["x"])) <= 1e-7
+
+
+def test_gmres_runs_on_a_csr_with_srow(gk, oracle):
+    from gkomi import formats, solvers
+    n, rp, ci, v = matgen.poisson_2d_5pt(150, 130)
+    v = v.copy()
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    v[ci == rows - 1] -= 0.4
+    v[ci == rows] += 0.4
+    S = formats.Csr.from_host(gk, n, n, rp, ci, v)
+    b = np.cos(0.3 * np.arange(n))
+    xe = np.zeros(n)
+    it = oracle.ref_gmres_solve(n, rp, ci, v, None, None, b, xe, 30, 3000, 1e-10, 0, np.zeros(1))
+    res = solvers.solve_op(gk, "gmres", S, dev(b), max_iters=3000, reduction=1e-10, krylov_dim=30)
+    assert res["converged"] and abs(res["iterations"] - it) <= 1
+    assert matgen.rel_err(host(res["x"]), xe) <= 1e-6
