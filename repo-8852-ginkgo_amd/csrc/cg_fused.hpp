@@ -51,11 +51,15 @@ __global__ __launch_bounds__(fblock) void cg_fused_step1_kernel(
     int64_t n, double* __restrict__ p, const double* __restrict__ z,
     const double* __restrict__ rho_part, int n_rho,
     const double* __restrict__ tau_part, int n_tau, cg_scalars* scal,
-    long long it, long long max_iters, double goal)
+    long long it, long long max_iters, double goal, host_watch_line* watch = nullptr)
 {
     __shared__ double smem[fblock / wave_size];
     const bool stopped_before = status_has_stopped(scal->status);
-    if (stopped_before) return;
+    if (stopped_before) {
+        // (the host's view of the solve, internal.hpp: iteration reached, iteration stopped)
+        if (blockIdx.x == 0 && threadIdx.x == 0) host_watch_publish(watch, it, scal->stop_iter);
+        return;
+    }
     // the first sweep's loads do not depend on the scalars: issue them before
     // the partial sums so their latency hides behind the reduction
     const int64_t n2 = n / 2;
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(fblock) void cg_fused_step1_kernel(
             scal->stop_iter = it;
             scal->status = st;
         }
+        host_watch_publish(watch, it, st ? it : -1ll);
     }
     if (st) return;
     const double prev = scal->rho[(it + 1) & 1];

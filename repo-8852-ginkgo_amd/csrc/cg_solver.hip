@@ -385,33 +385,62 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_, g
         const double* tau_part = precond == nullptr ? part_a : part_b;
         long long it = 0;
         bool done = false;
-        while (!done) {
-            for (int c = 0; c < check_every; ++c, ++it) {
-                hipLaunchKernelGGL(cg_fused_step1_kernel, dim3(g), dim3(fblock), 0, stream, n, p, zz,
-                                   part_a, g, tau_part, g, scal, it,
-                                   static_cast<long long>(max_iters), reduction_factor);
-                if (spmv.fused()) {
-                    GKOMI_TRY(spmv.launch(stream, p, q, part_c, &scal->status));
-                } else {
-                    GKOMI_TRY(A.apply(s, 1, nullptr, p, nullptr, q));
-                    hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, p, q,
-                                       static_cast<const cg_scalars*>(scal), part_c,
-                                       static_cast<double*>(nullptr));
-                }
-                hipLaunchKernelGGL(cg_fused_step2_kernel, dim3(g), dim3(fblock), 0, stream, n, x, r, p,
-                                   q, part_c, nb, scal, it, precond == nullptr ? part_a : part_b);
-                if (precond != nullptr) {
-                    GKOMI_TRY(precond(precond_ctx, s, r, z));
-                    hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r,
-                                       z, static_cast<const cg_scalars*>(scal), part_a,
-                                       static_cast<double*>(nullptr));
-                }
-                if (it >= max_iters) {  // the launch with it == max_iters stops for sure
-                    ++it;
-                    break;
-                }
+        // The host does not look at device memory while the solve runs: K1's first thread reports the
+        // iteration it has evaluated (and the one at which the criterion fired) into pinned host memory
+        // (host_watch, internal.hpp), and the host keeps at most min(check_every, host_watch_lag)
+        // iterations ahead of what it has seen -- the queue never drains for a look.  Without that
+        // line (or if its stores never show up) the old way: a blocking look every check_every iterations.
+        host_watch watch;
+        const long long lag = std::min<long long>(check_every, host_watch_lag);
+        auto issue = [&](long long i) -> int {
+            hipLaunchKernelGGL(cg_fused_step1_kernel, dim3(g), dim3(fblock), 0, stream, n, p, zz,
+                               part_a, g, tau_part, g, scal, i,
+                               static_cast<long long>(max_iters), reduction_factor, watch.dev);
+            if (spmv.fused()) {
+                GKOMI_TRY(spmv.launch(stream, p, q, part_c, &scal->status));
+            } else {
+                GKOMI_TRY(A.apply(s, 1, nullptr, p, nullptr, q));
+                hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, p, q,
+                                   static_cast<const cg_scalars*>(scal), part_c,
+                                   static_cast<double*>(nullptr));
             }
-            GKOMI_TRY(check_launch());
+            hipLaunchKernelGGL(cg_fused_step2_kernel, dim3(g), dim3(fblock), 0, stream, n, x, r, p,
+                               q, part_c, nb, scal, i, precond == nullptr ? part_a : part_b);
+            if (precond != nullptr) {
+                GKOMI_TRY(precond(precond_ctx, s, r, z));
+                hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r,
+                                   z, static_cast<const cg_scalars*>(scal), part_a,
+                                   static_cast<double*>(nullptr));
+            }
+            return check_launch();
+        };
+        while (!done) {
+            bool look = false;
+            if (watch.dev != nullptr) {
+                GKOMI_TRY(issue(it));
+                const bool last = it >= max_iters;  // the launch with it == max_iters stops for sure
+                ++it;
+                if (last) {
+                    look = true;
+                } else if (it - 1 >= lag) {
+                    if (!watch.wait(stream, it - 1 - lag)) {
+                        watch.dev = nullptr;
+                        look = true;
+                    } else {
+                        look = watch.stop_iter() >= 0;
+                    }
+                }
+            } else {
+                for (int c = 0; c < check_every; ++c, ++it) {
+                    GKOMI_TRY(issue(it));
+                    if (it >= max_iters) {
+                        ++it;
+                        break;
+                    }
+                }
+                look = true;
+            }
+            if (!look) continue;
             GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&polled, scal, sizeof(cg_scalars),
                                                       hipMemcpyDeviceToHost, stream)));
             GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));

@@ -384,6 +384,7 @@ struct gmres_iteration_tail {
     gmres_stop_record* record;
     long long next_iter;
     int restart_iter;
+    host_watch_line* watch;  // the host's view of the solve (internal.hpp), or nullptr
 };
 
 template <int R>
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(pcg_block) void gmres_arnoldi_persistent_kernel(
         tail.flags[0] = all;
         tail.flags[1] = one_changed;
         if (all && tail.record->iter < 0) tail.record->iter = tail.next_iter;
+        host_watch_publish(tail.watch, tail.next_iter, tail.record->iter);
     }
 }
 
@@ -468,9 +470,10 @@ __global__ __launch_bounds__(pcg_block) void gmres_arnoldi_persistent_kernel(
 constexpr int64_t gmres_check_every = 4;
 
 __global__ void gmres_record_stop_kernel(const uint8_t* __restrict__ flags, long long iter,
-                                         gmres_stop_record* record)
+                                         gmres_stop_record* record, host_watch_line* watch)
 {
     if (flags[0] && record->iter < 0) record->iter = iter;
+    host_watch_publish(watch, iter, record->iter);
 }
 
 struct gmres_layout {
@@ -701,6 +704,7 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_
     } release{persistent};
     long long meeting = 0;
     bool criterion_done = false;
+    host_watch watch;  // the device reports the iteration it has reached into pinned host memory
     pcg_control host_ctl{};
     if (persistent) {
         hipLaunchKernelGGL(pcg_clear_kernel, dim3(1), dim3(256), 0, stream, pslots, pcg_default_stride,
@@ -755,17 +759,34 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_
                 GKOMI_TRY(gkomi_residual_norm_f64(s, nrhs, residual_norm, orig_tau, reduction_factor,
                                                   id_residual, 0, stop_status, dev_flags, nullptr));
                 hipLaunchKernelGGL(gmres_record_stop_kernel, dim3(1), dim3(1), 0, stream, dev_flags, total_iter,
-                                   record);
+                                   record, watch.dev);
             }
             criterion_done = false;
-            if (++unpolled >= gmres_check_every || restart_iter == krylov_dim) {
+            ++unpolled;
+            bool look = false;  // a blocking look at device memory
+            if (watch.dev != nullptr) {
+                // the device tells the host how far it is (host_watch): before a restart the host needs the
+                // criterion of THIS iteration, otherwise it only keeps within host_watch_lag iterations
+                const long long target = restart_iter == krylov_dim ? total_iter : total_iter - host_watch_lag;
+                if (target >= 0) {
+                    if (watch.wait(stream, target)) {
+                        host_record.iter = watch.stop_iter();
+                    } else {
+                        look = true;  // nothing to see and the stream has drained: a meeting timed out
+                        watch.dev = nullptr;                 // (or the stores do not reach this host)
+                    }
+                }
+            } else {
+                look = unpolled >= gmres_check_every || restart_iter == krylov_dim;
+            }
+            if (look) {
                 GKOMI_TRY(poll());
                 if (persistent && host_ctl.overrun != 0) return solve_again_without_meetings();
-                if (host_record.iter >= 0) {
-                    stop = true;
-                    converged = 1;
-                    total_iter = host_record.iter;
-                }
+            }
+            if (host_record.iter >= 0) {
+                stop = true;
+                converged = 1;
+                total_iter = host_record.iter;
             }
         }
         if (stop) break;
@@ -784,7 +805,7 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_
             const int steps = static_cast<int>(restart_iter + 1);
             const gmres_iteration_tail tail{gsin, gcos, residual_norm, rnc, final_iter_nums, stop_status, orig_tau,
                                             reduction_factor, dev_flags, record, total_iter + 1,
-                                            static_cast<int>(restart_iter)};
+                                            static_cast<int>(restart_iter), watch.dev};
 #define GKOMI_ARN(R)                                                                                  \
     hipLaunchKernelGGL(gmres_arnoldi_persistent_kernel<R>, dim3(cus), dim3(pcg_block), 0, stream,     \
                        static_cast<int>(n), pchunk, next_k, kb, steps, hess_iter, h_stride, pslots,   \

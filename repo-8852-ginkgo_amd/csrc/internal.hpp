@@ -40,6 +40,50 @@ bool persistent_try_acquire();
 void persistent_release();
 int device_cu_count();  // CUs of the current device, 0 = unknown
 
+// ---- the host's view of a running solve, without stopping it ---------------------------------------
+// The fused drivers evaluate their stopping criterion on the device; the host only has to learn, sooner
+// or later, that it fired, and must not run too far ahead of the device meanwhile.  A blocking look
+// (copy + synchronize) leaves the GPU idle for the host's turnaround -- ~85 us per look on this pool,
+// 21 us per GMRES iteration at a look every 4 iterations (profiles/r03_poll_gap.md).  Instead the ONE
+// thread that evaluates the criterion also stores {iteration reached, iteration stopped} into a line of
+// pinned, fine-grained host memory (system-scope release store, one PCIe write per iteration), and the
+// host reads that line between launches: no copy, no synchronisation, the queue never drains.  Nothing
+// depends on those stores for correctness: if they never show up, host_watch::wait notices that the
+// stream has drained and says so, and the driver looks at device memory the old way.
+struct host_watch_line {
+    long long done;       // the criterion has been evaluated for every iteration <= done (-1: none yet)
+    long long stop_iter;  // >= 0: the iteration at which it fired
+    long long pad_[6];
+};
+struct host_watch {
+    host_watch_line* host = nullptr;  // as the host reads it
+    host_watch_line* dev = nullptr;   // as kernels write it; nullptr = not available, drivers poll device memory
+    int slot = -1;
+    host_watch();                     // a free line of this thread's pinned block, reset to {-1, -1}
+    ~host_watch();
+    host_watch(const host_watch&) = delete;
+    host_watch& operator=(const host_watch&) = delete;
+    // Returns true once the device has evaluated iteration `target` or has stopped; false if the stream
+    // drained without either becoming visible (the caller then reads device memory and stops using this).
+    bool wait(hipStream_t stream, long long target);
+    long long stop_iter() const;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ void host_watch_publish(host_watch_line* w, long long done, long long stop_iter)
+{
+    if (w == nullptr) return;
+    // relaxed on purpose: a system-scope RELEASE writes back the XCD's dirty L2 lines first (microseconds, in
+    // the kernel's critical thread).  The two words may become visible in either order; a host that sees `done`
+    // before `stop_iter` learns of the stop one look later, which costs one more iteration of run-ahead.
+    if (stop_iter >= 0) __hip_atomic_store(&w->stop_iter, stop_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&w->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+// how far the host lets itself run ahead of the last iteration it has seen evaluated: enough to keep the
+// queue from draining (a launch costs the host ~4 us), few enough that the launches issued after the
+// criterion fired (they return at once, but a preconditioner's do not) stay cheap
+constexpr long long host_watch_lag = 3;
+
 // end-of-solve health check of a preconditioner callback (blocking): 0 or an error such as
 // GKOMI_ETRS_OVERRUN when one of the ILU's triangular solves gave up (precond.hip)
 int precond_status(gkomi_apply_fn precond, void* ctx, gkomi_stream_t s);

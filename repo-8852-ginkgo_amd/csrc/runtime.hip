@@ -1,9 +1,11 @@
 // Executor-level entry points: the parts of gko::HipExecutor that sit on the
 // boundary (core/device_hooks/hip_hooks.cpp:45-140: get_num_devices,
 // set_gpu_property / populate_exec_info, synchronize, error strings).
-#include "common.hpp"
+#include "internal.hpp"
 
 #include <atomic>
+#include <cstdlib>
+#include <thread>
 
 extern "C" const char* gkomi_version(void) { return "gkomi 0.1.0 (gfx950)"; }
 
@@ -197,3 +199,96 @@ extern "C" int gkomi_diag_stream_csr_bytes(gkomi_stream_t s, int blocks, int64_t
                        reinterpret_cast<double2*>(c));
     return gkomi::check_launch();
 }
+
+
+// ---- host_watch (internal.hpp): one 512-byte block of fine-grained pinned host memory per host thread,
+// eight lines of it, handed out like a stack (nested solves: an IR whose inner solver is another driver)
+namespace gkomi {
+namespace {
+struct watch_block {
+    host_watch_line* host = nullptr;
+    host_watch_line* dev = nullptr;
+    bool tried = false;
+    unsigned used = 0;  // bit i: line i is taken
+    ~watch_block()
+    {
+        if (host != nullptr) (void)hipHostFree(host);
+    }
+};
+constexpr int watch_lines = 8;
+watch_block& my_watch_block()
+{
+    thread_local watch_block b;
+    if (!b.tried) {
+        b.tried = true;
+        const char* off = std::getenv("GKOMI_HOST_WATCH");  // =0: drivers poll device memory (the old way)
+        if (off != nullptr && off[0] == '0') return b;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, sizeof(host_watch_line) * watch_lines, hipHostMallocMapped | hipHostMallocCoherent) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            return b;
+        }
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostFree(p);
+            return b;
+        }
+        b.host = static_cast<host_watch_line*>(p);
+        b.dev = static_cast<host_watch_line*>(d);
+    }
+    return b;
+}
+}  // namespace
+
+host_watch::host_watch()
+{
+    watch_block& b = my_watch_block();
+    if (b.host == nullptr) return;
+    for (int i = 0; i < watch_lines; ++i) {
+        if ((b.used & (1u << i)) == 0) {
+            b.used |= 1u << i;
+            slot = i;
+            host = b.host + i;
+            dev = b.dev + i;
+            __atomic_store_n(&host->stop_iter, -1ll, __ATOMIC_RELAXED);
+            __atomic_store_n(&host->done, -1ll, __ATOMIC_RELEASE);
+            return;
+        }
+    }
+}
+
+host_watch::~host_watch()
+{
+    if (slot >= 0) my_watch_block().used &= ~(1u << slot);
+}
+
+long long host_watch::stop_iter() const
+{
+    return host != nullptr ? __atomic_load_n(&host->stop_iter, __ATOMIC_ACQUIRE) : -1;
+}
+
+bool host_watch::wait(hipStream_t stream, long long target)
+{
+    if (host == nullptr) return false;
+    auto reached = [&] {
+        const long long done = __atomic_load_n(&host->done, __ATOMIC_ACQUIRE);
+        return done >= target || __atomic_load_n(&host->stop_iter, __ATOMIC_ACQUIRE) >= 0;
+    };
+    for (unsigned spins = 1;; ++spins) {
+        if (reached()) return true;
+        if ((spins & 255u) == 0) {
+            // everything issued so far has run and still nothing to see: the device never got to that
+            // iteration (a kernel returned early after a timed-out meeting) or its stores do not reach us
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) return reached();
+            if (q != hipErrorNotReady) {
+                (void)hipGetLastError();
+                return false;
+            }
+            std::this_thread::yield();
+        }
+    }
+}
+}  // namespace gkomi

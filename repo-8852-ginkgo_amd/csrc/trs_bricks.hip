@@ -40,6 +40,7 @@
 #include <cstdio>
 #include <new>
 #include <system_error>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -51,6 +52,7 @@ struct gkomi_trs_bricks {
     int mode = 2;     // 1: a brick starts when its predecessors have finished; 2: pipelined (inflow pump)
     int64_t nbricks = 0, nsteps = 0, coarse_levels = 0, critical_steps = 0, lds_bytes_max = 0;
     int64_t max_brick_steps = 0, nlevels_fine = 0;
+    int64_t levels_estimate = 0;  // levels of the factor if the guessed box geometry holds: sum (extent - 1) + 1 (cost models only)
     std::vector<int32_t> perm;             // plan position -> row
     std::vector<int32_t> inv_local;        // row -> LDS index inside its brick
     std::vector<int32_t> row_rank;         // row -> rank of its brick (topological order)
@@ -277,6 +279,8 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
     extent[dims - 1] = ceildiv(n, stride[dims - 1]);
     int active = 0;  // dimensions that are more than one point wide
     for (int k = 0; k < dims; ++k) active += extent[k] > 1;
+    h.levels_estimate = 1;
+    for (int k = 0; k < dims; ++k) h.levels_estimate += extent[k] - 1;
     // pipelined: the levels of a brick should fit the one compute wave, and a brick about fill a CU's LDS
     // (8 x 8 x 27, 45^2: fewer bricks = fewer hand-offs); else large bricks
     if (brick_rows <= 0) brick_rows = h.mode == 2 ? (active >= 3 ? 1728 : 2025) : 4096;
@@ -480,8 +484,11 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
             h.brick_ext_begin[r + 1] = h.brick_ext_begin[r] + brick_ext[b];
             level_off[r + 1] = level_off[r] + nfine[b];
         }
+        // (a layer's rows only touch the counters of that layer's bricks: layers side by side, no atomics)
         std::vector<int32_t> level_pos(static_cast<size_t>(level_off[nbricks]) + 1, 0);
-        for (int64_t row = 0; row < n; ++row) ++level_pos[level_off[rank[brick[row]]] + fine[row] + 1];
+        in_parallel(n, layer_rows, nthreads, [&](int, int64_t lo, int64_t hi) {
+            for (int64_t row = lo; row < hi; ++row) ++level_pos[level_off[rank[brick[row]]] + fine[row] + 1];
+        });
         for (size_t j = 0; j + 1 < level_pos.size(); ++j) level_pos[j + 1] += level_pos[j];
         // level_pos[level_off[r] + l] = first plan position of level l of the brick with rank r
         int max_level_rows = 0;
@@ -508,25 +515,42 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
         h.inv_local.assign(static_cast<size_t>(n), 0);
         h.row_rank.assign(static_cast<size_t>(n), 0);
         {
+            // rows of a level in row order: every layer walks its own rows in order and owns its bricks' cursors
             std::vector<int32_t> cursor(level_pos.begin(), level_pos.end() - 1);
-            for (int64_t row = 0; row < n; ++row) {
-                const int32_t r = rank[brick[row]];
-                const int32_t p = cursor[level_off[r] + fine[row]]++;
-                h.perm[p] = static_cast<int32_t>(row);
-                h.inv_local[row] = p - h.brick_row_begin[r];
-                h.row_rank[row] = r;
-            }
+            in_parallel(n, layer_rows, nthreads, [&](int, int64_t lo, int64_t hi) {
+                for (int64_t row = lo; row < hi; ++row) {
+                    const int32_t r = rank[brick[row]];
+                    const int32_t p = cursor[level_off[r] + fine[row]]++;
+                    h.perm[p] = static_cast<int32_t>(row);
+                    h.inv_local[row] = p - h.brick_row_begin[r];
+                    h.row_rank[row] = r;
+                }
+            });
         }
         mark("plan order, steps");
         // inflow lists in plan order, entries of a row in storage order
         h.ext_row_off.assign(static_cast<size_t>(n), 0);
         {
-            int32_t running = 0;
-            for (int64_t p = 0; p < n; ++p) {
-                h.ext_row_off[p] = running;
-                running += row_ext[h.perm[p]];
-            }
-            h.ext_col.assign(static_cast<size_t>(running), 0);
+            // exclusive scan of the rows' inflow counts in plan order: per-piece sums, then offsets
+            const int pieces = nthreads;
+            std::vector<int64_t> piece_sum(static_cast<size_t>(pieces) + 1, 0);
+            std::vector<int64_t> piece_lo(static_cast<size_t>(pieces) + 1, n);
+            in_parallel(n, 4096, pieces, [&](int t, int64_t lo, int64_t hi) {
+                int64_t sum = 0;
+                for (int64_t p = lo; p < hi; ++p) sum += row_ext[h.perm[p]];
+                piece_sum[t + 1] = sum;
+                piece_lo[t] = lo;
+            });
+            for (int t = 0; t < pieces; ++t) piece_sum[t + 1] += piece_sum[t];
+            if (piece_sum[pieces] > INT32_MAX) return GKOMI_ENOTSUPPORTED;
+            in_parallel(n, 4096, pieces, [&](int t, int64_t lo, int64_t hi) {
+                int32_t running = static_cast<int32_t>(piece_sum[t]);
+                for (int64_t p = lo; p < hi; ++p) {
+                    h.ext_row_off[p] = running;
+                    running += row_ext[h.perm[p]];
+                }
+            });
+            h.ext_col.assign(static_cast<size_t>(piece_sum[pieces]), 0);
         }
         in_parallel(n, 4096, nthreads, [&](int, int64_t lo, int64_t hi) {
             for (int64_t p = lo; p < hi; ++p) {
@@ -1295,6 +1319,95 @@ extern "C" int gkomi_trs_bricks_create_i32(gkomi_stream_t s, int64_t n, const in
     }
     return create_from_host(n, rp, ci, lower, brick_rows, threads, mode, out);
 }
+
+// ---- both factors of an ILU at once, on host threads, while the caller goes on ----------------------
+// LowerTrs / UpperTrs::generate of preconditioner::Ilu analyse two PATTERNS that are known long before the
+// factor's values are (factorization::initialize_l_u fixes them; the ParILU sweeps only change values).
+// begin copies both patterns to the host (blocking until the stream has produced them) and returns; the
+// two analyses run side by side on their own threads; end joins them.  A factor that is not for the brick
+// plan comes back as NULL (not an error): the caller keeps the level plan for it.
+struct gkomi_trs_bricks_job {
+    std::vector<int32_t> rp[2], ci[2];
+    gkomi_trs_bricks* out[2] = {nullptr, nullptr};
+    int err[2] = {0, 0};
+    std::thread worker[2];
+    bool started[2] = {false, false};
+};
+
+extern "C" int gkomi_trs_bricks_analyse_begin_i32(gkomi_stream_t s, int64_t n, const int32_t* l_row_ptrs,
+                                                  const int32_t* l_col_idxs, const int32_t* u_row_ptrs,
+                                                  const int32_t* u_col_idxs, int64_t brick_rows, int threads, int mode,
+                                                  gkomi_trs_bricks_job** out_job)
+{
+    if (out_job == nullptr) return GKOMI_EINVAL;
+    *out_job = nullptr;
+    gkomi_trs_bricks* probe = nullptr;
+    int err = 0;
+    if (!create_args_ok(n, threads, mode, &probe, &err)) return err;
+    if (l_row_ptrs == nullptr || u_row_ptrs == nullptr) return GKOMI_EINVAL;
+    hipStream_t stream = to_stream(s);
+    std::unique_ptr<gkomi_trs_bricks_job> job(new (std::nothrow) gkomi_trs_bricks_job);
+    if (!job) return GKOMI_EINVAL;
+    const int32_t* rps[2] = {l_row_ptrs, u_row_ptrs};
+    const int32_t* cis[2] = {l_col_idxs, u_col_idxs};
+    for (int f = 0; f < 2; ++f) {
+        job->rp[f].resize(static_cast<size_t>(n) + 1);
+        err = static_cast<int>(hipMemcpyAsync(job->rp[f].data(), rps[f], sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost, stream));
+        if (err) return err;
+    }
+    err = static_cast<int>(hipStreamSynchronize(stream));
+    if (err) return err;
+    for (int f = 0; f < 2; ++f) {
+        const int64_t nnz = job->rp[f][n];
+        if (nnz < 0 || (nnz > 0 && cis[f] == nullptr)) return GKOMI_EINVAL;
+        job->ci[f].resize(static_cast<size_t>(nnz > 0 ? nnz : 1));
+        if (nnz > 0) {
+            err = static_cast<int>(hipMemcpyAsync(job->ci[f].data(), cis[f], sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, stream));
+            if (err) return err;
+        }
+    }
+    err = static_cast<int>(hipStreamSynchronize(stream));
+    if (err) return err;
+    gkomi_trs_bricks_job* j = job.get();
+    for (int f = 0; f < 2; ++f) {
+        auto work = [j, f, n, brick_rows, threads, mode] {
+            j->err[f] = create_from_host(n, j->rp[f], j->ci[f], f == 0 ? 1 : 0, brick_rows, threads, mode, &j->out[f]);
+        };
+        try {
+            j->worker[f] = std::thread(work);
+            j->started[f] = true;
+        } catch (const std::system_error&) {
+            work();  // no thread to be had: on the caller's
+        }
+    }
+    *out_job = job.release();
+    return GKOMI_SUCCESS;
+}
+
+extern "C" int gkomi_trs_bricks_analyse_end(gkomi_trs_bricks_job* job, gkomi_trs_bricks** out_l, gkomi_trs_bricks** out_u)
+{
+    if (job == nullptr) return GKOMI_EINVAL;
+    for (int f = 0; f < 2; ++f) {
+        if (job->started[f] && job->worker[f].joinable()) job->worker[f].join();
+    }
+    int err = GKOMI_SUCCESS;
+    for (int f = 0; f < 2; ++f) {
+        if (job->err[f] != GKOMI_SUCCESS && job->err[f] != GKOMI_ENOTSUPPORTED) err = job->err[f];
+    }
+    gkomi_trs_bricks** outs[2] = {out_l, out_u};
+    for (int f = 0; f < 2; ++f) {
+        if (err == GKOMI_SUCCESS && outs[f] != nullptr) {
+            *outs[f] = job->out[f];
+        } else {
+            delete job->out[f];
+            if (outs[f] != nullptr) *outs[f] = nullptr;
+        }
+    }
+    delete job;
+    return err;
+}
+
+extern "C" int64_t gkomi_trs_bricks_levels_estimate(const gkomi_trs_bricks* h) { return h != nullptr ? h->levels_estimate : 0; }
 
 extern "C" int gkomi_trs_bricks_create_host_i32(int64_t n, const int32_t* host_row_ptrs,
                                                 const int32_t* host_col_idxs, int lower, int64_t brick_rows,

@@ -102,8 +102,11 @@ def test_fused_drivers_with_srow_agree_with_the_row_cut_kernels(gk, oracle, solv
     base = solvers.solve_op(gk, solver, A, dev(b), **kw)
     res = solvers.solve_op(gk, solver, S, dev(b), **kw)
     assert base["converged"] and res["converged"]
-    assert abs(res["iterations"] - base["iterations"]) <= max(1, base["iterations"] // 50)
-    assert matgen.rel_err(host(res["x"]), host(base["x"])) <= 1e-8
+    # CG / FCG: the same iteration to within rounding; BiCGSTAB / CGS converge irregularly, a different grouping
+    # of the dot products moves their stopping iteration by several percent (tests/test_krylov_gpu.py uses 20 %)
+    slack = max(1, base["iterations"] // 50) if solver in ("cg", "fcg") else max(2, base["iterations"] // 5)
+    assert abs(res["iterations"] - base["iterations"]) <= slack
+    assert matgen.rel_err(host(res["x"]), host(base["x"])) <= (1e-8 if solver in ("cg", "fcg") else 1e-7)
     r = b.copy().reshape(n, 1)
     oracle.ref_csr_advanced_spmv(n, 1, -1.0, rp, ci, v, host(res["x"]).reshape(n, 1), 1, 1.0, r, 1)
     assert np.linalg.norm(r) <= 1e-8 * np.linalg.norm(b)
