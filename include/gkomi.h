@@ -587,30 +587,18 @@ int gkomi_trs_plan_check_overrun(gkomi_stream_t s, const void* plan,
  *   solve    x = L^-1 b / U^-1 b from the plan alone; a handle solves on one stream at a time.
  * A solve whose bounded waits run out (GKOMI_TRS_MAX_POLLS polls, default 2^22) writes NaNs, and raises a
  * STICKY flag in the plan (gkomi_trs_bricks_check_overrun; cleared by the numeric phase).  The analysis
- * uses up to 8 host threads (GKOMI_ANALYSIS_THREADS). */
+ * (gkomi_trs_bricks_create_i32) runs on the device -- the pattern never leaves HBM; one workgroup per
+ * brick classifies the dependencies of its rows and relaxes their levels in LDS, the host only orders the
+ * few hundred bricks -- and blocks until it is done; GKOMI_TRS_ANALYSIS=host selects round 2's analysis on
+ * host threads (the one gkomi_trs_bricks_create_host_i32 runs, up to 8 threads, GKOMI_ANALYSIS_THREADS);
+ * both produce the same arrays. */
 typedef struct gkomi_trs_bricks gkomi_trs_bricks;
 int gkomi_trs_bricks_create_i32(gkomi_stream_t s, int64_t n, const int32_t* row_ptrs,
                                 const int32_t* col_idxs, int lower, int64_t brick_rows,
                                 int threads, int mode, gkomi_trs_bricks** out);
-/* Both factors of an Ilu at once, on host threads, while the caller goes on (LowerTrs and
- * UpperTrs::generate inside preconditioner::Ilu::generate, ilu.hpp:320-370): the PATTERNS of L
- * and U are final after factorization::initialize_l_u, long before the values are, so the
- * analysis can run beside the ParILU sweeps.  begin copies the two patterns to the host
- * (blocks until the stream has produced them), starts one thread per factor and returns;
- * end joins them.  A factor that is not for the brick plan comes back as NULL (not an error).
- * The numeric phase (gkomi_trs_bricks_numeric_f64_i32) is called later, with arrays of the
- * same pattern and the final values.
- * gkomi_trs_bricks_levels_estimate: the dependency levels of the factor if the box geometry
+/* gkomi_trs_bricks_levels_estimate: the dependency levels of the factor if the box geometry
  * the analysis guessed holds (sum of (extent - 1) + 1) -- for cost models only, so that a
  * caller that takes the brick plan does not need the level analysis just to count levels. */
-typedef struct gkomi_trs_bricks_job gkomi_trs_bricks_job;
-int gkomi_trs_bricks_analyse_begin_i32(gkomi_stream_t s, int64_t n,
-                                       const int32_t* l_row_ptrs, const int32_t* l_col_idxs,
-                                       const int32_t* u_row_ptrs, const int32_t* u_col_idxs,
-                                       int64_t brick_rows, int threads, int mode,
-                                       gkomi_trs_bricks_job** out_job);
-int gkomi_trs_bricks_analyse_end(gkomi_trs_bricks_job* job, gkomi_trs_bricks** out_l,
-                                 gkomi_trs_bricks** out_u);
 int64_t gkomi_trs_bricks_levels_estimate(const gkomi_trs_bricks* h);
 /* the same analysis from HOST copies of row_ptrs / col_idxs (no device needed), and read-only
  * views of the handle's host arrays for inspection: which = 0 perm (plan position -> row),

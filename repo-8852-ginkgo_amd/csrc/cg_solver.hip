@@ -391,7 +391,8 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_, g
         // iterations ahead of what it has seen -- the queue never drains for a look.  Without that
         // line (or if its stores never show up) the old way: a blocking look every check_every iterations.
         host_watch watch;
-        const long long lag = std::min<long long>(check_every, host_watch_lag);
+        // launches issued after the criterion fired return at once -- unless a preconditioner's are among them
+        const long long lag = std::min<long long>(check_every, precond == nullptr ? 4 * host_watch_lag : host_watch_lag);
         auto issue = [&](long long i) -> int {
             hipLaunchKernelGGL(cg_fused_step1_kernel, dim3(g), dim3(fblock), 0, stream, n, p, zz,
                                part_a, g, tau_part, g, scal, i,

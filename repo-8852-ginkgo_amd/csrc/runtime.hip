@@ -4,6 +4,7 @@
 #include "internal.hpp"
 
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <thread>
 
@@ -276,18 +277,22 @@ bool host_watch::wait(hipStream_t stream, long long target)
         const long long done = __atomic_load_n(&host->done, __ATOMIC_ACQUIRE);
         return done >= target || __atomic_load_n(&host->stop_iter, __ATOMIC_ACQUIRE) >= 0;
     };
+    // a look at the line costs nothing; asking the runtime whether the stream has drained does (and takes the
+    // lock the launches take): only after 40 us without news, then every 40 us
+    auto quiet_since = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
         if (reached()) return true;
-        if ((spins & 255u) == 0) {
-            // everything issued so far has run and still nothing to see: the device never got to that
-            // iteration (a kernel returned early after a timed-out meeting) or its stores do not reach us
-            const hipError_t q = hipStreamQuery(stream);
-            if (q == hipSuccess) return reached();
-            if (q != hipErrorNotReady) {
-                (void)hipGetLastError();
-                return false;
-            }
-            std::this_thread::yield();
+        if ((spins & 63u) != 0) continue;
+        const auto now = std::chrono::steady_clock::now();
+        if (now - quiet_since < std::chrono::microseconds(40)) continue;
+        quiet_since = now;
+        // everything issued so far has run and still nothing to see: the device never got to that
+        // iteration (a kernel returned early after a timed-out meeting) or its stores do not reach us
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) return reached();
+        if (q != hipErrorNotReady) {
+            (void)hipGetLastError();
+            return false;
         }
     }
 }

@@ -64,6 +64,19 @@ struct gkomi_trs_bricks {
     std::vector<int32_t> ext_col;          // row whose x an inflow entry needs
     std::vector<int32_t> pred_ptr, pred_idx;
     std::vector<int64_t> image_off;        // pipelined solve: byte offset of a brick's LDS image, nbricks + 1
+    // sizes of the index arrays (what the plan layout needs), valid for both analyses
+    int64_t n_step_begin = 0, n_ext_col = 0, n_pred_idx = 0, image_bytes = 0;
+    // analysis on the device (gkomi_trs_bricks_create_i32): the index arrays stay in device memory owned by
+    // the handle -- the numeric phase copies them into the plan device to device -- and come to the host
+    // only when gkomi_trs_bricks_host_array asks for them
+    char* dev_index = nullptr;
+    size_t dev_perm = 0, dev_row_rank = 0, dev_inv_local = 0, dev_ext_row_off = 0, dev_ext_col = 0,
+           dev_brick_row_begin = 0, dev_brick_step_ptr = 0, dev_step_begin = 0, dev_brick_ext_begin = 0, dev_bytes = 0;
+    bool host_arrays_valid = true;
+    ~gkomi_trs_bricks()
+    {
+        if (dev_index != nullptr) (void)hipFree(dev_index);
+    }
     uint32_t epoch = 0;
     const void* uploaded_to = nullptr;
     uint64_t token = 0;  // written into the plan with the index arrays: a later numeric phase skips the upload only
@@ -114,18 +127,18 @@ brick_layout make_layout(const gkomi_trs_bricks& h)
     l.vals = off; off += align_up(sizeof(double) * n * h.width, 256);
     l.brick_row_begin = off; off += ints(nb + 1);
     l.brick_step_ptr = off; off += ints(nb + 1);
-    l.step_begin = off; off += ints(h.step_begin.size());
+    l.step_begin = off; off += ints(static_cast<size_t>(h.n_step_begin));
     l.brick_ext_begin = off; off += ints(nb + 1);
-    l.ext_col = off; off += ints(h.ext_col.size());
+    l.ext_col = off; off += ints(static_cast<size_t>(h.n_ext_col));
     l.pred_ptr = off; off += ints(nb + 1);
-    l.pred_idx = off; off += ints(h.pred_idx.size());
+    l.pred_idx = off; off += ints(static_cast<size_t>(h.n_pred_idx));
     l.done = off; off += ints(nb);
     l.row_rank = off; off += ints(n);
     l.inv_local = off; off += ints(n);
     l.ext_row_off = off; off += ints(n);
     l.stamps = off; off += std::max<size_t>(8 * 1024, 64 * nb);  // tools only: shader-clock stamps
     l.image_off = off; off += align_up(sizeof(int64_t) * (nb + 1), 256);
-    l.image = off; off += align_up(h.image_off.empty() ? 0 : static_cast<size_t>(h.image_off.back()), 256);
+    l.image = off; off += align_up(static_cast<size_t>(h.image_bytes), 256);
     l.total = off;
     return l;
 }
@@ -592,10 +605,684 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
                                                                     h.brick_ext_begin[r + 1] - h.brick_ext_begin[r],
                                                                     h.brick_step_ptr[r + 1] - h.brick_step_ptr[r], slots);
         }
+        h.n_step_begin = static_cast<int64_t>(h.step_begin.size());
+        h.n_ext_col = static_cast<int64_t>(h.ext_col.size());
+        h.n_pred_idx = static_cast<int64_t>(h.pred_idx.size());
+        h.image_bytes = h.image_off.empty() ? 0 : h.image_off.back();
         return GKOMI_SUCCESS;
     }
     return GKOMI_ENOTSUPPORTED;
 }
+
+// ---------------------------------------------------------------- analysis (device) --------
+// The same symbolic analysis as `analyse` above, arrays in HBM from start to end (round 2's ran on host
+// threads after copying the pattern out: 17 ms per 108^3 factor + the copies both ways).  Integer work on
+// the pattern, one workgroup per brick:
+//   A  ana_offsets_kernel   the distinct dependency offsets |row - col| (<= 16) and the longest dependency
+//                           list; the host turns them into strides / extents / brick edges (a handful of
+//                           numbers) -- the one decision that needs no data
+//   D  ana_brick_kernel     a workgroup enumerates ITS brick's rows from the brick's coordinates, classifies
+//                           every dependency (same brick: LDS index; other brick: inflow + predecessor list),
+//                           relaxes the levels inside the brick in LDS, and leaves per brick: rows, inflow
+//                           entries, levels, steps, predecessors; per row: level and inflow count
+//   --  host: longest-path levels of the brick graph (Kahn, a few hundred nodes), ranks, prefix sums of the
+//       per-brick sizes, the LDS check
+//   E  ana_place_kernel     a workgroup places its brick's rows in plan order -- by level, rows of a level
+//                           in row order (a stable counting pass in LDS) -- and writes perm, inv_local,
+//                           row_rank, the step table and the rows' inflow counts in plan order
+//   F  prefix sum of the inflow counts (gkomi_prefix_sum_i32), G  ana_inflow_kernel fills the inflow lists
+// Every array is identical to the host analysis' (tests/test_trs_bricks_gpu.py compares them all).
+struct ana_geometry {
+    int dims;
+    int n;
+    int lower;
+    int stride[max_dims], extent[max_dims], edge[max_dims], nbk[max_dims], mul[max_dims];
+};
+
+__device__ __forceinline__ bool ana_is_dep(const ana_geometry& g, int col, int row)
+{
+    return (g.lower ? col < row : col > row) && col >= 0 && col < g.n;
+}
+
+// brick id of a row and, on request, its index among the cells of that brick (dimension 0 fastest)
+__device__ __forceinline__ int ana_brick_of(const ana_geometry& g, int row, int* cell)
+{
+    int id = 0, local = 0, radix = 1;
+#pragma unroll
+    for (int k = 0; k < max_dims; ++k) {
+        if (k >= g.dims) break;
+        const int c = k + 1 < g.dims ? (row / g.stride[k]) % g.extent[k] : row / g.stride[k];
+        const int bc = c / g.edge[k];
+        id += bc * g.mul[k];
+        const int lo = bc * g.edge[k];
+        const int len = min(g.edge[k], g.extent[k] - lo);
+        local += (c - lo) * radix;
+        radix *= len;
+    }
+    if (cell != nullptr) *cell = local;
+    return id;
+}
+
+constexpr unsigned long long ana_empty = ~0ull;
+
+__global__ __launch_bounds__(256) void ana_offsets_kernel(int n, int lower, const int32_t* __restrict__ rp,
+                                                          const int32_t* __restrict__ ci, unsigned long long* table,
+                                                          int* width, int* too_many)
+{
+    // a snapshot of the table first: once the first waves have entered the (few) offsets, every later row
+    // finds all of its own in the snapshot and touches nothing shared
+    unsigned long long seen[max_offsets];
+#pragma unroll
+    for (int j = 0; j < max_offsets; ++j) seen[j] = __hip_atomic_load(table + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int widest = 0;
+    for (int row = blockIdx.x * 256 + threadIdx.x; row < n; row += gridDim.x * 256) {
+        int deps = 0;
+        for (int k = rp[row]; k < rp[row + 1]; ++k) {
+            const int col = ci[k];
+            if (!((lower ? col < row : col > row) && col >= 0 && col < n)) continue;
+            ++deps;
+            const unsigned long long d = static_cast<unsigned long long>(lower ? row - col : col - row);
+            bool found = false;
+#pragma unroll
+            for (int j = 0; j < max_offsets; ++j) found = found || seen[j] == d;
+            if (found) continue;
+            for (int j = 0; j < max_offsets && !found; ++j) {
+                unsigned long long cur = __hip_atomic_load(table + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == ana_empty) {
+                    const unsigned long long old = atomicCAS(table + j, ana_empty, d);
+                    cur = old == ana_empty ? d : old;
+                }
+                seen[j] = cur;
+                found = cur == d;
+            }
+            if (!found) atomicExch(too_many, 1);
+        }
+        widest = max(widest, deps);
+    }
+    widest = max(widest, __shfl_xor(widest, 32, 64));
+    for (int off = 16; off > 0; off >>= 1) widest = max(widest, __shfl_xor(widest, off, 64));
+    if ((threadIdx.x & 63) == 0 && widest > 0) atomicMax(width, widest);
+}
+
+// per brick, in this order: rows, inflow entries, levels, steps with 64 / 128 / 256 threads, widest level,
+// predecessors, failed
+constexpr int ana_rows = 0, ana_ext = 1, ana_nfine = 2, ana_steps64 = 3, ana_steps128 = 4, ana_steps256 = 5,
+              ana_widest = 6, ana_npred = 7, ana_failed = 8, ana_stats = 9;
+constexpr int ana_max_cells = 2048;
+constexpr int ana_block = 256;
+
+// coordinates of brick b: first cell and lengths along every dimension; returns the number of cells
+__device__ __forceinline__ int ana_brick_box(const ana_geometry& g, int b, int* lo, int* len)
+{
+    int cells = 1;
+#pragma unroll
+    for (int k = 0; k < max_dims; ++k) {
+        if (k >= g.dims) break;
+        const int bc = (b / g.mul[k]) % g.nbk[k];
+        lo[k] = bc * g.edge[k];
+        len[k] = min(g.edge[k], g.extent[k] - lo[k]);
+        cells *= len[k];
+    }
+    return cells;
+}
+
+__device__ __forceinline__ int ana_row_of_cell(const ana_geometry& g, const int* lo, const int* len, int cell)
+{
+    int row = 0;
+#pragma unroll
+    for (int k = 0; k < max_dims; ++k) {
+        if (k >= g.dims) break;
+        const int c = cell % len[k];
+        cell /= len[k];
+        row += (lo[k] + c) * g.stride[k];
+    }
+    return row;  // may be >= n in the last, incomplete plane
+}
+
+__global__ __launch_bounds__(ana_block) void ana_brick_kernel(ana_geometry g, const int32_t* __restrict__ rp,
+                                                              const int32_t* __restrict__ ci, int32_t* __restrict__ fine_out,
+                                                              uint8_t* __restrict__ row_ext, int32_t* __restrict__ stats,
+                                                              int32_t* __restrict__ preds)
+{
+    __shared__ short fine[ana_max_cells];
+    __shared__ short dep_cell[ana_max_cells * max_width];  // in-brick dependencies as cells, -1 = none
+    __shared__ int hist[ana_max_cells + 1];
+    __shared__ int pred_list[max_preds];
+    __shared__ int s_rows, s_ext, s_failed, s_changed;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int lo[max_dims], len[max_dims];
+    const int cells = ana_brick_box(g, b, lo, len);
+    if (tid == 0) {
+        s_rows = 0; s_ext = 0; s_failed = cells > ana_max_cells ? 1 : 0;
+    }
+    for (int j = tid; j < max_preds; j += ana_block) pred_list[j] = -1;
+    __syncthreads();
+    if (cells > ana_max_cells) {
+        if (tid == 0) stats[b * ana_stats + ana_failed] = 1;
+        return;
+    }
+    // 1. classify every dependency of every row of the brick
+    int my_rows = 0, my_ext = 0;
+    for (int cell = tid; cell < cells; cell += ana_block) {
+        fine[cell] = 0;
+        for (int e = 0; e < max_width; ++e) dep_cell[cell * max_width + e] = -1;
+        const int row = ana_row_of_cell(g, lo, len, cell);
+        if (row >= g.n) {
+            fine[cell] = -1;  // no such row
+            continue;
+        }
+        ++my_rows;
+        int inside = 0, outside = 0;
+        for (int k = rp[row]; k < rp[row + 1]; ++k) {
+            const int col = ci[k];
+            if (!ana_is_dep(g, col, row)) continue;
+            int other_cell;
+            const int other = ana_brick_of(g, col, &other_cell);
+            if (other == b) {
+                if (inside < max_width) dep_cell[cell * max_width + inside] = static_cast<short>(other_cell);
+                ++inside;
+                continue;
+            }
+            ++outside;
+            bool known = false;
+            for (int j = 0; j < max_preds && !known; ++j) {
+                int cur = pred_list[j];
+                if (cur == -1) {
+                    const int old = atomicCAS(&pred_list[j], -1, other);
+                    cur = old == -1 ? other : old;
+                }
+                known = cur == other;
+            }
+            if (!known) atomicExch(&s_failed, 1);
+        }
+        if (inside + outside > max_width) atomicExch(&s_failed, 1);
+        row_ext[row] = static_cast<uint8_t>(outside);
+        my_ext += outside;
+    }
+    atomicAdd(&s_rows, my_rows);
+    atomicAdd(&s_ext, my_ext);
+    __syncthreads();
+    // 2. levels inside the brick: fine(row) = 1 + max over its in-brick dependencies, by relaxation (values only
+    //    grow; a triangular pattern has no cycles, so this ends after at most `levels` rounds)
+    for (int round = 0; round <= cells; ++round) {
+        if (tid == 0) s_changed = 0;
+        __syncthreads();
+        int changed = 0;
+        for (int cell = tid; cell < cells; cell += ana_block) {
+            if (fine[cell] < 0) continue;
+            int lvl = 0;
+            for (int e = 0; e < max_width; ++e) {
+                const int d = dep_cell[cell * max_width + e];
+                if (d >= 0) lvl = max(lvl, fine[d] + 1);
+            }
+            if (lvl != fine[cell]) {
+                fine[cell] = static_cast<short>(lvl);
+                changed = 1;
+            }
+        }
+        if (changed) s_changed = 1;
+        __syncthreads();
+        const int again = s_changed;
+        __syncthreads();
+        if (!again) break;
+    }
+    // 3. what the host needs of this brick
+    for (int l = tid; l <= cells; l += ana_block) hist[l] = 0;
+    __syncthreads();
+    for (int cell = tid; cell < cells; cell += ana_block) {
+        if (fine[cell] < 0) continue;
+        atomicAdd(&hist[fine[cell]], 1);
+        fine_out[ana_row_of_cell(g, lo, len, cell)] = fine[cell];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int nfine = 0, s64 = 0, s128 = 0, s256 = 0, widest = 0, npred = 0;
+        for (int l = 0; l < cells && hist[l] > 0; ++l) {
+            ++nfine;
+            s64 += (hist[l] + 63) / 64;
+            s128 += (hist[l] + 127) / 128;
+            s256 += (hist[l] + 255) / 256;
+            widest = max(widest, hist[l]);
+        }
+        for (int j = 0; j < max_preds; ++j) {
+            if (pred_list[j] >= 0) ++npred;
+        }
+        int32_t* st = stats + b * ana_stats;
+        st[ana_rows] = s_rows; st[ana_ext] = s_ext; st[ana_nfine] = nfine; st[ana_steps64] = s64;
+        st[ana_steps128] = s128; st[ana_steps256] = s256; st[ana_widest] = widest; st[ana_npred] = npred;
+        st[ana_failed] = s_failed;
+    }
+    // the host analysis lists a brick's predecessors in the order its rows meet them; the LDS list fills in
+    // arrival order -- sorted by id here, and there (after the fact) too: only the SET matters downstream
+    for (int j = tid; j < max_preds; j += ana_block) preds[b * max_preds + j] = pred_list[j];
+}
+
+// per brick (by id): its rank, first plan position, first step, first level slot -- from the host
+struct ana_place_args {
+    const int32_t* rank;             // brick id -> rank
+    const int32_t* brick_row_begin;  // by rank
+    const int32_t* brick_step_ptr;   // by rank
+};
+
+__global__ __launch_bounds__(ana_block) void ana_place_kernel(ana_geometry g, int threads, ana_place_args a,
+                                                              const int32_t* __restrict__ fine_in,
+                                                              const uint8_t* __restrict__ row_ext,
+                                                              int32_t* __restrict__ perm, int32_t* __restrict__ inv_local,
+                                                              int32_t* __restrict__ row_rank, int32_t* __restrict__ step_begin,
+                                                              int32_t* __restrict__ ext_in_plan_order)
+{
+    __shared__ short fine[ana_max_cells];
+    __shared__ int base[ana_max_cells + 1];   // next free plan position of every level
+    __shared__ int count[ana_max_cells + 1];  // rows of every level, then its first step
+    __shared__ short chunk_level[ana_block];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int r = a.rank[b];
+    const int p0 = a.brick_row_begin[r];
+    int lo[max_dims], len[max_dims];
+    const int cells = ana_brick_box(g, b, lo, len);
+    for (int l = tid; l <= cells; l += ana_block) count[l] = 0;
+    __syncthreads();
+    for (int cell = tid; cell < cells; cell += ana_block) {
+        const int row = ana_row_of_cell(g, lo, len, cell);
+        const int lvl = row < g.n ? fine_in[row] : -1;
+        fine[cell] = static_cast<short>(lvl);
+        if (lvl >= 0) atomicAdd(&count[lvl], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // first plan position and first step of every level; the step table (a level in chunks of `threads`)
+        int pos = p0, step = a.brick_step_ptr[r];
+        for (int l = 0; l < cells && count[l] > 0; ++l) {
+            base[l] = pos;
+            for (int q = 0; q < count[l]; q += threads) step_begin[step++] = q == 0 ? ((pos + q) | level_bit) : (pos + q);
+            pos += count[l];
+        }
+    }
+    __syncthreads();
+    // rows of a level in row order: cells in ascending order, a chunk of ana_block at a time; inside a chunk
+    // a row's place is the number of earlier cells of its level
+    for (int c0 = 0; c0 < cells; c0 += ana_block) {
+        const int cell = c0 + tid;
+        const int lvl = cell < cells ? fine[cell] : -1;
+        chunk_level[tid] = static_cast<short>(lvl);
+        __syncthreads();
+        int before = 0, after = 0;
+        if (lvl >= 0) {
+            for (int u = 0; u < ana_block; ++u) {
+                const int same = chunk_level[u] == lvl;
+                before += same & (u < tid);
+                after += same & (u > tid);
+            }
+        }
+        int p = -1;
+        if (lvl >= 0) p = base[lvl] + before;
+        __syncthreads();
+        if (lvl >= 0) {
+            if (after == 0) base[lvl] = p + 1;  // the last of its level in this chunk moves the level on
+            const int row = ana_row_of_cell(g, lo, len, cell);
+            perm[p] = row;
+            inv_local[row] = p - p0;
+            row_rank[row] = r;
+            ext_in_plan_order[p] = row_ext[row];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void ana_inflow_kernel(ana_geometry g, const int32_t* __restrict__ rp,
+                                                         const int32_t* __restrict__ ci, const int32_t* __restrict__ perm,
+                                                         const int32_t* __restrict__ ext_row_off, int32_t* __restrict__ ext_col)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= g.n) return;
+    const int row = perm[p];
+    const int mine = ana_brick_of(g, row, nullptr);
+    int at = ext_row_off[p];
+    for (int k = rp[row]; k < rp[row + 1]; ++k) {
+        const int col = ci[k];
+        if (!ana_is_dep(g, col, row)) continue;
+        if (ana_brick_of(g, col, nullptr) != mine) ext_col[at++] = col;
+    }
+}
+
+struct device_buffer {
+    void* p = nullptr;
+    ~device_buffer()
+    {
+        if (p != nullptr) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) { return static_cast<int>(hipMalloc(&p, bytes > 0 ? bytes : 8)); }
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+// edges of the bricks for a box of `dims` dimensions (the rule of the host analysis, step 3)
+void pick_edges(const gkomi_trs_bricks& h, int dims, int active, const int64_t* extent, int64_t brick_rows, int64_t* edge,
+                int64_t* nbk)
+{
+    if (h.mode == 2 && active >= 3) {
+        const int64_t cross = active == 3 ? 8 : 4;
+        int last = dims - 1;
+        while (extent[last] <= 1) --last;
+        int64_t product = 1;
+        for (int k = 0; k < dims; ++k) {
+            if (k == last) continue;
+            edge[k] = std::min<int64_t>(extent[k], extent[k] > 1 ? cross : 1);
+            product *= edge[k];
+        }
+        edge[last] = std::max<int64_t>(1, std::min<int64_t>(extent[last], brick_rows / product));
+        for (int k = 0; k < dims; ++k) {
+            nbk[k] = ceildiv(extent[k], edge[k]);
+            if (k == last) edge[k] = ceildiv(extent[k], nbk[k]);
+            nbk[k] = ceildiv(extent[k], edge[k]);
+        }
+    } else {
+        int order[max_dims];
+        for (int k = 0; k < dims; ++k) order[k] = k;
+        std::sort(order, order + dims, [&](int a, int b) { return extent[a] < extent[b]; });
+        double remaining = static_cast<double>(std::max<int64_t>(brick_rows, 1));
+        for (int q = 0; q < dims; ++q) {
+            const int k = order[q];
+            const double want = std::pow(remaining, 1.0 / (dims - q));
+            int64_t e = std::max<int64_t>(1, static_cast<int64_t>(std::llround(want)));
+            e = std::min(e, extent[k]);
+            nbk[k] = ceildiv(extent[k], e);
+            edge[k] = ceildiv(extent[k], nbk[k]);
+            nbk[k] = ceildiv(extent[k], edge[k]);
+            remaining = std::max(1.0, remaining / static_cast<double>(edge[k]));
+        }
+    }
+    if (const char* forced = getenv("GKOMI_TRS_BRICK_EDGES")) {
+        int k = 0;
+        for (const char* q = forced; *q != 0 && k < dims; ++k) {
+            edge[k] = std::max<int64_t>(1, std::min<int64_t>(extent[k], atoll(q)));
+            nbk[k] = ceildiv(extent[k], edge[k]);
+            while (*q != 0 && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
+}
+
+#define ANA_TRY(expr)                              \
+    do {                                           \
+        const int e_ = static_cast<int>(expr);     \
+        if (e_) return e_;                         \
+    } while (0)
+
+int analyse_device(gkomi_trs_bricks& h, hipStream_t stream, const int32_t* rp, const int32_t* ci, int64_t brick_rows,
+                   int threads, int mode)
+{
+    h.mode = mode == 1 ? 1 : 2;
+    if (h.mode == 2) threads = 64;
+    const int64_t n = h.n;
+    const bool lower = h.lower != 0;
+    // A. offsets and width
+    device_buffer small;
+    ANA_TRY(small.alloc(sizeof(unsigned long long) * max_offsets + 2 * sizeof(int)));
+    struct {
+        unsigned long long table[max_offsets];
+        int width, too_many;
+    } head;
+    for (unsigned long long& t : head.table) t = ana_empty;
+    head.width = 0;
+    head.too_many = 0;
+    ANA_TRY(hipMemcpyAsync(small.p, &head, sizeof(head), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(ana_offsets_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, static_cast<int>(n), lower ? 1 : 0, rp,
+                       ci, small.as<unsigned long long>(), reinterpret_cast<int*>(small.as<unsigned long long>() + max_offsets),
+                       reinterpret_cast<int*>(small.as<unsigned long long>() + max_offsets) + 1);
+    ANA_TRY(check_launch());
+    ANA_TRY(hipMemcpyAsync(&head, small.p, sizeof(head), hipMemcpyDeviceToHost, stream));
+    ANA_TRY(hipStreamSynchronize(stream));
+    if (head.too_many) return GKOMI_ENOTSUPPORTED;
+    int64_t offs[max_offsets];
+    int noffs = 0;
+    for (unsigned long long t : head.table) {
+        if (t != ana_empty) offs[noffs++] = static_cast<int64_t>(t);
+    }
+    const int width = head.width;
+    if (noffs == 0 || width > max_width) return GKOMI_ENOTSUPPORTED;
+    std::sort(offs, offs + noffs);
+    // strides of a lexicographic box numbering: a divisor chain (step 2 of the host analysis)
+    int64_t stride[max_dims];
+    int dims = 0;
+    stride[dims++] = 1;
+    for (int j = 0; j < noffs; ++j) {
+        if (offs[j] == stride[dims - 1]) continue;
+        if (offs[j] % stride[dims - 1] != 0 || dims == max_dims) return GKOMI_ENOTSUPPORTED;
+        stride[dims++] = offs[j];
+    }
+    int64_t extent[max_dims];
+    for (int k = 0; k + 1 < dims; ++k) extent[k] = stride[k + 1] / stride[k];
+    extent[dims - 1] = ceildiv(n, stride[dims - 1]);
+    int active = 0;
+    for (int k = 0; k < dims; ++k) active += extent[k] > 1;
+    h.levels_estimate = 1;
+    for (int k = 0; k < dims; ++k) h.levels_estimate += extent[k] - 1;
+    if (brick_rows <= 0) brick_rows = h.mode == 2 ? (active >= 3 ? 1728 : 2025) : 4096;
+    const int slots = width <= 2 ? 2 : width <= 3 ? 3 : width <= 4 ? 4 : 8;
+
+    device_buffer fine, row_ext;
+    ANA_TRY(fine.alloc(sizeof(int32_t) * n));
+    ANA_TRY(row_ext.alloc(static_cast<size_t>(n)));
+    for (int attempt = 0; attempt < 8; ++attempt, brick_rows = std::max<int64_t>(brick_rows / 2, 8)) {
+        int64_t edge[max_dims], nbk[max_dims];
+        pick_edges(h, dims, active, extent, brick_rows, edge, nbk);
+        int64_t nbricks = 1, cells = 1;
+        for (int k = 0; k < dims; ++k) {
+            nbricks *= nbk[k];
+            cells *= edge[k];
+            if (nbricks > (1 << 24)) return GKOMI_ENOTSUPPORTED;
+        }
+        if (cells > ana_max_cells) {
+            if (brick_rows <= 8) return GKOMI_ENOTSUPPORTED;
+            continue;  // smaller bricks (the host analysis would find max_rows > 2048 or too much LDS)
+        }
+        ana_geometry g{};
+        g.dims = dims;
+        g.n = static_cast<int>(n);
+        g.lower = lower ? 1 : 0;
+        for (int k = 0, m = 1; k < dims; ++k) {
+            g.stride[k] = static_cast<int>(stride[k]);
+            g.extent[k] = static_cast<int>(extent[k]);
+            g.edge[k] = static_cast<int>(edge[k]);
+            g.nbk[k] = static_cast<int>(nbk[k]);
+            g.mul[k] = m;
+            m *= static_cast<int>(nbk[k]);
+        }
+        // D. one workgroup per brick
+        device_buffer stats, preds;
+        ANA_TRY(stats.alloc(sizeof(int32_t) * ana_stats * nbricks));
+        ANA_TRY(preds.alloc(sizeof(int32_t) * max_preds * nbricks));
+        hipLaunchKernelGGL(ana_brick_kernel, dim3(static_cast<unsigned>(nbricks)), dim3(ana_block), 0, stream, g, rp, ci,
+                           fine.as<int32_t>(), row_ext.as<uint8_t>(), stats.as<int32_t>(), preds.as<int32_t>());
+        ANA_TRY(check_launch());
+        std::vector<int32_t> hstats(static_cast<size_t>(ana_stats * nbricks)), hpreds(static_cast<size_t>(max_preds * nbricks));
+        ANA_TRY(hipMemcpyAsync(hstats.data(), stats.p, sizeof(int32_t) * hstats.size(), hipMemcpyDeviceToHost, stream));
+        ANA_TRY(hipMemcpyAsync(hpreds.data(), preds.p, sizeof(int32_t) * hpreds.size(), hipMemcpyDeviceToHost, stream));
+        ANA_TRY(hipStreamSynchronize(stream));
+        std::vector<int32_t> npred(static_cast<size_t>(nbricks), 0);
+        for (int64_t b = 0; b < nbricks; ++b) {
+            if (hstats[b * ana_stats + ana_failed]) return GKOMI_ENOTSUPPORTED;
+            // the set of predecessors, in ascending id order
+            int32_t* list = hpreds.data() + b * max_preds;
+            int cnt = 0;
+            for (int j = 0; j < max_preds; ++j) {
+                if (list[j] >= 0) list[cnt++] = list[j];
+            }
+            std::sort(list, list + cnt);
+            npred[b] = cnt;
+        }
+        // coarse levels by longest path (Kahn); a cycle = the guessed geometry is wrong
+        std::vector<int32_t> succ_ptr(static_cast<size_t>(nbricks) + 1, 0);
+        for (int64_t b = 0; b < nbricks; ++b) {
+            for (int j = 0; j < npred[b]; ++j) ++succ_ptr[hpreds[b * max_preds + j] + 1];
+        }
+        for (int64_t b = 0; b < nbricks; ++b) succ_ptr[b + 1] += succ_ptr[b];
+        std::vector<int32_t> succ(static_cast<size_t>(succ_ptr[nbricks]));
+        {
+            std::vector<int32_t> cursor(succ_ptr.begin(), succ_ptr.end() - 1);
+            for (int64_t b = 0; b < nbricks; ++b) {
+                for (int j = 0; j < npred[b]; ++j) succ[cursor[hpreds[b * max_preds + j]]++] = static_cast<int32_t>(b);
+            }
+        }
+        std::vector<int32_t> coarse(static_cast<size_t>(nbricks), 0), waiting(npred);
+        std::vector<int32_t> topo;
+        topo.reserve(static_cast<size_t>(nbricks));
+        for (int64_t b = 0; b < nbricks; ++b) {
+            if (waiting[b] == 0) topo.push_back(static_cast<int32_t>(b));
+        }
+        for (size_t q = 0; q < topo.size(); ++q) {
+            const int32_t b = topo[q];
+            for (int32_t j = succ_ptr[b]; j < succ_ptr[b + 1]; ++j) {
+                const int32_t t = succ[j];
+                coarse[t] = std::max(coarse[t], coarse[b] + 1);
+                if (--waiting[t] == 0) topo.push_back(t);
+            }
+        }
+        if (static_cast<int64_t>(topo.size()) != nbricks) return GKOMI_ENOTSUPPORTED;
+        int32_t ncoarse = 0;
+        for (int64_t b = 0; b < nbricks; ++b) ncoarse = std::max(ncoarse, coarse[b] + 1);
+        std::vector<int32_t> rank(static_cast<size_t>(nbricks));
+        {
+            std::vector<int32_t> count(static_cast<size_t>(ncoarse) + 1, 0);
+            for (int64_t b = 0; b < nbricks; ++b) ++count[coarse[b] + 1];
+            for (int32_t l = 0; l < ncoarse; ++l) count[l + 1] += count[l];
+            for (int64_t b = 0; b < nbricks; ++b) rank[b] = count[coarse[b]]++;
+        }
+        int64_t max_lds = 0, max_rows = 0;
+        int max_level_rows = 0;
+        for (int64_t b = 0; b < nbricks; ++b) {
+            const int32_t* st = hstats.data() + b * ana_stats;
+            const int64_t r = st[ana_rows];
+            max_lds = std::max<int64_t>(max_lds, static_cast<int64_t>(brick_lds_bytes(r, st[ana_ext], st[ana_nfine] + r / 64 + 1, slots)));
+            max_rows = std::max<int64_t>(max_rows, r);
+            max_level_rows = std::max(max_level_rows, st[ana_widest]);
+        }
+        if (static_cast<size_t>(max_lds) + 256 > max_lds_bytes || (h.mode == 2 && max_rows > 2048)) {
+            if (brick_rows <= 8) return GKOMI_ENOTSUPPORTED;
+            continue;
+        }
+        if (threads <= 0) threads = max_level_rows <= 64 ? 64 : max_level_rows <= 160 ? 128 : 256;
+        const int steps_of = threads == 64 ? ana_steps64 : threads == 128 ? ana_steps128 : ana_steps256;
+        h.nbricks = nbricks;
+        h.coarse_levels = ncoarse;
+        h.width = slots;
+        h.lds_bytes_max = max_lds;
+        h.threads = threads;
+        std::vector<int32_t> by_rank(static_cast<size_t>(nbricks));
+        for (int64_t b = 0; b < nbricks; ++b) by_rank[rank[b]] = static_cast<int32_t>(b);
+        h.brick_row_begin.assign(static_cast<size_t>(nbricks) + 1, 0);
+        h.brick_ext_begin.assign(static_cast<size_t>(nbricks) + 1, 0);
+        h.brick_step_ptr.assign(static_cast<size_t>(nbricks) + 1, 0);
+        h.nlevels_fine = 0;
+        int64_t total_ext = 0;
+        for (int64_t r = 0; r < nbricks; ++r) {
+            const int32_t* st = hstats.data() + by_rank[r] * ana_stats;
+            h.brick_row_begin[r + 1] = h.brick_row_begin[r] + st[ana_rows];
+            total_ext += st[ana_ext];
+            if (total_ext > INT32_MAX) return GKOMI_ENOTSUPPORTED;
+            h.brick_ext_begin[r + 1] = static_cast<int32_t>(total_ext);
+            h.brick_step_ptr[r + 1] = h.brick_step_ptr[r] + st[steps_of];
+            h.nlevels_fine += st[ana_nfine];
+        }
+        h.nsteps = h.brick_step_ptr[nbricks];
+        // predecessors as ranks; critical path in steps
+        h.pred_ptr.assign(static_cast<size_t>(nbricks) + 1, 0);
+        h.pred_idx.clear();
+        std::vector<int64_t> path(static_cast<size_t>(nbricks), 0);
+        h.critical_steps = 0;
+        h.max_brick_steps = 0;
+        for (int64_t r = 0; r < nbricks; ++r) {
+            const int32_t b = by_rank[r];
+            int64_t before = 0;
+            for (int j = 0; j < npred[b]; ++j) {
+                const int32_t pr = rank[hpreds[static_cast<size_t>(b) * max_preds + j]];
+                h.pred_idx.push_back(pr);
+                before = std::max(before, path[pr]);
+            }
+            h.pred_ptr[r + 1] = static_cast<int32_t>(h.pred_idx.size());
+            const int64_t steps = h.brick_step_ptr[r + 1] - h.brick_step_ptr[r];
+            path[r] = before + steps;
+            h.critical_steps = std::max(h.critical_steps, path[r]);
+            h.max_brick_steps = std::max(h.max_brick_steps, steps);
+        }
+        h.image_off.assign(h.mode == 2 ? static_cast<size_t>(nbricks) + 1 : 0, 0);
+        for (int64_t r = 0; r < nbricks && h.mode == 2; ++r) {
+            h.image_off[r + 1] = h.image_off[r] + brick_image_bytes(h.brick_row_begin[r + 1] - h.brick_row_begin[r],
+                                                                    h.brick_ext_begin[r + 1] - h.brick_ext_begin[r],
+                                                                    h.brick_step_ptr[r + 1] - h.brick_step_ptr[r], slots);
+        }
+        h.n_step_begin = h.nsteps + 1;
+        h.n_ext_col = total_ext;
+        h.n_pred_idx = static_cast<int64_t>(h.pred_idx.size());
+        h.image_bytes = h.image_off.empty() ? 0 : h.image_off.back();
+        // the index arrays, in device memory owned by the handle
+        auto ints = [](size_t count) { return align_up(sizeof(int32_t) * (count > 0 ? count : 1), 256); };
+        size_t off = 0;
+        h.dev_perm = off; off += ints(n);
+        h.dev_row_rank = off; off += ints(n);
+        h.dev_inv_local = off; off += ints(n);
+        h.dev_ext_row_off = off; off += ints(n);
+        h.dev_ext_col = off; off += ints(static_cast<size_t>(total_ext));
+        h.dev_brick_row_begin = off; off += ints(nbricks + 1);
+        h.dev_brick_step_ptr = off; off += ints(nbricks + 1);
+        h.dev_step_begin = off; off += ints(static_cast<size_t>(h.n_step_begin));
+        h.dev_brick_ext_begin = off; off += ints(nbricks + 1);
+        h.dev_bytes = off;
+        void* index = nullptr;
+        ANA_TRY(hipMalloc(&index, off));
+        h.dev_index = static_cast<char*>(index);
+        char* d = h.dev_index;
+        device_buffer drank, scan_ws;
+        ANA_TRY(drank.alloc(sizeof(int32_t) * nbricks));
+        ANA_TRY(hipMemcpyAsync(drank.p, rank.data(), sizeof(int32_t) * nbricks, hipMemcpyHostToDevice, stream));
+        ANA_TRY(hipMemcpyAsync(d + h.dev_brick_row_begin, h.brick_row_begin.data(), sizeof(int32_t) * (nbricks + 1), hipMemcpyHostToDevice, stream));
+        ANA_TRY(hipMemcpyAsync(d + h.dev_brick_step_ptr, h.brick_step_ptr.data(), sizeof(int32_t) * (nbricks + 1), hipMemcpyHostToDevice, stream));
+        ANA_TRY(hipMemcpyAsync(d + h.dev_brick_ext_begin, h.brick_ext_begin.data(), sizeof(int32_t) * (nbricks + 1), hipMemcpyHostToDevice, stream));
+        const int32_t last_step = static_cast<int32_t>(n) | level_bit;
+        ANA_TRY(hipMemcpyAsync(d + h.dev_step_begin + sizeof(int32_t) * h.nsteps, &last_step, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        // E. plan order
+        const ana_place_args pa{drank.as<int32_t>(), reinterpret_cast<const int32_t*>(d + h.dev_brick_row_begin),
+                                reinterpret_cast<const int32_t*>(d + h.dev_brick_step_ptr)};
+        hipLaunchKernelGGL(ana_place_kernel, dim3(static_cast<unsigned>(nbricks)), dim3(ana_block), 0, stream, g, threads, pa,
+                           fine.as<int32_t>(), row_ext.as<uint8_t>(), reinterpret_cast<int32_t*>(d + h.dev_perm),
+                           reinterpret_cast<int32_t*>(d + h.dev_inv_local), reinterpret_cast<int32_t*>(d + h.dev_row_rank),
+                           reinterpret_cast<int32_t*>(d + h.dev_step_begin), reinterpret_cast<int32_t*>(d + h.dev_ext_row_off));
+        ANA_TRY(check_launch());
+        // F. first inflow entry of every plan position, G. the inflow lists
+        const size_t ws_bytes = gkomi_prefix_sum_workspace_bytes(n);
+        ANA_TRY(scan_ws.alloc(ws_bytes));
+        ANA_TRY(gkomi_prefix_sum_i32(reinterpret_cast<gkomi_stream_t>(stream), reinterpret_cast<int32_t*>(d + h.dev_ext_row_off), n,
+                                     scan_ws.p, ws_bytes));
+        hipLaunchKernelGGL(ana_inflow_kernel, dim3(static_cast<unsigned>(ceildiv(n, 256))), dim3(256), 0, stream, g, rp, ci,
+                           reinterpret_cast<const int32_t*>(d + h.dev_perm), reinterpret_cast<const int32_t*>(d + h.dev_ext_row_off),
+                           reinterpret_cast<int32_t*>(d + h.dev_ext_col));
+        ANA_TRY(check_launch());
+        ANA_TRY(hipStreamSynchronize(stream));  // the scratch buffers go out of scope here
+        h.host_arrays_valid = false;
+        return GKOMI_SUCCESS;
+    }
+    return GKOMI_ENOTSUPPORTED;
+}
+
+// the device-analysed index arrays on the host, when somebody asks (gkomi_trs_bricks_host_array)
+int fetch_host_arrays(gkomi_trs_bricks& h)
+{
+    if (h.host_arrays_valid || h.dev_index == nullptr) return GKOMI_SUCCESS;
+    auto get = [&](std::vector<int32_t>& v, size_t off, int64_t count) {
+        v.resize(static_cast<size_t>(count));
+        return count > 0 ? static_cast<int>(hipMemcpy(v.data(), h.dev_index + off, sizeof(int32_t) * count, hipMemcpyDeviceToHost)) : 0;
+    };
+    ANA_TRY(get(h.perm, h.dev_perm, h.n));
+    ANA_TRY(get(h.row_rank, h.dev_row_rank, h.n));
+    ANA_TRY(get(h.inv_local, h.dev_inv_local, h.n));
+    ANA_TRY(get(h.ext_row_off, h.dev_ext_row_off, h.n));
+    ANA_TRY(get(h.ext_col, h.dev_ext_col, h.n_ext_col));
+    ANA_TRY(get(h.step_begin, h.dev_step_begin, h.n_step_begin));
+    h.host_arrays_valid = true;
+    return GKOMI_SUCCESS;
+}
+#undef ANA_TRY
 
 // ---------------------------------------------------------------- numeric phase (device) ----
 
@@ -1302,6 +1989,29 @@ extern "C" int gkomi_trs_bricks_create_i32(gkomi_stream_t s, int64_t n, const in
     if (!create_args_ok(n, threads, mode, out, &err)) return err;
     if (row_ptrs == nullptr) return GKOMI_EINVAL;
     hipStream_t stream = to_stream(s);
+    static const bool on_host = [] {
+        const char* e = getenv("GKOMI_TRS_ANALYSIS");  // =host: round 2's analysis on host threads
+        return e != nullptr && e[0] == 'h';
+    }();
+    if (!on_host) {
+        // the analysis on the device: the pattern never leaves HBM
+        int32_t nnz32 = 0;
+        err = static_cast<int>(hipMemcpyAsync(&nnz32, row_ptrs + n, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        if (!err) err = static_cast<int>(hipStreamSynchronize(stream));
+        if (err) return err;
+        if (nnz32 < 0 || (nnz32 > 0 && col_idxs == nullptr)) return GKOMI_EINVAL;
+        gkomi_trs_bricks* h = new (std::nothrow) gkomi_trs_bricks;
+        if (h == nullptr) return GKOMI_EINVAL;
+        h->n = n;
+        h->lower = lower ? 1 : 0;
+        err = analyse_device(*h, stream, row_ptrs, col_idxs, brick_rows, threads, mode);
+        if (err != GKOMI_SUCCESS) {
+            delete h;
+            return err;
+        }
+        *out = h;
+        return GKOMI_SUCCESS;
+    }
     std::vector<int32_t> rp(static_cast<size_t>(n) + 1);
     err = static_cast<int>(hipMemcpyAsync(rp.data(), row_ptrs, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost, stream));
     if (err) return err;
@@ -1318,93 +2028,6 @@ extern "C" int gkomi_trs_bricks_create_i32(gkomi_stream_t s, int64_t n, const in
         if (err) return err;
     }
     return create_from_host(n, rp, ci, lower, brick_rows, threads, mode, out);
-}
-
-// ---- both factors of an ILU at once, on host threads, while the caller goes on ----------------------
-// LowerTrs / UpperTrs::generate of preconditioner::Ilu analyse two PATTERNS that are known long before the
-// factor's values are (factorization::initialize_l_u fixes them; the ParILU sweeps only change values).
-// begin copies both patterns to the host (blocking until the stream has produced them) and returns; the
-// two analyses run side by side on their own threads; end joins them.  A factor that is not for the brick
-// plan comes back as NULL (not an error): the caller keeps the level plan for it.
-struct gkomi_trs_bricks_job {
-    std::vector<int32_t> rp[2], ci[2];
-    gkomi_trs_bricks* out[2] = {nullptr, nullptr};
-    int err[2] = {0, 0};
-    std::thread worker[2];
-    bool started[2] = {false, false};
-};
-
-extern "C" int gkomi_trs_bricks_analyse_begin_i32(gkomi_stream_t s, int64_t n, const int32_t* l_row_ptrs,
-                                                  const int32_t* l_col_idxs, const int32_t* u_row_ptrs,
-                                                  const int32_t* u_col_idxs, int64_t brick_rows, int threads, int mode,
-                                                  gkomi_trs_bricks_job** out_job)
-{
-    if (out_job == nullptr) return GKOMI_EINVAL;
-    *out_job = nullptr;
-    gkomi_trs_bricks* probe = nullptr;
-    int err = 0;
-    if (!create_args_ok(n, threads, mode, &probe, &err)) return err;
-    if (l_row_ptrs == nullptr || u_row_ptrs == nullptr) return GKOMI_EINVAL;
-    hipStream_t stream = to_stream(s);
-    std::unique_ptr<gkomi_trs_bricks_job> job(new (std::nothrow) gkomi_trs_bricks_job);
-    if (!job) return GKOMI_EINVAL;
-    const int32_t* rps[2] = {l_row_ptrs, u_row_ptrs};
-    const int32_t* cis[2] = {l_col_idxs, u_col_idxs};
-    for (int f = 0; f < 2; ++f) {
-        job->rp[f].resize(static_cast<size_t>(n) + 1);
-        err = static_cast<int>(hipMemcpyAsync(job->rp[f].data(), rps[f], sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost, stream));
-        if (err) return err;
-    }
-    err = static_cast<int>(hipStreamSynchronize(stream));
-    if (err) return err;
-    for (int f = 0; f < 2; ++f) {
-        const int64_t nnz = job->rp[f][n];
-        if (nnz < 0 || (nnz > 0 && cis[f] == nullptr)) return GKOMI_EINVAL;
-        job->ci[f].resize(static_cast<size_t>(nnz > 0 ? nnz : 1));
-        if (nnz > 0) {
-            err = static_cast<int>(hipMemcpyAsync(job->ci[f].data(), cis[f], sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, stream));
-            if (err) return err;
-        }
-    }
-    err = static_cast<int>(hipStreamSynchronize(stream));
-    if (err) return err;
-    gkomi_trs_bricks_job* j = job.get();
-    for (int f = 0; f < 2; ++f) {
-        auto work = [j, f, n, brick_rows, threads, mode] {
-            j->err[f] = create_from_host(n, j->rp[f], j->ci[f], f == 0 ? 1 : 0, brick_rows, threads, mode, &j->out[f]);
-        };
-        try {
-            j->worker[f] = std::thread(work);
-            j->started[f] = true;
-        } catch (const std::system_error&) {
-            work();  // no thread to be had: on the caller's
-        }
-    }
-    *out_job = job.release();
-    return GKOMI_SUCCESS;
-}
-
-extern "C" int gkomi_trs_bricks_analyse_end(gkomi_trs_bricks_job* job, gkomi_trs_bricks** out_l, gkomi_trs_bricks** out_u)
-{
-    if (job == nullptr) return GKOMI_EINVAL;
-    for (int f = 0; f < 2; ++f) {
-        if (job->started[f] && job->worker[f].joinable()) job->worker[f].join();
-    }
-    int err = GKOMI_SUCCESS;
-    for (int f = 0; f < 2; ++f) {
-        if (job->err[f] != GKOMI_SUCCESS && job->err[f] != GKOMI_ENOTSUPPORTED) err = job->err[f];
-    }
-    gkomi_trs_bricks** outs[2] = {out_l, out_u};
-    for (int f = 0; f < 2; ++f) {
-        if (err == GKOMI_SUCCESS && outs[f] != nullptr) {
-            *outs[f] = job->out[f];
-        } else {
-            delete job->out[f];
-            if (outs[f] != nullptr) *outs[f] = nullptr;
-        }
-    }
-    delete job;
-    return err;
 }
 
 extern "C" int64_t gkomi_trs_bricks_levels_estimate(const gkomi_trs_bricks* h) { return h != nullptr ? h->levels_estimate : 0; }
@@ -1427,6 +2050,10 @@ extern "C" int gkomi_trs_bricks_host_array(const gkomi_trs_bricks* h, int which,
                                            int64_t* count)
 {
     if (h == nullptr || data == nullptr || count == nullptr) return GKOMI_EINVAL;
+    if (!h->host_arrays_valid) {  // analysed on the device: the arrays come to the host on first request
+        const int err = fetch_host_arrays(*const_cast<gkomi_trs_bricks*>(h));
+        if (err) return err;
+    }
     const std::vector<int32_t>* v = nullptr;
     switch (which) {
     case 0: v = &h->perm; break;
@@ -1495,7 +2122,28 @@ extern "C" int gkomi_trs_bricks_numeric_f64_i32(gkomi_stream_t s, gkomi_trs_bric
     hd.token = h->token;
     err = static_cast<int>(hipMemcpyAsync(plan, &hd, sizeof(hd), hipMemcpyHostToDevice, stream));
     if (err) return err;
-    if (!index_arrays_there) {
+    if (!index_arrays_there && h->dev_index != nullptr) {
+        // analysed on the device: the index arrays move device to device
+        auto copy = [&](size_t to, size_t from, int64_t count) {
+            return count > 0 ? static_cast<int>(hipMemcpyAsync(p + to, h->dev_index + from, sizeof(int32_t) * count,
+                                                               hipMemcpyDeviceToDevice, stream))
+                             : 0;
+        };
+        err = copy(l.perm, h->dev_perm, h->n);
+        if (!err) err = copy(l.brick_row_begin, h->dev_brick_row_begin, h->nbricks + 1);
+        if (!err) err = copy(l.brick_step_ptr, h->dev_brick_step_ptr, h->nbricks + 1);
+        if (!err) err = copy(l.step_begin, h->dev_step_begin, h->n_step_begin);
+        if (!err) err = copy(l.brick_ext_begin, h->dev_brick_ext_begin, h->nbricks + 1);
+        if (!err) err = copy(l.ext_col, h->dev_ext_col, h->n_ext_col);
+        if (!err) err = copy(l.row_rank, h->dev_row_rank, h->n);
+        if (!err) err = copy(l.inv_local, h->dev_inv_local, h->n);
+        if (!err) err = copy(l.ext_row_off, h->dev_ext_row_off, h->n);
+        if (!err) err = upload(stream, p, l.pred_ptr, h->pred_ptr);
+        if (!err) err = upload(stream, p, l.pred_idx, h->pred_idx);
+        if (!err) err = upload(stream, p, l.image_off, h->image_off);
+        if (err) return err;
+        h->uploaded_to = plan;
+    } else if (!index_arrays_there) {
         err = upload(stream, p, l.perm, h->perm);
         if (!err) err = upload(stream, p, l.brick_row_begin, h->brick_row_begin);
         if (!err) err = upload(stream, p, l.brick_step_ptr, h->brick_step_ptr);

@@ -342,7 +342,6 @@ class TrsBricks:
     when the factor is not stencil-shaped; callers then keep TrsPlan."""
 
     def __init__(self, gk, n, row_ptrs, col_idxs, vals, lower, brick_rows=0, threads=0, mode=0, handle=None):
-        """handle: an analysis that has been run already (BricksJob.finish) on arrays of the same pattern"""
         self.gk, self.n, self.lower = gk, int(n), bool(lower)
         self.row_ptrs, self.col_idxs = row_ptrs, col_idxs
         self.handle = ctypes.c_void_p(0)
@@ -389,32 +388,6 @@ class TrsBricks:
             self.gk.trs_bricks_destroy(h.value)
 
 
-class BricksJob:
-    """The brick analysis of both factors of an Ilu on host threads (gkomi_trs_bricks_analyse_begin / _end):
-    started as soon as the PATTERNS of L and U exist, finished when the values do."""
-
-    def __init__(self, gk, n, L_pattern, U_pattern, brick_rows=0):
-        self.gk, self.n = gk, int(n)
-        self.job = ctypes.c_void_p(0)
-        s = torch.cuda.current_stream().cuda_stream
-        gk.trs_bricks_analyse_begin_i32(s, n, L_pattern[0], L_pattern[1], U_pattern[0], U_pattern[1], int(brick_rows), 0, 0,
-                                        ctypes.addressof(self.job))
-
-    def finish(self):
-        """-> (handle of L or None, handle of U or None)"""
-        hl, hu = ctypes.c_void_p(0), ctypes.c_void_p(0)
-        job, self.job = self.job, ctypes.c_void_p(0)
-        self.gk.trs_bricks_analyse_end(job.value, ctypes.addressof(hl), ctypes.addressof(hu))
-        return hl.value, hu.value
-
-    def __del__(self):
-        if getattr(self, "job", None) is not None and self.job.value:
-            hl, hu = self.finish()
-            for h in (hl, hu):
-                if h:
-                    self.gk.trs_bricks_destroy(h)
-
-
 # a level must hold this many rows on average for the level-scheduled solve to pay: below it
 # (chains, narrow bands) the analysis-free kernel with its in-workgroup LDS hand-offs is faster
 TRS_PLAN_MIN_ROWS_PER_LEVEL = 64
@@ -427,16 +400,15 @@ TRS_BRICK_STEP_US = 0.17
 TRS_BRICK_HOP_US = 5.0
 
 
-def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True, bricks=True, brick_rows=0, job=None):
+def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True, bricks=True, brick_rows=0):
     """preconditioner::Ilu over given CSR factors L = (row_ptrs, col_idxs, vals), U likewise.
     analyse: LowerTrs / UpperTrs::generate -- the dependency analysis of both factors (True / False / "force");
     a factor of a grid problem gets the brick plan (bricks=True; csrc/trs_bricks.hip), one whose levels are
     wide enough the level-scheduled kernel, anything else keeps the analysis-free solve.
     brick_rows: rows per brick of the brick plan (0: the library's default); bricks="force" takes the
     brick plan whenever the factor admits one, whatever the cost model says.
-    job: a BricksJob started earlier on the same patterns (par_ilu_generate starts it before the sweeps).
-    The brick analysis of the two factors runs side by side on host threads; a factor that takes the brick
-    plan skips the level analysis (its level count is estimated from the box geometry the bricks found)."""
+    The brick analysis runs on the device; a factor that takes the brick plan skips the level analysis (its
+    level count is estimated from the box geometry the bricks found)."""
     dv = L[2].device
     inter = torch.zeros((n, nrhs), dtype=torch.float64, device=dv)
     nb = gk.trs_workspace_bytes()
@@ -444,14 +416,15 @@ def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True, brick
     plans = [None, None]
     brick_plans = [None, None]
     if analyse and n > 0:
-        handles = (None, None)
-        if bricks and n >= 2:
-            if job is None:
-                job = BricksJob(gk, n, L, U, brick_rows=brick_rows)
-            handles = job.finish()
         for i, (f, lower) in enumerate(((L, True), (U, False))):
-            if handles[i]:
-                bk = TrsBricks(gk, n, f[0], f[1], f[2], lower, handle=handles[i])
+            bk = None
+            if bricks and n >= 2:
+                try:
+                    bk = TrsBricks(gk, n, f[0], f[1], f[2], lower, brick_rows=brick_rows)
+                except GkomiError as e:
+                    if e.code != GKOMI_ENOTSUPPORTED:
+                        raise
+            if bk is not None:
                 nlevels = bk.levels_estimate
                 # pipelined: about one step per level of the factor
                 if nlevels > 16 and (bricks == "force" or TRS_BRICK_STEP_US * nlevels + TRS_BRICK_HOP_US * bk.coarse_levels
@@ -532,9 +505,7 @@ def _transpose(gk, n, rp, ci, v):
 
 def par_ilu_generate(gk, n, row_ptrs, col_idxs, vals, iterations=0, nrhs=1):
     """preconditioner::Ilu over factorization::ParIlu (core/factorization/par_ilu.cpp:74-163):
-    returns the Preconditioner (L^-1 then U^-1); .L / .U hold the factors.
-    The brick analysis of L and U (LowerTrs / UpperTrs::generate) needs their patterns only: it starts on
-    host threads right after initialize_l_u and runs beside the transposes and the sweeps."""
+    returns the Preconditioner (L^-1 then U^-1); .L / .U hold the factors."""
     s = torch.cuda.current_stream().cuda_stream
     dv = vals.device
     rp, ci, v = _with_diagonal(gk, n, row_ptrs, col_idxs, vals)
@@ -548,22 +519,12 @@ def par_ilu_generate(gk, n, row_ptrs, col_idxs, vals, iterations=0, nrhs=1):
     lc, lv = torch.zeros(lnnz, dtype=torch.int32, device=dv), torch.zeros(lnnz, dtype=torch.float64, device=dv)
     uc, uv = torch.zeros(unnz, dtype=torch.int32, device=dv), torch.zeros(unnz, dtype=torch.float64, device=dv)
     gk.factorization_initialize_l_u_f64_i32(s, n, rp, ci, v, lrp, lc, lv, urp, uc, uv)
-    # U comes back from two transposes with its rows sorted by column: the pattern initialize_l_u wrote is that
-    # one exactly when the rows of A are sorted -- then the analysis can start now
-    job = None
-    if n >= 2:
-        flag = ctypes.c_int(0)
-        wb = gk.prefix_sum_workspace_bytes(n + 1)
-        ws2 = torch.empty(max(wb, 8), dtype=torch.uint8, device=dv)
-        gk.csr_is_sorted_by_column_index_i32(s, n, rp, ci, ws2, wb, ctypes.addressof(flag))
-        if flag.value:
-            job = BricksJob(gk, n, (lrp, lc), (urp, uc))
     utrp, utc, utv = _transpose(gk, n, urp, uc, uv)
     rows = torch.zeros(max(nnz, 1), dtype=torch.int32, device=dv)
     gk.convert_ptrs_to_idxs_i32(s, rp, n, rows)
     gk.par_ilu_compute_l_u_factors_f64_i32(s, iterations, nnz, rows, ci, v, lrp, lc, lv, utrp, utc, utv)
     U = _transpose(gk, n, utrp, utc, utv)
-    p = ilu_from_factors(gk, n, (lrp, lc, lv), U, nrhs=nrhs, job=job)
+    p = ilu_from_factors(gk, n, (lrp, lc, lv), U, nrhs=nrhs)
     p.L, p.U = (lrp, lc, lv), U
     return p
 

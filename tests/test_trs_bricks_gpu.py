@@ -172,3 +172,81 @@ def test_bricks_config4_factor_full_size(gk, oracle, lower, mode):
     x, bk = brick_solve(gk, n, rp, ci, v, lower, False, b, 0, 0, mode)
     assert np.array_equal(x, oracle_solve(oracle, n, rp, ci, v, lower, False, b))
     assert bk.coarse_levels < 64
+
+
+# ---- round 3: the analysis itself runs on the device ------------------------------------------------------------
+def _host_and_device_analysis(gk, n, rp, ci, lower, brick_rows, mode):
+    import ctypes
+    from test_trs_bricks_analysis import Bricks
+    hb = Bricks(gk, n, rp, ci, lower, brick_rows=brick_rows, mode=mode)
+    handle = ctypes.c_void_p(0)
+    s = torch.cuda.current_stream().cuda_stream
+    gk.trs_bricks_create_i32(s, n, dev(np.ascontiguousarray(rp, np.int32)), dev(np.ascontiguousarray(ci, np.int32)), int(lower),
+                             brick_rows, 0, mode, ctypes.addressof(handle))
+    db = Bricks.__new__(Bricks)
+    db.gk, db.handle = gk, handle
+    info = (ctypes.c_int64 * 8)()
+    gk.trs_bricks_info(handle.value, ctypes.addressof(info))
+    (db.nbricks, db.coarse_levels, db.nsteps, db.critical_steps, db.max_lds, db.width, db.threads, db.mode) = (int(x) for x in info)
+    return hb, db
+
+
+@pytest.mark.parametrize("case", ["2d_61x47", "3d_20x17x23", "3d_unsorted_rows", "2d_upper", "odd_tail"])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_device_analysis_equals_host_analysis(gk, case, mode):
+    """gkomi_trs_bricks_create_i32 analyses the pattern on the device (one workgroup per brick); every array
+    of the plan -- permutation, brick and step tables, inflow lists, LDS indices -- must be the one the host
+    analysis (gkomi_trs_bricks_create_host_i32, pinned by tests/test_trs_bricks_analysis.py) produces.
+    Predecessor lists are compared as sets per brick (the host lists them in the order it meets them)."""
+    from test_trs_bricks_analysis import triangle
+    lower = case != "2d_upper"
+    if case in ("2d_61x47", "2d_upper"):
+        n, rp, ci, v = matgen.poisson_2d_5pt(61, 47)
+    elif case == "3d_20x17x23":
+        n, rp, ci, v = matgen.poisson_3d_7pt(20, 17, 23)
+    elif case == "3d_unsorted_rows":
+        # the entries of every row in a random storage order: inflow lists follow storage order
+        n, rp, ci, v = matgen.poisson_3d_7pt(14, 15, 16)
+        rng = np.random.default_rng(5)
+        ci, v = ci.copy(), v.copy()
+        for r in range(n):
+            q = rng.permutation(rp[r + 1] - rp[r])
+            ci[rp[r]:rp[r + 1]] = ci[rp[r]:rp[r + 1]][q]
+            v[rp[r]:rp[r + 1]] = v[rp[r]:rp[r + 1]][q]
+    else:
+        n, rp, ci, v = matgen.poisson_3d_7pt(12, 12, 12)
+        keep = 12 * 12 * 11 + 77       # the last plane is incomplete
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        m = (rows < keep) & (ci < keep)
+        n = keep
+        rp, ci, v = matgen.coo_to_csr(n, rows[m].astype(np.int32), ci[m].astype(np.int32), v[m])
+    trp, tci, tv = triangle(n, rp, ci, v, lower)
+    for brick_rows in (0, 300):
+        hb, db = _host_and_device_analysis(gk, n, trp, tci, lower, brick_rows, mode)
+        try:
+            assert (hb.nbricks, hb.coarse_levels, hb.nsteps, hb.critical_steps, hb.max_lds, hb.width, hb.threads, hb.mode) == \
+                (db.nbricks, db.coarse_levels, db.nsteps, db.critical_steps, db.max_lds, db.width, db.threads, db.mode)
+            assert gk.trs_bricks_plan_bytes(hb.handle.value) == gk.trs_bricks_plan_bytes(db.handle.value)
+            assert gk.trs_bricks_levels_estimate(hb.handle.value) == gk.trs_bricks_levels_estimate(db.handle.value)
+            for which in (0, 1, 2, 3, 4, 5, 6, 8, 9, 10):
+                assert np.array_equal(hb.array(which), db.array(which)), (case, mode, brick_rows, which)
+            hp, dp, ptr = hb.array(7), db.array(7), hb.array(6)
+            for r in range(hb.nbricks):
+                assert sorted(hp[ptr[r]:ptr[r + 1]]) == sorted(dp[ptr[r]:ptr[r + 1]])
+        finally:
+            hb.close()
+            db.close()
+
+
+def test_device_analysis_refuses_what_the_host_analysis_refuses(gk):
+    """a random pattern has no divisor chain of offsets: GKOMI_ENOTSUPPORTED from both"""
+    import ctypes
+    import gkomi
+    n = 500
+    rp, ci, v = matgen.random_csr(500, 500, 2, 6, 11)
+    from test_trs_bricks_analysis import triangle
+    trp, tci, tv = triangle(n, rp, ci, v, True)
+    h = ctypes.c_void_p(0)
+    with pytest.raises(gkomi._lib.GkomiError) as e:
+        gk.trs_bricks_create_i32(torch.cuda.current_stream().cuda_stream, n, dev(trp), dev(tci), 1, 0, 0, 2, ctypes.addressof(h))
+    assert e.value.code == -2 and not h.value
