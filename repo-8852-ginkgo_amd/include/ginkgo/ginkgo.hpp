@@ -817,9 +817,12 @@ template <typename V, typename I>
 class Sellp;
 template <typename V, typename I>
 class Hybrid;
+template <typename V, typename I>
+class CsrBuilder;
 
 template <typename V = double, typename I = int32>
 class Csr : public LinOp {
+    friend class CsrBuilder<V, I>;
 public:
     using value_type = V;
     using index_type = I;
@@ -993,6 +996,25 @@ protected:
     mutable array<I> srow_;
     mutable int64_t srow_tile_{0};
     mutable bool srow_valid_{false};
+};
+
+// core/matrix/csr_builder.hpp:47-83: intrusive access to a Csr's arrays for kernels that rebuild them
+// (factorization::add_diagonal_elements); the srow is rebuilt when the builder goes away
+template <typename V = double, typename I = int32>
+class CsrBuilder {
+public:
+    array<I>& get_col_idx_array() { return matrix_->col_idxs_; }
+    array<V>& get_value_array() { return matrix_->values_; }
+    explicit CsrBuilder(Csr<V, I>* matrix) : matrix_{matrix} {}
+    ~CsrBuilder()
+    {
+        matrix_->max_row_nnz_ = -1;
+        matrix_->invalidate_srow();
+    }
+    CsrBuilder(const CsrBuilder&) = delete;
+    CsrBuilder& operator=(const CsrBuilder&) = delete;
+private:
+    Csr<V, I>* matrix_;
 };
 
 template <typename V = double, typename I = int32>
@@ -2165,20 +2187,19 @@ protected:
         ws_.fill(0);
         auto csr = as<const matrix::Csr<V, I>>(A_.get());
         const int64_t n = static_cast<int64_t>(size_[0]);
-        array<char> symbolic(exec_, gkomi_trs_symbolic_workspace_bytes(n));
-        int64_t out[4] = {};
-        GKOMI_CALL(gkomi_trs_analyse_symbolic_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), Lower ? 1 : 0, symbolic.get_data(),
-                                                  symbolic.get_num_elems(), out));
-        nslices_ = out[0]; entries_ = out[1]; nlevels_ = out[2]; max_deps_ = out[3];
         // factors of grid problems (many levels, stencil-shaped): the brick plan -- bricks solved out of LDS,
-        // about one LDS step per level instead of one memory hand-off (csrc/trs_bricks.hip)
-        if (nlevels_ > 16) {
+        // about one LDS step per level instead of one memory hand-off (csrc/trs_bricks.hip).  Its analysis runs
+        // on the device and says itself how many levels the factor has if its box geometry holds, so a factor
+        // that takes the brick plan never pays for the level analysis (generate on the 108^3 ILU: 55 -> 7 ms).
+        if (n >= 2) {
             const int err = gkomi_trs_bricks_create_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), Lower ? 1 : 0, 0, 0, 0, &bricks_);
             if (err != GKOMI_SUCCESS && err != GKOMI_ENOTSUPPORTED) GKOMI_CALL(err);
             if (bricks_ != nullptr) {
                 int64_t info[8] = {};
                 GKOMI_CALL(gkomi_trs_bricks_info(bricks_, info));
-                if (0.17 * nlevels_ + 5.0 * info[1] < 1.7 * nlevels_) {  // us per level / per brick level (profiles/r02_trs_bricks.md) vs the level plan
+                const int64_t levels = gkomi_trs_bricks_levels_estimate(bricks_);
+                if (levels > 16 && 0.17 * levels + 5.0 * info[1] < 1.7 * levels) {  // us per level / per brick level (profiles/r02_trs_bricks.md) vs the level plan
+                    nlevels_ = levels;
                     plan_.resize_and_reset(gkomi_trs_bricks_plan_bytes(bricks_));
                     GKOMI_CALL(gkomi_trs_bricks_numeric_f64_i32(nullptr, bricks_, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(), plan_.get_data(),
                                                                 plan_.get_num_elems()));
@@ -2188,6 +2209,11 @@ protected:
                 bricks_ = nullptr;
             }
         }
+        array<char> symbolic(exec_, gkomi_trs_symbolic_workspace_bytes(n));
+        int64_t out[4] = {};
+        GKOMI_CALL(gkomi_trs_analyse_symbolic_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), Lower ? 1 : 0, symbolic.get_data(),
+                                                  symbolic.get_num_elems(), out));
+        nslices_ = out[0]; entries_ = out[1]; nlevels_ = out[2]; max_deps_ = out[3];
         // wide levels: level-scheduled; chains and narrow bands: the analysis-free kernel's in-workgroup hand-offs
         planned_ = n > 0 && n >= 64 * std::max<int64_t>(nlevels_, 1);
         if (planned_) {

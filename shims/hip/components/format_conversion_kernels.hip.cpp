@@ -22,12 +22,8 @@ void convert_idxs_to_ptrs(std::shared_ptr<const HipExecutor> exec, const int32* 
 
 void convert_ptrs_to_sizes(std::shared_ptr<const HipExecutor> exec, const int32* ptrs, size_type num_blocks, size_type* sizes)
 {
-    // the C ABI writes int32 sizes; the reference's are size_type: widen through a temporary
-    array<int32> narrow(exec, num_blocks);
-    GKOMI_CALL(gkomi_convert_ptrs_to_sizes_i32(GKOMI_NULL_STREAM, ptrs, static_cast<int64_t>(num_blocks), narrow.get_data()));
-    array<int32> host(exec->get_master(), narrow);
-    std::vector<size_type> wide(host.get_const_data(), host.get_const_data() + num_blocks);
-    exec->copy_from(exec->get_master().get(), num_blocks, wide.data(), sizes);
+    static_assert(sizeof(size_type) == sizeof(uint64_t), "sizes are 64-bit");
+    GKOMI_CALL(gkomi_convert_ptrs_to_sizes_i32(GKOMI_NULL_STREAM, ptrs, static_cast<int64_t>(num_blocks), reinterpret_cast<uint64_t*>(sizes)));
 }
 
 }  // namespace components

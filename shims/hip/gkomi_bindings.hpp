@@ -24,6 +24,28 @@ inline void gkomi_check(int code, const char* file, int line, const char* fn)
 }  // namespace kernels
 }  // namespace gko
 #define GKOMI_CALL(expr) ::gko::kernels::hip::gkomi_check((expr), __FILE__, __LINE__, #expr)
+
+// The row statistic the strategy objects of a reference tree keep (csr.hpp:240-277 classical, :600-705
+// automatical: max_length_per_row_, filled by strategy_type::process at make_srow time): the SpMV's row-length
+// hint.  -1 = the strategy keeps none (load_balance, merge_path, sparselib).  [reference-tree branch: not
+// compiled by this repository's tests, which take the definition of shims/test/prelude_mirror.hpp]
+#include <ginkgo/core/matrix/csr.hpp>
+namespace gko {
+namespace kernels {
+namespace hip {
+inline int64_t gkomi_row_hint(const matrix::Csr<double, int32>* a)
+{
+    using csr = matrix::Csr<double, int32>;
+    auto s = a->get_strategy();
+    if (auto c = std::dynamic_pointer_cast<csr::classical>(s)) return c->get_max_length_per_row();
+    if (auto c = std::dynamic_pointer_cast<csr::automatical>(s)) {
+        return c->get_name() == "classical" ? static_cast<int64_t>(c->get_max_length_per_row()) : -1;
+    }
+    return -1;
+}
+}  // namespace hip
+}  // namespace kernels
+}  // namespace gko
 #endif
 
 // All reference kernels run on the null stream (common/cuda_hip/base/kernel_launch.hpp.inc:66).

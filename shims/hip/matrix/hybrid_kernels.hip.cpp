@@ -1,9 +1,9 @@
 // hip/matrix/hybrid_kernels.hip.cpp: hybrid::compute_coo_row_ptrs (core/matrix/hybrid_kernels.hpp).
 // Hybrid::apply itself is composed in core/ from ell::spmv and coo::spmv2 (core/matrix/hybrid.cpp:133-159), so
 // it needs no kernel of its own at this boundary; gkomi_hybrid_spmv_f64_i32 is that composition for C callers.
-// compute_coo_row_ptrs takes the row lengths as size_type and writes int64 pointers in the reference; the C ABI's
-// kernel works on int32 row pointers of the CSR source (core/matrix/csr.cpp:438-470 is its only caller), so this
-// binding serves matrices whose pointers fit 32 bits and refuses the rest.
+// compute_coo_row_ptrs takes the row lengths as size_type in the reference; the C ABI's kernel reads the int32
+// row pointers of the CSR source (core/matrix/csr.cpp:438-470 is its only caller), so this binding turns the lengths
+// back into pointers (setup path, O(rows) on the host) and serves matrices whose pointers fit 32 bits.
 #include "../gkomi_bindings.hpp"
 
 #include <vector>
@@ -26,13 +26,10 @@ void compute_coo_row_ptrs(std::shared_ptr<const HipExecutor> exec, const array<s
         ptrs[i + 1] = static_cast<int32>(next);
     }
     array<int32> dev_ptrs(exec, ptrs.begin(), ptrs.end());
-    array<int32> out32(exec, n + 1);
     array<char> tmp(exec, gkomi_prefix_sum_workspace_bytes(static_cast<int64_t>(n) + 1));
     GKOMI_CALL(gkomi_hybrid_compute_coo_row_ptrs_i32(GKOMI_NULL_STREAM, dev_ptrs.get_const_data(), static_cast<int64_t>(n),
-                                                     static_cast<int64_t>(ell_lim), out32.get_data(), tmp.get_data(), tmp.get_num_elems()));
-    array<int32> host_out(exec->get_master(), out32);
-    std::vector<int64> wide(host_out.get_const_data(), host_out.get_const_data() + n + 1);
-    exec->copy_from(exec->get_master().get(), n + 1, wide.data(), coo_row_ptrs);
+                                                     static_cast<int64_t>(ell_lim), reinterpret_cast<int64_t*>(coo_row_ptrs), tmp.get_data(),
+                                                     tmp.get_num_elems()));
 }
 
 }  // namespace hybrid

@@ -32,19 +32,18 @@ void generate(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double,
     const int64_t n = static_cast<int64_t>(matrix->get_size()[0]);
     st->workspace.resize_and_reset(gkomi_trs_workspace_bytes());
     st->workspace.fill(0);  // the analysis-free kernel's ticket and its sticky give-up flag
-    st->symbolic.resize_and_reset(gkomi_trs_symbolic_workspace_bytes(n));
-    int64_t out[4] = {};
-    GKOMI_CALL(gkomi_trs_analyse_symbolic_i32(GKOMI_NULL_STREAM, n, matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(), /*lower=*/0,
-                                              st->symbolic.get_data(), st->symbolic.get_num_elems(), out));
-    st->nslices = out[0]; st->entries = out[1]; st->nlevels = out[2]; st->max_deps = out[3];
-    // many levels on a box grid: bricks solved out of LDS (one LDS step per level, a memory hand-off per brick level)
-    if (st->nlevels > 16) {
+    // many levels on a box grid: bricks solved out of LDS (one LDS step per level, a memory hand-off per brick level).
+    // The brick analysis runs on the device and estimates the factor's levels from the box geometry it found, so a
+    // factor that takes the brick plan skips the level analysis altogether.
+    if (n >= 2) {
         const int err = gkomi_trs_bricks_create_i32(GKOMI_NULL_STREAM, n, matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(), /*lower=*/0,
                                                     0, 0, 0, &st->bricks);
         if (err != GKOMI_SUCCESS && err != GKOMI_ENOTSUPPORTED) GKOMI_CALL(err);
         int64_t info[8] = {};
         if (st->bricks != nullptr) GKOMI_CALL(gkomi_trs_bricks_info(st->bricks, info));
-        if (st->bricks != nullptr && 0.17 * st->nlevels + 5.0 * info[1] < 1.7 * st->nlevels) {
+        const int64_t levels = st->bricks != nullptr ? gkomi_trs_bricks_levels_estimate(st->bricks) : 0;
+        if (st->bricks != nullptr && levels > 16 && 0.17 * levels + 5.0 * info[1] < 1.7 * levels) {
+            st->nlevels = levels;
             st->plan.resize_and_reset(gkomi_trs_bricks_plan_bytes(st->bricks));
             GKOMI_CALL(gkomi_trs_bricks_numeric_f64_i32(GKOMI_NULL_STREAM, st->bricks, matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(),
                                                         matrix->get_const_values(), st->plan.get_data(), st->plan.get_num_elems()));
@@ -54,6 +53,11 @@ void generate(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double,
         gkomi_trs_bricks_destroy(st->bricks);
         st->bricks = nullptr;
     }
+    st->symbolic.resize_and_reset(gkomi_trs_symbolic_workspace_bytes(n));
+    int64_t out[4] = {};
+    GKOMI_CALL(gkomi_trs_analyse_symbolic_i32(GKOMI_NULL_STREAM, n, matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(), /*lower=*/0,
+                                              st->symbolic.get_data(), st->symbolic.get_num_elems(), out));
+    st->nslices = out[0]; st->entries = out[1]; st->nlevels = out[2]; st->max_deps = out[3];
     // wide levels: the level-scheduled solve; chains and narrow bands: the in-workgroup hand-offs of the other kernel
     st->planned = n >= 64 * (st->nlevels > 0 ? st->nlevels : 1);
     if (st->planned) {
