@@ -927,9 +927,12 @@ int launch_split_dot(hipStream_t stream, int nrows, int nnz, const int32_t* row_
 {
     constexpr int Block = 256;
     const int ntiles = nnz / Tile + 1;
-    const int per = static_cast<int>(ceildiv(ntiles, num_xcd));
-    const bool swz = swizzle && ntiles >= 2 * num_xcd;
-    dim3 grid(swz ? per * num_xcd : ntiles, 1);
+    // Infinity-Cache resident: one contiguous eighth of the tiles per XCD; streaming from HBM: 16 consecutive
+    // tiles per XCD (see the automatic strategy of gkomi_csr_spmv_srow_f64_i32)
+    const int per = swizzle ? static_cast<int>(ceildiv(ntiles, num_xcd)) : 16;
+    const bool swz = ntiles >= 2 * num_xcd;
+    const int groups = static_cast<int>(ceildiv(ntiles, per * num_xcd));
+    dim3 grid(swz ? groups * per * num_xcd : ntiles, 1);
 #define GKOMI_SPLIT_DOT(SWZ, NT)                                                                          \
     hipLaunchKernelGGL((csr_split_kernel<Block, Tile, split_max_over, false, SWZ, true, NT, true>), grid, \
                        dim3(Block), 0, stream, nrows, nnz, row_ptrs, col_idxs, vals, p, int64_t{1}, q,    \
@@ -1087,6 +1090,7 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
     bool no_swizzle = (strategy >> 16) & 1;
     const int chunk_code = (strategy >> 17) & 0x7f;  // XCD chunk = 2^(code-1) row blocks, 0 = one eighth each
     const int chunk = chunk_code ? 1 << (chunk_code - 1) : 0;
+    int auto_chunk = 0;  // the automatic strategy's choice for matrices that stream from HBM
     const bool automatic = kind == GKOMI_CSR_AUTO;
     const bool aligned = (reinterpret_cast<uintptr_t>(vals) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(col_idxs) % 8 == 0);
@@ -1121,6 +1125,15 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
         // 256 threads, 256 rows, 1536-nonzero tile: fastest measured
         no_swizzle = !csr_auto_swizzle(nrows, nnz);
         nt = no_swizzle || ((strategy & GKOMI_CSR_STREAMING) != 0);
+        // A matrix that streams from HBM, cut by nonzeros: consecutive tiles on consecutive XCDs (no swizzle) pull
+        // the x lines of neighbouring rows into up to three L2s (1.19x the algorithmic traffic on the 256^3 7-point
+        // matrix); one contiguous eighth per XCD reads every line once but is 6 % slower there (eight far-apart
+        // streams).  16 consecutive tiles per XCD keep a row's near neighbours in one L2 and the streams together:
+        // 282 vs 291 (no swizzle) vs 308 us (eighths), tools/p3_chunk_sweep.py, profiles/r03_p3_chunk_sweep.log.
+        if (no_swizzle && kind == GKOMI_CSR_SPLIT && chunk == 0) {
+            no_swizzle = false;
+            auto_chunk = 16;
+        }
         // rows of 32+ entries: the padded LDS tile (row-sum reads of
         // neighbouring lanes are 32+ doubles apart) is 6-15 % faster, shorter
         // rows lose 1-2 % to the split LDS stores (profiles/r01_tune_pad.log)
@@ -1174,7 +1187,7 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
             int err = GKOMI_EINVAL;
 #define GKOMI_SPLIT_ARGS                                                            \
     stream, !no_swizzle, n, z, row_ptrs, col_idxs, vals, b + j, b_stride, c + j,    \
-        c_stride, alpha, beta, srow, over, chunk
+        c_stride, alpha, beta, srow, over, chunk > 0 ? chunk : auto_chunk
             // variant bit 2: nontemporal streams.  (Write-through stores of c, 8 or 16 bytes wide, and
             // nontemporal stores of c were measured and dropped: 17.2 / 16.9 vs 16.6 us cold,
             // profiles/r02_tune_split.log, r02_tune_ntstore.log.)

@@ -909,10 +909,13 @@ __device__ __forceinline__ void st2(double* p, int64_t i, double2 v)
 __global__ __launch_bounds__(fblock) void bicgstab_fused_step1_kernel(
     int64_t n, const double* __restrict__ r, double* __restrict__ p, const double* __restrict__ v,
     const double* __restrict__ rho_part, const double* __restrict__ tau_part, int nparts,
-    bicgstab_scalars* scal, long long it, long long max_iters, double goal)
+    bicgstab_scalars* scal, long long it, long long max_iters, double goal, host_watch_line* watch = nullptr)
 {
     __shared__ double smem[fblock / wave_size];
-    if (fused_stopped(scal)) return;
+    if (fused_stopped(scal)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) host_watch_publish(watch, it, scal->stop_iter);  // internal.hpp
+        return;
+    }
     const pair_sweep sw(n);
     double2 r0 = make_double2(0.0, 0.0), p0 = r0, v0 = r0;
     if (sw.first()) {
@@ -939,6 +942,7 @@ __global__ __launch_bounds__(fblock) void bicgstab_fused_step1_kernel(
             scal->status = st;
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) host_watch_publish(watch, it, st ? it : -1ll);
     if (st) return;
     // bicgstab::step_1 (reference/solver/bicgstab_kernels.cpp)
     const bool update = prev * omega != 0.0;
@@ -1154,13 +1158,20 @@ int bicgstab_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_app
     bicgstab_scalars h{};
     long long it = 0;
     bool done = false;
+    // the host's view of the solve (host_watch, internal.hpp): the first kernel of every iteration reports the
+    // iteration it evaluated; the host stays a few iterations ahead and looks at device memory only once the
+    // criterion has fired -- no blocking look every check_every iterations
+    host_watch watch;
+    const long long lag = std::min<long long>(c.check_every, precond == nullptr ? 4 * host_watch_lag : host_watch_lag);
     while (!done) {
-        for (int64_t k = 0; k < c.check_every && !done; ++k, ++it) {
+        bool last = false;
+        for (int64_t k = 0; k < (watch.dev != nullptr ? 1 : c.check_every) && !done; ++k, ++it) {
             hipLaunchKernelGGL(bicgstab_fused_step1_kernel, dim3(g), dim3(fblock), 0, stream, n, r, p, v,
                                part_rho, part_tau, g, scal, it, static_cast<long long>(max_iters),
-                               reduction_factor);
+                               reduction_factor, watch.dev);
             if (it >= max_iters) {  // this launch stops for sure
                 ++it;
+                last = true;
                 break;
             }
             if (precond != nullptr) GKOMI_TRY(precond(precond_ctx, s, p, y));
@@ -1175,6 +1186,14 @@ int bicgstab_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_app
                                sv, t, y, z, rr, part_gamma, part_tt, nb, scal, part_rho, part_tau);
         }
         GKOMI_TRY(check_launch());
+        if (watch.dev != nullptr && !last) {
+            if (it - 1 < lag) continue;
+            if (watch.wait(stream, it - 1 - lag)) {
+                if (watch.stop_iter() < 0) continue;  // still running: no look at device memory
+            } else {
+                watch.dev = nullptr;  // its stores do not reach this host: the blocking look from here on
+            }
+        }
         GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&h, scal, sizeof(h), hipMemcpyDeviceToHost, stream)));
         GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
         done = h.stop_iter >= 0;
@@ -1361,10 +1380,13 @@ __global__ __launch_bounds__(fblock) void fcg_fused_step1_kernel(
     int64_t n, double* __restrict__ p, const double* __restrict__ z,
     const double* __restrict__ rho_part, const double* __restrict__ rhot_part,
     const double* __restrict__ tau_part, int nparts, fcg_scalars* scal, long long it,
-    long long max_iters, double goal)
+    long long max_iters, double goal, host_watch_line* watch = nullptr)
 {
     __shared__ double smem[fblock / wave_size];
-    if (status_has_stopped(scal->status)) return;
+    if (status_has_stopped(scal->status)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) host_watch_publish(watch, it, scal->stop_iter);  // internal.hpp
+        return;
+    }
     const pair_sweep sw(n);
     double2 z0 = make_double2(0.0, 0.0), p0 = z0;
     if (sw.first()) {
@@ -1389,6 +1411,7 @@ __global__ __launch_bounds__(fblock) void fcg_fused_step1_kernel(
             scal->status = st;
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) host_watch_publish(watch, it, st ? it : -1ll);
     if (st) return;
     const bool restart = prev == 0.0;
     const double tmp = restart ? 0.0 : rho_t / prev;
@@ -1522,13 +1545,20 @@ int fcg_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_apply_fn
     fcg_scalars h{};
     long long it = 0;
     bool done = false;
+    // the host's view of the solve (host_watch, internal.hpp): the first kernel of every iteration reports the
+    // iteration it evaluated; the host stays a few iterations ahead and looks at device memory only once the
+    // criterion has fired -- no blocking look every check_every iterations
+    host_watch watch;
+    const long long lag = std::min<long long>(c.check_every, precond == nullptr ? 4 * host_watch_lag : host_watch_lag);
     while (!done) {
-        for (int64_t k = 0; k < c.check_every && !done; ++k, ++it) {
+        bool last = false;
+        for (int64_t k = 0; k < (watch.dev != nullptr ? 1 : c.check_every) && !done; ++k, ++it) {
             hipLaunchKernelGGL(fcg_fused_step1_kernel, dim3(g), dim3(fblock), 0, stream, n, p, z, part_rho,
                                part_rhot, identity ? part_rho : part_tau, g, scal, it,
-                               static_cast<long long>(max_iters), reduction_factor);
+                               static_cast<long long>(max_iters), reduction_factor, watch.dev);
             if (it >= max_iters) {
                 ++it;
+                last = true;
                 break;
             }
             if (csr_epilogue) {
@@ -1549,6 +1579,14 @@ int fcg_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_apply_fn
             }
         }
         GKOMI_TRY(check_launch());
+        if (watch.dev != nullptr && !last) {
+            if (it - 1 < lag) continue;
+            if (watch.wait(stream, it - 1 - lag)) {
+                if (watch.stop_iter() < 0) continue;  // still running: no look at device memory
+            } else {
+                watch.dev = nullptr;  // its stores do not reach this host: the blocking look from here on
+            }
+        }
         GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&h, scal, sizeof(h), hipMemcpyDeviceToHost, stream)));
         GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
         done = h.stop_iter >= 0;
@@ -1690,10 +1728,13 @@ __global__ __launch_bounds__(fblock) void cgs_fused_step1_kernel(
     int64_t n, const double* __restrict__ r, double* __restrict__ u, double* __restrict__ p,
     const double* __restrict__ q, const double* __restrict__ rho_part,
     const double* __restrict__ tau_part, int nparts, cgs_scalars* scal, long long it,
-    long long max_iters, double goal)
+    long long max_iters, double goal, host_watch_line* watch = nullptr)
 {
     __shared__ double smem[fblock / wave_size];
-    if (status_has_stopped(scal->status)) return;
+    if (status_has_stopped(scal->status)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) host_watch_publish(watch, it, scal->stop_iter);  // internal.hpp
+        return;
+    }
     const pair_sweep sw(n);
     double2 r0 = make_double2(0.0, 0.0), q0 = r0, p0 = r0;
     if (sw.first()) {
@@ -1723,6 +1764,7 @@ __global__ __launch_bounds__(fblock) void cgs_fused_step1_kernel(
             scal->beta = bt;
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) host_watch_publish(watch, it, st ? it : -1ll);
     if (st) return;
     auto step1 = [&](double rv, double qv, double pv, double* uo, double* po) {
         const double uu = rv + bt * qv;
@@ -1888,12 +1930,19 @@ int cgs_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_apply_fn
     cgs_scalars h{};
     long long it = 0;
     bool done = false;
+    // the host's view of the solve (host_watch, internal.hpp): the first kernel of every iteration reports the
+    // iteration it evaluated; the host stays a few iterations ahead and looks at device memory only once the
+    // criterion has fired -- no blocking look every check_every iterations
+    host_watch watch;
+    const long long lag = std::min<long long>(c.check_every, precond == nullptr ? 4 * host_watch_lag : host_watch_lag);
     while (!done) {
-        for (int64_t k = 0; k < c.check_every && !done; ++k, ++it) {
+        bool last = false;
+        for (int64_t k = 0; k < (watch.dev != nullptr ? 1 : c.check_every) && !done; ++k, ++it) {
             hipLaunchKernelGGL(cgs_fused_step1_kernel, dim3(g), dim3(fblock), 0, stream, n, r, u, p, q, part_rho,
-                               part_tau, g, scal, it, static_cast<long long>(max_iters), reduction_factor);
+                               part_tau, g, scal, it, static_cast<long long>(max_iters), reduction_factor, watch.dev);
             if (it >= max_iters) {
                 ++it;
+                last = true;
                 break;
             }
             // v_hat = A (M p), gamma = r_tld . v_hat
@@ -1929,6 +1978,14 @@ int cgs_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_apply_fn
                                r_tld, scal, part_rho, part_tau);
         }
         GKOMI_TRY(check_launch());
+        if (watch.dev != nullptr && !last) {
+            if (it - 1 < lag) continue;
+            if (watch.wait(stream, it - 1 - lag)) {
+                if (watch.stop_iter() < 0) continue;  // still running: no look at device memory
+            } else {
+                watch.dev = nullptr;  // its stores do not reach this host: the blocking look from here on
+            }
+        }
         GKOMI_TRY(static_cast<int>(hipMemcpyAsync(&h, scal, sizeof(h), hipMemcpyDeviceToHost, stream)));
         GKOMI_TRY(static_cast<int>(hipStreamSynchronize(stream)));
         done = h.stop_iter >= 0;

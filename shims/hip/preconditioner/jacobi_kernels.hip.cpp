@@ -1,5 +1,5 @@
-// hip/preconditioner/jacobi_*_kernel.hip.cpp: jacobi::simple_apply / apply
-// (core/preconditioner/jacobi_kernels.hpp:95-130; reference/preconditioner/jacobi_kernels.cpp:447-598).
+// hip/preconditioner/jacobi_*_kernel.hip.cpp: jacobi::find_blocks / generate / simple_apply / apply, the scalar
+// variants, transpose_jacobi (core/preconditioner/jacobi_kernels.hpp; reference/preconditioner/jacobi_kernels.cpp:66-625).
 #include "../gkomi_bindings.hpp"
 
 namespace gko {
@@ -54,6 +54,80 @@ void apply(std::shared_ptr<const HipExecutor> exec, size_type num_blocks, uint32
                                               blocks.get_const_data(), b->get_size()[1], alpha->get_const_values(), b->get_const_values(),
                                               b->get_stride(), beta->get_const_values(), x->get_values(), x->get_stride()));
     }
+}
+
+void find_blocks(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double, int32>* system_matrix, uint32 max_block_size,
+                 size_type& num_blocks, array<int32>& block_pointers)
+{
+    const int64_t n = static_cast<int64_t>(system_matrix->get_size()[0]);
+    array<char> tmp(exec, gkomi_jacobi_find_blocks_workspace_bytes(n));
+    array<int64> device_count(exec, 1);
+    int64_t count = 0;
+    GKOMI_CALL(gkomi_jacobi_find_blocks_i32(GKOMI_NULL_STREAM, n, system_matrix->get_const_row_ptrs(), system_matrix->get_const_col_idxs(),
+                                            static_cast<int>(max_block_size), block_pointers.get_data(),
+                                            reinterpret_cast<int64_t*>(device_count.get_data()), tmp.get_data(), tmp.get_num_elems(), &count));
+    num_blocks = static_cast<size_type>(count);
+}
+
+void generate(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double, int32>* system_matrix, size_type num_blocks,
+              uint32 max_block_size, double accuracy, const preconditioner::block_interleaved_storage_scheme<int32>& storage_scheme,
+              array<double>& conditioning, array<precision_reduction>& block_precisions, const array<int32>& block_pointers,
+              array<double>& blocks)
+{
+    check_scheme(max_block_size, storage_scheme);
+    const int64_t n = static_cast<int64_t>(system_matrix->get_size()[0]);
+    if (block_precisions.get_num_elems() > 0) {  // adaptive precision: the detection runs in the generating wave
+        GKOMI_CALL(gkomi_jacobi_generate_adaptive_f64_i32(
+            GKOMI_NULL_STREAM, n, system_matrix->get_const_row_ptrs(), system_matrix->get_const_col_idxs(), system_matrix->get_const_values(),
+            static_cast<int64_t>(num_blocks), static_cast<int>(max_block_size), block_pointers.get_const_data(), accuracy,
+            conditioning.get_data(), reinterpret_cast<uint8_t*>(block_precisions.get_data()), blocks.get_data()));
+    } else {
+        GKOMI_CALL(gkomi_jacobi_generate_f64_i32(
+            GKOMI_NULL_STREAM, n, system_matrix->get_const_row_ptrs(), system_matrix->get_const_col_idxs(), system_matrix->get_const_values(),
+            static_cast<int64_t>(num_blocks), static_cast<int>(max_block_size), block_pointers.get_const_data(),
+            conditioning.get_num_elems() > 0 ? conditioning.get_data() : nullptr, blocks.get_data()));
+    }
+}
+
+void invert_diagonal(std::shared_ptr<const HipExecutor> exec, const array<double>& diag, array<double>& inv_diag)
+{
+    GKOMI_CALL(gkomi_jacobi_invert_diagonal_f64(GKOMI_NULL_STREAM, static_cast<int64_t>(diag.get_num_elems()), diag.get_const_data(),
+                                                inv_diag.get_data()));
+}
+
+void simple_scalar_apply(std::shared_ptr<const HipExecutor> exec, const array<double>& diag, const matrix::Dense<double>* b,
+                         matrix::Dense<double>* x)
+{
+    GKOMI_CALL(gkomi_jacobi_scalar_apply_f64(GKOMI_NULL_STREAM, b->get_size()[0], b->get_size()[1], diag.get_const_data(), nullptr,
+                                             b->get_const_values(), b->get_stride(), nullptr, x->get_values(), x->get_stride()));
+}
+
+void scalar_apply(std::shared_ptr<const HipExecutor> exec, const array<double>& diag, const matrix::Dense<double>* alpha,
+                  const matrix::Dense<double>* b, const matrix::Dense<double>* beta, matrix::Dense<double>* x)
+{
+    GKOMI_CALL(gkomi_jacobi_scalar_apply_f64(GKOMI_NULL_STREAM, b->get_size()[0], b->get_size()[1], diag.get_const_data(),
+                                             alpha->get_const_values(), b->get_const_values(), b->get_stride(), beta->get_const_values(),
+                                             x->get_values(), x->get_stride()));
+}
+
+void transpose_jacobi(std::shared_ptr<const HipExecutor> exec, size_type num_blocks, uint32 max_block_size,
+                      const array<precision_reduction>& block_precisions, const array<int32>& block_pointers, const array<double>& blocks,
+                      const preconditioner::block_interleaved_storage_scheme<int32>& storage_scheme, array<double>& out_blocks)
+{
+    check_scheme(max_block_size, storage_scheme);
+    GKOMI_CALL(gkomi_jacobi_transpose_f64_i32(
+        GKOMI_NULL_STREAM, static_cast<int64_t>(num_blocks), static_cast<int>(max_block_size), block_pointers.get_const_data(),
+        block_precisions.get_num_elems() > 0 ? reinterpret_cast<const uint8_t*>(block_precisions.get_const_data()) : nullptr,
+        blocks.get_const_data(), out_blocks.get_data()));
+}
+
+// real values: the conjugate transpose is the transpose
+void conj_transpose_jacobi(std::shared_ptr<const HipExecutor> exec, size_type num_blocks, uint32 max_block_size,
+                           const array<precision_reduction>& block_precisions, const array<int32>& block_pointers,
+                           const array<double>& blocks, const preconditioner::block_interleaved_storage_scheme<int32>& storage_scheme,
+                           array<double>& out_blocks)
+{
+    transpose_jacobi(exec, num_blocks, max_block_size, block_precisions, block_pointers, blocks, storage_scheme, out_blocks);
 }
 
 }  // namespace jacobi
