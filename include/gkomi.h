@@ -1275,7 +1275,8 @@ typedef struct gkomi_ilu_ctx {
     void* trs_workspace;
     size_t trs_workspace_bytes;
     int32_t l_unit_diag;     /* ParIlu stores the unit diagonal of L explicitly: 0 */
-    int32_t pad_;
+    int32_t pad_;            /* set to 0; gkomi_ilu_apply_cb keeps its chain state here (1: the
+                              * intermediate vector is armed for the next lower brick solve) */
     /* analysed factors (gkomi_trs_analyse_*): when non-NULL the level-scheduled
      * solve replaces the analysis-free one for that factor */
     void* l_plan;

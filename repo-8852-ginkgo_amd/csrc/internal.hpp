@@ -84,6 +84,10 @@ __device__ __forceinline__ void host_watch_publish(host_watch_line* w, long long
 // criterion fired (they return at once, but a preconditioner's do not) stay cheap
 constexpr long long host_watch_lag = 3;
 
+// a brick solve as one link of a chain on contiguous vectors (trs_bricks.hip): see the definition
+int trs_bricks_solve_chained(gkomi_stream_t s, gkomi_trs_bricks* h, void* plan, int unit_diag, const double* b, double* x,
+                             bool x_is_armed, double* arm, double* rearm_b);
+
 // end-of-solve health check of a preconditioner callback (blocking): 0 or an error such as
 // GKOMI_ETRS_OVERRUN when one of the ILU's triangular solves gave up (precond.hip)
 int precond_status(gkomi_apply_fn precond, void* ctx, gkomi_stream_t s);

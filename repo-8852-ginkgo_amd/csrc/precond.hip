@@ -31,6 +31,25 @@ extern "C" int gkomi_ilu_apply_cb(void* ctx_, gkomi_stream_t s, const double* in
     // factors analysed at generate (LowerTrs / UpperTrs::generate): the brick plan where the factor
     // has one, else the level-scheduled solve, else the analysis-free kernel
     int err;
+    if (c->l_bricks != nullptr && c->u_bricks != nullptr && c->nrhs == 1 && in != out) {
+        // both factors on the brick plan, one column: the two solves are a chain -- the lower solve's bricks arm
+        // `out` for the upper solve, the upper solve's bricks re-arm the intermediate vector for the next apply,
+        // and neither needs a launch that pre-fills its output with the sentinel (2 x ~6 us per apply).  The
+        // intermediate vector is armed the ordinary way the first time (state in the context record).
+        gkomi_ilu_ctx* state = static_cast<gkomi_ilu_ctx*>(ctx_);
+        const bool armed = state->pad_ == 1;
+        state->pad_ = 0;
+        err = gkomi::trs_bricks_solve_chained(s, static_cast<gkomi_trs_bricks*>(c->l_bricks), c->l_bricks_plan, c->l_unit_diag, in,
+                                              c->intermediate, armed, out, nullptr);
+        if (err == GKOMI_SUCCESS) {
+            err = gkomi::trs_bricks_solve_chained(s, static_cast<gkomi_trs_bricks*>(c->u_bricks), c->u_bricks_plan, 0, c->intermediate,
+                                                  out, true, nullptr, c->intermediate);
+            if (err == GKOMI_SUCCESS) state->pad_ = 1;
+            if (err != GKOMI_ENOTSUPPORTED) return err;
+            return gkomi_trs_bricks_solve_f64(s, c->u_bricks, c->u_bricks_plan, 1, 0, c->intermediate, 1, out, 1);
+        }
+        if (err != GKOMI_ENOTSUPPORTED) return err;
+    }
     if (c->l_bricks != nullptr) {
         err = gkomi_trs_bricks_solve_f64(s, c->l_bricks, c->l_bricks_plan, c->nrhs, c->l_unit_diag, in, c->nrhs,
                                          c->intermediate, c->nrhs);

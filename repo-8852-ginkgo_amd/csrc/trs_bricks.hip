@@ -30,7 +30,7 @@
 // brick graph, so the bricks a workgroup waits for belong to workgroups that have started; waits
 // are bounded and a brick that gives up poisons its rows (NaN), marks itself finished (no
 // cascade of timeouts) and raises a STICKY flag.
-#include "common.hpp"
+#include "internal.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -669,11 +669,17 @@ __global__ __launch_bounds__(256) void ana_offsets_kernel(int n, int lower, cons
                                                           const int32_t* __restrict__ ci, unsigned long long* table,
                                                           int* width, int* too_many)
 {
-    // a snapshot of the table first: once the first waves have entered the (few) offsets, every later row
-    // finds all of its own in the snapshot and touches nothing shared
+    // the workgroup collects its offsets in LDS (a handful of distinct values: after the first few rows every
+    // lookup is a hit in the lane's own snapshot) and merges them into the global table once, at its end --
+    // half a million lanes compare-and-swapping the same three global words took 1.6 ms of a 2.6 ms analysis
+    __shared__ unsigned long long local[max_offsets];
+    __shared__ int s_too_many;
+    if (threadIdx.x < max_offsets) local[threadIdx.x] = ana_empty;
+    if (threadIdx.x == 0) s_too_many = 0;
+    __syncthreads();
     unsigned long long seen[max_offsets];
 #pragma unroll
-    for (int j = 0; j < max_offsets; ++j) seen[j] = __hip_atomic_load(table + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < max_offsets; ++j) seen[j] = ana_empty;
     int widest = 0;
     for (int row = blockIdx.x * 256 + threadIdx.x; row < n; row += gridDim.x * 256) {
         int deps = 0;
@@ -687,21 +693,36 @@ __global__ __launch_bounds__(256) void ana_offsets_kernel(int n, int lower, cons
             for (int j = 0; j < max_offsets; ++j) found = found || seen[j] == d;
             if (found) continue;
             for (int j = 0; j < max_offsets && !found; ++j) {
-                unsigned long long cur = __hip_atomic_load(table + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long cur = local[j];
                 if (cur == ana_empty) {
-                    const unsigned long long old = atomicCAS(table + j, ana_empty, d);
+                    const unsigned long long old = atomicCAS(&local[j], ana_empty, d);
                     cur = old == ana_empty ? d : old;
                 }
                 seen[j] = cur;
                 found = cur == d;
             }
-            if (!found) atomicExch(too_many, 1);
+            if (!found) s_too_many = 1;
         }
         widest = max(widest, deps);
     }
     widest = max(widest, __shfl_xor(widest, 32, 64));
     for (int off = 16; off > 0; off >>= 1) widest = max(widest, __shfl_xor(widest, off, 64));
     if ((threadIdx.x & 63) == 0 && widest > 0) atomicMax(width, widest);
+    __syncthreads();
+    if (threadIdx.x < max_offsets && local[threadIdx.x] != ana_empty) {
+        const unsigned long long d = local[threadIdx.x];
+        bool found = false;
+        for (int j = 0; j < max_offsets && !found; ++j) {
+            unsigned long long cur = __hip_atomic_load(table + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == ana_empty) {
+                const unsigned long long old = atomicCAS(table + j, ana_empty, d);
+                cur = old == ana_empty ? d : old;
+            }
+            found = cur == d;
+        }
+        if (!found) atomicExch(too_many, 1);
+    }
+    if (threadIdx.x == 0 && s_too_many) atomicExch(too_many, 1);
 }
 
 // per brick, in this order: rows, inflow entries, levels, steps with 64 / 128 / 256 threads, widest level,
@@ -1642,7 +1663,7 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
     const int32_t* __restrict__ ext_col, const int32_t* __restrict__ ext_row_off, int32_t n,
     const double* __restrict__ b, int64_t b_stride, double* x, int64_t x_stride, long long max_polls,
     int nap_max, const char* __restrict__ image, const int64_t* __restrict__ image_off,
-    long long* __restrict__ stamps = nullptr, int stamp_brick = 0)
+    long long* __restrict__ stamps = nullptr, int stamp_brick = 0, double* arm = nullptr, double* rearm_b = nullptr)
 {
     constexpr int T = 64;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1711,6 +1732,20 @@ __global__ __launch_bounds__(128) void trs_brick_pipelined_kernel(
             lx[scratch_cell] = 0.0;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the image has landed
+        // Chained solves (Ilu = L^-1 then U^-1, precond.hip): instead of a launch that pre-fills the NEXT solve's
+        // output with the sentinel, every brick arms its own rows of it here -- `arm` (the lower solve arms the
+        // upper solve's output) -- and, having read its right-hand side, re-arms those rows for the solve that
+        // will write them next -- `rearm_b` (the upper solve re-arms the intermediate vector for the next apply).
+        // Behind the wait above: the loads of b have returned before their cells are overwritten.
+        if (arm != nullptr || rearm_b != nullptr) {
+#pragma unroll
+            for (int u = 0; u < gather_max; ++u) {
+                if (tid + 128 * u < rows) {
+                    if (arm != nullptr) reinterpret_cast<unsigned long long*>(arm)[my_row[u] * x_stride] = sentinel_bits;
+                    if (rearm_b != nullptr) reinterpret_cast<unsigned long long*>(rearm_b)[my_row[u] * b_stride] = sentinel_bits;
+                }
+            }
+        }
     }
     __syncthreads();
     if (x_stride != 1) {  // the image holds row * 8: the store offsets of a strided x
@@ -2232,7 +2267,8 @@ int launch_solve(hipStream_t stream, gkomi_trs_bricks* h, char* p, const brick_l
 
 template <int K, bool Unit>
 int launch_pipelined(hipStream_t stream, gkomi_trs_bricks* h, char* p, const brick_layout& l, const double* b,
-                     int64_t b_stride, double* x, int64_t x_stride, long long max_polls)
+                     int64_t b_stride, double* x, int64_t x_stride, long long max_polls, bool x_is_armed = false,
+                     double* arm = nullptr, double* rearm_b = nullptr)
 {
     const size_t lds_bytes = static_cast<size_t>(h->lds_bytes_max > 0 ? h->lds_bytes_max : 16);
     if (lds_bytes > 64 * 1024) {
@@ -2243,7 +2279,9 @@ int launch_pipelined(hipStream_t stream, gkomi_trs_bricks* h, char* p, const bri
     }
     const char* env_nap = getenv("GKOMI_TRS_BRICK_NAP");  // tuning knob (tools/trs_bricks_probe.py)
     const int nap_max = env_nap != nullptr && env_nap[0] != 0 ? std::max(1, atoi(env_nap)) : 8;
-    hipLaunchKernelGGL(trs_brick_prepare_kernel, dim3(grid_for(h->n, 256)), dim3(256), 0, stream, h->n, x, x_stride);
+    if (!x_is_armed) {
+        hipLaunchKernelGGL(trs_brick_prepare_kernel, dim3(grid_for(h->n, 256)), dim3(256), 0, stream, h->n, x, x_stride);
+    }
     const char* env_stamps = getenv("GKOMI_TRS_BRICK_STAMPS");  // tools/trs_bricks_probe.py stamps
     if (!Unit && env_stamps != nullptr && env_stamps[0] != 0) {
         if (lds_bytes > 64 * 1024) {
@@ -2276,18 +2314,20 @@ int launch_pipelined(hipStream_t stream, gkomi_trs_bricks* h, char* p, const bri
                        reinterpret_cast<const int32_t*>(p + l.brick_ext_begin),
                        reinterpret_cast<const int32_t*>(p + l.ext_col),
                        reinterpret_cast<const int32_t*>(p + l.ext_row_off), static_cast<int32_t>(h->n), b, b_stride, x,
-                       x_stride, max_polls, nap_max, p + l.image, reinterpret_cast<const int64_t*>(p + l.image_off));
+                       x_stride, max_polls, nap_max, p + l.image, reinterpret_cast<const int64_t*>(p + l.image_off),
+                       static_cast<long long*>(nullptr), 0, arm, rearm_b);
     return check_launch();
 }
 
 template <bool Unit>
 int launch_pipelined_width(hipStream_t stream, gkomi_trs_bricks* h, char* p, const brick_layout& l, const double* b,
-                           int64_t b_stride, double* x, int64_t x_stride, long long max_polls)
+                           int64_t b_stride, double* x, int64_t x_stride, long long max_polls, bool x_is_armed = false,
+                           double* arm = nullptr, double* rearm_b = nullptr)
 {
-    if (h->width <= 2) return launch_pipelined<2, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
-    if (h->width <= 3) return launch_pipelined<3, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
-    if (h->width <= 4) return launch_pipelined<4, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
-    return launch_pipelined<8, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls);
+    if (h->width <= 2) return launch_pipelined<2, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls, x_is_armed, arm, rearm_b);
+    if (h->width <= 3) return launch_pipelined<3, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls, x_is_armed, arm, rearm_b);
+    if (h->width <= 4) return launch_pipelined<4, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls, x_is_armed, arm, rearm_b);
+    return launch_pipelined<8, Unit>(stream, h, p, l, b, b_stride, x, x_stride, max_polls, x_is_armed, arm, rearm_b);
 }
 
 template <int T, bool Unit>
@@ -2342,6 +2382,25 @@ extern "C" int gkomi_trs_bricks_solve_f64(gkomi_stream_t s, gkomi_trs_bricks* h,
         if (err) return err;
     }
     return GKOMI_SUCCESS;
+}
+
+// One solve of a CHAIN of brick solves on contiguous vectors (internal.hpp; precond.hip chains L^-1 and U^-1):
+// x_is_armed = x already holds the sentinel in every row (no pre-fill launch); arm = a vector whose rows every
+// brick arms for a later solve; rearm_b = b itself, re-armed row by row once it has been read.
+// GKOMI_ENOTSUPPORTED when the plan is not the pipelined one (the caller takes the ordinary entry).
+int gkomi::trs_bricks_solve_chained(gkomi_stream_t s, gkomi_trs_bricks* h, void* plan, int unit_diag, const double* b,
+                                    double* x, bool x_is_armed, double* arm, double* rearm_b)
+{
+    if (h == nullptr || plan == nullptr) return GKOMI_EINVAL;
+    if (h->uploaded_to != plan) return GKOMI_EINVAL;
+    if (h->mode != 2 || x == b || h->n * 8 > INT32_MAX) return GKOMI_ENOTSUPPORTED;
+    const brick_layout l = make_layout(*h);
+    static const long long max_polls_default = default_max_polls;
+    const char* env_polls = getenv("GKOMI_TRS_MAX_POLLS");
+    const long long max_polls = env_polls != nullptr && env_polls[0] != 0 ? atoll(env_polls) : max_polls_default;
+    char* p = static_cast<char*>(plan);
+    return unit_diag != 0 ? launch_pipelined_width<true>(to_stream(s), h, p, l, b, 1, x, 1, max_polls, x_is_armed, arm, rearm_b)
+                          : launch_pipelined_width<false>(to_stream(s), h, p, l, b, 1, x, 1, max_polls, x_is_armed, arm, rearm_b);
 }
 
 // tools only (not in gkomi.h): the stamps a solve under GKOMI_TRS_BRICK_STAMPS=<brick> left, 1024 entries:
