@@ -1089,7 +1089,10 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
     int variant = (strategy >> 8) & 0xff;
     bool no_swizzle = (strategy >> 16) & 1;
     const int chunk_code = (strategy >> 17) & 0x7f;  // XCD chunk = 2^(code-1) row blocks, 0 = one eighth each
-    const int chunk = chunk_code ? 1 << (chunk_code - 1) : 0;
+    int chunk = chunk_code ? 1 << (chunk_code - 1) : 0;
+    if (const char* e = getenv("GKOMI_CSR_XCD_CHUNK")) {  // experiments (tools/p3_chunk_sweep.py): any chunk size
+        if (e[0] != 0 && chunk_code == 127) chunk = std::max(1, atoi(e));
+    }
     int auto_chunk = 0;  // the automatic strategy's choice for matrices that stream from HBM
     const bool automatic = kind == GKOMI_CSR_AUTO;
     const bool aligned = (reinterpret_cast<uintptr_t>(vals) % 16 == 0) &&

@@ -20,11 +20,15 @@ y = torch.empty((n, 1), dtype=torch.float64, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 bytes_ = 12 * nnz + 4 * (n + 1) + 16 * n
 SPLIT, NT = 4, 2 << 8
+literal = [int(t) for t in os.environ.get("CHUNKS", "").split(",") if t]
 for tile in (3072, 2048):
     srow = torch.empty(int(gk.csr_srow_entries(nnz, tile)), dtype=torch.int32, device="cuda")
     gk.csr_make_srow_i32(s, n, nnz, a[0], tile, srow, srow.numel())
     ref = None
-    for name, word in [("no swizzle", SPLIT | NT | (1 << 16))] + [(f"chunk {1 << (c - 1)}", SPLIT | NT | (c << 17)) for c in (5, 7, 9, 10, 11, 12, 13)] + [("one eighth each", SPLIT | NT)]:
+    for name, word in [("no swizzle", SPLIT | NT | (1 << 16))] + [(f"chunk {1 << (c - 1)}", SPLIT | NT | (c << 17)) for c in (5, 7, 9, 10, 11, 12, 13)] + [(f"literal {c}", ("lit", c)) for c in literal] + [("one eighth each", SPLIT | NT)]:
+        if isinstance(word, tuple):
+            os.environ["GKOMI_CSR_XCD_CHUNK"] = str(word[1])
+            word = SPLIT | NT | (127 << 17)
         run = lambda: gk.csr_spmv_srow_f64_i32(s, n, n, 1, nnz, a[0], a[1], a[2], x, 1, y, 1, None, None, word, 7, srow, tile)
         for _ in range(3):
             run()
