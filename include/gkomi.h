@@ -772,6 +772,19 @@ size_t gkomi_cg_workspace_bytes(int64_t n, int64_t nrhs);
  * kernel boundaries (16 vs 31 us per iteration on the 1M-row Poisson matrix).
  * Everything else -- and a solve whose workgroups could not all be resident --
  * runs the three-launch iteration.  GKOMI_CG_PERSISTENT=0 disables it. */
+/* Diagnostics / test entries of the library's own device-wide stable radix sort and scans
+ * (csrc/sort_scan.hip: what device_matrix_data::sort_row_major, the level analysis of the
+ * triangular solves, Jacobi's block detection and build_local_nonlocal run -- no vendor
+ * library).  Sort: ascending by key bits [0, end_bit), stable, keys of key_bytes = 4 or 8
+ * bytes, optional 32-bit payloads (vals_in == NULL: keys only), outputs must not alias
+ * inputs.  Scan kind 0: exclusive sum, 1: inclusive maximum, of int32 (in == out allowed);
+ * its workspace: 4 bytes per 2048 items, rounded up to 256. */
+size_t gkomi_diag_radix_sort_workspace_bytes(int64_t n, int key_bytes, int pairs);
+int gkomi_diag_radix_sort(gkomi_stream_t s, int64_t n, int key_bytes, const void* keys_in,
+                          void* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                          int end_bit, void* workspace, size_t workspace_bytes);
+int gkomi_diag_scan_i32(gkomi_stream_t s, int kind, const int32_t* in, int32_t* out,
+                        int64_t n, void* workspace, size_t workspace_bytes);
 /* Diagnostics: a pure streaming kernel over the arrays of a CSR SpMV -- reads
  * vals, col_idxs, row_ptrs and b, writes c (c is OVERWRITTEN with meaningless
  * values), 16 B per lane, `blocks` workgroups of 256 threads, grid-stride --

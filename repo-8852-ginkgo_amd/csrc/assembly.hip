@@ -8,7 +8,7 @@
 // then convert_idxs_to_ptrs on the sorted row indices (core/matrix/csr.cpp:
 // 453-470, conversions.hip).
 //
-//  * sort_row_major: stable LSD radix sort (rocPRIM) of the 64-bit keys
+//  * sort_row_major: stable LSD radix sort (sort_scan.hip) of the 64-bit keys
 //    row << 32 | col carrying the entry's position, then one gather of the
 //    values.  The reference uses std::sort, which leaves the order of duplicate
 //    (row, col) entries unspecified; this sort keeps their input order.
@@ -23,7 +23,7 @@
 
 #include "common.hpp"
 
-#include <rocprim/device/device_radix_sort.hpp>
+#include "sort_scan.hpp"
 
 namespace gkomi {
 namespace {
@@ -36,16 +36,7 @@ struct layout {
     size_t keys_in, keys_out, idx_in, idx_out, vals, flags, scan_ws, sort_tmp, total;
 };
 
-size_t sort_tmp_bytes(int64_t nnz)
-{
-    size_t tmp = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp, static_cast<uint64_t*>(nullptr),
-                                    static_cast<uint64_t*>(nullptr),
-                                    static_cast<uint32_t*>(nullptr),
-                                    static_cast<uint32_t*>(nullptr), static_cast<size_t>(nnz), 0,
-                                    64, hipStream_t{nullptr});
-    return tmp;
-}
+size_t sort_tmp_bytes(int64_t nnz) { return radix_sort_workspace_bytes(nnz, sizeof(uint64_t), true); }
 
 layout make_layout(int64_t nnz)
 {
@@ -229,10 +220,8 @@ extern "C" int gkomi_matrix_data_sort_row_major_f64_i32(gkomi_stream_t s, int64_
     int err = static_cast<int>(hipMemcpyAsync(vals_copy, values, 8 * static_cast<size_t>(nnz),
                                               hipMemcpyDeviceToDevice, stream));
     if (err) return err;
-    size_t tmp_bytes = l.total - l.sort_tmp;
-    err = static_cast<int>(rocprim::radix_sort_pairs(ws + l.sort_tmp, tmp_bytes, keys_in, keys_out,
-                                                     idx_in, idx_out, static_cast<size_t>(nnz), 0,
-                                                     64, stream));
+    // stable LSD radix sort of the 64-bit (row, column) keys carrying the entry's position (sort_scan.hip)
+    err = radix_sort_u64(stream, nnz, keys_in, keys_out, idx_in, idx_out, 64, ws + l.sort_tmp, l.total - l.sort_tmp);
     if (err) return err;
     hipLaunchKernelGGL(apply_sort_kernel, grid, dim3(block), 0, stream, nnz, keys_out, idx_out,
                        vals_copy, row_idxs, col_idxs, values);

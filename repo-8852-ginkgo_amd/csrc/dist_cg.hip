@@ -21,7 +21,7 @@
 //         host looks every `check_every` iterations.
 #include "cg_fused.hpp"
 
-#include <rocprim/device/device_scan.hpp>
+#include "sort_scan.hpp"
 
 namespace gkomi {
 namespace {
@@ -143,10 +143,7 @@ extern "C" int gkomi_dist_ctx_destroy(gkomi_dist_ctx* c)
 extern "C" size_t gkomi_dist_nonlocal_rows_workspace_bytes(int64_t n_local)
 {
     if (n_local < 0) return 0;
-    size_t scan_bytes = 0;
-    (void)rocprim::exclusive_scan(nullptr, scan_bytes, static_cast<int32_t*>(nullptr),
-                                  static_cast<int32_t*>(nullptr), 0, static_cast<size_t>(n_local + 1),
-                                  rocprim::plus<int32_t>(), hipStreamDefault);
+    const size_t scan_bytes = scan_workspace_bytes(n_local + 1);
     return 2 * align_up(sizeof(int32_t) * (n_local + 1), 256) + align_up(scan_bytes, 256) + 256;
 }
 
@@ -172,9 +169,7 @@ extern "C" int gkomi_dist_nonlocal_rows_i32(gkomi_stream_t s, int64_t n_local, c
     const int n = static_cast<int>(n_local);
     const dim3 grid(static_cast<unsigned>(ceildiv(n_local + 1, 256)));
     hipLaunchKernelGGL(dist_flag_rows_kernel, grid, dim3(256), 0, stream, n, row_ptrs, flag);
-    GKOMI_TRY(static_cast<int>(rocprim::exclusive_scan(tmp, tmp_bytes, flag, pos, 0,
-                                                       static_cast<size_t>(n_local + 1),
-                                                       rocprim::plus<int32_t>(), stream)));
+    GKOMI_TRY(exclusive_sum_i32(stream, flag, pos, n_local + 1, tmp, tmp_bytes));
     hipLaunchKernelGGL(dist_compact_rows_kernel, grid, dim3(256), 0, stream, n, row_ptrs, pos, row_idxs_out,
                        compact_ptrs_out);
     int32_t count = 0;

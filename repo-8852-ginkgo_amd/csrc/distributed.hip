@@ -12,13 +12,13 @@
 // the communication plan.  build_local_nonlocal works on the device-resident
 // COO input: classify -> exclusive scans -> stable compaction; the non-local
 // columns are renumbered by sorting the 64-bit keys (owning part << 40 | global
-// column) with rocPRIM's radix sort, unique-ing with a flag scan and binary
+// column) with the library's radix sort (sort_scan.hip), unique-ing with a flag scan and binary
 // searching each entry's key.  All integer work: bit-exact.
 #include <cstring>
 
 #include "common.hpp"
 
-#include <rocprim/device/device_radix_sort.hpp>
+#include "sort_scan.hpp"
 
 #include <algorithm>
 
@@ -173,11 +173,7 @@ dist_layout make_layout(int64_t nnz)
     l.unique_pos = off; off += align_up(8 * n1, 256);
     l.unique_keys = off; off += align_up(8 * n1, 256);
     l.scan = off; off += align_up(gkomi_prefix_sum_workspace_bytes(nnz + 1) + 8, 256);
-    size_t tmp = 0;
-    if (nnz > 0) {
-        (void)rocprim::radix_sort_keys(nullptr, tmp, static_cast<uint64_t*>(nullptr),
-                                 static_cast<uint64_t*>(nullptr), static_cast<size_t>(nnz), 0, 64);
-    }
+    const size_t tmp = nnz > 0 ? radix_sort_workspace_bytes(nnz, sizeof(uint64_t), false) : 0;
     l.sort_tmp_bytes = tmp;
     l.sort_tmp = off; off += align_up(tmp + 8, 256);
     l.total = off;
@@ -300,8 +296,8 @@ extern "C" int gkomi_dist_build_local_nonlocal_sizes(
     if (err) return err;
     if (nnz > 0) {
         size_t tmp_bytes = l.sort_tmp_bytes;
-        err = static_cast<int>(rocprim::radix_sort_keys(ws + l.sort_tmp, tmp_bytes, keys, sorted,
-                                                        static_cast<size_t>(nnz), 0, 64, stream));
+        // keys = part << 40 | global column: 64-bit stable radix sort (sort_scan.hip)
+        err = radix_sort_u64(stream, nnz, keys, sorted, nullptr, nullptr, 64, ws + l.sort_tmp, tmp_bytes);
         if (err) return err;
     }
     hipLaunchKernelGGL(unique_flag_kernel, dim3(grid_for(nnz + 1, block)), dim3(block), 0, stream,

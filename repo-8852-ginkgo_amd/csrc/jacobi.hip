@@ -28,8 +28,7 @@
 
 #include "common.hpp"
 
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/functional.hpp>
+#include "sort_scan.hpp"
 
 namespace gkomi {
 namespace {
@@ -190,9 +189,7 @@ fb_layout make_fb_layout(int64_t nrows)
     l.flags = take(4 * (n + 1));
     l.exits = take(4 * 32 * nchunks);
     l.entry = take(4 * (nchunks + 1));
-    size_t tmp = 0;
-    (void)rocprim::inclusive_scan(nullptr, tmp, static_cast<int*>(nullptr), static_cast<int*>(nullptr), n,
-                                  rocprim::maximum<int>(), hipStream_t{nullptr});
+    const size_t tmp = scan_workspace_bytes(n);
     l.scan_tmp_bytes = tmp;
     l.scan_tmp = take(tmp);
     l.psum_bytes = gkomi_prefix_sum_workspace_bytes(static_cast<int64_t>(n) + 1);
@@ -758,16 +755,12 @@ extern "C" int gkomi_jacobi_find_blocks_i32(gkomi_stream_t s, int64_t nrows,
                            0, stream, nrows, row_ptrs, col_idxs, same);
         hipLaunchKernelGGL(fb_run_start_values_kernel, grid_n, dim3(block), 0, stream, n, same, a);
         size_t tmp_bytes = l.scan_tmp_bytes;
-        err = static_cast<int>(rocprim::inclusive_scan(ws + l.scan_tmp, tmp_bytes, a, a,
-                                                       static_cast<size_t>(n),
-                                                       rocprim::maximum<int>(), stream));
+        err = inclusive_max_i32(stream, a, a, n, ws + l.scan_tmp, tmp_bytes);
         if (err) return err;
         hipLaunchKernelGGL(fb_natural_values_kernel, grid_n, dim3(block), 0, stream, n,
                            max_block_size, a);
         tmp_bytes = l.scan_tmp_bytes;
-        err = static_cast<int>(rocprim::inclusive_scan(ws + l.scan_tmp, tmp_bytes, a, a,
-                                                       static_cast<size_t>(n),
-                                                       rocprim::maximum<int>(), stream));
+        err = inclusive_max_i32(stream, a, a, n, ws + l.scan_tmp, tmp_bytes);
         if (err) return err;
         err = static_cast<int>(hipMemsetAsync(flags, 0, sizeof(int) * (static_cast<size_t>(n) + 1), stream));
         if (err) return err;

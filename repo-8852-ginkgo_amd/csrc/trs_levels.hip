@@ -38,8 +38,7 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
+#include "sort_scan.hpp"
 
 namespace gkomi {
 namespace {
@@ -92,7 +91,7 @@ plan_layout make_plan_layout(int64_t nslices, int64_t entries)
 }
 
 // symbolic workspace: levels[n] | sorted levels[n] | rows[n] | perm[n] | dep count[n] |
-// slice_len[nslices + 1] | slice_off[nslices + 1] | flags | rocPRIM temporary
+// slice_len[nslices + 1] | slice_off[nslices + 1] | flags | sort / scan scratch
 struct symbolic_layout {
     size_t level, level_sorted, rows, perm, cnt, slice_len, slice_off, flags, tmp, tmp_bytes, total;
 };
@@ -111,15 +110,8 @@ symbolic_layout make_symbolic_layout(int64_t n)
     l.slice_len = off; off += align_up(sizeof(int32_t) * (nslices + 1), 256);
     l.slice_off = off; off += align_up(sizeof(int32_t) * (nslices + 1), 256);
     l.flags = off; off += 256;
-    size_t sort_bytes = 0, scan_bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, static_cast<int32_t*>(nullptr),
-                                    static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
-                                    static_cast<int32_t*>(nullptr), static_cast<size_t>(n > 0 ? n : 1), 0,
-                                    32, hipStreamDefault);
-    (void)rocprim::exclusive_scan(nullptr, scan_bytes, static_cast<int32_t*>(nullptr),
-                                  static_cast<int32_t*>(nullptr), 0,
-                                  static_cast<size_t>(nslices + 1), rocprim::plus<int32_t>(),
-                                  hipStreamDefault);
+    const size_t sort_bytes = radix_sort_workspace_bytes(n > 0 ? n : 1, sizeof(uint32_t), true);
+    const size_t scan_bytes = scan_workspace_bytes(nslices + 1);
     l.tmp_bytes = align_up(sort_bytes > scan_bytes ? sort_bytes : scan_bytes, 256) + 256;
     l.tmp = off; off += l.tmp_bytes;
     l.total = off;
@@ -462,16 +454,15 @@ int analyse_symbolic(hipStream_t stream, int64_t n, const int32_t* row_ptrs, con
     hipLaunchKernelGGL(trs_iota_kernel, grid, dim3(256), 0, stream, n32, rows);
     size_t tmp_bytes = l.tmp_bytes;
     // stable: rows of one level keep their storage order (deterministic layout)
-    err = static_cast<int>(rocprim::radix_sort_pairs(ws + l.tmp, tmp_bytes, level, level_sorted, rows, perm,
-                                                     static_cast<size_t>(n), 0, 32, stream));
+    // (levels are non-negative: their order as unsigned 32-bit keys is their order; sort_scan.hip)
+    err = radix_sort_u32(stream, n, reinterpret_cast<const uint32_t*>(level), reinterpret_cast<uint32_t*>(level_sorted),
+                         reinterpret_cast<const uint32_t*>(rows), reinterpret_cast<uint32_t*>(perm), 32, ws + l.tmp, tmp_bytes);
     if (err) return err;
     hipLaunchKernelGGL(trs_invert_perm_kernel, grid, dim3(256), 0, stream, n32, perm, rows);  // rows := inverse
     hipLaunchKernelGGL(trs_slice_len_kernel, dim3(static_cast<unsigned>(ceildiv(nslices + 1, 4))), dim3(256),
                        0, stream, n32, nslices, perm, cnt, slice_len, level_sorted, flags + 1);
     tmp_bytes = l.tmp_bytes;
-    err = static_cast<int>(rocprim::exclusive_scan(ws + l.tmp, tmp_bytes, slice_len, slice_off, 0,
-                                                   static_cast<size_t>(nslices + 1),
-                                                   rocprim::plus<int32_t>(), stream));
+    err = exclusive_sum_i32(stream, slice_len, slice_off, nslices + 1, ws + l.tmp, tmp_bytes);
     if (err) return err;
     int32_t h[3] = {0, 0, 0};
     err = static_cast<int>(hipMemcpyAsync(&h[0], slice_off + nslices, sizeof(int32_t), hipMemcpyDeviceToHost, stream));

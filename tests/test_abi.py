@@ -30,7 +30,7 @@ def test_no_torch_types_in_abi():
     # signatures only (comments cite C++ names of the reference)
     for name, (ret, params) in gkomi.parse_header().items():
         for ctype, _, _ in params:
-            assert ctype in ("int", "int32_t", "int64_t", "uint8_t", "uint64_t", "size_t", "double",
+            assert ctype in ("int", "int32_t", "int64_t", "uint8_t", "uint32_t", "uint64_t", "size_t", "double",
                              "float", "void", "gkomi_stream_t", "gkomi_apply_fn", "gkomi_matrix_apply_fn", "char",
                              # plain C records of the ABI itself (pointers and sizes, declared in gkomi.h)
                              "gkomi_comm", "gkomi_dist_matrix", "gkomi_dist_ctx",
