@@ -484,12 +484,22 @@ def main():
             res, el, all_s = timed_cg(A2, b)
             single_launch = gk.cg_persistent_solves() > before
             res3, el3, all_s3 = timed_cg(A2, b, single_launch=False)
+            # steady state of the three-launch iteration: 400 iterations that cannot converge (reduction 1e-30), so that
+            # set-up (r = b - A x, baseline norm) and the launches issued after the stop do not weigh on the figure
+            gk.cg_persistent_enable(0)
+            try:
+                r400, el400, _ = timed_solves(lambda: solvers.solve_op(gk, "cg", A2, b, max_iters=400, reduction=1e-30,
+                                                                       check_every=32, fused=True))
+            finally:
+                gk.cg_persistent_enable(1)
             out["cg"] = {"metric": "CG iters/sec to 1e-10 (fused driver, Identity preconditioner, sinus rhs "
                                    "b = A s/|s|, benchmark/solver default)",
                          "driver": ("single launch: x, r, p and the matrix (rows <= 5 nonzeros) stay in the register "
                                     "files, three device-wide meetings per iteration (csrc/cg_persistent.hpp)")
                          if single_launch else "three launches per iteration",
                          "three_launch_driver": dict(cg_entry(res3, el3, all_s3),
+                                                     steady_state_us_per_iteration=round(el400 / max(r400["iterations"], 1) * 1e6, 2),
+                                                     steady_state_note="400 iterations with reduction 1e-30: no set-up share, no launches after the stop",
                                                      spmv_kernel="csr_split_kernel<Dot> over the matrix's srow",
                                                      achieved_gbs=round(cg_bytes * res3["iterations"] / el3 / 1e9, 1)),
                          "timing": "median of 3 solves",
