@@ -205,6 +205,109 @@ __device__ __forceinline__ bool pcg_meet(pcg_slot* slots, int stride, int nap, i
     return true;
 }
 
+// A meeting over NV values at once (the blocked Gram-Schmidt sweep of gmres.hip): workgroup w's values in the NV
+// slots behind its own, the totals in the NV slots behind each copy.  lsum[0 .. NV): in = this workgroup's sums, out =
+// the totals (the same bits in every workgroup: workgroup 0 adds in a fixed order, once).  lred: (Block / 64) * NV + 1
+// doubles; lval: nwg * NV doubles of scratch (workgroup 0 only).  The polls of workgroup 0 are plain agent-scope loads of the two words of a slot -- all 2 NV in flight
+// together; a pair that does not fit the meeting (stale, torn) is asked for again, as in pcg_fetch.
+template <int Block, int NV>
+__device__ __forceinline__ bool pcg_meet_values(pcg_slot* slots, int stride, int nap, int nwg, long long meeting,
+                                                double* lsum, double* lred, double* lval, pcg_control* ctl,
+                                                long long max_polls)
+{
+    static_assert(NV <= pcg_default_stride, "a workgroup's values share its slot line");
+    static_assert(pcg_copies * NV <= Block, "one thread per copy and value");
+    constexpr int nwaves = Block / wave_size;
+    const int tid = threadIdx.x;
+    pcg_slot* bank = slots + (meeting & 1) * static_cast<int64_t>(nwg + pcg_copies) * stride;
+    pcg_slot* back = bank + static_cast<int64_t>(nwg) * stride;
+    if (tid < NV) pcg_publish(bank + blockIdx.x * stride + tid, lsum[tid], meeting);
+    if (tid == 0) lred[nwaves * NV] = 1.0;  // "nobody gave up"
+    pcg_sync_lds();
+    const unsigned long long key = pcg_key(meeting);
+    bool ok = true;
+    if (blockIdx.x == 0) {
+        // pair p = (workgroup p / NV, value p % NV); U pairs per thread in flight together, the values into lval
+        constexpr int U = 5;
+        const int npairs = nwg * NV;
+        for (int base = 0; base < npairs && ok; base += U * Block) {
+            unsigned int pending = 0u;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (base + u * Block + tid < npairs) pending |= 1u << u;
+            }
+            long long polls = 0;
+            while (pending != 0u) {
+                unsigned long long bits[U], chk[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if ((pending >> u) & 1u) {
+                        const int pr = base + u * Block + tid;
+                        const pcg_slot* slot = bank + (pr / NV) * stride + pr % NV;
+                        bits[u] = __hip_atomic_load(&slot->v_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        chk[u] = __hip_atomic_load(&slot->check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (((pending >> u) & 1u) && (bits[u] ^ chk[u]) == key) {
+                        lval[base + u * Block + tid] = __longlong_as_double(static_cast<long long>(bits[u]));
+                        pending &= ~(1u << u);
+                    }
+                }
+                if (pending != 0u) {
+                    for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(1);
+                    if (++polls > max_polls ||
+                        ((polls & 255) == 0 &&
+                         __hip_atomic_load(&ctl->overrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        ok = false;
+                        break;
+                    }
+                }
+            }
+        }
+        if (!ok) lred[nwaves * NV] = 0.0;
+        pcg_sync_lds();
+        ok = lred[nwaves * NV] != 0.0;
+        // value v: workgroups lane, lane + 64, ... in order, then the wave's fixed tree
+        if (ok) {
+            for (int v = tid >> 6; v < NV; v += nwaves) {
+                double t = 0.0;
+                for (int g = tid & 63; g < nwg; g += wave_size) t += lval[g * NV + v];
+                t = wave_reduce_sum(t);
+                if ((tid & 63) == 0) lsum[v] = t;
+            }
+        }
+        pcg_sync_lds();
+        ok = lred[nwaves * NV] != 0.0;
+        if (ok && tid < pcg_copies * NV) pcg_publish(back + (tid / NV) * stride + tid % NV, lsum[tid % NV], meeting);
+    } else {
+        if (tid < NV) {
+            double total = 0.0;
+            long long polls = 0;
+            while (!pcg_fetch(back + (blockIdx.x % pcg_copies) * stride + tid, meeting, &total)) {
+                for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(1);
+                if (++polls > max_polls ||
+                    ((polls & 255) == 0 &&
+                     __hip_atomic_load(&ctl->overrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    lred[nwaves * NV] = 0.0;
+                    total = 0.0;
+                    break;
+                }
+            }
+            lsum[tid] = total;
+        }
+        pcg_sync_lds();
+        ok = lred[nwaves * NV] != 0.0;
+    }
+    pcg_sync_lds();  // lred is free again, lsum holds the totals
+    if (!ok) {
+        if (tid == 0) __hip_atomic_store(&ctl->overrun, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    return true;
+}
+
 // a meeting without a value: "everybody's p is in memory"
 template <int Block>
 __device__ __forceinline__ bool pcg_barrier(pcg_slot* slots, int stride, int nap, int nwg, long long meeting,

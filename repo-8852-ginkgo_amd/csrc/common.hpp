@@ -40,6 +40,21 @@ __device__ __forceinline__ bool status_has_stopped(uint8_t s)
     return (s & GKOMI_STATUS_ID_MASK) != 0;
 }
 
+// The same question for a status byte every lane of the workgroup asks about, answered through the SCALAR cache: the
+// aligned word around the byte is a uniform, read-only load the compiler turns into s_load_dword (gfx950 has no scalar
+// byte load, so status[0] itself goes down the vector-memory pipe and queues behind the streaming loads of the other
+// workgroups on the compute unit -- about 1 us in front of every workgroup of a bandwidth-bound launch,
+// profiles/r03_p3_cg_kernels.md).  Status arrays are device allocations, so the word around a byte is inside them.
+__device__ __forceinline__ bool status_has_stopped_uniform(const uint8_t* __restrict__ status)
+{
+    // (constant address space = same addresses as global, not written while the kernel runs: what makes the load
+    // eligible for the scalar unit after the detour through an integer)
+    using scalar_word = const uint32_t __attribute__((address_space(4)));
+    const uintptr_t at = reinterpret_cast<uintptr_t>(status);
+    const uint32_t word = *reinterpret_cast<scalar_word*>(at & ~uintptr_t{3});
+    return status_has_stopped(static_cast<uint8_t>(word >> (8 * (at & 3))));
+}
+
 // full-wave sum via DPP/shuffles; every lane gets the total.  The order of
 // the tree is fixed, so results are run-to-run reproducible.
 __device__ __forceinline__ double wave_reduce_sum(double v)

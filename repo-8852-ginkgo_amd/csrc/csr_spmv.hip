@@ -86,7 +86,7 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
     const int logical =
         Swizzle ? xcd_chunked_block(blockIdx.x, per_xcd) : blockIdx.x;
     if (logical >= nblocks) return;
-    if (Dot && status_has_stopped(stop_status[0])) return;
+    if (Dot && status_has_stopped_uniform(stop_status)) return;
     // rhs column handled by this grid row
     b += blockIdx.y;
     c += blockIdx.y;
@@ -106,14 +106,21 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
 
     int ra[RowsPerThread], rb[RowsPerThread];
     double sum[RowsPerThread];
+    // Dot: partials of w . c (w = b unless given: CG's p.q, BiCGSTAB's rr.v and s.t) and, on request, of c . c
+    // (BiCGSTAB's t.t).  w's entries for my rows are asked for up here, not at the end of the workgroup.
+    const double* w = Dot && dot_w != nullptr ? dot_w : b;
+    const int64_t w_stride = Dot && dot_w != nullptr ? 1 : b_stride;
+    double wv[RowsPerThread];
 #pragma unroll
     for (int i = 0; i < RowsPerThread; ++i) {
         const int row = r0 + tid + i * Block;
+        wv[i] = 0.0;
         if (row < r1) {
             ra[i] = row_ptrs[row];
             rb[i] = row_ptrs[row + 1];
             // advanced: c = beta*c first, then accumulate (reference :119-126)
             sum[i] = Advanced ? c[row * c_stride] * beta : 0.0;
+            if (Dot) wv[i] = w[row * w_stride];
         } else {
             ra[i] = rb[i] = p1;
             sum[i] = 0.0;
@@ -192,17 +199,13 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
     }
 
     double pq = 0.0, qq = 0.0;
-    // Dot: partials of w . c (w = b unless given: CG's p.q, BiCGSTAB's rr.v and
-    // s.t) and, on request, of c . c (BiCGSTAB's t.t)
-    const double* w = Dot && dot_w != nullptr ? dot_w : b;
-    const int64_t w_stride = Dot && dot_w != nullptr ? 1 : b_stride;
 #pragma unroll
     for (int i = 0; i < RowsPerThread; ++i) {
         const int row = r0 + tid + i * Block;
         if (row < r1) {
             c[row * c_stride] = sum[i];
             if (Dot) {
-                pq += w[row * w_stride] * sum[i];
+                pq += wv[i] * sum[i];
                 qq += sum[i] * sum[i];
             }
         }
@@ -252,6 +255,11 @@ __device__ __forceinline__ double add_products(double sum, const double* prod, i
 // bit-identical to the reference for any row lengths, no atomics, no carries.
 // col_idxs are requested before vals: vector-memory results return in order,
 // so the gathers of b start while the values are still in flight.
+// tools/dot_probe.hip only: leaves parts of the dot epilogue out (bit 0 the status check, bit 1 the load of the other
+// factor, bit 2 the reduction across the workgroup) to price them one by one.  0 in the product.
+#ifndef GKOMI_DOT_PROBE
+#define GKOMI_DOT_PROBE 0
+#endif
 template <int Block, int Tile, int MaxOver, bool Advanced, bool Swizzle,
           bool Dot = false, bool NT = false, bool ColsFirst = true>
 __global__ __launch_bounds__(Block) void csr_split_kernel(
@@ -293,7 +301,6 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
     const int logical =
         Swizzle ? xcd_chunked_block(blockIdx.x, per_xcd) : blockIdx.x;
     if (logical >= ntiles) return;
-    if (Dot && status_has_stopped(stop_status[0])) return;
     b += blockIdx.y;
     c += blockIdx.y;
     const int tid = threadIdx.x;
@@ -305,6 +312,10 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
         stamps[8 * logical + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
     }
 #endif
+    // a solve that has stopped needs nothing from this launch; asked through the scalar cache (a byte load queues in
+    // the vector-memory pipe in front of every workgroup's streaming loads: 25 us of a 323-us launch on the 256^3
+    // matrix -- wherever the check stands in the source, the compiler sinks the loads behind its branch)
+    if (Dot && !(GKOMI_DOT_PROBE & 1) && status_has_stopped_uniform(stop_status)) return;
     // the rows that start in this tile (scalar loads, back long before the
     // streaming loads below)
     const int row_begin = srow[logical];
@@ -357,6 +368,12 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
     // 5-pt stencil starts 307 rows); more rounds re-read row_ptrs on demand
     int ra[2], rb[2];
     double c0[2];
+    // dot epilogue: the other factor of w . (A b) for my rows, asked for NOW -- behind the barrier it is one more
+    // dependent round trip at the end of every workgroup (28 us of a 326-us launch on the 256^3 matrix,
+    // profiles/r03_p3_cg_kernels.md)
+    const double* w = Dot && dot_w != nullptr ? dot_w : b;
+    const int64_t w_stride = Dot && dot_w != nullptr ? 1 : b_stride;
+    double wv[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         // (kept under its own branch up here: loaded unconditionally, the
@@ -364,11 +381,13 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
         const int row = row_begin + tid + i * Block;
         ra[i] = rb[i] = t0;
         c0[i] = 0.0;
+        wv[i] = 0.0;
         if (row < row_end) {
             ra[i] = NT ? __builtin_nontemporal_load(row_ptrs + row) : row_ptrs[row];
             rb[i] = NT ? __builtin_nontemporal_load(row_ptrs + row + 1) : row_ptrs[row + 1];
             // advanced: c = beta*c first, then accumulate (reference :119-126)
             if (Advanced) c0[i] = c[row * c_stride];
+            if (Dot) wv[i] = (GKOMI_DOT_PROBE & 2) ? 1.0 : w[row * w_stride];
         }
     }
 
@@ -403,8 +422,6 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
     GKOMI_STAMP(2);
 
     // 4) one thread per row, left to right
-    const double* w = Dot && dot_w != nullptr ? dot_w : b;
-    const int64_t w_stride = Dot && dot_w != nullptr ? 1 : b_stride;
     double pq = 0.0, qq = 0.0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -421,7 +438,7 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
                 sum += val * b[col_idxs[t0 + k] * b_stride];
             }
             if (Dot) {
-                pq += w[row * w_stride] * sum;
+                pq += wv[i] * sum;
                 qq += sum * sum;
             }
         }
@@ -443,7 +460,9 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
         }
     }
     GKOMI_STAMP(3);
-    if (Dot) {
+    if (Dot && (GKOMI_DOT_PROBE & 4)) {
+        if (tid == 0) dot_partial[logical] = pq;
+    } else if (Dot) {
         __shared__ double red[Block / wave_size];
         __syncthreads();
         const double total = block_reduce_sum<Block>(pq, red);

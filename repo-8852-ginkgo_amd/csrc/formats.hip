@@ -53,7 +53,7 @@ __global__ __launch_bounds__(block) void ell_spmv_kernel(
     const uint8_t* __restrict__ stop_status = nullptr,
     const double* __restrict__ dot_w = nullptr, double* __restrict__ dot_partial2 = nullptr)
 {
-    if (Dot && status_has_stopped(stop_status[0])) return;
+    if (Dot && status_has_stopped_uniform(stop_status)) return;
     double pq = 0.0, qq = 0.0;
     const double* w = Dot && dot_w != nullptr ? dot_w : b;
     b += blockIdx.y;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(block) void sellp_spmv_kernel(
     const uint8_t* __restrict__ stop_status = nullptr,
     const double* __restrict__ dot_w = nullptr, double* __restrict__ dot_partial2 = nullptr)
 {
-    if (Dot && status_has_stopped(stop_status[0])) return;
+    if (Dot && status_has_stopped_uniform(stop_status)) return;
     double pq = 0.0, qq = 0.0;
     const double* w = Dot && dot_w != nullptr ? dot_w : b;
     b += blockIdx.y;

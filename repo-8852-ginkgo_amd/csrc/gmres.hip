@@ -15,6 +15,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <string>
 #include <utility>
 
 namespace gkomi {
@@ -387,6 +388,29 @@ struct gmres_iteration_tail {
     host_watch_line* watch;  // the host's view of the solve (internal.hpp), or nullptr
 };
 
+// (one thread of workgroup 0, behind the sweep)
+__device__ __forceinline__ void gmres_finish_iteration(double* hess_iter, int64_t h_stride, const gmres_iteration_tail& tail)
+{
+    hessenberg_qr_column(0, 1, tail.gsin, tail.gcos, tail.residual_norm, tail.rnc, hess_iter, h_stride,
+                         tail.restart_iter, tail.final_iter_nums, tail.stop_status);
+    // stop::ResidualNorm on the updated estimate (residual_norm_kernel<false> of stop.hip, one column,
+    // not finalized) and gmres_record_stop_kernel
+    uint8_t st = tail.stop_status[0];
+    uint8_t one_changed = 0;
+    if (tail.residual_norm[0] < tail.goal * tail.orig_tau[0]) {
+        if (!status_has_stopped(st)) {
+            st |= GKOMI_STATUS_CONVERGED | 2;  // id_residual
+            tail.stop_status[0] = st;
+        }
+        one_changed = 1;
+    }
+    const uint8_t all = status_has_stopped(st) ? 1 : 0;
+    tail.flags[0] = all;
+    tail.flags[1] = one_changed;
+    if (all && tail.record->iter < 0) tail.record->iter = tail.next_iter;
+    host_watch_publish(tail.watch, tail.next_iter, tail.record->iter);
+}
+
 template <int R>
 __global__ __launch_bounds__(pcg_block) void gmres_arnoldi_persistent_kernel(
     int n, int chunk, double* __restrict__ next_k, const double* __restrict__ kb, int steps,
@@ -443,24 +467,155 @@ __global__ __launch_bounds__(pcg_block) void gmres_arnoldi_persistent_kernel(
     }
     if (blockIdx.x == 0 && tid == 0) {
         hess_iter[steps * h_stride] = hn;
-        hessenberg_qr_column(0, 1, tail.gsin, tail.gcos, tail.residual_norm, tail.rnc, hess_iter, h_stride,
-                             tail.restart_iter, tail.final_iter_nums, tail.stop_status);
-        // stop::ResidualNorm on the updated estimate (residual_norm_kernel<false> of stop.hip, one column,
-        // not finalized) and gmres_record_stop_kernel
-        uint8_t st = tail.stop_status[0];
-        uint8_t one_changed = 0;
-        if (tail.residual_norm[0] < tail.goal * tail.orig_tau[0]) {
-            if (!status_has_stopped(st)) {
-                st |= GKOMI_STATUS_CONVERGED | 2;  // id_residual
-                tail.stop_status[0] = st;
+        gmres_finish_iteration(hess_iter, h_stride, tail);
+    }
+}
+
+// ---- the same sweep with one meeting per B basis vectors ---------------------------------------------
+// What the sweep above costs is its meetings: 16 + 5.3 (k + 1) us on the 108^3 system, of which streaming a basis
+// vector is 2 us (profiles/r03_arnoldi_blocked.md).  Modified Gram-Schmidt against v_0 .. v_{B-1} is
+//     h_i = v_i . (w - sum_{m<i} h_m v_m) = v_i . w - sum_{m<i} (v_i . v_m) h_m ,
+// a unit lower triangular system in the B sums v_i . w and the B (B - 1) / 2 sums v_i . v_m -- none of which needs an
+// h.  So: B vectors travel together into registers, the B + B (B - 1) / 2 sums go through ONE meeting
+// (pcg_meet_values), every thread solves the little system (same bits everywhere) and w loses the B components in
+// the reference's order; the next B vectors are in flight meanwhile.  An identity, not an approximation: nothing
+// assumes the basis orthogonal (the v_i . v_m are the measured ones); against the sweep above only the rounding of
+// h_i differs (sum of products vs product of sums), by O(eps |v_i . v_m| |h_m|).  Each basis vector is still read
+// exactly once.  512 threads per workgroup: 256 registers per lane hold w, the block and the block in flight.
+constexpr int arn_block = 512;
+
+template <int NV>
+__device__ __forceinline__ void arn_block_sums(const double (&acc)[NV], double* lp, double* lsum)
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) lp[v * arn_block + tid] = acc[v];
+    pcg_sync_lds();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int v = wave; v < NV; v += arn_block / wave_size) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < arn_block / wave_size; ++k) s += lp[v * arn_block + lane + wave_size * k];
+        s = wave_reduce_sum(s);
+        if (lane == 0) lsum[v] = s;
+    }
+    pcg_sync_lds();
+}
+
+// R2 = pairs of consecutive rows per lane (rows chunk start + 2 (r * 512 + lane) and the one behind it); Wide: n and
+// the chunk are even, so a pair is one aligned 16-byte load.
+template <int R2, int B, bool Wide>
+__global__ __launch_bounds__(arn_block) void gmres_arnoldi_blocked_kernel(
+    int n, int chunk, double* __restrict__ next_k, const double* __restrict__ kb, int steps,
+    double* __restrict__ hess_iter, int64_t h_stride, pcg_slot* slots, int stride, int nap, pcg_control* ctl,
+    long long meeting, long long max_polls, gmres_iteration_tail tail)
+{
+    constexpr int R = 2 * R2;
+    constexpr int NV = B + B * (B - 1) / 2;
+    constexpr int nwaves = arn_block / wave_size;
+    __shared__ double lp[NV * arn_block];
+    __shared__ double lsum[NV];
+    __shared__ double lred[nwaves * NV + 1];
+    __shared__ double smem[nwaves + 1];
+    if (__hip_atomic_load(&ctl->overrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    const int nwg = gridDim.x;
+    const int tid = threadIdx.x;
+    const int b0 = min(static_cast<int>(blockIdx.x) * chunk, n);
+    const int b1 = min(b0 + chunk, n);
+    double w[R], v[B][R], vn[B][R];
+    auto load_vector = [&](const double* __restrict__ src, bool wanted, double (&dst)[R]) {
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const int row = b0 + 2 * (r * arn_block + tid);
+            dst[2 * r] = dst[2 * r + 1] = 0.0;
+            if (Wide) {
+                if (wanted && row < b1) {
+                    const double2 pair = *reinterpret_cast<const double2*>(src + row);
+                    dst[2 * r] = pair.x;
+                    dst[2 * r + 1] = pair.y;
+                }
+            } else {
+                if (wanted && row < b1) dst[2 * r] = src[row];
+                if (wanted && row + 1 < b1) dst[2 * r + 1] = src[row + 1];
             }
-            one_changed = 1;
         }
-        const uint8_t all = status_has_stopped(st) ? 1 : 0;
-        tail.flags[0] = all;
-        tail.flags[1] = one_changed;
-        if (all && tail.record->iter < 0) tail.record->iter = tail.next_iter;
-        host_watch_publish(tail.watch, tail.next_iter, tail.record->iter);
+    };
+    auto load_block = [&](int m, double (&dst)[B][R]) {
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int k = m * B + i;
+            load_vector(kb + static_cast<int64_t>(n) * min(k, steps - 1), k < steps, dst[i]);
+        }
+    };
+    load_vector(next_k, true, w);
+    load_block(0, vn);
+    const int nblocks = (steps + B - 1) / B;
+    for (int m = 0; m < nblocks; ++m) {
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[i][r] = vn[i][r];
+        }
+        if (m + 1 < nblocks) load_block(m + 1, vn);  // travels while the workgroups meet
+        double acc[NV];
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            acc[i] = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[i] += w[r] * v[i][r];
+        }
+#pragma unroll
+        for (int a = 1; a < B; ++a) {
+#pragma unroll
+            for (int c = 0; c < a; ++c) {
+                double g = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) g += v[a][r] * v[c][r];
+                acc[B + a * (a - 1) / 2 + c] = g;
+            }
+        }
+        arn_block_sums<NV>(acc, lp, lsum);
+        if (!pcg_meet_values<arn_block, NV>(slots, stride, nap, nwg, ++meeting, lsum, lred, lp, ctl, max_polls)) return;
+        double h[B];
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+            double t = lsum[a];
+#pragma unroll
+            for (int c = 0; c < a; ++c) t -= lsum[B + a * (a - 1) / 2 + c] * h[c];
+            h[a] = t;
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                if (m * B + a < steps) hess_iter[(m * B + a) * h_stride] = h[a];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) w[r] -= h[a] * v[a][r];
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc += w[r] * w[r];
+    const double mine = pcg_block_sum<arn_block>(acc, smem);
+    double hn2 = 0.0;
+    if (!pcg_meet<arn_block>(slots, stride, nap, nwg, ++meeting, mine, smem, ctl, max_polls, &hn2)) return;
+    const double hn = sqrt(hn2);
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        const int row = b0 + 2 * (r * arn_block + tid);
+        if (Wide) {
+            if (row < b1) *reinterpret_cast<double2*>(next_k + row) = make_double2(w[2 * r] / hn, w[2 * r + 1] / hn);
+        } else {
+            if (row < b1) next_k[row] = w[2 * r] / hn;
+            if (row + 1 < b1) next_k[row + 1] = w[2 * r + 1] / hn;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        hess_iter[steps * h_stride] = hn;
+        gmres_finish_iteration(hess_iter, h_stride, tail);
     }
 }
 
@@ -690,10 +845,17 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_
         const char* e = std::getenv("GKOMI_GMRES_PERSISTENT");
         return e == nullptr || e[0] != '0';
     }();
+    // GKOMI_GMRES_ARNOLDI=sweep: one meeting per basis vector (gmres_arnoldi_persistent_kernel) instead of one per
+    // block of them -- the A/B switch of tools/, not a product setting
+    static const bool blocked_sweep = [] {
+        const char* e = std::getenv("GKOMI_GMRES_ARNOLDI");
+        return e == nullptr || std::string(e) != "sweep";
+    }();
     static const int cus = device_cu_count();
     pcg_control* pctl = reinterpret_cast<pcg_control*>(ws + l.pcg_ctl);
     pcg_slot* pslots = reinterpret_cast<pcg_slot*>(ws + l.pcg_slots);
-    const int pchunk = cus > 0 ? static_cast<int>(ceildiv(n, cus)) : 0;
+    // (an even chunk of an even n: the blocked sweep loads pairs of rows)
+    const int pchunk = cus > 0 ? static_cast<int>(ceildiv(n, cus) + (n % 2 == 0 ? ceildiv(n, cus) % 2 : 0)) : 0;
     const int prows = static_cast<int>(ceildiv(pchunk, pcg_block));
     bool persistent = allow_persistent && persistent_on && nrhs == 1 && cus >= 8 && cus <= max_parts &&
                       n >= 64 * static_cast<int64_t>(cus) && n <= INT32_MAX && prows <= pcg_max_rows_per_thread &&
@@ -806,21 +968,52 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_
             const gmres_iteration_tail tail{gsin, gcos, residual_norm, rnc, final_iter_nums, stop_status, orig_tau,
                                             reduction_factor, dev_flags, record, total_iter + 1,
                                             static_cast<int>(restart_iter), watch.dev};
+            // pairs of rows per lane of the blocked sweep's 512-thread workgroups (prows <= 8 above: at most 8)
+            const int bpairs = static_cast<int>(ceildiv(pchunk, 2 * arn_block));
+            const bool wide = n % 2 == 0 && pchunk % 2 == 0;
+            if (blocked_sweep && cus <= arn_block) {  // (workgroup 0 keeps cus x values of a meeting in LDS)
+#define GKOMI_ARNB(R2, B)                                                                                     \
+    do {                                                                                                      \
+        if (wide) {                                                                                           \
+            hipLaunchKernelGGL((gmres_arnoldi_blocked_kernel<R2, B, true>), dim3(cus), dim3(arn_block), 0,    \
+                               stream, static_cast<int>(n), pchunk, next_k, kb, steps, hess_iter, h_stride,   \
+                               pslots, pcg_default_stride, 1, pctl, meeting, meet_max_polls, tail);           \
+        } else {                                                                                              \
+            hipLaunchKernelGGL((gmres_arnoldi_blocked_kernel<R2, B, false>), dim3(cus), dim3(arn_block), 0,   \
+                               stream, static_cast<int>(n), pchunk, next_k, kb, steps, hess_iter, h_stride,   \
+                               pslots, pcg_default_stride, 1, pctl, meeting, meet_max_polls, tail);           \
+        }                                                                                                     \
+        meeting += (steps + (B) - 1) / (B) + 1;                                                               \
+    } while (0)
+                // block sizes measured on the 108^3 system (5 pairs per lane): 3 vectors 31.1 ms per solve, 4 (spills
+                // seven registers) 32.2, 2 32.7 -- the sweep is bound by the basis' bytes, not by its meetings
+                if (bpairs <= 1) {
+                    GKOMI_ARNB(1, 4);
+                } else if (bpairs <= 3) {
+                    GKOMI_ARNB(3, 4);
+                } else if (bpairs <= 5) {
+                    GKOMI_ARNB(5, 3);
+                } else {
+                    GKOMI_ARNB(8, 2);
+                }
+#undef GKOMI_ARNB
+            } else {
 #define GKOMI_ARN(R)                                                                                  \
     hipLaunchKernelGGL(gmres_arnoldi_persistent_kernel<R>, dim3(cus), dim3(pcg_block), 0, stream,     \
                        static_cast<int>(n), pchunk, next_k, kb, steps, hess_iter, h_stride, pslots,   \
                        pcg_default_stride, 1, pctl, meeting, meet_max_polls, tail)
-            if (prows <= 1) {
-                GKOMI_ARN(1);
-            } else if (prows <= 2) {
-                GKOMI_ARN(2);
-            } else if (prows <= 4) {
-                GKOMI_ARN(4);
-            } else {
-                GKOMI_ARN(8);
-            }
+                if (prows <= 1) {
+                    GKOMI_ARN(1);
+                } else if (prows <= 2) {
+                    GKOMI_ARN(2);
+                } else if (prows <= 4) {
+                    GKOMI_ARN(4);
+                } else {
+                    GKOMI_ARN(8);
+                }
 #undef GKOMI_ARN
-            meeting += steps + 1;
+                meeting += steps + 1;
+            }
             criterion_done = true;
             GKOMI_TRY(check_launch());
             restart_iter++;
