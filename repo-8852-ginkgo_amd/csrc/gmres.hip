@@ -508,7 +508,7 @@ template <int R2, int B, bool Wide>
 __global__ __launch_bounds__(arn_block) void gmres_arnoldi_blocked_kernel(
     int n, int chunk, double* __restrict__ next_k, const double* __restrict__ kb, int steps,
     double* __restrict__ hess_iter, int64_t h_stride, pcg_slot* slots, int stride, int nap, pcg_control* ctl,
-    long long meeting, long long max_polls, gmres_iteration_tail tail)
+    long long meeting, long long max_polls, gmres_iteration_tail tail, bool nt_basis)
 {
     constexpr int R = 2 * R2;
     constexpr int NV = B + B * (B - 1) / 2;
@@ -530,7 +530,14 @@ __global__ __launch_bounds__(arn_block) void gmres_arnoldi_blocked_kernel(
             dst[2 * r] = dst[2 * r + 1] = 0.0;
             if (Wide) {
                 if (wanted && row < b1) {
-                    const double2 pair = *reinterpret_cast<const double2*>(src + row);
+                    typedef double nt_pair __attribute__((ext_vector_type(2)));
+                    double2 pair;
+                    if (nt_basis) {
+                        const nt_pair t = __builtin_nontemporal_load(reinterpret_cast<const nt_pair*>(src + row));
+                        pair = make_double2(t.x, t.y);
+                    } else {
+                        pair = *reinterpret_cast<const double2*>(src + row);
+                    }
                     dst[2 * r] = pair.x;
                     dst[2 * r + 1] = pair.y;
                 }
@@ -770,7 +777,15 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_
 {
     // what this solve moves between two applies of A decides how A is read (internal.hpp)
     sysmat A = A_;
-    A.note_working_set(static_cast<int64_t>(sizeof(double)) * n * nrhs * (krylov_dim + 6));
+    // What stays in the Infinity Cache between two uses (measured on the 108^3 system, 310 MB of basis, 106 MB of
+    // matrix; profiles/r03_arnoldi_blocked.md): when matrix + basis do not fit, the basis is read with nontemporal
+    // loads (it is the larger stream and every vector of it is read once per iteration) and the matrix keeps the
+    // cache -- 30.9 -> 28.7 ms without a preconditioner; behind a preconditioner (its factors or blocks are streams the
+    // driver knows nothing about) the matrix streams as well -- 43.8 -> 42.0 ms with ParILU.
+    const int64_t vec_bytes = static_cast<int64_t>(sizeof(double)) * n * nrhs;
+    const bool nt_basis = A.is_csr() && A.storage_bytes() + vec_bytes * (krylov_dim + 6) > infinity_cache_bytes;
+    A.note_working_set(nt_basis ? vec_bytes * 6 + (precond != nullptr ? infinity_cache_bytes : 0)
+                                : vec_bytes * (krylov_dim + 6));
     if (n < 0 || nrhs <= 0 || krylov_dim <= 0 || max_iters < 0) return GKOMI_EINVAL;
     if (baseline < 0 || baseline > 2) return GKOMI_EINVAL;
     const gmres_layout l = make_layout(n, nrhs, krylov_dim);
@@ -977,11 +992,11 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_
         if (wide) {                                                                                           \
             hipLaunchKernelGGL((gmres_arnoldi_blocked_kernel<R2, B, true>), dim3(cus), dim3(arn_block), 0,    \
                                stream, static_cast<int>(n), pchunk, next_k, kb, steps, hess_iter, h_stride,   \
-                               pslots, pcg_default_stride, 1, pctl, meeting, meet_max_polls, tail);           \
+                               pslots, pcg_default_stride, 1, pctl, meeting, meet_max_polls, tail, nt_basis);          \
         } else {                                                                                              \
             hipLaunchKernelGGL((gmres_arnoldi_blocked_kernel<R2, B, false>), dim3(cus), dim3(arn_block), 0,   \
                                stream, static_cast<int>(n), pchunk, next_k, kb, steps, hess_iter, h_stride,   \
-                               pslots, pcg_default_stride, 1, pctl, meeting, meet_max_polls, tail);           \
+                               pslots, pcg_default_stride, 1, pctl, meeting, meet_max_polls, tail, nt_basis);          \
         }                                                                                                     \
         meeting += (steps + (B) - 1) / (B) + 1;                                                               \
     } while (0)
