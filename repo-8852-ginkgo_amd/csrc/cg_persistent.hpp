@@ -210,10 +210,13 @@ __device__ __forceinline__ bool pcg_meet(pcg_slot* slots, int stride, int nap, i
 // the totals (the same bits in every workgroup: workgroup 0 adds in a fixed order, once).  lred: (Block / 64) * NV + 1
 // doubles; lval: nwg * NV doubles of scratch (workgroup 0 only).  The polls of workgroup 0 are plain agent-scope loads of the two words of a slot -- all 2 NV in flight
 // together; a pair that does not fit the meeting (stale, torn) is asked for again, as in pcg_fetch.
-template <int Block, int NV>
+// Published: the caller has stored this workgroup's NV values into its slots of `meeting` itself, has set
+// lred[(Block / 64) * NV] to 1.0 and has passed a workgroup barrier since (gmres.hip: the wave that adds up a value
+// publishes it -- one barrier less per meeting); lsum is then output only.
+template <int Block, int NV, bool Published = false, typename F>
 __device__ __forceinline__ bool pcg_meet_values(pcg_slot* slots, int stride, int nap, int nwg, long long meeting,
                                                 double* lsum, double* lred, double* lval, pcg_control* ctl,
-                                                long long max_polls)
+                                                long long max_polls, F after_publish)
 {
     static_assert(NV <= pcg_default_stride, "a workgroup's values share its slot line");
     static_assert(pcg_copies * NV <= Block, "one thread per copy and value");
@@ -221,12 +224,16 @@ __device__ __forceinline__ bool pcg_meet_values(pcg_slot* slots, int stride, int
     const int tid = threadIdx.x;
     pcg_slot* bank = slots + (meeting & 1) * static_cast<int64_t>(nwg + pcg_copies) * stride;
     pcg_slot* back = bank + static_cast<int64_t>(nwg) * stride;
-    if (tid < NV) pcg_publish(bank + blockIdx.x * stride + tid, lsum[tid], meeting);
-    if (tid == 0) lred[nwaves * NV] = 1.0;  // "nobody gave up"
-    pcg_sync_lds();
+    if (!Published && tid < NV) pcg_publish(bank + blockIdx.x * stride + tid, lsum[tid], meeting);
+    after_publish();  // (the caller's loads for its next step: behind the store, so they do not hold it back)
+    if (!Published) {
+        if (tid == 0) lred[nwaves * NV] = 1.0;  // "nobody gave up"
+        pcg_sync_lds();
+    }
     const unsigned long long key = pcg_key(meeting);
     bool ok = true;
     if (blockIdx.x == 0) {
+        if (Published) pcg_sync_lds();  // lval may be the buffer the caller's waves have just added their sums from
         // pair p = (workgroup p / NV, value p % NV); U pairs per thread in flight together, the values into lval
         constexpr int U = 5;
         const int npairs = nwg * NV;

@@ -484,22 +484,26 @@ __global__ __launch_bounds__(pcg_block) void gmres_arnoldi_persistent_kernel(
 // exactly once.  512 threads per workgroup: 256 registers per lane hold w, the block and the block in flight.
 constexpr int arn_block = 512;
 
+// The workgroup's NV sums, each published (slot v of this workgroup, pcg_meet_values<..., Published = true>) by the
+// wave that adds it up: through LDS transposed, wave v adds value v of all lanes in a fixed order.
 template <int NV>
-__device__ __forceinline__ void arn_block_sums(const double (&acc)[NV], double* lp, double* lsum)
+__device__ __forceinline__ void arn_sum_and_publish(const double (&acc)[NV], double* lp, double* flag, pcg_slot* slots,
+                                                    int stride, int nwg, long long meeting)
 {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int v = 0; v < NV; ++v) lp[v * arn_block + tid] = acc[v];
+    if (tid == 0) *flag = 1.0;  // "nobody gave up"
     pcg_sync_lds();
     const int wave = tid >> 6, lane = tid & 63;
+    pcg_slot* mine = slots + (meeting & 1) * static_cast<int64_t>(nwg + pcg_copies) * stride + blockIdx.x * stride;
     for (int v = wave; v < NV; v += arn_block / wave_size) {
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < arn_block / wave_size; ++k) s += lp[v * arn_block + lane + wave_size * k];
         s = wave_reduce_sum(s);
-        if (lane == 0) lsum[v] = s;
+        if (lane == 0) pcg_publish(mine + v, s, meeting);
     }
-    pcg_sync_lds();
 }
 
 // R2 = pairs of consecutive rows per lane (rows chunk start + 2 (r * 512 + lane) and the one behind it); Wide: n and
@@ -520,7 +524,11 @@ __global__ __launch_bounds__(arn_block) void gmres_arnoldi_blocked_kernel(
     if (__hip_atomic_load(&ctl->overrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int nwg = gridDim.x;
     const int tid = threadIdx.x;
-    const int b0 = min(static_cast<int>(blockIdx.x) * chunk, n);
+    // Workgroup 0 owns no rows: it is the one that adds up every meeting's values, and its polls must not queue
+    // behind a block of basis vectors in flight (vector-memory loads return in order) -- with rows of its own, a
+    // meeting ended when ITS next block had landed, i.e. meetings and streaming took turns (8.4 us per block of
+    // three vectors: 5.1 of bytes + 3.3 of meeting; profiles/r03_arnoldi_blocked.md).
+    const int b0 = blockIdx.x == 0 ? n : min((static_cast<int>(blockIdx.x) - 1) * chunk, n);
     const int b1 = min(b0 + chunk, n);
     double w[R], v[B][R], vn[B][R];
     auto load_vector = [&](const double* __restrict__ src, bool wanted, double (&dst)[R]) {
@@ -557,13 +565,22 @@ __global__ __launch_bounds__(arn_block) void gmres_arnoldi_blocked_kernel(
     load_vector(next_k, true, w);
     load_block(0, vn);
     const int nblocks = (steps + B - 1) / B;
+#ifdef GKOMI_ARN_STAMPS
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_ = wall_clock64();
+#define ARN_STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = wall_clock64(); ph[i] += n_ - t_; t_ = n_; } while (0)
+#define ARN_STAMP_NOWAIT(i) do { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - t_; t_ = n_; } while (0)
+#else
+#define ARN_STAMP(i)
+#define ARN_STAMP_NOWAIT(i)
+#endif
     for (int m = 0; m < nblocks; ++m) {
+        ARN_STAMP(0);  // waiting for the block in flight
 #pragma unroll
         for (int i = 0; i < B; ++i) {
 #pragma unroll
             for (int r = 0; r < R; ++r) v[i][r] = vn[i][r];
         }
-        if (m + 1 < nblocks) load_block(m + 1, vn);  // travels while the workgroups meet
+
         double acc[NV];
 #pragma unroll
         for (int i = 0; i < B; ++i) {
@@ -581,8 +598,17 @@ __global__ __launch_bounds__(arn_block) void gmres_arnoldi_blocked_kernel(
                 acc[B + a * (a - 1) / 2 + c] = g;
             }
         }
-        arn_block_sums<NV>(acc, lp, lsum);
-        if (!pcg_meet_values<arn_block, NV>(slots, stride, nap, nwg, ++meeting, lsum, lred, lp, ctl, max_polls)) return;
+        ARN_STAMP_NOWAIT(1);  // dots
+        ++meeting;
+        arn_sum_and_publish<NV>(acc, lp, lred + nwaves * NV, slots, stride, nwg, meeting);
+        ARN_STAMP_NOWAIT(2);  // sums of the workgroup
+        // the next block travels while the workgroups meet; asked for behind the publication of this block's sums
+        // (in front of it the loads' way into a busy memory pipe delayed every workgroup's sums: 3.9 -> 2.5 us)
+        auto next_block = [&]() {
+            if (m + 1 < nblocks) load_block(m + 1, vn);
+        };
+        if (!pcg_meet_values<arn_block, NV, true>(slots, stride, nap, nwg, meeting, lsum, lred, lp, ctl, max_polls, next_block)) return;
+        ARN_STAMP_NOWAIT(3);  // meeting
         double h[B];
 #pragma unroll
         for (int a = 0; a < B; ++a) {
@@ -602,7 +628,14 @@ __global__ __launch_bounds__(arn_block) void gmres_arnoldi_blocked_kernel(
 #pragma unroll
             for (int r = 0; r < R; ++r) w[r] -= h[a] * v[a][r];
         }
+        ARN_STAMP_NOWAIT(4);  // solve + update
     }
+#ifdef GKOMI_ARN_STAMPS
+    if (steps == 30 && tid == 0 && (blockIdx.x == 1 || blockIdx.x == 0 || blockIdx.x == 200)) {
+        printf("wg %d: %d blocks; wait for block %llu, dots %llu, sums %llu, meeting %llu, update %llu (10 ns ticks)\n",
+               static_cast<int>(blockIdx.x), nblocks, ph[0], ph[1], ph[2], ph[3], ph[4]);
+    }
+#endif
     double acc = 0.0;
 #pragma unroll
     for (int r = 0; r < R; ++r) acc += w[r] * w[r];
@@ -984,18 +1017,20 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_
                                             reduction_factor, dev_flags, record, total_iter + 1,
                                             static_cast<int>(restart_iter), watch.dev};
             // pairs of rows per lane of the blocked sweep's 512-thread workgroups (prows <= 8 above: at most 8)
-            const int bpairs = static_cast<int>(ceildiv(pchunk, 2 * arn_block));
-            const bool wide = n % 2 == 0 && pchunk % 2 == 0;
-            if (blocked_sweep && cus <= arn_block) {  // (workgroup 0 keeps cus x values of a meeting in LDS)
+            const int64_t per = ceildiv(n, cus - 1);  // workgroup 0 serves the meetings
+            const int bchunk = static_cast<int>(per + (n % 2 == 0 ? per % 2 : 0));
+            const int bpairs = static_cast<int>(ceildiv(bchunk, 2 * arn_block));
+            const bool wide = n % 2 == 0 && bchunk % 2 == 0;
+            if (blocked_sweep && cus <= arn_block && bpairs <= 8) {  // (workgroup 0 keeps cus x values of a meeting in LDS)
 #define GKOMI_ARNB(R2, B)                                                                                     \
     do {                                                                                                      \
         if (wide) {                                                                                           \
             hipLaunchKernelGGL((gmres_arnoldi_blocked_kernel<R2, B, true>), dim3(cus), dim3(arn_block), 0,    \
-                               stream, static_cast<int>(n), pchunk, next_k, kb, steps, hess_iter, h_stride,   \
+                               stream, static_cast<int>(n), bchunk, next_k, kb, steps, hess_iter, h_stride,   \
                                pslots, pcg_default_stride, 1, pctl, meeting, meet_max_polls, tail, nt_basis);          \
         } else {                                                                                              \
             hipLaunchKernelGGL((gmres_arnoldi_blocked_kernel<R2, B, false>), dim3(cus), dim3(arn_block), 0,   \
-                               stream, static_cast<int>(n), pchunk, next_k, kb, steps, hess_iter, h_stride,   \
+                               stream, static_cast<int>(n), bchunk, next_k, kb, steps, hess_iter, h_stride,   \
                                pslots, pcg_default_stride, 1, pctl, meeting, meet_max_polls, tail, nt_basis);          \
         }                                                                                                     \
         meeting += (steps + (B) - 1) / (B) + 1;                                                               \
