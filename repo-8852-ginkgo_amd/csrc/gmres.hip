@@ -131,6 +131,35 @@ __global__ __launch_bounds__(block) void gmres_solve_krylov_kernel(
     }
 }
 
+// One right-hand side: the same back substitution, operand by operand in the same order, out of LDS -- the loop
+// above waits for a dependent load from memory in every one of its m (m + 1) / 2 steps (45 us per restart of
+// GMRES(30); this one 4 us, profiles/r03_arnoldi_blocked.md).
+constexpr int solve_krylov_max = 64;
+__global__ __launch_bounds__(256) void gmres_solve_krylov_single_kernel(
+    const double* __restrict__ rnc, const double* __restrict__ hessenberg, int64_t h_stride,
+    double* __restrict__ y, const uint64_t* __restrict__ final_iter_nums, const uint8_t* __restrict__ stop_status)
+{
+    __shared__ double lh[solve_krylov_max * solve_krylov_max];
+    __shared__ double ly[solve_krylov_max];
+    if (stop_status[0] & GKOMI_STATUS_FINALIZED) return;
+    const int m = static_cast<int>(final_iter_nums[0]);
+    for (int e = threadIdx.x; e < m * m; e += 256) {
+        const int i = e / m, j = e % m;
+        if (j >= i) lh[i * solve_krylov_max + j] = hessenberg[i * h_stride + j];
+    }
+    for (int e = threadIdx.x; e < m; e += 256) ly[e] = rnc[e];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = m - 1; i >= 0; --i) {
+            double temp = ly[i];
+            for (int j = i + 1; j < m; ++j) temp -= lh[i * solve_krylov_max + j] * ly[j];
+            ly[i] = temp / lh[i * solve_krylov_max + i];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < m; e += 256) y[e] = ly[e];
+}
+
 // before_preconditioner = V y: each thread owns one (row, rhs) entry and adds
 // the Krylov vectors in index order, like the reference
 __global__ __launch_bounds__(block) void gmres_multi_axpy_kernel(
@@ -771,6 +800,20 @@ extern "C" int gkomi_gmres_solve_krylov_f64(gkomi_stream_t s, int64_t nrhs,
     return check_launch();
 }
 
+// the driver's call: it knows the restart length, so the one-column case goes through LDS
+static int solve_krylov_launch(gkomi_stream_t s, int64_t nrhs, int64_t krylov_dim, const double* rnc,
+                               const double* hessenberg, int64_t h_stride, double* y,
+                               const uint64_t* final_iter_nums, const uint8_t* stop_status)
+{
+    const char* e = std::getenv("GKOMI_GMRES_SOLVE_KRYLOV");  // "generic": the test's switch (bit-identity of the two)
+    if (nrhs == 1 && krylov_dim <= solve_krylov_max && (e == nullptr || std::string(e) != "generic")) {
+        hipLaunchKernelGGL(gmres_solve_krylov_single_kernel, dim3(1), dim3(256), 0, to_stream(s), rnc, hessenberg,
+                           h_stride, y, final_iter_nums, stop_status);
+        return check_launch();
+    }
+    return gkomi_gmres_solve_krylov_f64(s, nrhs, rnc, hessenberg, h_stride, y, final_iter_nums, stop_status);
+}
+
 extern "C" int gkomi_gmres_multi_axpy_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
                                           const double* krylov_bases, int64_t kb_stride,
                                           const double* y, double* before_preconditioner,
@@ -854,7 +897,7 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_
                                        final_iter_nums);
     };
     auto update_solution = [&](int64_t) -> int {
-        GKOMI_TRY(gkomi_gmres_solve_krylov_f64(s, nrhs, rnc, hess, h_stride, y, final_iter_nums,
+        GKOMI_TRY(solve_krylov_launch(s, nrhs, krylov_dim, rnc, hess, h_stride, y, final_iter_nums,
                                                stop_status));
         GKOMI_TRY(gkomi_gmres_multi_axpy_f64(s, n, nrhs, kb, nrhs, y, before, nrhs,
                                              final_iter_nums, stop_status));

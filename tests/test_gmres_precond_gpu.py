@@ -266,3 +266,17 @@ def test_gmres_meeting_timeout_falls_back_before_touching_x(gk, oracle, monkeypa
     monkeypatch.delenv("GKOMI_MEET_MAX_POLLS")
     cut_ok = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), krylov_dim=30, max_iters=7, reduction=1e-30)
     assert matgen.rel_err(host(cut["x"]), host(cut_ok["x"])) <= 1e-9
+
+
+def test_gmres_back_substitution_from_lds_is_bit_identical(gk, oracle, monkeypatch):
+    """One right-hand side: solve_krylov runs out of LDS (gmres_solve_krylov_single_kernel) -- the reference's loop
+    (common/unified/solver/gmres_kernels.cpp solve_krylov), operand by operand in the same order: the solution of
+    a solve with restarts has the same bits as with the one-thread-per-column kernel of the C ABI."""
+    n, rp, ci, v = convection_diffusion_3d(20)
+    b = np.cos(0.3 * np.arange(n))
+    args = dict(krylov_dim=7, max_iters=2000, reduction=1e-10)
+    res = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), **args)
+    monkeypatch.setenv("GKOMI_GMRES_SOLVE_KRYLOV", "generic")
+    ref = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), **args)
+    assert res["converged"] and res["iterations"] == ref["iterations"] and res["iterations"] > 14
+    assert host(res["x"]).tobytes() == host(ref["x"]).tobytes()
