@@ -938,7 +938,7 @@ int gmres_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_
     }();
     // GKOMI_GMRES_ARNOLDI=sweep: one meeting per basis vector (gmres_arnoldi_persistent_kernel) instead of one per
     // block of them -- the A/B switch of tools/, not a product setting
-    static const bool blocked_sweep = [] {
+    const bool blocked_sweep = [] {
         const char* e = std::getenv("GKOMI_GMRES_ARNOLDI");
         return e == nullptr || std::string(e) != "sweep";
     }();

@@ -280,3 +280,28 @@ def test_gmres_back_substitution_from_lds_is_bit_identical(gk, oracle, monkeypat
     ref = solvers.gmres_solve(gk, n, dev(rp), dev(ci), dev(v), dev(b), **args)
     assert res["converged"] and res["iterations"] == ref["iterations"] and res["iterations"] > 14
     assert host(res["x"]).tobytes() == host(ref["x"]).tobytes()
+
+
+@pytest.mark.parametrize("g3,krylov_dim", [(27, 30), (64, 30), (80, 10), (100, 30), (117, 12)],
+                         ids=["19683_odd_1pair", "262144_3pairs", "512000_3pairs", "1e6_5pairs", "1601613_odd_8pairs"])
+def test_gmres_blocked_sweep_against_the_one_by_one_sweep(gk, oracle, g3, krylov_dim, monkeypatch):
+    """The blocked modified Gram-Schmidt sweep (one meeting per 2-4 basis vectors, every register tiling of
+    gmres_arnoldi_blocked_kernel, 16-byte and 8-byte loads) against the sweep that meets once per vector
+    (GKOMI_GMRES_ARNOLDI=sweep; that one is pinned to the oracle by the tests above): the two differ in the rounding
+    of the Hessenberg entries only (core/solver/gmres.cpp:300-319 is an identity in the sums either way) -- same
+    iteration count +- 1, same solution to 1e-9, true residual at the goal."""
+    n, rp, ci, v = convection_diffusion_3d(g3)
+    b = np.cos(0.3 * np.arange(n))
+    a = [dev(rp), dev(ci), dev(v)]
+    args = dict(krylov_dim=krylov_dim, max_iters=3000, reduction=1e-10)
+    res = solvers.gmres_solve(gk, n, *a, dev(b), **args)
+    again = solvers.gmres_solve(gk, n, *a, dev(b), **args)
+    monkeypatch.setenv("GKOMI_GMRES_ARNOLDI", "sweep")
+    ref = solvers.gmres_solve(gk, n, *a, dev(b), **args)
+    assert res["converged"] and ref["converged"] and abs(res["iterations"] - ref["iterations"]) <= 1
+    assert res["iterations"] > krylov_dim                       # restarts included
+    assert again["iterations"] == res["iterations"] and host(again["x"]).tobytes() == host(res["x"]).tobytes()
+    assert matgen.rel_err(host(res["x"]), host(ref["x"])) <= 1e-9
+    r = b.copy().reshape(n, 1)
+    oracle.ref_csr_advanced_spmv(n, 1, -1.0, rp, ci, v, host(res["x"]).reshape(n, 1), 1, 1.0, r, 1)
+    assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(b)
