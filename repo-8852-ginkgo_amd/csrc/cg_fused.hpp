@@ -236,13 +236,7 @@ __global__ void cg_init_scalars_kernel(cg_scalars* scal, const double* orig_tau,
     scal->status = 0;
 }
 
-int vec_grid(int64_t n)
-{
-    int64_t g = ceildiv(n / 2 + 1, fblock);
-    if (g > max_parts) g = max_parts;
-    if (g < 1) g = 1;
-    return static_cast<int>(g);
-}
+int vec_grid(int64_t n) { return fused_vec_grid(n); }  // internal.hpp
 
 }  // namespace
 }  // namespace gkomi

@@ -22,6 +22,10 @@ bool csr_auto_swizzle(int64_t nrows, int64_t nnz);
 // `raw` partial sums -> at most spmv_dot_max_partials, in place order (each output = the sum of a run of
 // consecutive inputs, added in index order by one wave): what the consumers of a fused driver re-add
 constexpr int spmv_dot_max_partials = 4096;
+// ... but a launch that leaves up to twice as many is not followed by the compression: its consumers are the <= 512
+// workgroups of a system of that size (fused_vec_grid), 8192 partials are 64 KB of L2 reads each, and the extra
+// launch costs 4.8 us (108^3 system: 5711 tiles; profiles/r03_p3_cg_kernels.md)
+constexpr int spmv_dot_uncompressed_partials = 8192;
 int compress_partials_launch(hipStream_t stream, const double* raw, int nraw, double* out, int nout,
                              const double* raw2, double* out2, const uint8_t* stop_status);
 // room a fused driver keeps for the partials of one SpMV + dot launch (doubles): the row-cut
@@ -83,6 +87,25 @@ __device__ __forceinline__ void host_watch_publish(host_watch_line* w, long long
 // queue from draining (a launch costs the host ~4 us), few enough that the launches issued after the
 // criterion fired (they return at once, but a preconditioner's do not) stay cheap
 constexpr long long host_watch_lag = 3;
+
+constexpr int fused_vec_block = 1024, fused_vec_max_parts = 1024;
+// Workgroups of the fused vector kernels (1024 lanes, 16 B per lane and sweep): one per 2048 rows, at most fused_vec_max_parts.
+// Two are resident per CU; a grid between one and two rounds of resident workgroups would run a second, mostly empty
+// round -- on the 108^3 system (616 workgroups on 256 CUs) K1 + K3 of a CG iteration (cg_fused.hpp) took 4 us longer than with 512
+// workgroups that each sweep twice (47.6 -> 43.6 us per iteration).  Beyond two rounds (the 256^3 system) the full
+// fused_vec_max_parts stay: 1024 workgroups 532 us per iteration, 512 540 (profiles/r03_p3_cg_kernels.md).
+inline int fused_vec_grid(int64_t n)
+{
+    static const int64_t resident = 2 * static_cast<int64_t>(device_cu_count());
+    int64_t g = ceildiv(n / 2 + 1, fused_vec_block);
+    if (g > fused_vec_max_parts) {
+        g = fused_vec_max_parts;
+    } else if (g > resident && resident > 0) {
+        g = resident;
+    }
+    if (g < 1) g = 1;
+    return static_cast<int>(g);
+}
 
 // a brick solve as one link of a chain on contiguous vectors (trs_bricks.hip): see the definition
 int trs_bricks_solve_chained(gkomi_stream_t s, gkomi_trs_bricks* h, void* plan, int unit_diag, const double* b, double* x,
@@ -201,7 +224,7 @@ struct spmv_dot_plan {
         } else if (A.ctx != nullptr) {
             raw_partials = op_spmv_dot_num_partials(A.op, A.ctx);
         }
-        num_partials = raw_partials > spmv_dot_max_partials ? spmv_dot_max_partials : raw_partials;
+        num_partials = raw_partials > spmv_dot_uncompressed_partials ? spmv_dot_max_partials : raw_partials;
     }
     bool fused() const { return num_partials > 0; }
     // `partial` (and `partial2`) must hold spmv_dot_partials_room(n) doubles

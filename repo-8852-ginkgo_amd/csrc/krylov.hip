@@ -1129,10 +1129,7 @@ int bicgstab_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_app
     double* part_beta = part_ss + fused_max_parts;
     double* part_gamma = part_beta + per_spmv;
     double* part_tt = part_gamma + per_spmv;
-    int64_t gl = ceildiv(n / 2 + 1, fblock);  // 16 B per lane
-    if (gl > fused_max_parts) gl = fused_max_parts;
-    if (gl < 1) gl = 1;
-    const int g = static_cast<int>(gl);
+    const int g = fused_vec_grid(n);  // 16 B per lane (internal.hpp)
     // the dots in the SpMV's epilogue for CSR / ELL / SELL-P (internal.hpp)
     const spmv_dot_plan spmv(A);
     const bool csr_epilogue = spmv.fused();
@@ -1527,10 +1524,7 @@ int fcg_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_apply_fn
     double* part_tau = part_rhot + fused_max_parts;
     double* part_beta = part_tau + fused_max_parts;
     const size_t per_spmv = spmv_dot_partials_room(n);  // >= g: room for three arrays (layout)
-    int64_t gl = ceildiv(n / 2 + 1, fblock);
-    if (gl > fused_max_parts) gl = fused_max_parts;
-    if (gl < 1) gl = 1;
-    const int g = static_cast<int>(gl);
+    const int g = fused_vec_grid(n);
     // the dots in the SpMV's epilogue for CSR / ELL / SELL-P (internal.hpp)
     const spmv_dot_plan spmv(A);
     const bool csr_epilogue = spmv.fused();
@@ -1913,10 +1907,7 @@ int cgs_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_apply_fn
     double* part_tau = part_rho + fused_max_parts;
     double* part_gamma = part_tau + 2 * fused_max_parts;
     const size_t per_spmv = spmv_dot_partials_room(n);
-    int64_t gl = ceildiv(n / 2 + 1, fblock);
-    if (gl > fused_max_parts) gl = fused_max_parts;
-    if (gl < 1) gl = 1;
-    const int g = static_cast<int>(gl);
+    const int g = fused_vec_grid(n);
     // the dots in the SpMV's epilogue for CSR / ELL / SELL-P (internal.hpp)
     const spmv_dot_plan spmv(A);
     const bool csr_epilogue = spmv.fused();
