@@ -20,7 +20,7 @@ for lower in (True, False):
     b = torch.from_numpy(np.sin(0.1 * np.arange(n)) + 2.0).cuda().reshape(n, 1)
     x = torch.zeros_like(b)
     ref = None
-    for edges in ("27,8,8", "36,8,8", "18,8,8", "14,8,8", "54,8,8", "27,6,10", "27,4,16", "27,16,4", "27,9,7", "12,12,12", "27,5,12"):
+    for edges in (sys.argv[2].split(";") if len(sys.argv) > 2 else ("27,8,8", "36,8,8", "18,8,8", "14,8,8", "54,8,8", "27,6,10", "27,4,16", "27,16,4", "27,9,7", "12,12,12", "27,5,12")):
         os.environ["GKOMI_TRS_BRICK_EDGES"] = edges
         try:
             bk = solvers.TrsBricks(gk, n, rpd, cid, vd, lower, 0, 0, 2)
