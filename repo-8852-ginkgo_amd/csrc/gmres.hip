@@ -560,7 +560,7 @@ __global__ __launch_bounds__(arn_block) void gmres_arnoldi_blocked_kernel(
     const int b0 = blockIdx.x == 0 ? n : min((static_cast<int>(blockIdx.x) - 1) * chunk, n);
     const int b1 = min(b0 + chunk, n);
     double w[R], v[B][R], vn[B][R];
-    auto load_vector = [&](const double* __restrict__ src, bool wanted, double (&dst)[R]) {
+    auto load_vector = [&](const double* src, bool wanted, double (&dst)[R]) {
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             const int row = b0 + 2 * (r * arn_block + tid);
