@@ -793,16 +793,16 @@ int bicgstab_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat&
 //
 // The reference sequence above costs 25 launches per iteration (two-stage dots,
 // the criterion, the step kernels).  The fused driver keeps the same recurrences
-// and check points in 6 launches (+ the preconditioner's):
+// and check points in 5 launches (+ the preconditioner's):
 //   KA  re-adds the partials of rho = rr.r and |r|^2 left by KE, evaluates the
 //       criterion on r (phase 1) and -- unless stopped -- updates p (step_1)
 //   KB  v = A y with the partials of rr.v in the SpMV epilogue
 //   KC  re-adds them: alpha, s = r - alpha v (step_2), partials of |s|^2
-//   KD0 re-adds those, evaluates the criterion on s (phase 2); if it fires,
-//       x += alpha y (finalize)
 //   KD  t = A z with the partials of s.t and t.t in the epilogue
-//   KE  re-adds them: omega, x += alpha y + omega z, r = s - omega t (step_3),
-//       partials of rr.r and |r|^2 for the next KA
+//   KE  first re-adds the partials of |s|^2 and evaluates the criterion on s (phase 2; a launch of its own until
+//       round 3: 4.8 us per iteration): if it fires, x += alpha y (finalize) and nothing else -- KD ran once for
+//       nothing; otherwise re-adds KD's: omega, x += alpha y + omega z, r = s - omega t (step_3), partials of rr.r
+//       and |r|^2 for the next KA
 // Every workgroup re-adds the partials in the same order, so all agree on the
 // scalars bit for bit; workgroup 0 stores them for the kernels that follow.
 // Once a criterion fires the remaining launches return at once, so x and the
@@ -814,10 +814,10 @@ struct bicgstab_scalars {
     double rho[2];  // rho of iteration `it` lives in rho[it & 1]
     double alpha, omega, tau, orig_tau;
     long long stop_iter;
-    long long stop2_iter;   // iteration whose half step converged (KD0 only), -1 before
+    long long stop2_iter;   // iteration whose half step converged (written by KE only), -1 before
     int phase;
     unsigned char status;   // written by KA only
-    unsigned char status2;  // written by KD0 only
+    unsigned char status2;  // written by KE only (the half step's criterion)
     unsigned char pad[2];
 };
 
@@ -1001,46 +1001,22 @@ __global__ __launch_bounds__(fblock) void bicgstab_fused_step2_kernel(
     if (threadIdx.x == 0) ss_part[blockIdx.x] = total;
 }
 
-// KD0: a few workgroups are enough -- they only move data in the launch that stops
-__global__ __launch_bounds__(fblock) void bicgstab_fused_check2_kernel(
-    int64_t n, double* __restrict__ x, const double* __restrict__ y,
-    const double* __restrict__ ss_part, int nparts, bicgstab_scalars* scal, long long it,
-    double goal)
-{
-    __shared__ double smem[fblock / wave_size];
-    if (status_has_stopped(scal->status)) return;
-    // status2 / stop2_iter are this kernel's own: workgroup 0 may be writing
-    // them while a late workgroup of the same launch starts, so "stopped in an
-    // earlier launch" is read from the one 8-byte word
-    const long long stopped_at = scal->stop2_iter;
-    if (stopped_at >= 0 && stopped_at != it) return;
-    const double tau = sqrt(sum_partials_f(ss_part, nparts, smem));
-    if (!(tau < goal * scal->orig_tau)) return;
-    const double alpha = scal->alpha;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        scal->tau = tau;
-        scal->stop_iter = it;
-        scal->stop2_iter = it;
-        scal->phase = 2;
-        scal->status2 = GKOMI_STATUS_CONVERGED | 1 | GKOMI_STATUS_FINALIZED;
-    }
-    // bicgstab::finalize: x += alpha y
-    const int64_t step = static_cast<int64_t>(gridDim.x) * fblock;
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(fblock) + threadIdx.x; i < n; i += step) {
-        x[i] += alpha * y[i];
-    }
-}
-
 // KE
 __global__ __launch_bounds__(fblock) void bicgstab_fused_step3_kernel(
     int64_t n, double* __restrict__ x, double* __restrict__ r, const double* __restrict__ sv,
     const double* __restrict__ t, const double* __restrict__ y, const double* __restrict__ z,
     const double* __restrict__ rr, const double* __restrict__ gamma_part,
     const double* __restrict__ tt_part, int nparts, bicgstab_scalars* scal,
-    double* __restrict__ rho_part, double* __restrict__ tau_part)
+    double* __restrict__ rho_part, double* __restrict__ tau_part,
+    const double* __restrict__ ss_part, int nss, long long it, double goal)
 {
     __shared__ double smem[fblock / wave_size];
-    if (fused_stopped(scal)) return;
+    if (status_has_stopped(scal->status)) return;
+    // the half step's criterion (KD0 of round 1 was a launch of its own: 4.8 us per iteration for a kernel that moves
+    // data once per solve).  status2 / stop2_iter are written here: workgroup 0 may be writing them while a late
+    // workgroup of the same launch starts, so "stopped in an earlier launch" is read from the one 8-byte word
+    const long long stopped_at = scal->stop2_iter;
+    if (stopped_at >= 0 && stopped_at != it) return;
     const pair_sweep sw(n);
     double2 x0 = make_double2(0.0, 0.0), y0 = x0, z0 = x0, s0 = x0, t0 = x0, q0 = x0;
     if (sw.first()) {
@@ -1050,6 +1026,26 @@ __global__ __launch_bounds__(fblock) void bicgstab_fused_step3_kernel(
         s0 = ld2(sv, sw.i0);
         t0 = ld2(t, sw.i0);
         q0 = ld2(rr, sw.i0);
+    }
+    const double tau_s = sqrt(sum_partials_f(ss_part, nss, smem));
+    if (tau_s < goal * scal->orig_tau) {
+        // bicgstab::finalize (core/solver/bicgstab.cpp:196-203): s has converged, x += alpha y and nothing else
+        // (the preconditioner apply and the SpMV between step 2 and here ran on that s for nothing, once per solve)
+        const double alpha = scal->alpha;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            scal->tau = tau_s;
+            scal->stop_iter = it;
+            scal->stop2_iter = it;
+            scal->phase = 2;
+            scal->status2 = GKOMI_STATUS_CONVERGED | 1 | GKOMI_STATUS_FINALIZED;
+        }
+        if (sw.first()) st2(x, sw.i0, make_double2(x0.x + alpha * y0.x, x0.y + alpha * y0.y));
+        for (int64_t i = sw.i0 + sw.step; i < sw.n2; i += sw.step) {
+            const double2 xv = ld2(x, i), yv = ld2(y, i);
+            st2(x, i, make_double2(xv.x + alpha * yv.x, xv.y + alpha * yv.y));
+        }
+        if (sw.tail(n)) x[n - 1] += alpha * y[n - 1];
+        return;
     }
     const double gamma = sum_partials_f(gamma_part, nparts, smem);
     const double beta = sum_partials_f(tt_part, nparts, smem);
@@ -1175,12 +1171,11 @@ int bicgstab_fused_impl(gkomi_stream_t s, int64_t n, const sysmat& A_, gkomi_app
             GKOMI_TRY(spmv_dots(y, v, rr, part_beta, nullptr));
             hipLaunchKernelGGL(bicgstab_fused_step2_kernel, dim3(g), dim3(fblock), 0, stream, n, r, sv,
                                v, part_beta, nb, scal, it, part_ss);
-            hipLaunchKernelGGL(bicgstab_fused_check2_kernel, dim3(g < 64 ? g : 64), dim3(fblock), 0, stream, n, x, y,
-                               part_ss, g, scal, it, reduction_factor);
             if (precond != nullptr) GKOMI_TRY(precond(precond_ctx, s, sv, z));
             GKOMI_TRY(spmv_dots(z, t, sv, part_gamma, part_tt));
             hipLaunchKernelGGL(bicgstab_fused_step3_kernel, dim3(g), dim3(fblock), 0, stream, n, x, r,
-                               sv, t, y, z, rr, part_gamma, part_tt, nb, scal, part_rho, part_tau);
+                               sv, t, y, z, rr, part_gamma, part_tt, nb, scal, part_rho, part_tau, part_ss, g, it,
+                               reduction_factor);
         }
         GKOMI_TRY(check_launch());
         if (watch.dev != nullptr && !last) {
