@@ -47,8 +47,9 @@ workspace_layout make_layout(int64_t n, int64_t nrhs)
     l.p = off; off += vec;
     l.q = off; off += vec;
     l.scalars = off; off += 256;
-    l.part_a = off; off += align_up(sizeof(double) * max_parts, 256);   // r.z / r.r
-    l.part_b = off; off += align_up(sizeof(double) * max_parts, 256);   // r.r with a preconditioner
+    // (room for one partial per workgroup of a block-Jacobi apply that carries the dots, see the fused loop)
+    l.part_a = off; off += align_up(sizeof(double) * spmv_dot_partials_room(n), 256);   // r.z / r.r
+    l.part_b = off; off += align_up(sizeof(double) * spmv_dot_partials_room(n), 256);   // r.r with a preconditioner
     l.part_c = off; off += align_up(sizeof(double) * spmv_dot_partials_room(n), 256);    // p.q (internal.hpp)
     l.red = off; off += align_up(gkomi_dense_reduction_workspace_bytes(n, nrhs) + 8, 256);
     // mode 0 scalars: alpha-free set {prev_rho, rho, beta, tau, orig_tau, one, neg_one} x nrhs,
@@ -377,11 +378,37 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_, g
         }
         // partials of r.z (and r.r) for the first check
         const double* zz = precond == nullptr ? r : z;
-        if (precond != nullptr) GKOMI_TRY(precond(precond_ctx, s, r, z));
-        hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r, zz,
-                           static_cast<const cg_scalars*>(nullptr), part_a,
-                           precond == nullptr ? nullptr : part_b);
-        GKOMI_TRY(check_launch());
+        // The library's own block-Jacobi behind the callback: z = M^-1 r leaves the partials of r.z and r.r itself
+        // (jacobi_apply_kernel<..., Dot>: every lane holds both factors of its row) -- one launch and a pass over
+        // r and z less per iteration (profiles/r03_p3_cg_kernels.md).  `ng` = how many partials K1 re-adds: the
+        // apply's workgroups then, the vector grid otherwise.
+        const gkomi_jacobi_ctx* jac =
+            precond == &gkomi_jacobi_apply_cb ? static_cast<const gkomi_jacobi_ctx*>(precond_ctx) : nullptr;
+        int ng = g;
+        auto precondition = [&](bool first) -> int {  // z = M^-1 r and the partials of r.z (and, first / fused, r.r)
+            if (jac != nullptr) {
+                const int got = jacobi_apply_dot_launch(s, jac, r, z, part_a, part_b, spmv_dot_partials_room(n),
+                                                        &scal->status);
+                if (got < 0) return -got - 1000;
+                if (got > 0) {
+                    ng = got;
+                    return 0;
+                }
+                jac = nullptr;  // not for this one (scalar Jacobi): the general way from here on
+            }
+            GKOMI_TRY(precond(precond_ctx, s, r, z));
+            hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r, z,
+                               first ? static_cast<const cg_scalars*>(nullptr) : static_cast<const cg_scalars*>(scal),
+                               part_a, first ? part_b : static_cast<double*>(nullptr));
+            return check_launch();
+        };
+        if (precond != nullptr) {
+            GKOMI_TRY(precondition(true));
+        } else {
+            hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r, zz,
+                               static_cast<const cg_scalars*>(nullptr), part_a, static_cast<double*>(nullptr));
+            GKOMI_TRY(check_launch());
+        }
         const double* tau_part = precond == nullptr ? part_a : part_b;
         long long it = 0;
         bool done = false;
@@ -394,8 +421,9 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_, g
         // launches issued after the criterion fired return at once -- unless a preconditioner's are among them
         const long long lag = std::min<long long>(check_every, precond == nullptr ? 4 * host_watch_lag : host_watch_lag);
         auto issue = [&](long long i) -> int {
+            // (with the Jacobi apply's partials both sums have ng terms; K3's r.r partials, g of them, otherwise)
             hipLaunchKernelGGL(cg_fused_step1_kernel, dim3(g), dim3(fblock), 0, stream, n, p, zz,
-                               part_a, g, tau_part, g, scal, i,
+                               part_a, ng, tau_part, jac != nullptr ? ng : g, scal, i,
                                static_cast<long long>(max_iters), reduction_factor, watch.dev);
             if (spmv.fused()) {
                 GKOMI_TRY(spmv.launch(stream, p, q, part_c, &scal->status));
@@ -407,12 +435,7 @@ int cg_solve_impl(gkomi_stream_t s, int64_t n, int64_t nrhs, const sysmat& A_, g
             }
             hipLaunchKernelGGL(cg_fused_step2_kernel, dim3(g), dim3(fblock), 0, stream, n, x, r, p,
                                q, part_c, nb, scal, i, precond == nullptr ? part_a : part_b);
-            if (precond != nullptr) {
-                GKOMI_TRY(precond(precond_ctx, s, r, z));
-                hipLaunchKernelGGL(cg_dot2_partials_kernel, dim3(g), dim3(fblock), 0, stream, n, r,
-                                   z, static_cast<const cg_scalars*>(scal), part_a,
-                                   static_cast<double*>(nullptr));
-            }
+            if (precond != nullptr) GKOMI_TRY(precondition(false));
             return check_launch();
         };
         while (!done) {

@@ -107,6 +107,11 @@ inline int fused_vec_grid(int64_t n)
     return static_cast<int>(g);
 }
 
+// block-Jacobi apply with the partials of r . z and r . r in the same launch (jacobi.hip); > 0: number of partials,
+// 0: not for this preconditioner, < 0: -(error) - 1000
+int jacobi_apply_dot_launch(gkomi_stream_t s, const gkomi_jacobi_ctx* c, const double* in, double* out, double* part_rz,
+                            double* part_rr, size_t room, const uint8_t* stop_status);
+
 // a brick solve as one link of a chain on contiguous vectors (trs_bricks.hip): see the definition
 int trs_bricks_solve_chained(gkomi_stream_t s, gkomi_trs_bricks* h, void* plan, int unit_diag, const double* b, double* x,
                              bool x_is_armed, double* arm, double* rearm_b);

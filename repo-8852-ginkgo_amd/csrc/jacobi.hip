@@ -26,7 +26,7 @@
 // the same order as reference invert_block -> bit-identical inverse.
 #include <cstring>
 
-#include "common.hpp"
+#include "internal.hpp"
 
 #include "sort_scan.hpp"
 
@@ -536,13 +536,19 @@ __device__ __forceinline__ void load_row(const void* group, int idx0, int safe_i
 }
 
 // block_precisions == nullptr: fp64 storage
-template <int S, bool Advanced>
+// Dot (one column, the fused CG of cg_solver.hip): the launch also leaves, per workgroup, the partial sums of
+// b . x (= r . z) and b . b (= r . r) -- every lane holds both factors of its row anyway -- instead of a kernel of
+// its own re-reading both vectors; a solve that has stopped skips the launch.
+template <int S, bool Advanced, bool Dot = false>
 __global__ __launch_bounds__(block) void jacobi_apply_kernel(
     int64_t num_blocks, scheme_t scheme, const int32_t* __restrict__ block_ptrs,
     const uint8_t* __restrict__ block_precisions, const double* __restrict__ blocks, int64_t nrhs,
     const double* __restrict__ alpha_p, const double* __restrict__ b, int64_t b_stride,
-    const double* __restrict__ beta_p, double* __restrict__ x, int64_t x_stride)
+    const double* __restrict__ beta_p, double* __restrict__ x, int64_t x_stride,
+    double* __restrict__ part_bx = nullptr, double* __restrict__ part_bb = nullptr,
+    const uint8_t* __restrict__ stop_status = nullptr)
 {
+    if (Dot && status_has_stopped_uniform(stop_status)) return;
     constexpr int gs = 64 / S;
     const int lane = threadIdx.x & 63;
     const int g = lane / S, r = lane % S;
@@ -574,6 +580,7 @@ __global__ __launch_bounds__(block) void jacobi_apply_kernel(
     case pr_p2n0: load_row<S, pr_p2n0>(group, idx0, safe, stride, active, bs, rowv); break;
     default: load_row<S, pr_p0n0>(group, idx0, safe, stride, active, bs, rowv); break;
     }
+    double bx = 0.0, bb = 0.0;
     for (int64_t j = 0; j < nrhs; ++j) {
         const double bv = active ? b[(start + r) * b_stride + j] : 0.0;
         double acc = 0.0;
@@ -586,6 +593,30 @@ __global__ __launch_bounds__(block) void jacobi_apply_kernel(
             }
         }
         if (active) x[(start + r) * x_stride + j] = acc;
+        if (Dot && active) {
+            bx += bv * acc;
+            bb += bv * bv;
+        }
+    }
+    if (Dot) {
+        __shared__ double red[2 * (block / 64)];
+        bx = wave_reduce_sum(bx);
+        bb = wave_reduce_sum(bb);
+        if (lane == 0) {
+            red[threadIdx.x >> 6] = bx;
+            red[block / 64 + (threadIdx.x >> 6)] = bb;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tx = 0.0, tb = 0.0;
+#pragma unroll
+            for (int w = 0; w < block / 64; ++w) {
+                tx += red[w];
+                tb += red[block / 64 + w];
+            }
+            part_bx[blockIdx.x] = tx;
+            part_bb[blockIdx.x] = tb;
+        }
     }
 }
 
@@ -870,6 +901,36 @@ int jacobi_apply(gkomi_stream_t s, int64_t num_blocks, int max_block_size,
 }
 
 }  // namespace
+
+// z = M^-1 r together with the partials of r . z and r . r (cg_solver.hip, internal.hpp): fp64 or adaptive block
+// storage, one column.  Returns the number of partials (= workgroups) or a negative error code; 0 = not for this
+// preconditioner (scalar Jacobi, several columns): the caller applies it and adds up the dots itself.
+int gkomi::jacobi_apply_dot_launch(gkomi_stream_t s, const gkomi_jacobi_ctx* c, const double* in, double* out,
+                                   double* part_rz, double* part_rr, size_t room, const uint8_t* stop_status)
+{
+    if (c == nullptr || c->nrhs != 1 || c->max_block_size <= 1 || c->max_block_size > 32 || c->num_blocks <= 0) return 0;
+    const scheme_t sc = make_scheme(c->max_block_size);
+    const int sw = pow2ceil(c->max_block_size);
+    const int64_t groups = ceildiv(c->num_blocks, 64 / sw);
+    const int64_t grid = ceildiv(groups, block / 64);
+    if (grid > static_cast<int64_t>(room)) return 0;
+    hipStream_t stream = to_stream(s);
+#define GKOMI_APPLY_DOT(S)                                                                                        \
+    hipLaunchKernelGGL((jacobi_apply_kernel<S, false, true>), dim3(static_cast<unsigned>(grid)), dim3(block), 0,   \
+                       stream, c->num_blocks, sc, c->block_ptrs, c->block_precisions, c->blocks, int64_t{1},      \
+                       static_cast<const double*>(nullptr), in, int64_t{1}, static_cast<const double*>(nullptr),  \
+                       out, int64_t{1}, part_rz, part_rr, stop_status)
+    switch (sw) {
+    case 2: GKOMI_APPLY_DOT(2); break;
+    case 4: GKOMI_APPLY_DOT(4); break;
+    case 8: GKOMI_APPLY_DOT(8); break;
+    case 16: GKOMI_APPLY_DOT(16); break;
+    default: GKOMI_APPLY_DOT(32); break;
+    }
+#undef GKOMI_APPLY_DOT
+    const int err = check_launch();
+    return err ? -(err < 0 ? -err : err) - 1000 : static_cast<int>(grid);
+}
 
 extern "C" int gkomi_jacobi_generate_f64_i32(gkomi_stream_t s, int64_t nrows,
                                              const int32_t* row_ptrs, const int32_t* col_idxs,
