@@ -1754,6 +1754,21 @@ protected:
     }
     void apply_impl(const LinOp* b, LinOp* x) const override { run(nullptr, b, nullptr, x); }
     void apply_impl(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const override { run(alpha, b, beta, x); }
+public:
+    // this preconditioner as the record of the library's own callback (gkomi_jacobi_apply_cb): the native drivers
+    // then see a block-Jacobi, not an opaque operator (the fused CG lets its apply carry r.z and r.r)
+    void fill_callback_record(gkomi_jacobi_ctx& c, size_type nrhs) const
+    {
+        c.n = static_cast<int64_t>(size_[0]);
+        c.nrhs = static_cast<int64_t>(nrhs);
+        c.num_blocks = static_cast<int64_t>(num_blocks_);
+        c.max_block_size = static_cast<int32_t>(max_block_size_);
+        c.pad_ = 0;
+        c.block_ptrs = max_block_size_ == 1 ? nullptr : block_ptrs_.get_const_data();
+        c.blocks = blocks_.get_const_data();
+        c.block_precisions = precisions_.get_num_elems() > 0 ? precisions_.get_const_data() : nullptr;
+    }
+private:
     uint32 max_block_size_;
     size_type num_blocks_{0};
     array<I> block_ptrs_;
@@ -1762,6 +1777,31 @@ protected:
     array<double> conditioning_;
 };
 }  // namespace preconditioner
+
+namespace detail {
+// The preconditioner of a native solver driver as (gkomi_apply_fn, context): a preconditioner::Jacobi<double, int32>
+// goes by the library's own callback + record, any other LinOp by linop_callback.
+struct precond_callback {
+    linop_callback generic;
+    gkomi_jacobi_ctx jacobi{};
+    gkomi_apply_fn fn = nullptr;
+    void* ctx = nullptr;
+    precond_callback(const LinOp* op, std::shared_ptr<const Executor> exec, size_type n, size_type nrhs) : generic{op, std::move(exec), n, nrhs}
+    {
+        if (op == nullptr) return;
+        if (auto j = dynamic_cast<const preconditioner::Jacobi<double, int32>*>(op)) {
+            j->fill_callback_record(jacobi, nrhs);
+            fn = &gkomi_jacobi_apply_cb;
+            ctx = &jacobi;
+            return;
+        }
+        fn = &linop_callback::call;
+        ctx = &generic;
+    }
+    precond_callback(const precond_callback&) = delete;
+    precond_callback& operator=(const precond_callback&) = delete;
+};
+}  // namespace detail
 
 // ---- solvers ------------------------------------------------------------------------------
 namespace solver {
@@ -1834,9 +1874,9 @@ protected:
         if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
         array<char> ws(exec_, gkomi_cg_workspace_bytes(n, nrhs));
         std::vector<double> info(2 + 2 * nrhs, 0.0);
-        ::gko::detail::linop_callback cb{precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
-        auto pfn = precond_ ? &::gko::detail::linop_callback::call : nullptr;
-        void* pctx = precond_ ? &cb : nullptr;
+        ::gko::detail::precond_callback cb(precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs));
+        auto pfn = cb.fn;
+        void* pctx = cb.ctx;
         // a Csr system matrix travels as its record (srow, row statistic): detail::system_callback
         ::gko::detail::system_callback mcb(A_.get(), exec_, static_cast<size_type>(n));
         if (nrhs == 1) {  // the fused loop; Ell / Sellp with the dot in the SpMV's epilogue
@@ -1895,9 +1935,9 @@ protected:
         if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
         array<char> ws(exec_, gkomi_krylov_workspace_bytes(n, nrhs));
         std::vector<double> info(2 + 2 * nrhs, 0.0);
-        ::gko::detail::linop_callback cb{precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
-        auto pfn = precond_ ? &::gko::detail::linop_callback::call : nullptr;
-        void* pctx = precond_ ? &cb : nullptr;
+        ::gko::detail::precond_callback cb(precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs));
+        auto pfn = cb.fn;
+        void* pctx = cb.ctx;
         // a Csr system matrix travels as its record (srow, row statistic): detail::system_callback
         ::gko::detail::system_callback mcb(A_.get(), exec_, static_cast<size_type>(n));
         GKOMI_CALL(OpDriver(nullptr, n, nrhs, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), settings_.max_iters,
@@ -2120,9 +2160,9 @@ protected:
         if (db->get_stride() != static_cast<size_type>(nrhs) || dx->get_stride() != static_cast<size_type>(nrhs)) GKO_NOT_SUPPORTED("solver vectors must be contiguous (stride == #columns)");
         array<char> ws(exec_, gkomi_gmres_workspace_bytes(n, nrhs, krylov_dim_));
         std::vector<double> info(2 + 2 * nrhs, 0.0);
-        ::gko::detail::linop_callback cb{precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs)};
-        auto pfn = precond_ ? &::gko::detail::linop_callback::call : nullptr;
-        void* pctx = precond_ ? &cb : nullptr;
+        ::gko::detail::precond_callback cb(precond_.get(), exec_, static_cast<size_type>(n), static_cast<size_type>(nrhs));
+        auto pfn = cb.fn;
+        void* pctx = cb.ctx;
         // a Csr system matrix travels as its record (srow, row statistic): detail::system_callback
         ::gko::detail::system_callback mcb(A_.get(), exec_, static_cast<size_type>(n));
         GKOMI_CALL(gkomi_gmres_solve_op_f64(nullptr, n, nrhs, mcb.fn, mcb.ctx, pfn, pctx, db->get_const_values(), dx->get_values(), krylov_dim_,
