@@ -1492,6 +1492,13 @@ struct distributed_system {
 
 // ---- preconditioners -----------------------------------------------------------------
 namespace detail {
+// a preconditioner the library has a callback of its own for (gkomi_jacobi_apply_cb, gkomi_ilu_apply_cb): it hands
+// the native drivers that callback and its record instead of an opaque LinOp::apply
+struct native_preconditioner {
+    virtual ~native_preconditioner() = default;
+    // false: not in this configuration (the caller wraps LinOp::apply)
+    virtual bool native_callback(gkomi_apply_fn& fn, void*& ctx, size_type nrhs) const = 0;
+};
 // a LinOp as a gkomi_apply_fn for the native solver drivers
 struct linop_callback {
     const LinOp* op;
@@ -1638,7 +1645,7 @@ struct block_interleaved_storage_scheme {
 };
 
 template <typename V = double, typename I = int32>
-class Jacobi : public LinOp, public Transposable {
+class Jacobi : public LinOp, public Transposable, public ::gko::detail::native_preconditioner {
 public:
     class Factory : public LinOpFactory {
     public:
@@ -1756,9 +1763,12 @@ protected:
     void apply_impl(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const override { run(alpha, b, beta, x); }
 public:
     // this preconditioner as the record of the library's own callback (gkomi_jacobi_apply_cb): the native drivers
-    // then see a block-Jacobi, not an opaque operator (the fused CG lets its apply carry r.z and r.r)
-    void fill_callback_record(gkomi_jacobi_ctx& c, size_type nrhs) const
+    // then see a block-Jacobi, not an opaque operator (the fused CG lets its apply carry r.z and r.r).  The record
+    // lives in the object: one solve at a time per preconditioner object and column count.
+    bool native_callback(gkomi_apply_fn& fn, void*& ctx, size_type nrhs) const override
     {
+        if (!std::is_same<V, double>::value || !std::is_same<I, int32>::value) return false;
+        gkomi_jacobi_ctx& c = record_;
         c.n = static_cast<int64_t>(size_[0]);
         c.nrhs = static_cast<int64_t>(nrhs);
         c.num_blocks = static_cast<int64_t>(num_blocks_);
@@ -1767,8 +1777,12 @@ public:
         c.block_ptrs = max_block_size_ == 1 ? nullptr : block_ptrs_.get_const_data();
         c.blocks = blocks_.get_const_data();
         c.block_precisions = precisions_.get_num_elems() > 0 ? precisions_.get_const_data() : nullptr;
+        fn = &gkomi_jacobi_apply_cb;
+        ctx = &record_;
+        return true;
     }
 private:
+    mutable gkomi_jacobi_ctx record_{};
     uint32 max_block_size_;
     size_type num_blocks_{0};
     array<I> block_ptrs_;
@@ -1779,21 +1793,17 @@ private:
 }  // namespace preconditioner
 
 namespace detail {
-// The preconditioner of a native solver driver as (gkomi_apply_fn, context): a preconditioner::Jacobi<double, int32>
-// goes by the library's own callback + record, any other LinOp by linop_callback.
+// The preconditioner of a native solver driver as (gkomi_apply_fn, context): a preconditioner::Jacobi or Ilu
+// <double, int32> goes by the library's own callback + record (native_preconditioner), any other LinOp by linop_callback.
 struct precond_callback {
     linop_callback generic;
-    gkomi_jacobi_ctx jacobi{};
     gkomi_apply_fn fn = nullptr;
     void* ctx = nullptr;
     precond_callback(const LinOp* op, std::shared_ptr<const Executor> exec, size_type n, size_type nrhs) : generic{op, std::move(exec), n, nrhs}
     {
         if (op == nullptr) return;
-        if (auto j = dynamic_cast<const preconditioner::Jacobi<double, int32>*>(op)) {
-            j->fill_callback_record(jacobi, nrhs);
-            fn = &gkomi_jacobi_apply_cb;
-            ctx = &jacobi;
-            return;
+        if (auto native = dynamic_cast<const native_preconditioner*>(op)) {
+            if (native->native_callback(fn, ctx, nrhs)) return;
         }
         fn = &linop_callback::call;
         ctx = &generic;
@@ -2207,6 +2217,19 @@ public:
     int64_t get_num_levels() const noexcept { return nlevels_; }
     bool uses_level_schedule() const noexcept { return planned_; }
     bool uses_brick_plan() const noexcept { return bricks_ != nullptr; }
+    bool has_unit_diagonal() const noexcept { return unit_; }
+    // what gkomi_ilu_ctx carries of an analysed factor: its brick plan, else its level plan, else nothing
+    void fill_callback_record(void*& level_plan, int64_t& nslices, int64_t& entries, int64_t& max_deps, gkomi_trs_bricks*& bricks, void*& bricks_plan) const
+    {
+        level_plan = nullptr; bricks = nullptr; bricks_plan = nullptr; nslices = 0; entries = 0; max_deps = -1;
+        if (bricks_ != nullptr) {
+            bricks = bricks_;
+            bricks_plan = const_cast<char*>(plan_.get_const_data());
+        } else if (planned_) {
+            level_plan = const_cast<char*>(plan_.get_const_data());
+            nslices = nslices_; entries = entries_; max_deps = max_deps_;
+        }
+    }
     ~Trs() override { gkomi_trs_bricks_destroy(bricks_); }
     // a solve that gave up (spin bound) left NaNs in x; sticky until the next generate
     bool has_overrun() const
@@ -2372,8 +2395,49 @@ protected:
 
 namespace preconditioner {
 template <typename V = double, typename I = int32>
-class Ilu : public LinOp, public Transposable {
+class Ilu : public LinOp, public Transposable, public ::gko::detail::native_preconditioner {
 public:
+    // L^-1 then U^-1 as gkomi_ilu_apply_cb + record: the two brick solves of an apply then run as a chain (no launch
+    // that pre-fills an output with the ready flags), and no Dense objects are built per apply.  The record, the
+    // intermediate vector and the analysis-free kernels' workspace live in the object (the reference's Ilu caches its
+    // intermediate too): one solve at a time per preconditioner object.
+    bool native_callback(gkomi_apply_fn& fn, void*& ctx, size_type nrhs) const override
+    {
+        if (!std::is_same<V, double>::value || !std::is_same<I, int32>::value) return false;
+        auto l = dynamic_cast<const solver::LowerTrs<V, I>*>(l_solver_.get());
+        auto u = dynamic_cast<const solver::UpperTrs<V, I>*>(u_solver_.get());
+        if (l == nullptr || u == nullptr || u->has_unit_diagonal()) return false;
+        const size_type n = size_[0];
+        if (mid_.get_num_elems() != n * nrhs || mid_.get_executor() == nullptr) {
+            mid_ = array<V>(exec_, n * nrhs);
+            mid_.fill(V{0});
+            record_.pad_ = 0;
+        }
+        if (tws_.get_num_elems() == 0) {
+            tws_ = array<char>(exec_, gkomi_trs_workspace_bytes());
+            tws_.fill(0);
+        }
+        const int32_t chain_state = record_.pad_;
+        record_ = gkomi_ilu_ctx{};
+        record_.pad_ = chain_state;
+        record_.n = static_cast<int64_t>(n);
+        record_.nrhs = static_cast<int64_t>(nrhs);
+        record_.l_row_ptrs = l_factor_->get_const_row_ptrs();
+        record_.l_col_idxs = l_factor_->get_const_col_idxs();
+        record_.l_vals = l_factor_->get_const_values();
+        record_.u_row_ptrs = u_factor_->get_const_row_ptrs();
+        record_.u_col_idxs = u_factor_->get_const_col_idxs();
+        record_.u_vals = u_factor_->get_const_values();
+        record_.intermediate = mid_.get_data();
+        record_.trs_workspace = tws_.get_data();
+        record_.trs_workspace_bytes = tws_.get_num_elems();
+        record_.l_unit_diag = l->has_unit_diagonal() ? 1 : 0;
+        l->fill_callback_record(record_.l_plan, record_.l_nslices, record_.l_entries, record_.l_max_deps, record_.l_bricks, record_.l_bricks_plan);
+        u->fill_callback_record(record_.u_plan, record_.u_nslices, record_.u_entries, record_.u_max_deps, record_.u_bricks, record_.u_bricks_plan);
+        fn = &gkomi_ilu_apply_cb;
+        ctx = &record_;
+        return true;
+    }
     class Factory : public LinOpFactory {
     public:
         Factory() : LinOpFactory(nullptr) {}
@@ -2424,6 +2488,9 @@ protected:
     }
     std::shared_ptr<const matrix::Csr<V, I>> l_factor_, u_factor_;
     std::shared_ptr<const LinOp> l_solver_, u_solver_;
+    mutable gkomi_ilu_ctx record_{};
+    mutable array<V> mid_;
+    mutable array<char> tws_;
 };
 }  // namespace preconditioner
 
