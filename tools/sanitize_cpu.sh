@@ -5,7 +5,7 @@
 # usage: tools/sanitize_cpu.sh [log]      (run from the repo root)
 set -o pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-LOG=${1:-$ROOT/profiles/r02_sanitizers.log}
+LOG=${1:-$ROOT/profiles/r03_sanitizers.log}
 OUT=/tmp/gkomi_asan
 mkdir -p $OUT
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g"
