@@ -90,6 +90,9 @@ def parse():
     ap.add_argument("--min-region-seconds", type=float, default=0.05,
                     help="floor on the total length of the timed regions of K steps each (more regions, never more steps)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-n1-anchor", action="store_true",
+                    help="N > 1: skip rank 0's one-GPU measurement of the same matrix (n1_same_run)")
+    ap.add_argument("--rehearse-line", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, initialise the process group, report the rank count, exit (launch rehearsal; "
                          "GKOMI_BENCH_BACKEND=gloo runs it without GPUs)")
@@ -265,6 +268,64 @@ def _gather_ranks(dist, rank, world):
     return got
 
 
+def p3_metric(g):
+    """the metric string of every N > 1 line: the same for all N (the driver compares values across N)"""
+    return f"distributed CSR SpMV GFLOP/s (fp64, {g}^3 7-pt Poisson, row-partitioned, one rank per GPU)"
+
+
+def attach_anchor(out, anchor, world):
+    """`n1_same_run` = the same matrix on ONE GPU, measured by rank 0 on its own device before the ranks'
+    timed regions of THIS run; `parallel_efficiency` = (value(N) / value(1)) / N for the SpMV and the same
+    ratio of CG iterations/s (strong scaling: total work fixed).  Pure function of measured numbers
+    (tests/test_bench_launch.py rehearses it over gloo)."""
+    if anchor is None:
+        out["n1_same_run"] = None
+        out["parallel_efficiency"] = None
+        return out
+    n1 = {"workload": anchor.get("workload"), "gflops": anchor["spmv_gflops"], "spmv_us": anchor.get("spmv_us"),
+          "spmv_frac_of_8tbs": anchor.get("spmv_frac_of_8tbs"),
+          "cg_iters_per_sec": (anchor.get("cg") or {}).get("iters_per_sec"),
+          "cg_iterations": (anchor.get("cg") or {}).get("iterations"),
+          "measured_on": "rank 0's GPU, before the distributed timed regions of this run"}
+    out["n1_same_run"] = n1
+    eff = {"spmv": round(out["value"] / (world * n1["gflops"]), 4) if n1["gflops"] else None, "n_gpus": world,
+           "definition": "(value(N) / value(1)) / N, value(1) = n1_same_run (strong scaling)"}
+    cg = out.get("cg") or {}
+    if n1["cg_iters_per_sec"] and cg.get("iters_per_sec"):
+        eff["cg"] = round(cg["iters_per_sec"] / (world * n1["cg_iters_per_sec"]), 4)
+    out["parallel_efficiency"] = eff
+    return out
+
+
+def rehearse_line(args, world, rank):
+    """The N > 1 line's flow without a GPU (GKOMI_BENCH_BACKEND=gloo --rendezvous-only --rehearse-line): rank 0
+    'measures' the one-GPU anchor while the others wait at the barrier, every rank contributes a region time,
+    the max over ranks makes the value, rank 0 assembles the line with the functions the real run uses.  The
+    numbers are placeholders (marked "rehearsal"); the structure is the real one."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(os.environ.get("GKOMI_BENCH_BACKEND", "gloo"))
+    g = args.p3_grid
+    nnz_global = 7 * g ** 3 - 6 * g * g
+    anchor = None
+    if rank == 0:
+        time.sleep(0.5)   # the other ranks are held at the barrier meanwhile
+        anchor = {"workload": f"{g}^3 7-pt Poisson on one GPU (rehearsal)", "spmv_gflops": 1000.0, "spmv_us": 2e-3 * nnz_global,
+                  "spmv_frac_of_8tbs": 0.5, "cg": {"iters_per_sec": 100.0, "iterations": 500}}
+    dist.barrier()
+    steps = max(10, args.steps // 4)
+    t = torch.tensor([steps * 2e-9 * nnz_global / (world * 1000.0) * (1.0 + 0.1 * rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    out = {"metric": p3_metric(g), "value": round(2.0 * nnz_global * steps / wall / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world,
+           "steps": steps, "warmup": max(3, args.warmup // 4), "ms_per_step": round(wall / steps * 1e3, 5),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "rehearsal": True, "cg": {"iters_per_sec": 100.0 * world * 0.8, "iterations": 500}}
+    if rank == 0:
+        print(json.dumps(attach_anchor(out, anchor, world)), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -274,6 +335,9 @@ def main():
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)   # does not return
+    if args.rendezvous_only and args.rehearse_line:
+        rehearse_line(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
+        return
     if args.rendezvous_only:
         rendezvous_only(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),
                         int(os.environ.get("LOCAL_RANK", "0")))
@@ -314,7 +378,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
-    def timed_region(step_fn, steps):
+    def timed_region(step_fn, steps, local=False):
         """Timed regions of EXACTLY `steps` steps each (barrier + synchronize on both sides, max over
         ranks per region): at least TRIALS of them, and as many more as it takes for the measured steps
         to cover --min-region-seconds (a 20-step region of an 18-us kernel is 0.4 ms: one host stall --
@@ -323,8 +387,8 @@ def main():
         regions = []
         budget = max(args.min_region_seconds, 0.0)
         while len(regions) < TRIALS or (sum(w for w, _ in regions) < budget and len(regions) < 400):
-            wall, ev = time_loop(torch, step_fn, steps, barrier)
-            if distributed:
+            wall, ev = time_loop(torch, step_fn, steps, (lambda: None) if local else barrier)
+            if distributed and not local:
                 t = torch.tensor([wall, ev], dtype=torch.float64, device=device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 wall, ev = float(t[0].item()), float(t[1].item())
@@ -346,6 +410,95 @@ def main():
         t = torch.empty(int(gk.csr_srow_entries(nnz, tile)), dtype=torch.int32, device=device)
         gk.csr_make_srow_i32(stream, n, nnz, rp_d, tile, t, t.numel())
         return t, tile
+
+    import gkomi.solvers as solvers
+
+    import gkomi.formats as formats
+
+    def as_csr(nn, a):
+        """gko::matrix::Csr on the device: carries its srow and its longest row like the C++ mirror's Csr;
+        the solver drivers get it as a gkomi_csr_ctx record -> the nonzero-split kernel (with the
+        dot-product epilogue in the fused iterations), the kernel `value` is measured on"""
+        return formats.Csr(gk, nn, nn, a[0], a[1], a[2])
+
+    def timed_solves(fn):
+        fn()
+        runs = []
+        for _ in range(3):  # median of 3 whole solves, all of them reported
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = fn()
+            torch.cuda.synchronize()
+            runs.append((time.perf_counter() - t0, res))
+        runs.sort(key=lambda r: r[0])
+        el, res = runs[1]
+        return res, el, [round(r[0], 5) for r in runs]
+
+    def timed_cg(A, rhs, check_every=32, single_launch=True, precond=None):
+        """single_launch=False: gkomi_cg_persistent_enable(0) -- the three-launch iteration (what every
+        system beyond ~1M rows / 7 nonzeros per row, and every preconditioned solve, runs)"""
+        gk.cg_persistent_enable(1 if single_launch else 0)
+        try:
+            return timed_solves(lambda: solvers.solve_op(gk, "cg", A, rhs, max_iters=50000, reduction=1e-10,
+                                                         check_every=check_every, fused=True, precond=precond))
+        finally:
+            gk.cg_persistent_enable(1)
+
+    def sinus_system(A):
+        nn = A.nrows
+        s = np.sin(np.arange(nn, dtype=np.float64))
+        s /= np.linalg.norm(s)
+        sb = dev(s.reshape(nn, 1))
+        b = torch.empty((nn, 1), dtype=torch.float64, device=device)
+        A.apply(sb, b)
+        return sb, b
+
+    def cg_entry(res, el, all_s):
+        return {"iterations": res["iterations"], "seconds": round(el, 5), "all_seconds": all_s,
+                "iters_per_sec": round(res["iterations"] / el, 1), "us_per_iteration": round(el / max(res["iterations"], 1) * 1e6, 2),
+                "final_residual_norm_rel": res["rel_residual"], "converged": bool(res["converged"])}
+
+
+    def p3_one_gpu(local=False):
+        """BASELINE config 5's matrix (256^3 7-pt Poisson) on ONE GPU: SpMV + CG to 1e-10.  The N = 1 point of
+        the strong-scaling curve: an entry of the N = 1 line ("p3") and, with local=True (no collective inside
+        the timed regions), what rank 0 measures on its own device at the start of every N > 1 run
+        ("n1_same_run"), so that each line carries its own anchor."""
+        progress(f"P3: building the {args.p3_grid}^3 matrix on one GPU")
+        g = args.p3_grid
+        n3, rp3, ci3, v3 = matgen.poisson_3d_7pt(g)
+        nnz3 = int(rp3[-1])
+        a3 = [dev(rp3), dev(ci3), dev(v3)]
+        del rp3, ci3, v3
+        x3 = dev(np.sin(0.01 * np.arange(n3)).reshape(n3, 1))
+        y3 = torch.empty((n3, 1), dtype=torch.float64, device=device)
+        srow3, tile3 = make_srow(a3[0], n3, nnz3)
+        step3 = lambda i: gk.csr_spmv_srow_f64_i32(stream, n3, n3, 1, nnz3, a3[0], a3[1], a3[2], x3, 1, y3, 1,
+                                                   None, None, 0, 7, srow3, tile3)
+        for i in range(5):
+            step3(i)
+        steps3 = max(10, args.steps // 10)
+        (w3, e3), r3 = timed_region(step3, steps3, local=local)
+        b3 = algorithmic_bytes(n3, n3, nnz3)
+        p3 = {"workload": f"{g}^3 7-pt Poisson (n={n3}, nnz={nnz3}) on one GPU: the N=1 point of the N>1 lines",
+              "spmv_gflops": round(2.0 * nnz3 * steps3 / w3 / 1e9, 2), "spmv_us": round(e3 / steps3 * 1e6, 2),
+              "spmv_gbs": round(b3 * steps3 / e3 / 1e9, 1), "spmv_frac_of_8tbs": round(b3 * steps3 / e3 / 1e9 / HBM_PEAK_GBS, 4),
+              "timing_spread": spread(r3, steps3)}
+        if not args.no_cg:
+            A3 = as_csr(n3, a3)
+            sb3, bb3 = sinus_system(A3)
+            res, el, all_s = timed_cg(A3, bb3)
+            # per iteration (three launches): K1 3n + K2 (matrix + 2n) + K3 6n values
+            cg3_bytes = 11 * 8 * n3 + 12 * nnz3 + 4 * (n3 + 1)
+            p3["cg"] = dict(cg_entry(res, el, all_s), achieved_gbs=round(cg3_bytes * res["iterations"] / el / 1e9, 1),
+                            frac_of_8tbs=round(cg3_bytes * res["iterations"] / el / 1e9 / HBM_PEAK_GBS, 4),
+                            bytes_per_iteration=cg3_bytes,
+                            solution_rel_err=float(torch.linalg.norm(res["x"] - sb3) / torch.linalg.norm(sb3)))
+            p3["cg_rhs_ones"] = cg_entry(*timed_cg(A3, torch.ones((n3, 1), dtype=torch.float64, device=device)))
+            del A3
+        del a3, x3, y3, srow3
+        torch.cuda.empty_cache()
+        return p3
 
     out = {}
     if not distributed:
@@ -396,7 +549,11 @@ def main():
                            "traffic_source": (f"{traffic_file}: rocprofv3 --pmc passes of this command "
                                               "(tools/profile.sh), not re-measured in this run") if traffic_file else None,
                            "kernel": "csr_split_kernel", "bytes_per_launch": bytes_per_launch,
-                           "us_per_launch": round(kern_s * 1e6, 3)}
+                           "us_per_launch": round(kern_s * 1e6, 3),
+                           "clock": "HIP events on the launch stream around the K steps of the median region "
+                                    "(achieved, frac, us_per_launch); value / ms_per_step use the host wall clock of "
+                                    "the same region",
+                           "frac_by_wall_clock": round(bytes_per_launch * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4)}
         # the practical ceiling of THIS box for the same bytes: a pure 16-B streaming kernel over the same
         # rotating copies (no gather, no LDS, no dependent access), best grid of four, same region policy
         progress("P2: streaming ceiling for the same byte mix")
@@ -427,53 +584,6 @@ def main():
                        "us_per_launch": round(wev / args.steps * 1e6, 3), "timing_spread": spread(wregions, args.steps),
                        "note": "same matrix every step (benchmark/spmv methodology), automatic strategy; the 80 MB "
                                "working set is Infinity-Cache resident"}
-
-        import gkomi.solvers as solvers
-
-        import gkomi.formats as formats
-
-        def as_csr(nn, a):
-            """gko::matrix::Csr on the device: carries its srow and its longest row like the C++ mirror's Csr;
-            the solver drivers get it as a gkomi_csr_ctx record -> the nonzero-split kernel (with the
-            dot-product epilogue in the fused iterations), the kernel `value` is measured on"""
-            return formats.Csr(gk, nn, nn, a[0], a[1], a[2])
-
-        def timed_solves(fn):
-            fn()
-            runs = []
-            for _ in range(3):  # median of 3 whole solves, all of them reported
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                res = fn()
-                torch.cuda.synchronize()
-                runs.append((time.perf_counter() - t0, res))
-            runs.sort(key=lambda r: r[0])
-            el, res = runs[1]
-            return res, el, [round(r[0], 5) for r in runs]
-
-        def timed_cg(A, rhs, check_every=32, single_launch=True, precond=None):
-            """single_launch=False: gkomi_cg_persistent_enable(0) -- the three-launch iteration (what every
-            system beyond ~1M rows / 7 nonzeros per row, and every preconditioned solve, runs)"""
-            gk.cg_persistent_enable(1 if single_launch else 0)
-            try:
-                return timed_solves(lambda: solvers.solve_op(gk, "cg", A, rhs, max_iters=50000, reduction=1e-10,
-                                                             check_every=check_every, fused=True, precond=precond))
-            finally:
-                gk.cg_persistent_enable(1)
-
-        def sinus_system(A):
-            nn = A.nrows
-            s = np.sin(np.arange(nn, dtype=np.float64))
-            s /= np.linalg.norm(s)
-            sb = dev(s.reshape(nn, 1))
-            b = torch.empty((nn, 1), dtype=torch.float64, device=device)
-            A.apply(sb, b)
-            return sb, b
-
-        def cg_entry(res, el, all_s):
-            return {"iterations": res["iterations"], "seconds": round(el, 5), "all_seconds": all_s,
-                    "iters_per_sec": round(res["iterations"] / el, 1), "us_per_iteration": round(el / max(res["iterations"], 1) * 1e6, 2),
-                    "final_residual_norm_rel": res["rel_residual"], "converged": bool(res["converged"])}
 
         progress("P2: CG solves")
         if not args.no_cg:
@@ -515,42 +625,8 @@ def main():
         got_p2 = copies[0][4].cpu().numpy().copy()
 
         if not args.no_p3:
-            progress(f"P3: building the {args.p3_grid}^3 matrix")
-            # the one-GPU anchor of the strong-scaling curve: BASELINE config 5's matrix on one GPU
             del copies[1:]
-            g = args.p3_grid
-            n3, rp3, ci3, v3 = matgen.poisson_3d_7pt(g)
-            nnz3 = int(rp3[-1])
-            a3 = [dev(rp3), dev(ci3), dev(v3)]
-            del rp3, ci3, v3
-            x3 = dev(np.sin(0.01 * np.arange(n3)).reshape(n3, 1))
-            y3 = torch.empty((n3, 1), dtype=torch.float64, device=device)
-            srow3, tile3 = make_srow(a3[0], n3, nnz3)
-            step3 = lambda i: gk.csr_spmv_srow_f64_i32(stream, n3, n3, 1, nnz3, a3[0], a3[1], a3[2], x3, 1, y3, 1,
-                                                       None, None, 0, 7, srow3, tile3)
-            for i in range(5):
-                step3(i)
-            steps3 = max(10, args.steps // 10)
-            (w3, e3), r3 = timed_region(step3, steps3)
-            b3 = algorithmic_bytes(n3, n3, nnz3)
-            p3 = {"workload": f"{g}^3 7-pt Poisson (n={n3}, nnz={nnz3}) on one GPU: the N=1 point of the N>1 lines",
-                  "spmv_gflops": round(2.0 * nnz3 * steps3 / w3 / 1e9, 2), "spmv_us": round(e3 / steps3 * 1e6, 2),
-                  "spmv_gbs": round(b3 * steps3 / e3 / 1e9, 1), "spmv_frac_of_8tbs": round(b3 * steps3 / e3 / 1e9 / HBM_PEAK_GBS, 4),
-                  "timing_spread": spread(r3, steps3)}
-            if not args.no_cg:
-                A3 = as_csr(n3, a3)
-                sb3, bb3 = sinus_system(A3)
-                res, el, all_s = timed_cg(A3, bb3)
-                # per iteration (three launches): K1 3n + K2 (matrix + 2n) + K3 6n values
-                cg3_bytes = 11 * 8 * n3 + 12 * nnz3 + 4 * (n3 + 1)
-                p3["cg"] = dict(cg_entry(res, el, all_s), achieved_gbs=round(cg3_bytes * res["iterations"] / el / 1e9, 1),
-                                frac_of_8tbs=round(cg3_bytes * res["iterations"] / el / 1e9 / HBM_PEAK_GBS, 4),
-                                bytes_per_iteration=cg3_bytes,
-                                solution_rel_err=float(torch.linalg.norm(res["x"] - sb3) / torch.linalg.norm(sb3)))
-                p3["cg_rhs_ones"] = cg_entry(*timed_cg(A3, torch.ones((n3, 1), dtype=torch.float64, device=device)))
-                del A3
-            out["p3"] = p3
-            del a3, x3, y3, srow3
+            out["p3"] = p3_one_gpu()
 
         if not args.no_config4:
             # BASELINE config 4's shape (GMRES(30) + ParILU on a 1.26M-row 7-point convection-diffusion system):
@@ -694,6 +770,16 @@ def main():
         import gkomi.distributed as gd
         g = args.p3_grid
         n_global = g ** 3
+        # the curve's own N = 1 point: the whole matrix on rank 0's GPU (1.7 GB), SpMV + CG, before anything
+        # distributed is built; the other ranks wait at the barrier
+        anchor = None
+        if rank == 0 and not args.no_n1_anchor:
+            try:
+                anchor = p3_one_gpu(local=True)
+            except Exception as ex:  # noqa: BLE001 - the line says so instead of dying
+                anchor = None
+                progress(f"one-GPU anchor failed: {ex!r}")
+        barrier()
         part = gd.Partition.build_from_global_size_uniform(gk, world, n_global)
         lo, hi = int(part.range_bounds[rank]), int(part.range_bounds[rank + 1])
         rows, cols, vals = gd.poisson3d_rows(g, lo, hi)
@@ -727,7 +813,7 @@ def main():
         (wall, ev), regions = timed_region(step, steps)
         local_bytes = algorithmic_bytes(n_loc, n_loc + M.non_local[1], nnz_local)
         out = {
-            "metric": f"distributed CSR SpMV GFLOP/s (fp64, {g}^3 7-pt Poisson, row-partitioned over {world} GPUs)",
+            "metric": p3_metric(g),
             "value": round(2.0 * nnz_global * steps / wall / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world,
             "steps": steps, "warmup": max(3, args.warmup // 4), "ms_per_step": round(wall / steps * 1e3, 5),
             "timing": f"median of {len(regions)} timed regions of {steps} steps each", "timing_spread": spread(regions, steps),
@@ -792,6 +878,7 @@ def main():
         if A is not None:
             A.close()
             comm.close()
+        attach_anchor(out, anchor, world)
 
     if rank == 0:
         progress("done")

@@ -100,6 +100,19 @@ enum {
  * which is what it does by itself for matrices larger than the cache.  Pure
  * speed (cold 18.6 -> 16.6 us on the 1M-row 5-pt matrix), never results. */
 #define GKOMI_CSR_STREAMING (1 << 24)
+/* OR-ed into the strategy word: the gathers of b range over more than one XCD's
+ * 4 MiB L2 keeps (what gkomi_csr_analyse_gather_i32 finds for uniformly random or
+ * randomly permuted column patterns on > 400 k columns).  Half the gathers then
+ * miss L2 and each miss moves a 128-B line over the fabric for 8 useful bytes:
+ * the fabric, not HBM, bounds the SpMV (profiles/r04_gather_pmc.md).  With this
+ * flag the load-balanced kernel (GKOMI_CSR_BALANCED, or the automatic strategy on
+ * a matrix whose long rows select it anyway) runs one pass per window of 4 MiB of
+ * b: the matrix is streamed once per window, more of b comes from L2 (power-law
+ * class 140 -> 126 us, uniformly random columns 172 -> 144 us).  The partial sums
+ * of the passes add up in c: tolerance parity like the reference's own load_balance
+ * kernel, not bit for bit -- which is why matrices of short rows keep their
+ * bit-exact kernels under the automatic strategy, flag or not. */
+#define GKOMI_CSR_COLBLOCK (1 << 25)
 
 /* csr::spmv  c = A b   and   csr::advanced_spmv  c = alpha A b + beta c.
  * alpha == NULL && beta == NULL selects the simple form (c is never read).
@@ -147,6 +160,50 @@ int gkomi_csr_spmv_srow_f64_i32(gkomi_stream_t stream, int64_t nrows, int64_t nc
                                 const double* beta, int strategy,
                                 int64_t max_row_nnz_hint, const int32_t* srow,
                                 int64_t srow_tile);
+
+/* The <double, int64> instantiation of csr::spmv / advanced_spmv, Csr::make_srow and the
+ * row statistic (GKO_INSTANTIATE_FOR_EACH_VALUE_AND_INDEX_TYPE,
+ * include/ginkgo/core/base/types.hpp:544-560): the one a 288 GB GPU needs beyond
+ * <double, int32> (nnz > 2^31).  Same contracts as the _i32 entries; vals and
+ * col_idxs 16-byte aligned (GKOMI_ENOTSUPPORTED otherwise); the automatic strategy
+ * runs the nonzero-split kernel when the matrix carries its srow and the row-cut
+ * stream kernel otherwise -- both bit-identical to the reference for any row lengths;
+ * "classical" / "load_balance" requests are served by the stream kernel. */
+int gkomi_csr_spmv_f64_i64(gkomi_stream_t stream, int64_t nrows, int64_t ncols,
+                           int64_t nrhs, int64_t nnz, const int64_t* row_ptrs,
+                           const int64_t* col_idxs, const double* vals,
+                           const double* b, int64_t b_stride, double* c,
+                           int64_t c_stride, const double* alpha,
+                           const double* beta, int strategy,
+                           int64_t max_row_nnz_hint);
+int gkomi_csr_make_srow_i64(gkomi_stream_t stream, int64_t nrows, int64_t nnz,
+                            const int64_t* row_ptrs, int64_t tile, int64_t* srow,
+                            int64_t nsrow);
+int gkomi_csr_spmv_srow_f64_i64(gkomi_stream_t stream, int64_t nrows, int64_t ncols,
+                                int64_t nrhs, int64_t nnz, const int64_t* row_ptrs,
+                                const int64_t* col_idxs, const double* vals,
+                                const double* b, int64_t b_stride, double* c,
+                                int64_t c_stride, const double* alpha,
+                                const double* beta, int strategy,
+                                int64_t max_row_nnz_hint, const int64_t* srow,
+                                int64_t srow_tile);
+/* result: device int64[1] */
+int gkomi_csr_max_row_nnz_i64(gkomi_stream_t stream, int64_t nrows,
+                              const int64_t* row_ptrs, int64_t* result);
+
+/* One-time analysis of the column pattern (setup, like Csr::make_srow; blocking:
+ * one small launch + an 16-byte copy): the mean over (a sample of) 1536-nonzero
+ * tiles of the 64-KiB pages of b the tile's gathers touch, x the page size -- the
+ * bytes of b a tile's gathers range over (*host_footprint_bytes, may be NULL; a
+ * banded tile with a few far columns touches a few pages, a tile of uniformly
+ * random columns all of them) -- and the strategy
+ * flags the caller should OR into the strategy word of this matrix's applies
+ * (*host_flags: GKOMI_CSR_COLBLOCK or 0).  scratch: 2 device doubles.
+ * Role of the row statistics the reference's strategy objects collect in
+ * process() (include/ginkgo/core/matrix/csr.hpp:600-705). */
+int gkomi_csr_analyse_gather_i32(gkomi_stream_t stream, int64_t ncols, int64_t nnz,
+                                 const int32_t* col_idxs, double* scratch,
+                                 int* host_flags, int64_t* host_footprint_bytes);
 
 /* ell::compute_max_row_nnz analogue on a CSR row_ptrs array
  * (reference/matrix/ell_kernels.cpp:159-170 / csr strategy statistics).
@@ -357,6 +414,16 @@ int gkomi_convert_idxs_to_ptrs_i32(gkomi_stream_t s, const int32_t* idxs,
                                    int32_t* ptrs, void* workspace,
                                    size_t workspace_bytes);
 int gkomi_convert_ptrs_to_sizes_i32(gkomi_stream_t s, const int32_t* ptrs,
+                                    int64_t num_blocks, uint64_t* sizes);
+/* the same three for int64 index arrays (reference/components/format_conversion_kernels.cpp:50-95,
+ * instantiated for both index types) */
+int gkomi_convert_ptrs_to_idxs_i64(gkomi_stream_t s, const int64_t* ptrs,
+                                   int64_t num_blocks, int64_t* idxs);
+int gkomi_convert_idxs_to_ptrs_i64(gkomi_stream_t s, const int64_t* idxs,
+                                   int64_t num_idxs, int64_t num_blocks,
+                                   int64_t* ptrs, void* workspace,
+                                   size_t workspace_bytes);
+int gkomi_convert_ptrs_to_sizes_i64(gkomi_stream_t s, const int64_t* ptrs,
                                     int64_t num_blocks, uint64_t* sizes);
 /* csr::convert_to_ell (reference/matrix/csr_kernels.cpp:431-459) */
 int gkomi_csr_convert_to_ell_f64_i32(gkomi_stream_t s, int64_t nrows,
@@ -796,6 +863,15 @@ int gkomi_diag_stream_csr_bytes(gkomi_stream_t s, int blocks, int64_t nrows,
                                 int64_t nnz, const int32_t* row_ptrs,
                                 const int32_t* col_idxs, const double* vals,
                                 const double* b, double* c);
+/* Diagnostics / benchmark support: the 7-point Poisson matrix of a g^3 grid
+ * (row = (i g + j) g + k, ascending columns, 6 / -1: BASELINE config 5's matrix,
+ * tests/matgen.py poisson_3d_7pt) written on the device, row_ptrs in closed form.
+ * Arrays of g^3 + 1 and 7 g^3 - 6 g^2 entries.  The _i64 form builds matrices of
+ * more than 2^31 nonzeros (700^3) in place. */
+int gkomi_diag_poisson3d_7pt_f64_i32(gkomi_stream_t s, int64_t g, int32_t* row_ptrs,
+                                     int32_t* col_idxs, double* vals);
+int gkomi_diag_poisson3d_7pt_f64_i64(gkomi_stream_t s, int64_t g, int64_t* row_ptrs,
+                                     int64_t* col_idxs, double* vals);
 int64_t gkomi_cg_persistent_solves(void);
 /* Process-wide switch of the single-launch CG (what GKOMI_CG_PERSISTENT sets at
  * start-up): 0 = off (every solve runs the three-launch iteration), 1 = on. */
@@ -1118,6 +1194,17 @@ typedef struct gkomi_csr_ctx {
     const int32_t* srow;
     int64_t srow_tile;
 } gkomi_csr_ctx;
+/* Csr<double, int64> (gkomi_csr_spmv_srow_f64_i64) */
+typedef struct gkomi_csr64_ctx {
+    int64_t nrows, ncols, nnz;
+    const int64_t* row_ptrs;
+    const int64_t* col_idxs;
+    const double* vals;
+    int64_t strategy;
+    int64_t max_row_nnz_hint;
+    const int64_t* srow;
+    int64_t srow_tile;
+} gkomi_csr64_ctx;
 typedef struct gkomi_ell_ctx {
     int64_t nrows, ncols, num_stored_per_row, stride;
     const int32_t* col_idxs;
@@ -1149,6 +1236,10 @@ int gkomi_csr_matrix_apply_cb(void* ctx, gkomi_stream_t s, int64_t nrhs,
                               const double* alpha, const double* b,
                               int64_t b_stride, const double* beta, double* c,
                               int64_t c_stride);
+int gkomi_csr64_matrix_apply_cb(void* ctx, gkomi_stream_t s, int64_t nrhs,
+                                const double* alpha, const double* b,
+                                int64_t b_stride, const double* beta, double* c,
+                                int64_t c_stride);
 int gkomi_ell_matrix_apply_cb(void* ctx, gkomi_stream_t s, int64_t nrhs,
                               const double* alpha, const double* b,
                               int64_t b_stride, const double* beta, double* c,

@@ -16,6 +16,7 @@
 
 #include <vector>
 #include <algorithm>
+#include <type_traits>
 
 namespace gkomi {
 namespace {
@@ -124,9 +125,10 @@ int prefix_sum_impl(hipStream_t s, T* data, int64_t n, void* ws, size_t ws_bytes
     return check_launch();
 }
 
-__global__ __launch_bounds__(block) void ptrs_to_idxs_kernel(const int32_t* __restrict__ ptrs,
+template <typename I>
+__global__ __launch_bounds__(block) void ptrs_to_idxs_kernel(const I* __restrict__ ptrs,
                                                             int64_t num_blocks,
-                                                            int32_t* __restrict__ idxs)
+                                                            I* __restrict__ idxs)
 {
     // one sub-wave of 8 lanes per block entry keeps short rows coalesced
     constexpr int sub = 8;
@@ -134,22 +136,25 @@ __global__ __launch_bounds__(block) void ptrs_to_idxs_kernel(const int32_t* __re
     const int64_t step = static_cast<int64_t>(gridDim.x) * block / sub;
     const int lane = threadIdx.x % sub;
     for (int64_t blk = gid / sub; blk < num_blocks; blk += step) {
-        const int32_t end = ptrs[blk + 1];
-        for (int32_t i = ptrs[blk] + lane; i < end; i += sub) idxs[i] = static_cast<int32_t>(blk);
+        const I end = ptrs[blk + 1];
+        for (I i = ptrs[blk] + lane; i < end; i += sub) idxs[i] = static_cast<I>(blk);
     }
 }
 
-__global__ __launch_bounds__(block) void count_idxs_kernel(const int32_t* __restrict__ idxs,
+template <typename I>
+__global__ __launch_bounds__(block) void count_idxs_kernel(const I* __restrict__ idxs,
                                                           int64_t num_idxs,
-                                                          int32_t* __restrict__ ptrs)
+                                                          I* __restrict__ ptrs)
 {
+    using counter = typename std::conditional<sizeof(I) == 8, unsigned long long, int>::type;
     for (int64_t i = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; i < num_idxs;
          i += static_cast<int64_t>(gridDim.x) * block) {
-        atomicAdd(ptrs + idxs[i], 1);  // integer: exact in any order
+        atomicAdd(reinterpret_cast<counter*>(ptrs + idxs[i]), counter{1});  // integer: exact in any order
     }
 }
 
-__global__ __launch_bounds__(block) void ptrs_to_sizes_kernel(const int32_t* __restrict__ ptrs,
+template <typename I>
+__global__ __launch_bounds__(block) void ptrs_to_sizes_kernel(const I* __restrict__ ptrs,
                                                              int64_t num_blocks,
                                                              uint64_t* __restrict__ sizes)
 {
@@ -289,7 +294,7 @@ extern "C" int gkomi_convert_ptrs_to_idxs_i32(gkomi_stream_t s, const int32_t* p
 {
     if (num_blocks < 0) return GKOMI_EINVAL;
     if (num_blocks == 0) return GKOMI_SUCCESS;
-    hipLaunchKernelGGL(ptrs_to_idxs_kernel, dim3(grid_for(num_blocks * 8, block, 1 << 16)),
+    hipLaunchKernelGGL(ptrs_to_idxs_kernel<int32_t>, dim3(grid_for(num_blocks * 8, block, 1 << 16)),
                        dim3(block), 0, to_stream(s), ptrs, num_blocks, idxs);
     return check_launch();
 }
@@ -304,7 +309,7 @@ extern "C" int gkomi_convert_idxs_to_ptrs_i32(gkomi_stream_t s, const int32_t* i
         hipMemsetAsync(ptrs, 0, sizeof(int32_t) * static_cast<size_t>(num_blocks + 1), stream));
     if (err) return err;
     if (num_idxs > 0) {
-        hipLaunchKernelGGL(count_idxs_kernel, dim3(grid_for(num_idxs, block)), dim3(block), 0,
+        hipLaunchKernelGGL(count_idxs_kernel<int32_t>, dim3(grid_for(num_idxs, block)), dim3(block), 0,
                            stream, idxs, num_idxs, ptrs);
         err = check_launch();
         if (err) return err;
@@ -317,8 +322,43 @@ extern "C" int gkomi_convert_ptrs_to_sizes_i32(gkomi_stream_t s, const int32_t* 
 {
     if (num_blocks < 0) return GKOMI_EINVAL;
     if (num_blocks == 0) return GKOMI_SUCCESS;
-    hipLaunchKernelGGL(ptrs_to_sizes_kernel, dim3(grid_for(num_blocks, block)), dim3(block), 0,
+    hipLaunchKernelGGL(ptrs_to_sizes_kernel<int32_t>, dim3(grid_for(num_blocks, block)), dim3(block), 0,
                        to_stream(s), ptrs, num_blocks, sizes);
+    return check_launch();
+}
+
+// <int64>: the components:: kernels of the index type a > 2^31-nonzero matrix needs
+extern "C" int gkomi_convert_ptrs_to_idxs_i64(gkomi_stream_t s, const int64_t* ptrs, int64_t num_blocks, int64_t* idxs)
+{
+    if (num_blocks < 0) return GKOMI_EINVAL;
+    if (num_blocks == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(ptrs_to_idxs_kernel<int64_t>, dim3(grid_for(num_blocks * 8, block, 1 << 16)), dim3(block), 0,
+                       to_stream(s), ptrs, num_blocks, idxs);
+    return check_launch();
+}
+
+extern "C" int gkomi_convert_idxs_to_ptrs_i64(gkomi_stream_t s, const int64_t* idxs, int64_t num_idxs, int64_t num_blocks,
+                                              int64_t* ptrs, void* workspace, size_t workspace_bytes)
+{
+    if (num_idxs < 0 || num_blocks < 0) return GKOMI_EINVAL;
+    hipStream_t stream = to_stream(s);
+    int err = static_cast<int>(hipMemsetAsync(ptrs, 0, sizeof(int64_t) * static_cast<size_t>(num_blocks + 1), stream));
+    if (err) return err;
+    if (num_idxs > 0) {
+        hipLaunchKernelGGL(count_idxs_kernel<int64_t>, dim3(grid_for(num_idxs, block)), dim3(block), 0, stream, idxs,
+                           num_idxs, ptrs);
+        err = check_launch();
+        if (err) return err;
+    }
+    return gkomi_prefix_sum_i64(s, ptrs, num_blocks + 1, workspace, workspace_bytes);
+}
+
+extern "C" int gkomi_convert_ptrs_to_sizes_i64(gkomi_stream_t s, const int64_t* ptrs, int64_t num_blocks, uint64_t* sizes)
+{
+    if (num_blocks < 0) return GKOMI_EINVAL;
+    if (num_blocks == 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(ptrs_to_sizes_kernel<int64_t>, dim3(grid_for(num_blocks, block)), dim3(block), 0, to_stream(s), ptrs,
+                       num_blocks, sizes);
     return check_launch();
 }
 

@@ -54,6 +54,7 @@ constexpr int block = 256;
 constexpr int max_nr = 8;
 constexpr int halo_rows = 64;   // longest row the one-launch sorted variant takes
 constexpr int min_tile = 512;
+constexpr int coop_min = 128;    // row segments longer than this are summed by a whole wave
 
 // nonzeros per thread / per workgroup for NR columns per pass (LDS: 8 NR + 4 B per nonzero)
 template <int NR>
@@ -135,6 +136,11 @@ __global__ __launch_bounds__(block) void coo_tile_kernel(
     __shared__ __attribute__((aligned(8))) int32_t rowid[off + tile + 2];
     __shared__ int32_t seg_start[tile];
     __shared__ int wave_heads[block / wave_size];
+    // segments of more than coop_min products (Halo = 64 vouches for rows of at most 64)
+    constexpr bool coop = !with_halo;
+    __shared__ int s_nlong;
+    __shared__ int s_long[coop ? tile / (coop_min + 1) + 2 : 1];
+    if (threadIdx.x == 0) s_nlong = 0;
     b += static_cast<int64_t>(blockIdx.y) * NR;
     c += static_cast<int64_t>(blockIdx.y) * NR;
     const double alpha = alpha_p != nullptr ? alpha_p[0] : 1.0;
@@ -286,34 +292,9 @@ __global__ __launch_bounds__(block) void coo_tile_kernel(
     carry_slot* my_carries = with_carries
                                  ? carries + 2 * (static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x)
                                  : nullptr;
-    for (int ib = 0; ib < nseg; ib += block) {
-        const int i = ib + tid;
-        const bool active = i < nseg;
-        int from = active ? seg_start[i] : off;
-        const int to = !active ? from : (i + 1 < nseg ? seg_start[i + 1] : end);
-        const int row = rowid[from];
-        const int before = owner ? rowid[from - 1] : -1;
-        const bool starts_here = before != row;
-        if (with_halo && active && i == 0 && !starts_here) {  // back to the row's first nonzero
-            while (from > 0 && rowid[from - 1] == row) --from;
-            if (from == 0 && base > Halo) atomicOr(&hdr->violation, 1);  // longer than the caller said
-        }
-        double sum[NR];
-#pragma unroll
-        for (int j = 0; j < NR; ++j) sum[j] = 0.0;
-        for (int k = from; k < to; k += 4) {
-            double p[4][NR];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int j = 0; j < NR; ++j) p[u][j] = prod[j][min(k + u, cap)];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int j = 0; j < NR; ++j) sum[j] = k + u < to ? sum[j] + p[u][j] : sum[j];
-            }
-        }
+    // what becomes of a finished segment sum; called by whole waves (the empty-row fill is wave-cooperative),
+    // `active` lanes hold a segment
+    auto finish = [&](bool active, int i, int row, int before, bool starts_here, const double (&sum)[NR]) {
         bool mine = active;
         if (owner) {
             const bool ends_here = i + 1 < nseg || rowid[end] != row;
@@ -352,6 +333,67 @@ __global__ __launch_bounds__(block) void coo_tile_kernel(
             wave_fill_empty_rows<NR, CMode, Off32>(active && i == nseg - 1 && base + count == nnz && row + 1 < nrows,
                                                    row + 1, static_cast<int>(nrows), c, c_stride, beta);
         }
+    };
+    for (int ib = 0; ib < nseg; ib += block) {
+        const int i = ib + tid;
+        bool active = i < nseg;
+        int from = active ? seg_start[i] : off;
+        const int to = !active ? from : (i + 1 < nseg ? seg_start[i + 1] : end);
+        const int row = rowid[from];
+        const int before = owner ? rowid[from - 1] : -1;
+        const bool starts_here = before != row;
+        if (with_halo && active && i == 0 && !starts_here) {  // back to the row's first nonzero
+            while (from > 0 && rowid[from - 1] == row) --from;
+            if (from == 0 && base > Halo) atomicOr(&hdr->violation, 1);  // longer than the caller said
+        }
+        // a long segment is a dependent chain of additions on one lane (up to a whole tile: ~6 us per
+        // workgroup): it waits for a whole wave (below)
+        if (coop && active && to - from > coop_min) {
+            s_long[atomicAdd(&s_nlong, 1)] = i;
+            active = false;
+        }
+        double sum[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) sum[j] = 0.0;
+        for (int k = from; active && k < to; k += 4) {
+            double p[4][NR];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) p[u][j] = prod[j][min(k + u, cap)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) sum[j] = k + u < to ? sum[j] + p[u][j] : sum[j];
+            }
+        }
+        finish(active, i, row, before, starts_here, sum);
+    }
+    if (!coop) return;
+    // long segments: one wave each -- lane-strided partial sums in index order, then the fixed xor tree (the
+    // role of the reference's segmented scan, common/cuda_hip/matrix/coo_kernels.hpp.inc:57-120); same bits every run
+    __syncthreads();
+    const int nlong = s_nlong;
+    for (int q = wave; q < nlong; q += block / wave_size) {
+        const int i = s_long[q];
+        const int from = seg_start[i];
+        const int to = i + 1 < nseg ? seg_start[i + 1] : end;
+        const int row = rowid[from];
+        const int before = owner ? rowid[from - 1] : -1;
+        double sum[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            double a0 = 0.0, a1 = 0.0;
+            int k = from + lane;
+            for (; k + wave_size < to; k += 2 * wave_size) {
+                a0 += prod[j][k];
+                a1 += prod[j][k + wave_size];
+            }
+            if (k < to) a0 += prod[j][k];
+            sum[j] = wave_reduce_sum(a0 + a1);
+        }
+        finish(lane == 0, i, row, before, before != row, sum);
     }
 }
 

@@ -30,6 +30,8 @@ constexpr int num_xcd = 8;
 // over-read of the nonzero-split kernel: rows up to split_max_over + 1 entries
 // are summed from LDS alone
 constexpr int split_max_over = 64;
+// load-balanced kernel: row segments longer than this are reduced by a whole wave
+constexpr int balanced_coop_min = 128;
 
 // Blocks are dealt round-robin to the 8 XCDs (MI355X_MICROARCH.md §Workgroup
 // dispatch).  Give each XCD one contiguous chunk of row blocks so that the
@@ -56,6 +58,29 @@ typedef int nt_int2 __attribute__((ext_vector_type(2)));
 typedef double split_double2 __attribute__((ext_vector_type(2), aligned(8)));
 typedef int split_int2 __attribute__((ext_vector_type(2), aligned(4)));
 
+// Index types of the boundary's instantiations that exist here (include/ginkgo/core/base/types.hpp:544-560:
+// {int32, int64}): positions in the nonzero arrays are `pos` (int for int32 matrices: the address arithmetic of
+// the kernel of record stays 32-bit; int64_t for int64 ones: nnz > 2^31 on a 288 GB part), a pair of column
+// indices is 8 or 16 bytes.
+template <typename I>
+struct index_traits;
+template <>
+struct index_traits<int32_t> {
+    using pos = int;
+    typedef int vec2 __attribute__((ext_vector_type(2)));                  // aligned pairs (stream kernel)
+    typedef int split_vec2 __attribute__((ext_vector_type(2), aligned(4)));  // element-aligned pairs (split kernel)
+};
+template <>
+struct index_traits<int64_t> {
+    using pos = int64_t;
+    typedef long vec2 __attribute__((ext_vector_type(2)));
+    typedef long split_vec2 __attribute__((ext_vector_type(2), aligned(8)));
+};
+template <typename I>
+struct index_pair {
+    I x, y;
+};
+
 // Pad: one spare LDS slot per 32 products, so that rows of even length (stride
 // 8, 16, 32 doubles between neighbouring lanes in the row-sum phase) spread
 // over the banks instead of hitting the same one (2-way instead of 32-way).
@@ -65,11 +90,11 @@ __device__ __forceinline__ int lds_slot(int i)
     return Pad ? i + (i >> 5) : i;
 }
 
-template <int Block, int RowsPerThread, int Tile, bool Advanced, bool Swizzle,
+template <typename I, int Block, int RowsPerThread, int Tile, bool Advanced, bool Swizzle,
           bool Dot = false, bool NT = false, bool Pad = false>
 __global__ __launch_bounds__(Block) void csr_stream_kernel(
-    int nrows, const int32_t* __restrict__ row_ptrs,
-    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    I nrows, const I* __restrict__ row_ptrs,
+    const I* __restrict__ col_idxs, const double* __restrict__ vals,
     const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
     int64_t c_stride, const double* __restrict__ alpha_p,
     const double* __restrict__ beta_p, int nblocks, int per_xcd,
@@ -78,6 +103,8 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
     const double* __restrict__ dot_w = nullptr,
     double* __restrict__ dot_partial2 = nullptr)
 {
+    using pos_t = typename index_traits<I>::pos;
+    using ivec2 = typename index_traits<I>::vec2;
     constexpr int rows_per_block = Block * RowsPerThread;
     constexpr int pairs = Tile / (2 * Block);
     static_assert(Tile % (2 * Block) == 0, "tile must be a whole number of pair sweeps");
@@ -92,11 +119,11 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
     c += blockIdx.y;
 
     const int tid = threadIdx.x;
-    const int r0 = logical * rows_per_block;
-    const int r1 = min(r0 + rows_per_block, nrows);
-    const int p0 = row_ptrs[r0];
-    const int p1 = row_ptrs[r1];
-    const int nnz_total = row_ptrs[nrows];
+    const I r0 = static_cast<I>(logical) * rows_per_block;
+    const I r1 = min(r0 + rows_per_block, nrows);
+    const pos_t p0 = row_ptrs[r0];
+    const pos_t p1 = row_ptrs[r1];
+    const pos_t nnz_total = row_ptrs[nrows];
 
     double alpha = 1.0, beta = 0.0;
     if (Advanced) {
@@ -104,7 +131,7 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
         beta = beta_p[0];
     }
 
-    int ra[RowsPerThread], rb[RowsPerThread];
+    pos_t ra[RowsPerThread], rb[RowsPerThread];
     double sum[RowsPerThread];
     // Dot: partials of w . c (w = b unless given: CG's p.q, BiCGSTAB's rr.v and s.t) and, on request, of c . c
     // (BiCGSTAB's t.t).  w's entries for my rows are asked for up here, not at the end of the workgroup.
@@ -113,7 +140,7 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
     double wv[RowsPerThread];
 #pragma unroll
     for (int i = 0; i < RowsPerThread; ++i) {
-        const int row = r0 + tid + i * Block;
+        const I row = r0 + tid + i * Block;
         wv[i] = 0.0;
         if (row < r1) {
             ra[i] = row_ptrs[row];
@@ -127,27 +154,28 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
         }
     }
 
-    for (int t0 = p0 & ~1; t0 < p1; t0 += Tile) {
+    for (pos_t t0 = p0 & ~pos_t{1}; t0 < p1; t0 += Tile) {
         double2 v[pairs];
-        int2 ci[pairs];
+        index_pair<I> ci[pairs];
         // 1) issue every streaming load of this tile
 #pragma unroll
         for (int u = 0; u < pairs; ++u) {
-            const int k = t0 + 2 * (tid + u * Block);
+            const pos_t k = t0 + 2 * (tid + u * Block);
             v[u] = make_double2(0.0, 0.0);
-            ci[u] = make_int2(0, 0);
+            ci[u] = index_pair<I>{0, 0};
             if (k < p1) {
                 if (k + 1 < nnz_total) {
                     if (NT) {  // read-once streams: do not keep them in the caches b lives in
                         const nt_double2 tv = __builtin_nontemporal_load(
                             reinterpret_cast<const nt_double2*>(vals + k));
-                        const nt_int2 tc = __builtin_nontemporal_load(
-                            reinterpret_cast<const nt_int2*>(col_idxs + k));
+                        const ivec2 tc = __builtin_nontemporal_load(
+                            reinterpret_cast<const ivec2*>(col_idxs + k));
                         v[u] = make_double2(tv.x, tv.y);
-                        ci[u] = make_int2(tc.x, tc.y);
+                        ci[u] = index_pair<I>{static_cast<I>(tc.x), static_cast<I>(tc.y)};
                     } else {
                         v[u] = *reinterpret_cast<const double2*>(vals + k);
-                        ci[u] = *reinterpret_cast<const int2*>(col_idxs + k);
+                        const ivec2 tc = *reinterpret_cast<const ivec2*>(col_idxs + k);
+                        ci[u] = index_pair<I>{static_cast<I>(tc.x), static_cast<I>(tc.y)};
                     }
                 } else {
                     v[u].x = vals[k];
@@ -186,13 +214,13 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
         }
         __syncthreads();
         // 3) one thread per row: add this tile's part of the row in order
-        const int t1 = t0 + Tile;
+        const pos_t t1 = t0 + Tile;
 #pragma unroll
         for (int i = 0; i < RowsPerThread; ++i) {
-            const int lo = max(ra[i], t0);
-            const int hi = min(rb[i], t1);
+            const int lo = static_cast<int>(max(ra[i], t0) - t0);
+            const int hi = static_cast<int>(min(rb[i], t1) - t0);
             for (int k = lo; k < hi; ++k) {
-                sum[i] += prod[lds_slot<Pad>(k - t0)];
+                sum[i] += prod[lds_slot<Pad>(k)];
             }
         }
         if (t1 < p1) __syncthreads();
@@ -201,7 +229,7 @@ __global__ __launch_bounds__(Block) void csr_stream_kernel(
     double pq = 0.0, qq = 0.0;
 #pragma unroll
     for (int i = 0; i < RowsPerThread; ++i) {
-        const int row = r0 + tid + i * Block;
+        const I row = r0 + tid + i * Block;
         if (row < r1) {
             c[row * c_stride] = sum[i];
             if (Dot) {
@@ -260,14 +288,14 @@ __device__ __forceinline__ double add_products(double sum, const double* prod, i
 #ifndef GKOMI_DOT_PROBE
 #define GKOMI_DOT_PROBE 0
 #endif
-template <int Block, int Tile, int MaxOver, bool Advanced, bool Swizzle,
+template <typename I, int Block, int Tile, int MaxOver, bool Advanced, bool Swizzle,
           bool Dot = false, bool NT = false, bool ColsFirst = true>
 __global__ __launch_bounds__(Block) void csr_split_kernel(
-    int nrows, int nnz, const int32_t* __restrict__ row_ptrs,
-    const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
+    I nrows, typename index_traits<I>::pos nnz, const I* __restrict__ row_ptrs,
+    const I* __restrict__ col_idxs, const double* __restrict__ vals,
     const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
     int64_t c_stride, const double* __restrict__ alpha_p,
-    const double* __restrict__ beta_p, const int32_t* __restrict__ srow,
+    const double* __restrict__ beta_p, const I* __restrict__ srow,
     int ntiles, int per_xcd, int over,
     double* __restrict__ dot_partial = nullptr,
     const uint8_t* __restrict__ stop_status = nullptr,
@@ -278,6 +306,8 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
 #endif
     )
 {
+    using pos_t = typename index_traits<I>::pos;
+    using isplit2 = typename index_traits<I>::split_vec2;
     constexpr int pairs = Tile / (2 * Block);
     static_assert(Tile % (2 * Block) == 0, "tile must be a whole number of pair sweeps");
     static_assert(MaxOver <= 2 * Block && MaxOver % 2 == 0, "one extra pair per lane at most");
@@ -304,7 +334,7 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
     b += blockIdx.y;
     c += blockIdx.y;
     const int tid = threadIdx.x;
-    const int t0 = logical * Tile;
+    const pos_t t0 = static_cast<pos_t>(logical) * Tile;
     GKOMI_STAMP(0);
 #ifdef GKOMI_TIMELINE
     if (stamps != nullptr && threadIdx.x == 0) {
@@ -318,8 +348,8 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
     if (Dot && !(GKOMI_DOT_PROBE & 1) && status_has_stopped_uniform(stop_status)) return;
     // the rows that start in this tile (scalar loads, back long before the
     // streaming loads below)
-    const int row_begin = srow[logical];
-    const int row_end = srow[logical + 1];
+    const I row_begin = srow[logical];
+    const I row_end = srow[logical + 1];
 
     // 1) streaming loads: addresses known from the block index alone.  Branch-
     //    free (a branch per load makes the compiler drain the loads before it):
@@ -327,20 +357,20 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
     //    two nonzeros instead -- valid columns, products nobody adds -- and the
     //    lane that owns nonzero nnz-1 of an odd nnz picks it out of that pair.
     double2 v[pairs + 1];
-    int2 ci[pairs + 1];
-    auto load_cols = [&](int u, int k) {
-        const split_int2* src = reinterpret_cast<const split_int2*>(col_idxs + min(k, nnz - 2));
-        const split_int2 tc = NT ? __builtin_nontemporal_load(src) : *src;
-        ci[u] = make_int2(k == nnz - 1 ? tc.y : tc.x, tc.y);
+    index_pair<I> ci[pairs + 1];
+    auto load_cols = [&](int u, pos_t k) {
+        const isplit2* src = reinterpret_cast<const isplit2*>(col_idxs + min(k, nnz - 2));
+        const isplit2 tc = NT ? __builtin_nontemporal_load(src) : *src;
+        ci[u] = index_pair<I>{static_cast<I>(k == nnz - 1 ? tc.y : tc.x), static_cast<I>(tc.y)};
     };
-    auto load_vals = [&](int u, int k) {
+    auto load_vals = [&](int u, pos_t k) {
         const split_double2* src = reinterpret_cast<const split_double2*>(vals + min(k, nnz - 2));
         const split_double2 tv = NT ? __builtin_nontemporal_load(src) : *src;
         v[u] = make_double2(k == nnz - 1 ? tv.y : tv.x, tv.y);
     };
     // the pairs behind the tile (rows that start in the tile and end behind
     // it); lanes past `over` repeat the last useful pair (one request)
-    const int k_over = t0 + Tile + 2 * min(tid, max(over / 2 - 1, 0));
+    const pos_t k_over = t0 + Tile + 2 * min(tid, max(over / 2 - 1, 0));
     if (ColsFirst) {
 #pragma unroll
         for (int u = 0; u < pairs; ++u) load_cols(u, t0 + 2 * (tid + u * Block));
@@ -366,7 +396,7 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
     }
     // two rounds of rows are kept in registers (a 1536-nonzero tile of the
     // 5-pt stencil starts 307 rows); more rounds re-read row_ptrs on demand
-    int ra[2], rb[2];
+    pos_t ra[2], rb[2];
     double c0[2];
     // dot epilogue: the other factor of w . (A b) for my rows, asked for NOW -- behind the barrier it is one more
     // dependent round trip at the end of every workgroup (28 us of a 326-us launch on the 256^3 matrix,
@@ -378,7 +408,7 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
     for (int i = 0; i < 2; ++i) {
         // (kept under its own branch up here: loaded unconditionally, the
         // compiler sinks the loads into the row loop behind the barrier)
-        const int row = row_begin + tid + i * Block;
+        const I row = row_begin + tid + i * Block;
         ra[i] = rb[i] = t0;
         c0[i] = 0.0;
         wv[i] = 0.0;
@@ -414,7 +444,7 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
             // unconditional (lanes past `over` repeat the last useful pair and
             // store the same product to the same slot): a branch here makes the
             // compiler sink the pair's loads into it, behind all the others
-            *reinterpret_cast<double2*>(prod + (k_over - t0)) = pr;
+            *reinterpret_cast<double2*>(prod + static_cast<int>(k_over - t0)) = pr;
         }
     }
     GKOMI_STAMP(1);
@@ -425,15 +455,15 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
     double pq = 0.0, qq = 0.0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int row = row_begin + tid + i * Block;
+        const I row = row_begin + tid + i * Block;
         const bool active = row < row_end;
         double sum = 0.0;
         if (active) {
             sum = Advanced ? c0[i] * beta : 0.0;
-            const int hi = rb[i] - t0;
-            sum = add_products(sum, prod, ra[i] - t0, min(hi, Tile + over), Tile + MaxOver);
+            const pos_t hi = rb[i] - t0;
+            sum = add_products(sum, prod, static_cast<int>(ra[i] - t0), static_cast<int>(min(hi, pos_t{Tile} + over)), Tile + MaxOver);
             // a row longer than the caller's hint promised: finish it from memory
-            for (int k = max(ra[i] - t0, Tile + over); k < hi; ++k) {
+            for (pos_t k = max(ra[i] - t0, pos_t{Tile} + over); k < hi; ++k) {
                 const double val = Advanced ? alpha * vals[t0 + k] : vals[t0 + k];
                 sum += val * b[col_idxs[t0 + k] * b_stride];
             }
@@ -444,12 +474,12 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
         }
         if (active) c[row * c_stride] = sum;
     }
-    for (int row = row_begin + tid + 2 * Block; row < row_end; row += Block) {
+    for (I row = row_begin + tid + 2 * Block; row < row_end; row += Block) {
         double sum = Advanced ? c[row * c_stride] * beta : 0.0;
-        const int lo = row_ptrs[row] - t0;
-        const int hi = row_ptrs[row + 1] - t0;
-        sum = add_products(sum, prod, lo, min(hi, Tile + over), Tile + MaxOver);
-        for (int k = max(lo, Tile + over); k < hi; ++k) {
+        const pos_t lo = row_ptrs[row] - t0;
+        const pos_t hi = row_ptrs[row + 1] - t0;
+        sum = add_products(sum, prod, static_cast<int>(lo), static_cast<int>(min(hi, pos_t{Tile} + over)), Tile + MaxOver);
+        for (pos_t k = max(lo, pos_t{Tile} + over); k < hi; ++k) {
             const double val = Advanced ? alpha * vals[t0 + k] : vals[t0 + k];
             sum += val * b[col_idxs[t0 + k] * b_stride];
         }
@@ -478,16 +508,17 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
 
 // srow[t] = first row in [0, nrows] whose row_ptrs entry is >= t * tile
 // (lower bound; nrows if there is none), for t = 0 .. ntiles.
+template <typename I>
 __global__ __launch_bounds__(256) void csr_make_srow_kernel(
-    int nrows, const int32_t* __restrict__ row_ptrs, int tile, int ntiles,
-    int32_t* __restrict__ srow)
+    I nrows, const I* __restrict__ row_ptrs, int tile, int64_t ntiles,
+    I* __restrict__ srow)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (t > ntiles) return;
-    const int64_t target = static_cast<int64_t>(t) * tile;
-    int lo = 0, hi = nrows;  // answer in [lo, hi]
+    const int64_t target = t * tile;
+    I lo = 0, hi = nrows;  // answer in [lo, hi]
     while (lo < hi) {
-        const int mid = lo + (hi - lo) / 2;
+        const I mid = lo + (hi - lo) / 2;
         if (row_ptrs[mid] >= target) {
             hi = mid;
         } else {
@@ -654,16 +685,56 @@ __device__ __forceinline__ int wave_find_row(const int32_t* __restrict__ row_ptr
     return lo;
 }
 
-template <int Block, int Tile, bool Advanced>
+// Row segments of a tile: a segment of at most CoopMin products is added by ONE
+// thread, left to right (the reference's order: a short row that lies inside one
+// tile gets the reference's bits).  A longer one would be a dependent chain of up
+// to Tile additions on one lane while the other 255 idle (1536 x ~10 cycles = 6 us
+// per workgroup: what bounded the power-law class at 0.8 TB/s): it goes on a list
+// in LDS and is reduced by a whole wave -- lane-strided partial sums, each in index
+// order, then the fixed xor tree; the role of the reference's segmented scan
+// (common/cuda_hip/components/segment_scan.hpp.inc:43-64 inside
+// common/cuda_hip/matrix/csr_kernels.hpp.inc:98), same bits on every run.
+// Rows that lie inside the tile are stored (c holds 0 or beta*c from the launch in
+// front and nobody else touches them); only a row cut by a tile boundary needs the
+// atomic.
+struct long_segment {
+    int row, from, to;  // products [from, to) of the tile's LDS image
+};
+
+// sum of prod[from, to) by the whole wave, result in every lane
+__device__ __forceinline__ double wave_segment_sum(const double* prod, int from, int to)
+{
+    const int lane = threadIdx.x & (wave_size - 1);
+    double acc0 = 0.0, acc1 = 0.0;
+    int k = from + lane;
+    for (; k + wave_size < to; k += 2 * wave_size) {
+        acc0 += prod[k];
+        acc1 += prod[k + wave_size];
+    }
+    if (k < to) acc0 += prod[k];
+    return wave_reduce_sum(acc0 + acc1);
+}
+
+// Column windows (Window = true): when the gathers of b are spread over more than an XCD's 4 MiB L2 (uniformly random
+// columns of a 1M-column matrix: 8 MB of b), half of them miss it and every miss moves a 128-B line across the fabric
+// for 8 useful bytes -- 10.2 M fabric requests per launch, 8.6 M of them for b, 1.3 GB at 7.6 TB/s: the fabric is
+// saturated by the gather (profiles/r04_gather_pmc.md).  The launch is then repeated once per window of columns
+// [col_lo, col_hi) that does fit (the matrix stream is read again, 12 B per nonzero, but b is read from L2): a product
+// outside the window is +0.0 in that pass, the row's partial sums of the passes add up in c.  Pass 0 stores / adds to
+// the pre-set c as the single pass does, later passes add (Accum).
+template <int Block, int Tile, bool Advanced, bool NT, int CoopMin, bool Window, bool Accum>
 __global__ __launch_bounds__(Block) void csr_balanced_kernel(
     int nrows, int nnz_total, const int32_t* __restrict__ row_ptrs,
     const int32_t* __restrict__ col_idxs, const double* __restrict__ vals,
     const double* __restrict__ b, int64_t b_stride, double* __restrict__ c,
-    int64_t c_stride, const double* __restrict__ alpha_p)
+    int64_t c_stride, const double* __restrict__ alpha_p, const int32_t* __restrict__ srow, int col_lo, int col_hi)
 {
     constexpr int pairs = Tile / (2 * Block);
+    constexpr int max_long = Tile / (CoopMin + 1) + 2;
     __shared__ __attribute__((aligned(16))) double prod[Tile];
     __shared__ int s_rows[2];
+    __shared__ int s_nlong;
+    __shared__ long_segment s_long[max_long];
     b += blockIdx.y;
     c += blockIdx.y;
     const int tid = threadIdx.x;
@@ -672,51 +743,109 @@ __global__ __launch_bounds__(Block) void csr_balanced_kernel(
     const double alpha = Advanced ? alpha_p[0] : 1.0;
     double2 v[pairs];
     int2 ci[pairs];
+    if (tid == 0) s_nlong = 0;
 #pragma unroll
     for (int u = 0; u < pairs; ++u) {
         const int k = t0 + 2 * (tid + u * Block);
         v[u] = make_double2(0.0, 0.0);
-        ci[u] = make_int2(0, 0);
+        ci[u] = make_int2(Window ? col_lo : 0, Window ? col_lo : 0);
         if (k + 1 < t1) {
-            v[u] = *reinterpret_cast<const double2*>(vals + k);
-            ci[u] = *reinterpret_cast<const int2*>(col_idxs + k);
+            if (NT) {
+                const nt_double2 tv = __builtin_nontemporal_load(reinterpret_cast<const nt_double2*>(vals + k));
+                const nt_int2 tc = __builtin_nontemporal_load(reinterpret_cast<const nt_int2*>(col_idxs + k));
+                v[u] = make_double2(tv.x, tv.y);
+                ci[u] = make_int2(tc.x, tc.y);
+            } else {
+                v[u] = *reinterpret_cast<const double2*>(vals + k);
+                ci[u] = *reinterpret_cast<const int2*>(col_idxs + k);
+            }
         } else if (k < t1) {
             v[u].x = vals[k];
             ci[u].x = col_idxs[k];
         }
     }
-    // rows intersecting the tile (wave 0 searches while the loads fly)
-    if (tid < 64) {
-        const int first = wave_find_row(row_ptrs, nrows, t0);
-        const int last = wave_find_row(row_ptrs, nrows, t1 - 1);
-        if (tid == 0) {
-            s_rows[0] = first;
-            s_rows[1] = last;
+    // rows intersecting the tile: from the matrix's srow (the rows that START in the tile, plus the one that runs
+    // into it: three scalar loads), else wave 0 searches row_ptrs while the loads fly
+    int first, last;
+    if (srow != nullptr) {
+        const int s0 = srow[blockIdx.x];
+        first = (s0 < nrows && row_ptrs[s0] == t0) ? s0 : s0 - 1;
+        last = min(srow[blockIdx.x + 1], nrows) - 1;
+    } else {
+        if (tid < 64) {
+            const int f = wave_find_row(row_ptrs, nrows, t0);
+            const int l = wave_find_row(row_ptrs, nrows, t1 - 1);
+            if (tid == 0) {
+                s_rows[0] = f;
+                s_rows[1] = l;
+            }
         }
     }
+    // with srow the first round of rows asks for its row_ptrs now, not behind the barrier
+    int ra0 = 0, rb0 = 0;
+    if (srow != nullptr && first + tid <= last) {
+        ra0 = row_ptrs[first + tid];
+        rb0 = row_ptrs[first + tid + 1];
+    }
     double2 xv[pairs];
+    bool in0[pairs], in1[pairs];
 #pragma unroll
     for (int u = 0; u < pairs; ++u) {
-        xv[u].x = b[ci[u].x * b_stride];
-        xv[u].y = b[ci[u].y * b_stride];
+        // outside the window: the gather goes to the window's first entry (one hot line) and the product is
+        // replaced by +0.0 below (not multiplied by zero: b may hold Inf / NaN there)
+        in0[u] = !Window || (ci[u].x >= col_lo && ci[u].x < col_hi);
+        in1[u] = !Window || (ci[u].y >= col_lo && ci[u].y < col_hi);
+        xv[u].x = b[(in0[u] ? ci[u].x : col_lo) * b_stride];
+        xv[u].y = b[(in1[u] ? ci[u].y : col_lo) * b_stride];
     }
 #pragma unroll
     for (int u = 0; u < pairs; ++u) {
         double2 pr;
         pr.x = Advanced ? (alpha * v[u].x) * xv[u].x : v[u].x * xv[u].x;
         pr.y = Advanced ? (alpha * v[u].y) * xv[u].y : v[u].y * xv[u].y;
+        if (Window) {
+            pr.x = in0[u] ? pr.x : 0.0;
+            pr.y = in1[u] ? pr.y : 0.0;
+        }
         *reinterpret_cast<double2*>(prod + 2 * (tid + u * Block)) = pr;
     }
     __syncthreads();
-    const int first = s_rows[0], last = min(s_rows[1], nrows - 1);
-    for (int row = first + tid; row <= last; row += Block) {
-        const int lo = max(row_ptrs[row], t0);
-        const int hi = min(row_ptrs[row + 1], t1);
-        if (lo < hi) {
-            double sum = prod[lo - t0];
-            for (int k = lo + 1; k < hi; ++k) sum += prod[k - t0];
-            unsafeAtomicAdd(c + row * c_stride, sum);
+    if (srow == nullptr) {
+        first = s_rows[0];
+        last = min(s_rows[1], nrows - 1);
+    }
+    const int count = t1 - t0;
+    // a row inside the tile: c[row] (0 or beta * c, or the passes before) + sum, by the one thread that owns it;
+    // a row cut by the tile: one atomic per tile it runs through
+    auto emit = [&](int row, bool whole, double sum) {
+        double* dst = c + row * c_stride;
+        if (whole) {
+            *dst = (Advanced || Accum) ? *dst + sum : sum;
+        } else {
+            unsafeAtomicAdd(dst, sum);
         }
+    };
+    for (int row = first + tid, round = 0; row <= last; row += Block, ++round) {
+        const int ra = (srow != nullptr && round == 0) ? ra0 : row_ptrs[row];
+        const int rb = (srow != nullptr && round == 0) ? rb0 : row_ptrs[row + 1];
+        const int lo = max(ra, t0) - t0;
+        const int hi = min(rb, t1) - t0;
+        if (lo < hi) {
+            if (hi - lo > CoopMin) {
+                const int slot = atomicAdd(&s_nlong, 1);
+                s_long[slot] = long_segment{row, lo, hi};
+            } else {
+                emit(row, ra >= t0 && rb <= t1, add_products(0.0, prod, lo, hi, count));
+            }
+        }
+    }
+    if (CoopMin >= Tile) return;
+    __syncthreads();
+    const int nlong = s_nlong;
+    for (int i = tid / wave_size; i < nlong; i += Block / wave_size) {
+        const long_segment seg = s_long[i];
+        const double sum = wave_segment_sum(prod, seg.from, seg.to);
+        if ((tid & (wave_size - 1)) == 0) emit(seg.row, seg.to - seg.from == row_ptrs[seg.row + 1] - row_ptrs[seg.row], sum);
     }
 }
 
@@ -764,15 +893,16 @@ __global__ __launch_bounds__(256) void csr_vector_kernel(
     }
 }
 
+template <typename I>
 __global__ __launch_bounds__(256) void csr_max_row_nnz_kernel(
-    int64_t nrows, const int32_t* __restrict__ row_ptrs,
-    int32_t* __restrict__ result)
+    int64_t nrows, const I* __restrict__ row_ptrs,
+    I* __restrict__ result)
 {
-    __shared__ int smax[4];
-    int m = 0;
+    __shared__ I smax[4];
+    I m = 0;
     for (int64_t row = blockIdx.x * 256 + threadIdx.x; row < nrows;
          row += static_cast<int64_t>(gridDim.x) * 256) {
-        m = max(m, row_ptrs[row + 1] - row_ptrs[row]);
+        m = max(m, static_cast<I>(row_ptrs[row + 1] - row_ptrs[row]));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
@@ -780,13 +910,18 @@ __global__ __launch_bounds__(256) void csr_max_row_nnz_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
         m = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
-        atomicMax(result, m);  // integer max: order-independent, exact
+        // integer max: order-independent, exact
+        if (sizeof(I) == 8) {
+            atomicMax(reinterpret_cast<long long*>(result), static_cast<long long>(m));
+        } else {
+            atomicMax(reinterpret_cast<int*>(result), static_cast<int>(m));
+        }
     }
 }
 
-template <int Block, int RowsPerThread, int Tile, bool NT = false, bool Pad = false>
-int launch_stream(hipStream_t stream, bool swizzle, int chunk, int nrows, int nrhs,
-                  const int32_t* row_ptrs, const int32_t* col_idxs,
+template <int Block, int RowsPerThread, int Tile, bool NT = false, bool Pad = false, typename I = int32_t>
+int launch_stream(hipStream_t stream, bool swizzle, int chunk, I nrows, int nrhs,
+                  const I* row_ptrs, const I* col_idxs,
                   const double* vals, const double* b, int64_t b_stride,
                   double* c, int64_t c_stride, const double* alpha,
                   const double* beta)
@@ -801,7 +936,7 @@ int launch_stream(hipStream_t stream, bool swizzle, int chunk, int nrows, int nr
     dim3 grid(swz ? groups * per * num_xcd : nblocks, nrhs);
 #define GKOMI_LAUNCH(ADV, SWZ)                                                 \
     hipLaunchKernelGGL(                                                        \
-        (csr_stream_kernel<Block, RowsPerThread, Tile, ADV, SWZ, false, NT, Pad>), \
+        (csr_stream_kernel<I, Block, RowsPerThread, Tile, ADV, SWZ, false, NT, Pad>), \
         grid,                                                                  \
         dim3(Block), 0, stream, nrows, row_ptrs, col_idxs, vals, b, b_stride,  \
         c, c_stride, alpha, beta, nblocks, per)
@@ -859,15 +994,15 @@ int launch_vector(hipStream_t stream, int nrows, int nrhs,
     return check_launch();
 }
 
-template <int Block, int Tile, bool NT>
-int launch_split(hipStream_t stream, bool swizzle, int nrows, int nnz,
-                 const int32_t* row_ptrs, const int32_t* col_idxs,
+template <int Block, int Tile, bool NT, typename I = int32_t>
+int launch_split(hipStream_t stream, bool swizzle, I nrows, typename index_traits<I>::pos nnz,
+                 const I* row_ptrs, const I* col_idxs,
                  const double* vals, const double* b, int64_t b_stride,
                  double* c, int64_t c_stride, const double* alpha,
-                 const double* beta, const int32_t* srow, int over, int chunk = 0)
+                 const double* beta, const I* srow, int over, int chunk = 0)
 {
     constexpr int MaxOver = split_max_over;
-    const int ntiles = nnz / Tile + 1;
+    const int ntiles = static_cast<int>(nnz / Tile + 1);
     int per = static_cast<int>(ceildiv(ntiles, num_xcd));
     if (chunk > 0 && chunk < per) per = chunk;  // XCD k takes `chunk` consecutive tiles of every 8 * chunk
     const bool swz = swizzle && ntiles >= 2 * num_xcd;
@@ -875,7 +1010,7 @@ int launch_split(hipStream_t stream, bool swizzle, int nrows, int nnz,
     dim3 grid(swz ? groups * per * num_xcd : ntiles, 1);
 #define GKOMI_LAUNCH(ADV, SWZ)                                                 \
     hipLaunchKernelGGL(                                                        \
-        (csr_split_kernel<Block, Tile, MaxOver, ADV, SWZ, false, NT, true>), \
+        (csr_split_kernel<I, Block, Tile, MaxOver, ADV, SWZ, false, NT, true>), \
         grid, dim3(Block), 0, stream, nrows, nnz, row_ptrs, col_idxs, vals, b, \
         b_stride, c, c_stride, alpha, beta, srow, ntiles, per, over)
     if (alpha != nullptr) {
@@ -885,6 +1020,85 @@ int launch_split(hipStream_t stream, bool swizzle, int nrows, int nnz,
     }
 #undef GKOMI_LAUNCH
     return check_launch();
+}
+
+// column window of the load-balanced kernel: what of b an XCD's 4 MiB L2 keeps next to the matrix streams that pass
+// through it (GKOMI_CSR_COLBLOCK_KIB: tuning hook)
+inline int64_t colblock_window_bytes()
+{
+    static const int64_t bytes = [] {
+        const char* e = std::getenv("GKOMI_CSR_COLBLOCK_KIB");
+        const long long kib = e != nullptr ? std::atoll(e) : 0;
+        // 4 MiB: two windows for the 8 MB of b of a 1M-column matrix -- 126 vs 140 us on the power-law class, 144 vs
+        // 172 us on uniformly random columns; 3 windows of 2.7 MiB 153 / 166, 4 of 2 MiB 191 / 198: every window is
+        // one more pass over the matrix at ~45 us (profiles/r04_colblock_sweep.md)
+        return static_cast<int64_t>(kib > 0 ? kib : 4096) << 10;
+    }();
+    return bytes;
+}
+
+// number of column windows for a b of ncols rows of b_stride doubles (1 = no windows)
+inline int colblock_passes(int64_t ncols, int64_t b_stride)
+{
+    const int64_t bytes = 8 * ncols * b_stride;
+    // a b that nearly fits is left alone: two passes cost a second read of the matrix
+    if (bytes <= colblock_window_bytes() * 5 / 4) return 1;
+    return static_cast<int>(std::min<int64_t>(ceildiv(bytes, colblock_window_bytes()), 64));
+}
+
+template <int Tile, bool Advanced, bool NT>
+int launch_balanced(hipStream_t stream, int nrows, int ncols, int nrhs, int nnz, const int32_t* row_ptrs,
+                    const int32_t* col_idxs, const double* vals, const double* b, int64_t b_stride, double* c,
+                    int64_t c_stride, const double* alpha, const int32_t* srow, int passes, bool serial)
+{
+    constexpr int Block = 256;
+    dim3 grid(static_cast<unsigned>(ceildiv(nnz, Tile)), nrhs);
+#define GKOMI_BALANCED(COOP, WIN, ACC, LO, HI)                                                                     \
+    hipLaunchKernelGGL((csr_balanced_kernel<Block, Tile, Advanced, NT, COOP, WIN, ACC>), grid, dim3(Block), 0,    \
+                       stream, nrows, nnz, row_ptrs, col_idxs, vals, b, b_stride, c, c_stride, alpha, srow, LO, HI)
+    if (serial) {  // every segment by one thread: the kernel of rounds 1-3, kept for A/B timings
+        GKOMI_BALANCED(Tile, false, false, 0, 0);
+    } else if (passes <= 1) {
+        GKOMI_BALANCED(balanced_coop_min, false, false, 0, 0);
+    } else {
+        const int width = static_cast<int>(ceildiv(ncols, passes));
+        for (int p = 0; p < passes; ++p) {
+            const int lo = p * width, hi = std::min(ncols, lo + width);
+            if (lo >= hi) break;
+            if (p == 0) {
+                GKOMI_BALANCED(balanced_coop_min, true, false, lo, hi);
+            } else {
+                GKOMI_BALANCED(balanced_coop_min, true, true, lo, hi);
+            }
+        }
+    }
+#undef GKOMI_BALANCED
+    return check_launch();
+}
+
+// pages of b (page_cols columns each, at most 4096 pages) that the gathers of one tile touch, one tile per workgroup,
+// summed over the sampled tiles (out[0]) with their count (out[1]).  Pages, not max - min or a deviation from the mean:
+// a banded tile with one far column (an arrow matrix) touches two pages, a tile of uniformly random columns all of them.
+__global__ __launch_bounds__(256) void csr_col_spread_kernel(int64_t nnz, const int32_t* __restrict__ col_idxs, int tile,
+                                                              int64_t tile_step, int page_cols, double* __restrict__ out)
+{
+    __shared__ unsigned bitmap[4096 / 32];
+    __shared__ double red[256 / wave_size];
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * tile_step * tile;
+    const int count = static_cast<int>(min(static_cast<int64_t>(tile), nnz - t0));
+    if (count <= 0) return;
+    if (threadIdx.x < 4096 / 32) bitmap[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < count; i += 256) {
+        const int page = min(max(col_idxs[t0 + i], 0) / page_cols, 4095);
+        atomicOr(&bitmap[page >> 5], 1u << (page & 31));
+    }
+    __syncthreads();
+    const double pages = block_reduce_sum<256>(threadIdx.x < 4096 / 32 ? static_cast<double>(__popc(bitmap[threadIdx.x])) : 0.0, red);
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(out, pages);
+        unsafeAtomicAdd(out + 1, 1.0);
+    }
 }
 
 }  // namespace
@@ -910,7 +1124,7 @@ int csr_spmv_dot_launch(hipStream_t stream, int nrows, int64_t nnz,
     // the matrix streams from HBM every iteration, read it with nontemporal loads (see csr_auto_swizzle)
     const bool nt = nontemporal || !swizzle;
 #define GKOMI_STREAM_DOT(SWZ, NT)                                                              \
-    hipLaunchKernelGGL((csr_stream_kernel<Block, 1, Tile, false, SWZ, true, NT>), grid, dim3(Block), 0, stream, \
+    hipLaunchKernelGGL((csr_stream_kernel<int32_t, Block, 1, Tile, false, SWZ, true, NT>), grid, dim3(Block), 0, stream, \
                        nrows, row_ptrs, col_idxs, vals, p, int64_t{1}, q, int64_t{1}, nullptr, nullptr, nblocks, \
                        per, partial, stop_status, dot_w, partial2)
     if (swz) {
@@ -953,7 +1167,7 @@ int launch_split_dot(hipStream_t stream, int nrows, int nnz, const int32_t* row_
     const int groups = static_cast<int>(ceildiv(ntiles, per * num_xcd));
     dim3 grid(swz ? groups * per * num_xcd : ntiles, 1);
 #define GKOMI_SPLIT_DOT(SWZ, NT)                                                                          \
-    hipLaunchKernelGGL((csr_split_kernel<Block, Tile, split_max_over, false, SWZ, true, NT, true>), grid, \
+    hipLaunchKernelGGL((csr_split_kernel<int32_t, Block, Tile, split_max_over, false, SWZ, true, NT, true>), grid, \
                        dim3(Block), 0, stream, nrows, nnz, row_ptrs, col_idxs, vals, p, int64_t{1}, q,    \
                        int64_t{1}, nullptr, nullptr, srow, ntiles, per, over, partial, stop_status, dot_w, partial2)
     if (swz) {
@@ -1066,7 +1280,7 @@ extern "C" int gkomi_csr_make_srow_i32(gkomi_stream_t stream_, int64_t nrows, in
     }
     if (nsrow < gkomi_csr_srow_entries(nnz, tile)) return GKOMI_EWORKSPACE;
     const int ntiles = static_cast<int>(nnz / tile) + 1;
-    hipLaunchKernelGGL(csr_make_srow_kernel, dim3(static_cast<unsigned>(ceildiv(ntiles + 1, 256))),
+    hipLaunchKernelGGL(csr_make_srow_kernel<int32_t>, dim3(static_cast<unsigned>(ceildiv(ntiles + 1, 256))),
                        dim3(256), 0, to_stream(stream_), static_cast<int>(nrows), row_ptrs,
                        static_cast<int>(tile), ntiles, srow);
     return check_launch();
@@ -1127,6 +1341,9 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
         // dwarf the average (max > 64 x mean) split by nonzeros instead
         // (an unknown row length too: a row longer than the 64 nonzeros read behind its tile is
         // finished from memory by its thread -- correct for any matrix; callers that know better say so)
+        // (GKOMI_CSR_COLBLOCK changes nothing here: matrices of short rows keep the kernels that give the
+        // reference's bits; the flag adds column windows to the load-balanced kernel where that one is chosen
+        // anyway, or with an explicit GKOMI_CSR_BALANCED)
         if (split_ok && r == 1 && max_row_nnz_hint <= split_max_over + 1) {
             kind = GKOMI_CSR_SPLIT;
         } else if (max_row_nnz_hint < 0 || max_row_nnz_hint <= 256) {
@@ -1263,18 +1480,32 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
                       : gkomi_dense_scale_f64(stream_, nrows, nrhs, beta, 1, c, c_stride);
         if (err) return err;
         if (nnz == 0) return GKOMI_SUCCESS;
-        constexpr int Block = 256, Tile = 1536;
-        dim3 grid(static_cast<unsigned>(ceildiv(nnz, Tile)), r);
-        if (alpha != nullptr) {
-            hipLaunchKernelGGL((csr_balanced_kernel<Block, Tile, true>), grid, dim3(Block), 0, stream, n,
-                               static_cast<int>(nnz), row_ptrs, col_idxs, vals, b, b_stride, c, c_stride,
-                               alpha);
-        } else {
-            hipLaunchKernelGGL((csr_balanced_kernel<Block, Tile, false>), grid, dim3(Block), 0, stream, n,
-                               static_cast<int>(nnz), row_ptrs, col_idxs, vals, b, b_stride, c, c_stride,
-                               alpha);
-        }
-        return check_launch();
+        // nontemporal matrix streams by the rule of the stream kernels; variant 1: every segment by one thread;
+        // GKOMI_CSR_COLBLOCK: one pass per column window of b (see csr_balanced_kernel)
+        const int passes = (strategy & GKOMI_CSR_COLBLOCK) != 0 && variant != 1 ? colblock_passes(ncols, b_stride) : 1;
+        // (nontemporal matrix streams in the windowed passes, so that they do not push the window of b out of L2, were
+        // measured and lost: 138 vs 126 us on the power-law class -- the 170 MB matrix is Infinity-Cache resident
+        // between the passes and nontemporal loads give that up; profiles/r04_colblock_sweep.md)
+        const bool bnt = automatic ? nt : (!csr_auto_swizzle(nrows, nnz) || (strategy & GKOMI_CSR_STREAMING) != 0);
+        const int z = static_cast<int>(nnz), nc = static_cast<int>(ncols);
+        // the matrix's srow spares the search for the rows of a tile when it was built for a tile of this kernel
+        const bool with_srow = srow != nullptr && variant != 1 && nnz >= 2 &&
+                               (srow_tile == 1536 || srow_tile == 2048 || srow_tile == 3072);
+        const int32_t* sr = with_srow ? srow : nullptr;
+#define GKOMI_BALANCED_TILE(TILE)                                                                                 \
+    (alpha != nullptr                                                                                              \
+         ? (bnt ? launch_balanced<TILE, true, true>(stream, n, nc, r, z, row_ptrs, col_idxs, vals, b, b_stride, c, \
+                                                    c_stride, alpha, sr, passes, variant == 1)                     \
+                : launch_balanced<TILE, true, false>(stream, n, nc, r, z, row_ptrs, col_idxs, vals, b, b_stride,  \
+                                                     c, c_stride, alpha, sr, passes, variant == 1))                \
+         : (bnt ? launch_balanced<TILE, false, true>(stream, n, nc, r, z, row_ptrs, col_idxs, vals, b, b_stride,   \
+                                                     c, c_stride, alpha, sr, passes, variant == 1)                 \
+                : launch_balanced<TILE, false, false>(stream, n, nc, r, z, row_ptrs, col_idxs, vals, b, b_stride,  \
+                                                      c, c_stride, alpha, sr, passes, variant == 1)))
+        if (with_srow && srow_tile == 2048) return GKOMI_BALANCED_TILE(2048);
+        if (with_srow && srow_tile == 3072) return GKOMI_BALANCED_TILE(3072);
+        return GKOMI_BALANCED_TILE(1536);
+#undef GKOMI_BALANCED_TILE
     }
     if (kind == GKOMI_CSR_VECTOR) {
         int64_t len = max_row_nnz_hint;
@@ -1302,7 +1533,144 @@ extern "C" int gkomi_csr_max_row_nnz_i32(gkomi_stream_t stream_,
     int err = static_cast<int>(hipMemsetAsync(result, 0, sizeof(int32_t), stream));
     if (err) return err;
     if (nrows <= 0) return GKOMI_SUCCESS;
-    hipLaunchKernelGGL(csr_max_row_nnz_kernel, dim3(grid_for(nrows, 256)),
+    hipLaunchKernelGGL(csr_max_row_nnz_kernel<int32_t>, dim3(grid_for(nrows, 256)),
                        dim3(256), 0, stream, nrows, row_ptrs, result);
     return check_launch();
+}
+
+
+extern "C" int gkomi_csr_analyse_gather_i32(gkomi_stream_t stream_, int64_t ncols, int64_t nnz, const int32_t* col_idxs,
+                                            double* scratch, int* host_flags, int64_t* host_footprint_bytes)
+{
+    using namespace gkomi;
+    if (host_flags == nullptr || scratch == nullptr || nnz < 0 || ncols < 0) return GKOMI_EINVAL;
+    *host_flags = 0;
+    if (host_footprint_bytes != nullptr) *host_footprint_bytes = 0;
+    if (nnz == 0 || ncols == 0) return GKOMI_SUCCESS;
+    hipStream_t stream = to_stream(stream_);
+    constexpr int tile = 1536;
+    const int64_t ntiles = ceildiv(nnz, tile);
+    const int64_t step = std::max<int64_t>(1, ntiles / 4096);   // at most ~4096 evenly spaced tiles
+    const int64_t sampled = ceildiv(ntiles, step);
+    int err = static_cast<int>(hipMemsetAsync(scratch, 0, 2 * sizeof(double), stream));
+    if (err) return err;
+    // 64 KiB pages of b (8192 columns), coarser when b has more than 4096 of them
+    const int page_cols = static_cast<int>(std::max<int64_t>(8192, ceildiv(ncols, 4096)));
+    hipLaunchKernelGGL(csr_col_spread_kernel, dim3(static_cast<unsigned>(sampled)), dim3(256), 0, stream, nnz, col_idxs,
+                       tile, step, page_cols, scratch);
+    err = check_launch();
+    if (err) return err;
+    double h[2] = {0.0, 0.0};
+    err = static_cast<int>(hipMemcpyAsync(h, scratch, sizeof(h), hipMemcpyDeviceToHost, stream));
+    if (err) return err;
+    err = static_cast<int>(hipStreamSynchronize(stream));
+    if (err) return err;
+    const double pages = h[1] > 0.0 ? h[0] / h[1] : 0.0;
+    // bytes of b (one column) a tile's gathers range over; a single page says nothing (a tile's rows span < a page)
+    const int64_t footprint = pages <= 1.0 ? 0 : std::min<int64_t>(static_cast<int64_t>(pages * page_cols * 8.0), 8 * ncols);
+    if (host_footprint_bytes != nullptr) *host_footprint_bytes = footprint;
+    // windows pay when a tile's gathers range over more of b than an XCD's L2 keeps AND b itself is larger than that
+    if (footprint > (int64_t{3} << 20) && colblock_passes(ncols, 1) > 1) *host_flags = GKOMI_CSR_COLBLOCK;
+    return GKOMI_SUCCESS;
+}
+
+
+// ---- <double, int64>: the instantiation a 288 GB part needs (nnz > 2^31; include/ginkgo/core/base/types.hpp:544-560
+// lists it next to <double, int32>).  Same kernels (templates over the index type), 16 B per nonzero.  The automatic
+// strategy cuts by nonzeros when the matrix carries its srow (rows of any length are correct: a row longer than the 64
+// nonzeros read behind its tile is finished from memory), by rows otherwise; "classical" / "load_balance" requests are
+// served by the row-cut stream kernel (bit-exact for any row lengths, no sub-wave / atomic variants for this index type).
+extern "C" int gkomi_csr_make_srow_i64(gkomi_stream_t stream_, int64_t nrows, int64_t nnz, const int64_t* row_ptrs,
+                                       int64_t tile, int64_t* srow, int64_t nsrow)
+{
+    using namespace gkomi;
+    if (nrows < 0 || nnz < 0 || tile <= 0 || tile % 2 != 0) return GKOMI_EINVAL;
+    if (tile > (1 << 20) || nnz / tile + 2 > INT32_MAX) return GKOMI_ENOTSUPPORTED;
+    if (nsrow < gkomi_csr_srow_entries(nnz, tile)) return GKOMI_EWORKSPACE;
+    const int64_t ntiles = nnz / tile + 1;
+    hipLaunchKernelGGL(csr_make_srow_kernel<int64_t>, dim3(static_cast<unsigned>(ceildiv(ntiles + 1, 256))), dim3(256), 0,
+                       to_stream(stream_), nrows, row_ptrs, static_cast<int>(tile), ntiles, srow);
+    return check_launch();
+}
+
+extern "C" int gkomi_csr_max_row_nnz_i64(gkomi_stream_t stream_, int64_t nrows, const int64_t* row_ptrs, int64_t* result)
+{
+    using namespace gkomi;
+    hipStream_t stream = to_stream(stream_);
+    int err = static_cast<int>(hipMemsetAsync(result, 0, sizeof(int64_t), stream));
+    if (err) return err;
+    if (nrows <= 0) return GKOMI_SUCCESS;
+    hipLaunchKernelGGL(csr_max_row_nnz_kernel<int64_t>, dim3(grid_for(nrows, 256)), dim3(256), 0, stream, nrows, row_ptrs,
+                       result);
+    return check_launch();
+}
+
+extern "C" int gkomi_csr_spmv_srow_f64_i64(gkomi_stream_t stream_, int64_t nrows, int64_t ncols, int64_t nrhs, int64_t nnz,
+                                           const int64_t* row_ptrs, const int64_t* col_idxs, const double* vals,
+                                           const double* b, int64_t b_stride, double* c, int64_t c_stride,
+                                           const double* alpha, const double* beta, int strategy,
+                                           int64_t max_row_nnz_hint, const int64_t* srow, int64_t srow_tile)
+{
+    using namespace gkomi;
+    if (nrows < 0 || ncols < 0 || nrhs < 0 || nnz < 0) return GKOMI_EINVAL;
+    if ((alpha == nullptr) != (beta == nullptr)) return GKOMI_EINVAL;
+    if (nrhs > 65535 || ceildiv(nrows, 256) + 8 > INT32_MAX || nnz / 1536 + 2 > INT32_MAX) return GKOMI_ENOTSUPPORTED;
+    if (nrows == 0 || nrhs == 0) return GKOMI_SUCCESS;
+    if (b_stride < nrhs || c_stride < nrhs) return GKOMI_EINVAL;
+    // pairs of values and of 8-byte column indices are loaded with one 16-byte instruction each
+    if (reinterpret_cast<uintptr_t>(vals) % 16 != 0 || reinterpret_cast<uintptr_t>(col_idxs) % 16 != 0) {
+        return GKOMI_ENOTSUPPORTED;
+    }
+    hipStream_t stream = to_stream(stream_);
+    const int kind = strategy & 0xff;
+    const bool split_ok = srow != nullptr && nnz >= 2 && (srow_tile == 1536 || srow_tile == 2048 || srow_tile == 3072);
+    if (kind == GKOMI_CSR_SPLIT && !split_ok) return srow == nullptr ? GKOMI_EINVAL : GKOMI_ENOTSUPPORTED;
+    // nontemporal matrix streams for a matrix the Infinity Cache will not hold at its next use (csr_auto_swizzle's rule
+    // at 16 B per nonzero), or when the caller says so
+    const bool resident = 16 * nnz + 24 * nrows < (int64_t{288} << 20);
+    const bool nt = !resident || (strategy & GKOMI_CSR_STREAMING) != 0;
+    const int r = static_cast<int>(nrhs);
+    if (split_ok && (kind == GKOMI_CSR_SPLIT || (kind == GKOMI_CSR_AUTO && r == 1))) {
+        int over = split_max_over;
+        if (max_row_nnz_hint >= 1 && max_row_nnz_hint <= split_max_over) {
+            over = static_cast<int>(max_row_nnz_hint / 2 * 2);
+        } else if (max_row_nnz_hint == 0) {
+            over = 0;
+        }
+        // streams from HBM: 16 consecutive tiles per XCD (see the int32 entry); resident: one eighth each
+        const int chunk = resident ? 0 : 16;
+        for (int j = 0; j < r; ++j) {
+            int err;
+#define GKOMI_SPLIT64(TILE)                                                                                          \
+    err = nt ? launch_split<256, TILE, true, int64_t>(stream, true, nrows, nnz, row_ptrs, col_idxs, vals, b + j, b_stride, \
+                                                      c + j, c_stride, alpha, beta, srow, over, chunk)               \
+             : launch_split<256, TILE, false, int64_t>(stream, true, nrows, nnz, row_ptrs, col_idxs, vals, b + j,    \
+                                                       b_stride, c + j, c_stride, alpha, beta, srow, over, chunk)
+            if (srow_tile == 1536) {
+                GKOMI_SPLIT64(1536);
+            } else if (srow_tile == 2048) {
+                GKOMI_SPLIT64(2048);
+            } else {
+                GKOMI_SPLIT64(3072);
+            }
+#undef GKOMI_SPLIT64
+            if (err) return err;
+        }
+        return GKOMI_SUCCESS;
+    }
+    if (nt) {
+        return launch_stream<256, 1, 1536, true, false, int64_t>(stream, resident, 0, nrows, r, row_ptrs, col_idxs, vals, b,
+                                                                  b_stride, c, c_stride, alpha, beta);
+    }
+    return launch_stream<256, 1, 1536, false, false, int64_t>(stream, resident, 0, nrows, r, row_ptrs, col_idxs, vals, b,
+                                                               b_stride, c, c_stride, alpha, beta);
+}
+
+extern "C" int gkomi_csr_spmv_f64_i64(gkomi_stream_t stream_, int64_t nrows, int64_t ncols, int64_t nrhs, int64_t nnz,
+                                      const int64_t* row_ptrs, const int64_t* col_idxs, const double* vals, const double* b,
+                                      int64_t b_stride, double* c, int64_t c_stride, const double* alpha,
+                                      const double* beta, int strategy, int64_t max_row_nnz_hint)
+{
+    return gkomi_csr_spmv_srow_f64_i64(stream_, nrows, ncols, nrhs, nnz, row_ptrs, col_idxs, vals, b, b_stride, c, c_stride,
+                                       alpha, beta, strategy, max_row_nnz_hint, nullptr, 0);
 }

@@ -55,9 +55,14 @@ int device_cu_count();  // CUs of the current device, 0 = unknown
 // depends on those stores for correctness: if they never show up, host_watch::wait notices that the
 // stream has drained and says so, and the driver looks at device memory the old way.
 struct host_watch_line {
-    long long done;       // the criterion has been evaluated for every iteration <= done (-1: none yet)
-    long long stop_iter;  // >= 0: the iteration at which it fired
-    long long pad_[6];
+    // ONE 64-bit word, so that the host never sees `done` of one publication with `stop_iter` of another (two
+    // words may arrive in either order: at a GMRES restart boundary a host that saw `done` without the stop ran an
+    // extra update + residual on a solve that had stopped):  low half = done + 1 (the criterion has been
+    // evaluated for every iteration <= done; 0: none yet), high half = stop_iter + 1 (0: not stopped)
+    unsigned long long word;
+    long long pad_[7];
+    static long long done_of(unsigned long long w) { return static_cast<long long>(w & 0xffffffffull) - 1; }
+    static long long stop_of(unsigned long long w) { return static_cast<long long>(w >> 32) - 1; }
 };
 struct host_watch {
     host_watch_line* host = nullptr;  // as the host reads it
@@ -77,10 +82,10 @@ __device__ __forceinline__ void host_watch_publish(host_watch_line* w, long long
 {
     if (w == nullptr) return;
     // relaxed on purpose: a system-scope RELEASE writes back the XCD's dirty L2 lines first (microseconds, in
-    // the kernel's critical thread).  The two words may become visible in either order; a host that sees `done`
-    // before `stop_iter` learns of the stop one look later, which costs one more iteration of run-ahead.
-    if (stop_iter >= 0) __hip_atomic_store(&w->stop_iter, stop_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&w->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // the kernel's critical thread).  One word: both values of one publication arrive together.
+    const unsigned long long word = (static_cast<unsigned long long>(done + 1) & 0xffffffffull) |
+                                    (static_cast<unsigned long long>(stop_iter >= 0 ? stop_iter + 1 : 0) << 32);
+    __hip_atomic_store(&w->word, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #endif
 // how far the host lets itself run ahead of the last iteration it has seen evaluated: enough to keep the

@@ -913,13 +913,20 @@ int gkomi::jacobi_apply_dot_launch(gkomi_stream_t s, const gkomi_jacobi_ctx* c, 
     const int sw = pow2ceil(c->max_block_size);
     const int64_t groups = ceildiv(c->num_blocks, 64 / sw);
     const int64_t grid = ceildiv(groups, block / 64);
-    if (grid > static_cast<int64_t>(room)) return 0;
+    // One partial per workgroup, about n / 256 of them, and every workgroup of the consumer (cg_fused_step1_kernel,
+    // up to 1024 of them) re-adds them all, every iteration: beyond spmv_dot_uncompressed_partials the launch writes
+    // them behind the first spmv_dot_max_partials slots and a second, small launch compresses them into those --
+    // the rule of spmv_dot_plan::launch (at 256^3 rows 65 k partials would be ~1 GB of L2 reads per iteration).
+    const bool squeeze = grid > spmv_dot_uncompressed_partials;
+    if (grid + (squeeze ? spmv_dot_max_partials : 0) > static_cast<int64_t>(room)) return 0;
+    double* raw_rz = squeeze ? part_rz + spmv_dot_max_partials : part_rz;
+    double* raw_rr = squeeze ? part_rr + spmv_dot_max_partials : part_rr;
     hipStream_t stream = to_stream(s);
 #define GKOMI_APPLY_DOT(S)                                                                                        \
     hipLaunchKernelGGL((jacobi_apply_kernel<S, false, true>), dim3(static_cast<unsigned>(grid)), dim3(block), 0,   \
                        stream, c->num_blocks, sc, c->block_ptrs, c->block_precisions, c->blocks, int64_t{1},      \
                        static_cast<const double*>(nullptr), in, int64_t{1}, static_cast<const double*>(nullptr),  \
-                       out, int64_t{1}, part_rz, part_rr, stop_status)
+                       out, int64_t{1}, raw_rz, raw_rr, stop_status)
     switch (sw) {
     case 2: GKOMI_APPLY_DOT(2); break;
     case 4: GKOMI_APPLY_DOT(4); break;
@@ -928,8 +935,13 @@ int gkomi::jacobi_apply_dot_launch(gkomi_stream_t s, const gkomi_jacobi_ctx* c, 
     default: GKOMI_APPLY_DOT(32); break;
     }
 #undef GKOMI_APPLY_DOT
-    const int err = check_launch();
-    return err ? -(err < 0 ? -err : err) - 1000 : static_cast<int>(grid);
+    int err = check_launch();
+    if (err == 0 && squeeze) {
+        err = compress_partials_launch(stream, raw_rz, static_cast<int>(grid), part_rz, spmv_dot_max_partials, raw_rr,
+                                       part_rr, stop_status);
+    }
+    if (err) return -(err < 0 ? -err : err) - 1000;
+    return squeeze ? spmv_dot_max_partials : static_cast<int>(grid);
 }
 
 extern "C" int gkomi_jacobi_generate_f64_i32(gkomi_stream_t s, int64_t nrows,

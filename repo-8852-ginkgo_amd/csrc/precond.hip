@@ -118,6 +118,17 @@ extern "C" int gkomi_csr_matrix_apply_cb(void* ctx_, gkomi_stream_t s, int64_t n
                                        m->srow != nullptr ? m->srow_tile : 0);
 }
 
+// Csr<double, int64> as a system matrix of the *_solve_op_f64 drivers
+extern "C" int gkomi_csr64_matrix_apply_cb(void* ctx_, gkomi_stream_t s, int64_t nrhs, const double* alpha, const double* b,
+                                           int64_t b_stride, const double* beta, double* c, int64_t c_stride)
+{
+    const gkomi_csr64_ctx* m = static_cast<const gkomi_csr64_ctx*>(ctx_);
+    if (m == nullptr) return GKOMI_EINVAL;
+    return gkomi_csr_spmv_srow_f64_i64(s, m->nrows, m->ncols, nrhs, m->nnz, m->row_ptrs, m->col_idxs, m->vals, b, b_stride,
+                                       c, c_stride, alpha, beta, static_cast<int>(m->strategy), m->max_row_nnz_hint,
+                                       m->srow, m->srow != nullptr ? m->srow_tile : 0);
+}
+
 extern "C" int gkomi_ell_matrix_apply_cb(void* ctx_, gkomi_stream_t s, int64_t nrhs,
                                          const double* alpha, const double* b, int64_t b_stride,
                                          const double* beta, double* c, int64_t c_stride)

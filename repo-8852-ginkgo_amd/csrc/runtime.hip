@@ -253,8 +253,7 @@ host_watch::host_watch()
             slot = i;
             host = b.host + i;
             dev = b.dev + i;
-            __atomic_store_n(&host->stop_iter, -1ll, __ATOMIC_RELAXED);
-            __atomic_store_n(&host->done, -1ll, __ATOMIC_RELEASE);
+            __atomic_store_n(&host->word, 0ull, __ATOMIC_RELEASE);
             return;
         }
     }
@@ -267,15 +266,15 @@ host_watch::~host_watch()
 
 long long host_watch::stop_iter() const
 {
-    return host != nullptr ? __atomic_load_n(&host->stop_iter, __ATOMIC_ACQUIRE) : -1;
+    return host != nullptr ? host_watch_line::stop_of(__atomic_load_n(&host->word, __ATOMIC_ACQUIRE)) : -1;
 }
 
 bool host_watch::wait(hipStream_t stream, long long target)
 {
     if (host == nullptr) return false;
     auto reached = [&] {
-        const long long done = __atomic_load_n(&host->done, __ATOMIC_ACQUIRE);
-        return done >= target || __atomic_load_n(&host->stop_iter, __ATOMIC_ACQUIRE) >= 0;
+        const unsigned long long w = __atomic_load_n(&host->word, __ATOMIC_ACQUIRE);
+        return host_watch_line::done_of(w) >= target || host_watch_line::stop_of(w) >= 0;
     };
     // a look at the line costs nothing; asking the runtime whether the stream has drained does (and takes the
     // lock the launches take): only after 40 us without news, then every 40 us
@@ -297,3 +296,68 @@ bool host_watch::wait(hipStream_t stream, long long target)
     }
 }
 }  // namespace gkomi
+
+
+// ---- diagnostics / benchmark support: the 7-point Poisson matrix of an g x g x g grid (row = (i g + j) g + k, ascending
+// columns, -1 off the diagonal, 6 on it: tests/matgen.py poisson_3d_7pt, BASELINE config 5), written on the device.
+// row_ptrs in closed form (7 row minus the neighbours that rows before it lack), so no scan and no host copy: what
+// lets a > 2^31-nonzero matrix (700^3: 2.4 G nonzeros) be built in the 288 GB of one GPU.
+namespace gkomi {
+namespace {
+template <typename I>
+__device__ __forceinline__ int64_t poisson3d_row_ptr(int64_t row, int64_t g)
+{
+    const int64_t g2 = g * g;
+    const int64_t i = row / g2, rem = row - i * g2, j = rem / g, k = rem - j * g;
+    int64_t missing = (row < g2 ? row : g2);                       // rows with i == 0 lack (i-1)
+    missing += row > (g - 1) * g2 ? row - (g - 1) * g2 : 0;        // rows with i == g-1 lack (i+1)
+    missing += i * g + (rem < g ? rem : g);                        // j == 0 lack (j-1): the first g rows of a slab
+    missing += i * g + (rem > (g - 1) * g ? rem - (g - 1) * g : 0);  // j == g-1: the last g rows of a slab
+    missing += i * g + j + (k > 0 ? 1 : 0);                        // k == 0: the first row of a line
+    missing += i * g + j;                                          // k == g-1: the last row of a line
+    return 7 * row - missing;
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void poisson3d_kernel(int64_t g, I* __restrict__ row_ptrs, I* __restrict__ col_idxs,
+                                                        double* __restrict__ vals)
+{
+    const int64_t n = g * g * g, g2 = g * g;
+    for (int64_t row = blockIdx.x * int64_t{256} + threadIdx.x; row <= n; row += int64_t{256} * gridDim.x) {
+        if (row == n) {
+            row_ptrs[n] = static_cast<I>(7 * n - 6 * g2);
+            continue;
+        }
+        const int64_t i = row / g2, rem = row - i * g2, j = rem / g, k = rem - j * g;
+        int64_t at = poisson3d_row_ptr<I>(row, g);
+        row_ptrs[row] = static_cast<I>(at);
+        const int64_t off[7] = {-g2, -g, -1, 0, 1, g, g2};
+        const bool ok[7] = {i > 0, j > 0, k > 0, true, k < g - 1, j < g - 1, i < g - 1};
+#pragma unroll
+        for (int e = 0; e < 7; ++e) {
+            if (ok[e]) {
+                col_idxs[at] = static_cast<I>(row + off[e]);
+                vals[at] = e == 3 ? 6.0 : -1.0;
+                ++at;
+            }
+        }
+    }
+}
+}  // namespace
+}  // namespace gkomi
+
+extern "C" int gkomi_diag_poisson3d_7pt_f64_i32(gkomi_stream_t s, int64_t g, int32_t* row_ptrs, int32_t* col_idxs, double* vals)
+{
+    if (g < 1 || 7 * g * g * g > INT32_MAX) return GKOMI_EINVAL;
+    hipLaunchKernelGGL(gkomi::poisson3d_kernel<int32_t>, dim3(gkomi::grid_for(g * g * g + 1, 256, 1 << 16)), dim3(256), 0,
+                       gkomi::to_stream(s), g, row_ptrs, col_idxs, vals);
+    return gkomi::check_launch();
+}
+
+extern "C" int gkomi_diag_poisson3d_7pt_f64_i64(gkomi_stream_t s, int64_t g, int64_t* row_ptrs, int64_t* col_idxs, double* vals)
+{
+    if (g < 1 || g > 2000000) return GKOMI_EINVAL;
+    hipLaunchKernelGGL(gkomi::poisson3d_kernel<int64_t>, dim3(gkomi::grid_for(g * g * g + 1, 256, 1 << 16)), dim3(256), 0,
+                       gkomi::to_stream(s), g, row_ptrs, col_idxs, vals);
+    return gkomi::check_launch();
+}

@@ -144,7 +144,8 @@ __device__ __forceinline__ int32_t block_scan(int32_t (&v)[scan_items], int32_t*
 }
 
 template <typename Op, bool Inclusive>
-__global__ __launch_bounds__(scan_block) void scan_tiles_op_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out,
+// (in == out allowed, and what every caller in the tree passes: no __restrict__ on the two)
+__global__ __launch_bounds__(scan_block) void scan_tiles_op_kernel(const int32_t* in, int32_t* out,
                                                                   int64_t n, int32_t* __restrict__ tile_totals)
 {
     __shared__ int32_t smem[scan_block / 64];

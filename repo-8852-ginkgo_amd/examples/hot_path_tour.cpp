@@ -72,6 +72,24 @@ int main()
         hyb->apply(x.get(), y2.get());
         std::cout << "hybrid_diff " << diff_norm(exec, y.get(), y2.get()) << " coo_nnz " << hyb->get_coo_num_stored_elements() << "\n";
 
+        // Csr<double, int64>: the index type of matrices beyond 2^31 nonzeros, same bits as <double, int32>
+        {
+            gko::matrix_data<double, gko::int64> d64;
+            auto d32 = stencil(g, 0.0);
+            d64.size = d32.size;
+            for (const auto& e : d32.nonzeros) d64.nonzeros.push_back({e.row, e.column, e.value});
+            auto A64 = gko::matrix::Csr<double, gko::int64>::create(exec);
+            A64->read(d64);
+            A64->apply(x.get(), y2.get());
+            std::cout << "csr_int64_diff " << diff_norm(exec, y.get(), y2.get()) << " srow_entries " << A64->get_num_srow_elements() << "\n";
+            auto two = gko::initialize<vec>({2.0}, exec);
+            auto one = gko::initialize<vec>({1.0}, exec);
+            auto y3 = y->clone();
+            A64->apply(two.get(), x.get(), one.get(), y2.get());   // y2 = 2 A x + y2 = 3 A x
+            A->apply(two.get(), x.get(), one.get(), y3.get());
+            std::cout << "csr_int64_advanced_diff " << diff_norm(exec, y3.get(), y2.get()) << "\n";
+        }
+
         // CG + block-Jacobi
         auto b = vec::create(exec, gko::dim<2>(n, 1));
         b->fill(1.0);

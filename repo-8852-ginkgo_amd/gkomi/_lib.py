@@ -16,6 +16,9 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 HEADER = os.path.join(REPO_ROOT, "include", "gkomi.h")
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libgkomi.so")
+# A/B timings against an older build of the same library (tools/ only): GKOMI_LIB=path/to/libgkomi_rNN.so;
+# entry points that build lacks are left out instead of failing the load
+LIB_OVERRIDE = os.environ.get("GKOMI_LIB")
 
 
 class GkomiError(RuntimeError):
@@ -77,7 +80,8 @@ def _as_arg(value, is_ptr, ctype):
 
 
 class _Lib:
-    def __init__(self, path=LIB_PATH):
+    def __init__(self, path=None):
+        path = path or LIB_OVERRIDE or LIB_PATH
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} not found: build it with `make -C {PKG_ROOT}` "
@@ -86,6 +90,8 @@ class _Lib:
         self.path = path
         self.protos = parse_header()
         for name, (ret, params) in self.protos.items():
+            if LIB_OVERRIDE and not hasattr(self._cdll, name):
+                continue
             fn = getattr(self._cdll, name)  # AttributeError if not exported
             fn.argtypes = [
                 ctypes.c_void_p if is_ptr else _SCALARS[t]

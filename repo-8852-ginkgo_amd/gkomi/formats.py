@@ -8,6 +8,9 @@ import ctypes
 import numpy as np
 import torch
 
+from ._lib import GkomiError
+
+ENOTSUPPORTED = -2  # GKOMI_ENOTSUPPORTED of include/gkomi.h
 I32, I64, F64, U8 = torch.int32, torch.int64, torch.float64, torch.uint8
 
 
@@ -16,6 +19,9 @@ def _ctx_type(name, fields):
 
 
 _i64, _ptr = ctypes.c_int64, ctypes.c_void_p
+Csr64Ctx = _ctx_type("Csr64Ctx", [("nrows", _i64), ("ncols", _i64), ("nnz", _i64), ("row_ptrs", _ptr), ("col_idxs", _ptr),
+                                  ("vals", _ptr), ("strategy", _i64), ("max_row_nnz_hint", _i64), ("srow", _ptr),
+                                  ("srow_tile", _i64)])
 CsrCtx = _ctx_type("CsrCtx", [("nrows", _i64), ("ncols", _i64), ("nnz", _i64), ("row_ptrs", _ptr), ("col_idxs", _ptr),
                               ("vals", _ptr), ("strategy", _i64), ("max_row_nnz_hint", _i64), ("srow", _ptr),
                               ("srow_tile", _i64)])
@@ -61,6 +67,8 @@ class Csr:
         self._max_row_nnz = None
         self._srow = None
         self.srow_tile = 0
+        self._gather_flags = None
+        self.gather_footprint = None
 
     @classmethod
     def from_host(cls, gk, nrows, ncols, row_ptrs, col_idxs, vals, device="cuda:0", strategy=0, split=True):
@@ -110,22 +118,37 @@ class Csr:
             try:
                 gk.csr_make_srow_i32(_stream(self.vals), self.nrows, self.nnz, self.row_ptrs, self.srow_tile,
                                      self._srow, ne)
-            except Exception:  # too large for the split kernel: the row-cut kernels serve it
+            except GkomiError as e:  # too large for the split kernel: the row-cut kernels serve it
+                if e.code != ENOTSUPPORTED:
+                    raise
                 self._srow, self.srow_tile = False, 0
         return self._srow if self._srow is not False else None
+
+    def gather_flags(self):
+        """the column-pattern statistic of the strategy object (one-time, like max_row_nnz and srow):
+        GKOMI_CSR_COLBLOCK when the gathers of b overflow an XCD's L2 (gkomi_csr_analyse_gather_i32)"""
+        if self._gather_flags is None:
+            self._gather_flags = 0
+            if self.nnz > 0 and (self.strategy & 0xff) in (0, 3) and not (self.strategy >> 30) & 1 and hasattr(self.gk, "csr_analyse_gather_i32"):
+                scratch = torch.zeros(2, dtype=F64, device=self.vals.device)
+                flags, foot = ctypes.c_int(0), ctypes.c_int64(0)
+                self.gk.csr_analyse_gather_i32(_stream(self.vals), self.ncols, self.nnz, self.col_idxs, scratch,
+                                               ctypes.addressof(flags), ctypes.addressof(foot))
+                self._gather_flags, self.gather_footprint = int(flags.value), int(foot.value)
+        return self._gather_flags
 
     def apply(self, b, x, alpha=None, beta=None):
         dv = self.vals.device
         self.gk.csr_spmv_srow_f64_i32(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.nnz, self.row_ptrs,
                                       self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0), _scalar(dv, alpha),
-                                      _scalar(dv, beta), self.strategy, self.max_row_nnz(), self.srow(),
-                                      self.srow_tile)
+                                      _scalar(dv, beta), (self.strategy & ~(1 << 30)) | self.gather_flags(), self.max_row_nnz(),
+                                      self.srow(), self.srow_tile)
         return x
 
     def callback(self):
         srow = self.srow()
         ctx = CsrCtx(self.nrows, self.ncols, self.nnz, self.row_ptrs.data_ptr(), self.col_idxs.data_ptr(),
-                     self.vals.data_ptr(), self.strategy, self.max_row_nnz(),
+                     self.vals.data_ptr(), self.strategy & ~(1 << 30), self.max_row_nnz(),
                      srow.data_ptr() if srow is not None else None, self.srow_tile)
         return MatrixCallback(self.gk, "gkomi_csr_matrix_apply_cb", ctx, self)
 
@@ -137,7 +160,8 @@ class Csr:
     # benchmark/utils/formats.hpp:272-290: "csr" = automatical, "csri" = load_balance,
     # "csrm" = merge_path, "csrc" = classical, "csrs" = sparselib (served by the automatic
     # kernel here, like Csr::sparselib in the C++ mirror); GKOMI_CSR_* codes of include/gkomi.h
-    CSR_STRATEGIES = {"csr": 0, "csrs": 0, "csrm": 1, "csrc": 2, "csri": 3}
+    CSR_STRATEGIES = {"csr": 0, "csrs": 0, "csrm": 1, "csrc": 2, "csri": 3, "csri_serial": 3 | (1 << 8),
+                      "csr_1pass": 0 | (1 << 30), "csri_1pass": 3 | (1 << 30)}   # bit 30: no column-pattern analysis (A/B)
 
     def to(self, fmt, **kw):
         if fmt in self.CSR_STRATEGIES:
@@ -146,6 +170,73 @@ class Csr:
                 return self
             return Csr(self.gk, self.nrows, self.ncols, self.row_ptrs, self.col_idxs, self.vals, code, self.split)
         return {"coo": Coo, "ell": Ell, "sellp": Sellp, "hybrid": Hybrid}[fmt].from_csr(self, **kw)
+
+
+class Csr64:
+    """gko::matrix::Csr<double, int64>: the index type of matrices with more than 2^31 nonzeros
+    (gkomi_csr_*_i64).  Same object model as Csr: carries its srow and its longest row; apply and the
+    solver callback run the nonzero-split kernel (automatic strategy)."""
+    name = "csr64"
+
+    def __init__(self, gk, nrows, ncols, row_ptrs, col_idxs, vals, strategy=0, split=True):
+        assert row_ptrs.dtype == I64 and col_idxs.dtype == I64
+        self.gk, self.nrows, self.ncols = gk, int(nrows), int(ncols)
+        self.row_ptrs, self.col_idxs, self.vals = row_ptrs, col_idxs, vals
+        self.nnz = int(vals.numel())
+        self.strategy, self.split = strategy, bool(split)
+        self._max_row_nnz = None
+        self._srow = None
+        self.srow_tile = 0
+
+    @classmethod
+    def from_host(cls, gk, nrows, ncols, row_ptrs, col_idxs, vals, device="cuda:0", strategy=0, split=True):
+        d = lambda a, t: torch.from_numpy(np.ascontiguousarray(a, dtype=t)).to(device)
+        return cls(gk, nrows, ncols, d(row_ptrs, np.int64), d(col_idxs, np.int64), d(vals, np.float64), strategy, split)
+
+    @classmethod
+    def poisson_3d_7pt(cls, gk, g, device="cuda:0"):
+        """BASELINE config 5's matrix for a g^3 grid, written on the device (gkomi_diag_poisson3d_7pt_f64_i64)"""
+        n, nnz = g ** 3, 7 * g ** 3 - 6 * g * g
+        rp = torch.empty(n + 1, dtype=I64, device=device)
+        ci = torch.empty(nnz, dtype=I64, device=device)
+        v = torch.empty(nnz, dtype=F64, device=device)
+        gk.diag_poisson3d_7pt_f64_i64(_stream(v), g, rp, ci, v)
+        return cls(gk, n, n, rp, ci, v)
+
+    def storage_bytes(self):
+        return 8 * (self.nrows + 1) + 16 * self.nnz
+
+    def max_row_nnz(self):
+        if self._max_row_nnz is None:
+            mx = torch.zeros(1, dtype=I64, device=self.vals.device)
+            self.gk.csr_max_row_nnz_i64(_stream(self.vals), self.nrows, self.row_ptrs, mx)
+            self._max_row_nnz = int(mx.item())
+        return self._max_row_nnz
+
+    def srow(self):
+        if not self.split or self.nnz < 2:
+            return None
+        if self._srow is None:
+            gk = self.gk
+            self.srow_tile = int(gk.csr_srow_tile_for(self.nnz))
+            ne = int(gk.csr_srow_entries(self.nnz, self.srow_tile))
+            self._srow = torch.zeros(max(ne, 1), dtype=I64, device=self.vals.device)
+            gk.csr_make_srow_i64(_stream(self.vals), self.nrows, self.nnz, self.row_ptrs, self.srow_tile, self._srow, ne)
+        return self._srow
+
+    def apply(self, b, x, alpha=None, beta=None):
+        dv = self.vals.device
+        self.gk.csr_spmv_srow_f64_i64(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.nnz, self.row_ptrs,
+                                      self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0), _scalar(dv, alpha),
+                                      _scalar(dv, beta), self.strategy, self.max_row_nnz(), self.srow(), self.srow_tile)
+        return x
+
+    def callback(self):
+        srow = self.srow()
+        ctx = Csr64Ctx(self.nrows, self.ncols, self.nnz, self.row_ptrs.data_ptr(), self.col_idxs.data_ptr(),
+                       self.vals.data_ptr(), self.strategy, self.max_row_nnz(),
+                       srow.data_ptr() if srow is not None else None, self.srow_tile)
+        return MatrixCallback(self.gk, "gkomi_csr64_matrix_apply_cb", ctx, self)
 
 
 class Coo:

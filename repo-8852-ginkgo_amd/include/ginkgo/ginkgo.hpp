@@ -820,6 +820,28 @@ class Hybrid;
 template <typename V, typename I>
 class CsrBuilder;
 
+namespace detail_abi {
+// the C-ABI entry points of the two index types this backend instantiates for the SpMV path
+// (GKO_INSTANTIATE_FOR_EACH_VALUE_AND_INDEX_TYPE, include/ginkgo/core/base/types.hpp:544-560: <double, int32> and
+// <double, int64>; the other format / factorisation kernels exist for int32 only and do not compile for int64)
+template <typename I>
+struct csr_abi;
+template <>
+struct csr_abi<int32> {
+    static constexpr auto spmv_srow = &gkomi_csr_spmv_srow_f64_i32;
+    static constexpr auto make_srow = &gkomi_csr_make_srow_i32;
+    static constexpr auto max_row_nnz = &gkomi_csr_max_row_nnz_i32;
+    static constexpr auto idxs_to_ptrs = &gkomi_convert_idxs_to_ptrs_i32;
+};
+template <>
+struct csr_abi<int64> {
+    static constexpr auto spmv_srow = &gkomi_csr_spmv_srow_f64_i64;
+    static constexpr auto make_srow = &gkomi_csr_make_srow_i64;
+    static constexpr auto max_row_nnz = &gkomi_csr_max_row_nnz_i64;
+    static constexpr auto idxs_to_ptrs = &gkomi_convert_idxs_to_ptrs_i64;
+};
+}  // namespace detail_abi
+
 template <typename V = double, typename I = int32>
 class Csr : public LinOp {
     friend class CsrBuilder<V, I>;
@@ -899,8 +921,8 @@ public:
         values_ = std::move(arrays.values);
         col_idxs_ = std::move(arrays.col_idxs);
         array<char> ws(exec_, gkomi_prefix_sum_workspace_bytes(size[0] + 1));
-        GKOMI_CALL(gkomi_convert_idxs_to_ptrs_i32(nullptr, arrays.row_idxs.get_const_data(), arrays.row_idxs.get_num_elems(), size[0], row_ptrs_.get_data(),
-                                                  ws.get_data(), ws.get_num_elems()));
+        GKOMI_CALL(detail_abi::csr_abi<I>::idxs_to_ptrs(nullptr, arrays.row_idxs.get_const_data(), arrays.row_idxs.get_num_elems(), size[0], row_ptrs_.get_data(),
+                                                    ws.get_data(), ws.get_num_elems()));
         max_row_nnz_ = -1;
         invalidate_srow();
     }
@@ -955,11 +977,11 @@ protected:
         detail::require_device(exec_, "csr::spmv");
         auto db = detail_fmt::dense(b); auto dx = detail_fmt::dense(x);
         make_srow();
-        GKOMI_CALL(gkomi_csr_spmv_srow_f64_i32(nullptr, size_[0], size_[1], db->cols(), get_num_stored_elements(), get_const_row_ptrs(), get_const_col_idxs(),
-                                               get_const_values(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(),
-                                               alpha ? detail_fmt::dense(alpha)->get_const_values() : nullptr,
-                                               beta ? detail_fmt::dense(beta)->get_const_values() : nullptr, strategy_->get_code(), max_row_nnz_,
-                                               get_num_srow_elements() ? get_const_srow() : nullptr, srow_tile_));
+        GKOMI_CALL(detail_abi::csr_abi<I>::spmv_srow(nullptr, size_[0], size_[1], db->cols(), get_num_stored_elements(), get_const_row_ptrs(), get_const_col_idxs(),
+                                                 get_const_values(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(),
+                                                 alpha ? detail_fmt::dense(alpha)->get_const_values() : nullptr,
+                                                 beta ? detail_fmt::dense(beta)->get_const_values() : nullptr, strategy_->get_code(), max_row_nnz_,
+                                                 get_num_srow_elements() ? get_const_srow() : nullptr, srow_tile_));
     }
 public:
     // Csr::srow_ / make_srow (csr.hpp:1139-1157, 1265-1266): the tile start rows of the nonzero-split
@@ -973,14 +995,14 @@ public:
         const int64_t nnz = static_cast<int64_t>(get_num_stored_elements());
         if (nnz >= 2 && max_row_nnz_ < 0) {  // row statistics of the strategy objects (csr.hpp:526-705)
             array<I> mx(exec_, 1);
-            GKOMI_CALL(gkomi_csr_max_row_nnz_i32(nullptr, size_[0], get_const_row_ptrs(), mx.get_data()));
+            GKOMI_CALL(detail_abi::csr_abi<I>::max_row_nnz(nullptr, size_[0], get_const_row_ptrs(), mx.get_data()));
             max_row_nnz_ = exec_->copy_val_to_host(mx.get_const_data());
         }
         srow_tile_ = gkomi_csr_srow_tile_for(static_cast<int64_t>(get_num_stored_elements()));
         if (nnz >= 2) {
             srow_ = array<I>(exec_, static_cast<size_type>(gkomi_csr_srow_entries(nnz, srow_tile_)));
-            GKOMI_CALL(gkomi_csr_make_srow_i32(nullptr, size_[0], nnz, get_const_row_ptrs(), srow_tile_, srow_.get_data(),
-                                               static_cast<int64_t>(srow_.get_num_elems())));
+            GKOMI_CALL(detail_abi::csr_abi<I>::make_srow(nullptr, size_[0], nnz, get_const_row_ptrs(), srow_tile_, srow_.get_data(),
+                                                     static_cast<int64_t>(srow_.get_num_elems())));
         } else {
             srow_ = array<I>(exec_, 0);
         }

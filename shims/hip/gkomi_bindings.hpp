@@ -27,8 +27,13 @@ inline void gkomi_check(int code, const char* file, int line, const char* fn)
 
 // The row statistic the strategy objects of a reference tree keep (csr.hpp:240-277 classical, :600-705
 // automatical: max_length_per_row_, filled by strategy_type::process at make_srow time): the SpMV's row-length
-// hint.  -1 = the strategy keeps none (load_balance, merge_path, sparselib).  [reference-tree branch: not
-// compiled by this repository's tests, which take the definition of shims/test/prelude_mirror.hpp]
+// hint.  -1 = the strategy keeps none (load_balance, merge_path, sparselib, gkomi_split).  The hint only ever
+// selects a kernel and a sub-wave width: every kernel it can select is correct for ANY row length (the split
+// kernel finishes a row longer than its hint from memory, csr_spmv.hip step 4; tests/test_csr_split_gpu.py
+// "rows longer than the hint"), so a statistic that is stale because row_ptrs were edited without process()
+// costs speed, never the result.  [reference-tree branch: not compiled by this repository's tests, which take
+// the definition of shims/test/prelude_mirror.hpp; the reference's include/ needs its cmake-generated
+// config.hpp, so it cannot be syntax-checked here either]
 #include <ginkgo/core/matrix/csr.hpp>
 namespace gko {
 namespace kernels {

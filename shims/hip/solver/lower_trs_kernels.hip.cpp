@@ -88,12 +88,14 @@ void solve(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double, in
                                                  x->get_stride(), st->workspace.get_data(), st->workspace.get_num_elems()));
     }
     // A solve whose bounded waits ran out leaves NaNs in x and a STICKY flag (the reference's nan_produced
-    // guard, cuda/solver/common_trs_kernels.cuh:444-449).  Reading it is a blocking 4-byte copy, so it is
-    // looked at after the first solve, then every 256th (GKOMI_TRS_CHECK_EVERY=1: every solve); sticky
-    // means a later look still reports an earlier give-up.
+    // guard, cuda/solver/common_trs_kernels.cuh:444-449, which is checked on every solve).  Behind this
+    // binding the caller is the reference's core/, not one of the native drivers (those look at the flag at
+    // the end of a solve): the flag is read after EVERY solve -- a blocking 4-byte copy, as the reference's own
+    // guard is.  GKOMI_TRS_CHECK_EVERY=N reads it after the first solve and then every Nth (sticky: a later
+    // look still reports an earlier give-up).
     static const unsigned long long every = [] {
         const char* e = std::getenv("GKOMI_TRS_CHECK_EVERY");
-        return e != nullptr && std::atoll(e) > 0 ? static_cast<unsigned long long>(std::atoll(e)) : 256ull;
+        return e != nullptr && std::atoll(e) > 0 ? static_cast<unsigned long long>(std::atoll(e)) : 1ull;
     }();
     if (st->solves++ % every == 0) {
         int gave_up = 0;

@@ -344,3 +344,27 @@ def test_concurrent_solves_share_the_gpu(gk, oracle):
     for r in results:
         assert r["converged"] and abs(r["iterations"] - it) <= 1
         assert matgen.rel_err(host(r["x"]), xe) <= 1e-7
+
+
+def test_fused_cg_block_jacobi_compresses_the_partials_of_a_large_system(gk, oracle):
+    """The block-Jacobi apply of the fused CG leaves one partial of r.z / r.r per workgroup (about n / 256).
+    Beyond 8192 of them (n > 2.1 M rows at block size 32) they are compressed to 4096 before every workgroup of
+    the update kernel re-adds them (the rule of the SpMV's partials).  1500^2 5-pt Poisson + I
+    (2.25 M rows, 8790 partials): the fused driver and the reference kernel sequence stop at the same iteration
+    with the same solution, and the true residual (oracle SpMV) is where the criterion says."""
+    n, rp, ci, v = matgen.poisson_2d_5pt(1500)
+    v = v.copy()
+    v[v == 4.0] = 5.0
+    assert n // 256 > 8192
+    rpd, cid, vd = dev(rp), dev(ci), dev(v)
+    pre = solvers.jacobi_generate(gk, n, rpd, cid, vd, max_block_size=32)
+    b = np.cos(0.001 * np.arange(n))
+    bd = dev(b)
+    fused = solvers.cg_solve(gk, n, rpd, cid, vd, bd, max_iters=2000, reduction=1e-10, mode=1, check_every=8, precond=pre)
+    seq = solvers.cg_solve(gk, n, rpd, cid, vd, bd, max_iters=2000, reduction=1e-10, mode=0, precond=pre)
+    assert fused["converged"] and seq["converged"]
+    assert abs(fused["iterations"] - seq["iterations"]) <= 1, (fused["iterations"], seq["iterations"])
+    assert matgen.rel_err(host(fused["x"]), host(seq["x"])) <= 1e-9
+    r = b.reshape(n, 1).copy()
+    oracle.ref_csr_advanced_spmv(n, 1, -1.0, rp, ci, v, np.ascontiguousarray(host(fused["x"])).reshape(n, 1), 1, 1.0, r, 1)
+    assert np.linalg.norm(r) / np.linalg.norm(b) <= 2e-10

@@ -4,8 +4,9 @@ gkomi_coo_spmv2_sorted_f64_i32) and the any-order multi-column pass behind
 gkomi_coo_spmv2_f64_i32, against the oracle's COO loops
 (reference/matrix/coo_kernels.cpp:63-131).
 
-Tolerance: a row whose nonzeros lie inside one 1536-nonzero tile is summed in the
-reference's order -- bit-exact for c = A b; the advanced / apply2 forms add the
+Tolerance: a row of at most 128 nonzeros that lie inside one 1536-nonzero tile is summed in the
+reference's order -- bit-exact for c = A b; a longer row segment is reduced by a whole wave
+(lane-strided partial sums + fixed tree, the role of the reference's segmented scan); the advanced / apply2 forms add the
 finished row sum to beta*c (the reference adds product by product) and rows cut
 by a tile boundary add per-tile partial sums: <= 1e-14 relative.  The sorted path
 has no atomics: two runs give the same bits.  Edge cases as in
@@ -119,10 +120,10 @@ def run_sorted(gk, mode, nrows, ncols, rows_d, ci_d, v_d, b_d, c_d, alpha, beta,
 
 
 def uncut_rows(nrows, rows):
-    """rows whose nonzeros all lie in one tile (and rows without nonzeros), for each of
+    """rows of at most 128 nonzeros, all in one tile (and rows without nonzeros), for each of
     the tile sizes in use: 1536 / 1024 / 512 nonzeros for 1 / 2 / 4 columns per pass"""
     nnz = len(rows)
-    cut = np.zeros(nrows, dtype=bool)
+    cut = np.bincount(rows, minlength=nrows) > 128
     for tile in (TILE, 1024, 512):   # (8 columns per pass: 512 too)
         for t in range(tile, nnz, tile):
             if rows[t - 1] == rows[t]:

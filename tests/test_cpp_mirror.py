@@ -94,6 +94,9 @@ def test_hot_path_tour(bins):
     assert float(kv["ell_diff"][0]) == 0.0 and float(kv["sellp_diff"][0]) == 0.0
     assert float(kv["coo_diff"][0]) < 1e-12 and float(kv["hybrid_diff"][0]) < 1e-12
     assert kv["coo_sorted"][0] == "1" and float(kv["coo_sorted"][2]) < 1e-12
+    # Csr<double, int64> through the mirror: bit-identical to the int32 matrix, carries its srow
+    assert float(kv["csr_int64_diff"][0]) == 0.0 and int(kv["csr_int64_diff"][2]) > 0
+    assert float(kv["csr_int64_advanced_diff"][0]) == 0.0
     assert int(kv["hybrid_diff"][2]) > 0
     assert kv["cg_jacobi_iters"][2] == "1" and float(kv["cg_jacobi_iters"][4]) < 1e-9
     # adaptive block storage: some blocks reduced, same convergence within a few iterations

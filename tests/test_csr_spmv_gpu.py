@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import matgen
-from gpu_util import DevCsr, csr_apply, dev, host, sync
+from gpu_util import DevCsr, csr_apply, csr_apply_srow, dev, host, make_srow, sync
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -23,7 +23,8 @@ STRATEGIES = {"auto": 0, "stream": STREAM, "stream_v1": STREAM | (1 << 8),
               "stream_v13": STREAM | (13 << 8), "stream_v11_noswz": STREAM | (11 << 8) | (1 << 16),
               "stream_spmm": STREAM | (20 << 8), "stream_v15_pad": STREAM | (15 << 8),
               "stream_v16_nt_pad": STREAM | (16 << 8) | (1 << 16), "stream_v14_nt": STREAM | (14 << 8) | (1 << 16),
-              "vector": VECTOR, "vector64": VECTOR | (64 << 8), "vector2": VECTOR | (2 << 8), "balanced": 3}
+              "vector": VECTOR, "vector64": VECTOR | (64 << 8), "vector2": VECTOR | (2 << 8), "balanced": 3,
+              "balanced_serial": 3 | (1 << 8)}
 BITEXACT = {k for k in STRATEGIES if k.startswith("stream") or k == "auto"}
 
 
@@ -78,7 +79,7 @@ def test_random_532x231(gk, oracle, strategy, advanced, nrhs, sort):
 
 
 @pytest.mark.parametrize("strategy", ["stream", "stream_v1", "stream_v3", "stream_v5", "stream_v8", "stream_v11_noswz", "stream_v15_pad",
-                                      "stream_v16_nt_pad", "vector", "balanced", "auto"])
+                                      "stream_v16_nt_pad", "vector", "balanced", "balanced_serial", "auto"])
 def test_ragged_and_empty_rows(gk, oracle, strategy):
     # empty rows, rows longer than one LDS tile (8192), an empty last row
     rng = np.random.default_rng(7)
@@ -243,7 +244,7 @@ def test_load_balanced_on_skewed_matrices(gk, oracle, advanced, nrhs):
     c0 = rng.standard_normal((n, nrhs))
     A = DevCsr(n, ncols, rp, ci, v)
     assert A.max_row_nnz > 64 * (A.nnz // n + 1)
-    for strat in ("balanced", "auto"):
+    for strat in ("balanced", "balanced_serial", "auto"):
         if advanced:
             expect = _oracle_apply(oracle, n, rp, ci, v, b, c0, -0.5, 2.0)
             got = host(csr_apply(gk, A, dev(b), dev(c0), -0.5, 2.0, STRATEGIES[strat]))
@@ -252,3 +253,128 @@ def test_load_balanced_on_skewed_matrices(gk, oracle, advanced, nrhs):
             got = host(csr_apply(gk, A, dev(b), strategy=STRATEGIES[strat]))
         assert matgen.rel_err(got, expect) <= 1e-14, strat
         assert got[0, 0] == (2.0 * c0[0, 0] if advanced else 0.0)  # empty row: just beta*c / 0
+
+
+@pytest.mark.parametrize("advanced", [False, True], ids=["simple", "advanced"])
+def test_load_balanced_long_rows_are_reduced_by_whole_waves(gk, oracle, advanced):
+    """Power-law shape with a 200 k-nonzero row (130 tiles of one row), rows around the
+    cooperative threshold (127 / 128 / 129 / 130 nonzeros), rows that end exactly on a tile
+    boundary, an odd nnz: the load-balanced kernel adds segments of more than 128 products
+    with a whole wave (lane-strided partial sums + tree), so the bar is the tolerance of a
+    tree-ordered sum, 4 eps sqrt(longest row), per entry relative to sum |a_ij b_j|; rows of
+    at most 128 nonzeros that lie inside one 1536-nonzero tile keep the reference's bits;
+    two runs give the same bits for rows that are not cut by a tile boundary."""
+    rng = np.random.default_rng(77)
+    n, ncols = 30000, 400000
+    counts = np.maximum(1, (4 * rng.pareto(1.3, size=n)).astype(np.int64))
+    counts = np.minimum(counts, 5000)
+    counts[17] = 200_000
+    counts[100:104] = [127, 128, 129, 130]
+    counts[5000] = 1536 * 3           # whole tiles
+    counts[20000] = 0
+    counts[-1] = 2001
+    rp, ci, v = matgen.random_rows_csr(n, ncols, counts, seed=78)
+    if int(rp[-1]) % 2 == 0:       # (the generator merges duplicate columns) odd nnz: drop the last nonzero
+        rp = rp.copy()
+        rp[-1] -= 1
+        ci, v = ci[:-1], v[:-1]
+    counts = np.diff(rp)
+    nnz = int(rp[-1])
+    assert nnz % 2 == 1 and counts.max() >= 150_000
+    b = rng.standard_normal((ncols, 1))
+    c0 = rng.standard_normal((n, 1))
+    A = DevCsr(n, ncols, rp, ci, v)
+    if advanced:
+        expect = _oracle_apply(oracle, n, rp, ci, v, b, c0, -0.5, 2.0)
+        run = lambda s: host(csr_apply(gk, A, dev(b), dev(c0), -0.5, 2.0, STRATEGIES[s]))
+        scale = np.abs(2.0 * c0)
+    else:
+        expect = _oracle_apply(oracle, n, rp, ci, v, b)
+        run = lambda s: host(csr_apply(gk, A, dev(b), strategy=STRATEGIES[s]))
+        scale = np.zeros((n, 1))
+    # magnitude of each row's sum: sum |a_ij| |b_j| (+ |beta c|)
+    absrow = np.zeros(n)
+    np.add.at(absrow, np.repeat(np.arange(n), counts), np.abs(v) * np.abs(b[ci, 0]) * (0.5 if advanced else 1.0))
+    bound = 4 * np.finfo(np.float64).eps * np.sqrt(counts.max()) * (absrow.reshape(n, 1) + scale) + 1e-300
+    for strat in ("balanced", "auto"):
+        got = run(strat)
+        assert np.all(np.abs(got - expect) <= bound), (strat, int(np.argmax(np.abs(got - expect) / bound)))
+    got = run("balanced")
+    first_tile, last_tile = rp[:-1] // 1536, (np.maximum(rp[1:], rp[:-1] + 1) - 1) // 1536
+    inside = first_tile == last_tile
+    if not advanced:
+        short = inside & (counts <= 128)
+        assert np.array_equal(got[short], expect[short])     # the reference's order
+    again = run("balanced")
+    assert np.array_equal(again[inside], got[inside])        # fixed order: same bits
+
+
+COLBLOCK = 1 << 25
+
+
+@pytest.mark.parametrize("advanced", [False, True], ids=["simple", "advanced"])
+@pytest.mark.parametrize("nrhs", [1, 2])
+@pytest.mark.parametrize("with_srow", [False, True], ids=["search", "srow"])
+def test_column_windows_of_the_load_balanced_kernel(gk, oracle, advanced, nrhs, with_srow):
+    """GKOMI_CSR_COLBLOCK: one pass per 4 MiB window of b (1.2 M columns: 3 windows; two columns of b:
+    5), partial sums added up in c.  Power-law rows with uniformly random columns, an empty row, a row of
+    one tile and a half; b holds Inf at the first entry of the second window in a column no row touches
+    (a product outside the window is replaced by +0.0, never multiplied by zero).  Tolerance of a
+    re-grouped sum; the automatic strategy with the flag takes the same path."""
+    rng = np.random.default_rng(5)
+    n, ncols = 20000, 1_200_000
+    counts = np.maximum(1, (3 * rng.pareto(1.3, size=n)).astype(np.int64))
+    counts = np.minimum(counts, 3000)
+    counts[7] = 0
+    counts[11] = 2304
+    rp, ci, v = matgen.random_rows_csr(n, ncols, counts, seed=6)
+    counts = np.diff(rp)
+    b = rng.standard_normal((ncols, nrhs))
+    passes = -(-8 * ncols * nrhs // (4096 << 10))
+    width = -(-ncols // passes)
+    untouched = width if width not in set(ci.tolist()) else None
+    if untouched is not None:
+        b[untouched, :] = np.inf
+    c0 = rng.standard_normal((n, nrhs))
+    A = DevCsr(n, ncols, rp, ci, v)
+    srow, tile = make_srow(gk, A) if with_srow else (None, 0)
+    absrow = np.zeros(n)
+    finite_b = np.where(np.isfinite(b), b, 0.0)
+    for j in range(nrhs):
+        np.add.at(absrow, np.repeat(np.arange(n), counts), np.abs(v) * np.abs(finite_b[ci, j]))
+    for strat in (3 | COLBLOCK, COLBLOCK):
+        if advanced:
+            expect = _oracle_apply(oracle, n, rp, ci, v, b, c0, -0.5, 2.0)
+            got = host(csr_apply_srow(gk, A, dev(b), srow, tile, dev(c0), -0.5, 2.0, strat))
+        else:
+            expect = _oracle_apply(oracle, n, rp, ci, v, b)
+            got = host(csr_apply_srow(gk, A, dev(b), srow, tile, strategy=strat))
+        assert np.all(np.isfinite(got))
+        bound = 4 * np.finfo(np.float64).eps * np.sqrt(counts.max()) * (absrow.reshape(n, 1) + np.abs(2.0 * c0)) + 1e-300
+        assert np.all(np.abs(got - expect) <= bound), strat
+        assert np.all(got[7] == (2.0 * c0[7] if advanced else 0.0))
+
+
+def test_gather_analysis_flags_spread_columns_only(gk):
+    """gkomi_csr_analyse_gather_i32: uniformly random columns over 1 M columns -> COLBLOCK (a tile's gathers
+    range over ~8 MB of b); a banded matrix with one far column per row (arrow) and a stencil -> no flag;
+    random columns over 200 k columns (1.6 MB of b: fits L2) -> no flag."""
+    import ctypes
+    def analyse(ncols, ci):
+        scratch = torch.zeros(2, dtype=torch.float64, device="cuda:0")
+        flags, foot = ctypes.c_int(-1), ctypes.c_int64(-1)
+        gk.csr_analyse_gather_i32(torch.cuda.current_stream().cuda_stream, ncols, len(ci), dev(ci.astype(np.int32)), scratch,
+                                  ctypes.addressof(flags), ctypes.addressof(foot))
+        return flags.value, foot.value
+    rng = np.random.default_rng(1)
+    f, foot = analyse(1_000_000, np.sort(rng.integers(0, 1_000_000, size=(100_000, 8)), axis=1).ravel())
+    assert f == COLBLOCK and 6_000_000 < foot <= 8_000_000
+    rows = np.repeat(np.arange(100_000), 8)
+    band = np.clip(rows + rng.integers(-50, 50, size=len(rows)), 0, 999_999)
+    band[::8] = 999_999    # the arrow's column
+    f, foot = analyse(1_000_000, band)
+    assert f == 0
+    n, rp, ci, v = matgen.poisson_2d_5pt(600)
+    assert analyse(n, ci)[0] == 0
+    assert analyse(200_000, rng.integers(0, 200_000, size=500_000))[0] == 0
+    assert analyse(10, np.zeros(0, np.int32)) == (0, 0)

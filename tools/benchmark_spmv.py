@@ -82,7 +82,8 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--formats", default="csr,coo,ell,sellp,hybrid",
                     help="as benchmark/utils/formats.hpp: csr (automatical), csri (load_balance), csrm (merge_path), "
-                         "csrc (classical), csrs, coo, ell, sellp, hybrid")
+                         "csrc (classical), csrs, coo, ell, sellp, hybrid; csri_serial = load_balance with every row "
+                         "segment added by one thread (the kernel of rounds 1-3, for A/B timings)")
     ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--min_repetitions", type=int, default=10)
@@ -121,8 +122,8 @@ def main():
                 entry["max_relative_norm2"] = float(torch.max(num / torch.where(den == 0, torch.ones_like(den), den)))
                 t, reps = timed(lambda: M.apply(b, x), args.warmup, args.min_repetitions, args.min_runtime)
                 # not in the reference's schema: algorithmic GB/s (storage + b + x once)
-                entry.update(time=t, repetitions=reps, completed=True,
-                             bandwidth_gbs=(entry["storage"] + 8 * args.nrhs * (A.ncols + A.nrows)) / t / 1e9)
+                gbs = (entry["storage"] + 8 * args.nrhs * (A.ncols + A.nrows)) / t / 1e9
+                entry.update(time=t, repetitions=reps, completed=True, bandwidth_gbs=gbs, frac_of_8tbs=gbs / 8000.0)
                 if best is None or t < best[1]:
                     best = (fmt, t)
             except Exception as e:

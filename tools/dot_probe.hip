@@ -14,11 +14,11 @@ extern "C" int probe_launch(void* stream, int dot, int nrows, int nnz, const int
     dim3 grid(static_cast<unsigned>(ceildiv(ntiles, num_xcd * per) * num_xcd * per), 1);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dot) {
-        hipLaunchKernelGGL((csr_split_kernel<Block, Tile, split_max_over, false, true, true, true, true>), grid,
+        hipLaunchKernelGGL((csr_split_kernel<int32_t, Block, Tile, split_max_over, false, true, true, true, true>), grid,
                            dim3(Block), 0, s, nrows, nnz, row_ptrs, col_idxs, vals, b, int64_t{1}, c, int64_t{1},
                            nullptr, nullptr, srow, ntiles, per, over, partial, status, nullptr, nullptr);
     } else {
-        hipLaunchKernelGGL((csr_split_kernel<Block, Tile, split_max_over, false, true, false, true, true>), grid,
+        hipLaunchKernelGGL((csr_split_kernel<int32_t, Block, Tile, split_max_over, false, true, false, true, true>), grid,
                            dim3(Block), 0, s, nrows, nnz, row_ptrs, col_idxs, vals, b, int64_t{1}, c, int64_t{1},
                            nullptr, nullptr, srow, ntiles, per, over, nullptr, nullptr, nullptr, nullptr);
     }

@@ -19,7 +19,7 @@ extern "C" int timeline_launch(void* stream, int nt, int swizzle, int nrows, int
     dim3 grid(swizzle ? per * num_xcd : ntiles, 1);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define TL(SWZ, NT)                                                                                   \
-    hipLaunchKernelGGL((csr_split_kernel<Block, Tile, split_max_over, false, SWZ, false, NT, true>), \
+    hipLaunchKernelGGL((csr_split_kernel<int32_t, Block, Tile, split_max_over, false, SWZ, false, NT, true>), \
                        grid, dim3(Block), 0, s, nrows, nnz, row_ptrs, col_idxs, vals, b, int64_t{1}, c, \
                        int64_t{1}, nullptr, nullptr, srow, ntiles, per, over, nullptr, nullptr, nullptr, \
                        nullptr, stamps)
