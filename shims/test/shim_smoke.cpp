@@ -108,5 +108,16 @@ int main()
     const bool step_ok = std::abs(pn - 6.0 * std::sqrt(static_cast<double>(n))) < 1e-9;
     std::cout << "ell / sellp / coo shims vs mirror apply: " << d_ell << " / " << d_sellp << " / " << d_coo << "\nprefix_sum shim: "
               << (scan_ok ? "ok" : "WRONG") << "\nfcg::step_1 shim: " << (step_ok ? "ok" : "WRONG") << std::endl;
+    // one line per kernel, like shim_smoke2.cpp (tests/test_cpp_mirror.py compares the list with INTEGRATION.md)
+    auto ran = [](const char* name, bool ok) { std::cout << "ran " << name << (ok ? " ok" : " WRONG") << "\n"; };
+    ran("csr::spmv", diff == 0.0);
+    ran("dense::compute_norm2", diff == 0.0 && res < 1e-10);
+    ran("lower_trs::generate", st != nullptr);
+    ran("lower_trs::solve", res < 1e-10);
+    ran("ell::spmv", d_ell == 0.0);
+    ran("sellp::advanced_spmv", d_sellp == 0.0);
+    ran("coo::spmv2", d_coo < 1e-10);
+    ran("components::prefix_sum<int32>", scan_ok);
+    ran("fcg::step_1", step_ok);
     return diff == 0.0 && res < 1e-10 && d_ell == 0.0 && d_sellp == 0.0 && d_coo < 1e-10 && scan_ok && step_ok ? 0 : 2;
 }

@@ -112,6 +112,8 @@ void simple_scalar_apply(std::shared_ptr<const HipExecutor>, const array<double>
 void scalar_apply(std::shared_ptr<const HipExecutor>, const array<double>&, const Vec*, const Vec*, const Vec*, Vec*);
 void transpose_jacobi(std::shared_ptr<const HipExecutor>, size_type, uint32, const array<precision_reduction>&, const array<int32>&, const array<double>&,
                       const scheme&, array<double>&);
+void conj_transpose_jacobi(std::shared_ptr<const HipExecutor>, size_type, uint32, const array<precision_reduction>&, const array<int32>&,
+                           const array<double>&, const scheme&, array<double>&);
 }
 namespace factorization {
 void add_diagonal_elements(std::shared_ptr<const HipExecutor>, Mtx*, bool);
@@ -624,6 +626,9 @@ int main()
         k::jacobi::transpose_jacobi(hip, nb, 8, precisions, ptrs, blocks, scheme, tblocks);
         k::jacobi::transpose_jacobi(hip, nb, 8, precisions, ptrs, tblocks, scheme, ttblocks);
         ran("jacobi::transpose_jacobi", ttblocks.to_host() == blocks.to_host() && tblocks.to_host() != blocks.to_host());
+        ttblocks.fill(0.0);
+        k::jacobi::conj_transpose_jacobi(hip, nb, 8, precisions, ptrs, blocks, scheme, ttblocks);   // real values: the transpose
+        ran("jacobi::conj_transpose_jacobi", ttblocks.to_host() == tblocks.to_host());
         std::vector<double> hd(n);
         for (size_type i = 0; i < n; ++i) hd[i] = 2.0 + (i % 4);
         array<double> diag(hip, hd.begin(), hd.end()), inv(hip, n);

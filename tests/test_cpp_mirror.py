@@ -214,13 +214,57 @@ def test_shims_compile_against_the_mirror(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
+def _shim_kernel_list():
+    """the machine-readable list of INTEGRATION.md: every bound kernel, `namespace::kernel`, one per line in the
+    fenced block that follows 'Kernels run on the device through their shims'"""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text.split("Kernels run on the device through their shims", 1)[1].split("```", 2)[1]
+    names = [ln.strip() for ln in block.splitlines() if "::" in ln]
+    assert len(names) == len(set(names)) and len(names) > 80
+    return set(names)
+
+
+def test_every_bound_kernel_is_on_the_device_list():
+    """INTEGRATION.md's table of bindings and its device-run list agree: each `ns::kernel` a shim file defines is
+    on the list or named under 'compile-only'."""
+    import re
+    listed = _shim_kernel_list()
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    compile_only = set(re.findall(r"`([a-z_]+::[a-z_0-9]+)`", text.split("compile-only", 1)[1].split("\n\n", 1)[0]))
+    defined = set()
+    for f in SHIMS:
+        src = open(os.path.join(ROOT, "shims", "hip", f + ".hip.cpp")).read()
+        ns = None
+        for line in src.splitlines():
+            m = re.match(r"namespace ([a-z_]+) \{", line)
+            if m and m.group(1) not in ("gko", "kernels", "hip"):
+                ns = m.group(1)
+            m = re.match(r"void ([a-z_0-9]+)\(std::shared_ptr<const HipExecutor>", line)
+            if m and ns:
+                defined.add(f"{ns}::{m.group(1)}")
+    plain = {n.split("<")[0] for n in listed}
+    missing = {d for d in defined if d not in plain and d not in compile_only}
+    assert not missing, sorted(missing)
+
+
 @pytest.mark.gpu
 def test_shims_run_on_the_device(tmp_path):
+    """Every shim on the device: shim_smoke.cpp + shim_smoke2.cpp print one line per kernel
+    they ran and checked (against the mirror's own apply or a closed form); the set of lines equals INTEGRATION.md's list."""
     objs = _build_shims(tmp_path)
-    exe = tmp_path / "shim_smoke"
-    r = subprocess.run(["g++", "-std=c++14", f"-I{ROOT}/include", f"-I{PKG}/include", f"-I{ROOT}/shims/test",
-                        os.path.join(ROOT, "shims", "test", "shim_smoke.cpp")] + objs +
-                       ["-o", str(exe), f"-L{PKG}/lib", "-lgkomi", f"-Wl,-rpath,{PKG}/lib"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    run = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert run.returncode == 0, run.stdout + run.stderr
+    ran = {}
+    for name in ("shim_smoke", "shim_smoke2"):
+        exe = tmp_path / name
+        r = subprocess.run(["g++", "-std=c++14", f"-I{ROOT}/include", f"-I{PKG}/include", f"-I{ROOT}/shims/test",
+                            os.path.join(ROOT, "shims", "test", name + ".cpp")] + objs +
+                           ["-o", str(exe), f"-L{PKG}/lib", "-lgkomi", f"-Wl,-rpath,{PKG}/lib"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        run = subprocess.run([str(exe)], capture_output=True, text=True)
+        for line in run.stdout.splitlines():
+            t = line.split()
+            if len(t) == 3 and t[0] == "ran":
+                ran[t[1]] = t[2]
+        assert run.returncode == 0, run.stdout + run.stderr
+    wrong = sorted(k for k, v in ran.items() if v != "ok")
+    assert not wrong, wrong
+    assert set(ran) == _shim_kernel_list(), (sorted(set(ran) ^ _shim_kernel_list()))
