@@ -9,9 +9,10 @@ N = 1  (configs[1], SURVEY.md 8(d) "P2"): a step = one `Csr::apply` (y = A x) on
        the 1M-row 5-pt Poisson matrix.  Inputs are resident in HBM before the
        timed region.  `value` is measured COLD: steps rotate over 8 independent
        copies of (A, srow, x, y) -- 640 MB, so the 256 MiB Infinity Cache cannot
-       serve the 80 MB problem on-die -- and the strategy word carries
-       GKOMI_CSR_STREAMING, the caller's statement that its working set exceeds
-       the cache (nontemporal matrix streams).  The warm figure (same matrix
+       serve the 80 MB problem on-die -- with the automatic strategy and no
+       caller flag (what Csr::apply through the reference interface passes): the
+       library's residency tracker sees the other copies go by and selects the
+       nontemporal matrix streams itself.  The warm figure (same matrix
        every step = the reference's benchmark/spmv methodology, automatic
        strategy) is reported under "warm", CG on P2 under "cg", and the one-GPU
        anchor of the multi-GPU curve (P3: 256^3 7-pt Poisson, SpMV + CG to
@@ -515,7 +516,10 @@ def main():
             c = [dev(rp), dev(ci), dev(v), dev(x_host), torch.empty((n, 1), dtype=torch.float64, device=device)]
             c += list(make_srow(c[0], n, nnz))   # Csr::make_srow: part of the matrix, like its row_ptrs
             copies.append(c)
-        cold_strategy = args.strategy if args.strategy else GKOMI_CSR_STREAMING
+        # automatic strategy, no caller flag: what Csr::apply through the reference's interface (shims/hip/matrix/
+        # csr_kernels.hip.cpp) passes.  The library's own residency tracker (csr_probably_evicted) sees 560 MB of other
+        # matrices go by between two applies of a copy and reads the matrix with nontemporal loads by itself.
+        cold_strategy = args.strategy if args.strategy else 0
 
         def launch(c, strategy):
             gk.csr_spmv_srow_f64_i32(stream, n, n, 1, nnz, c[0], c[1], c[2], c[3], 1, c[4], 1, None, None,
@@ -538,8 +542,10 @@ def main():
                                    "(n=1e6, nnz=4996000), x=sin(0.01 i)",
                        "cache_state": f"cold: rotating over {ncopies} copies (> 256 MiB Infinity Cache)",
                        "partition": "one GPU", "strategy": cold_strategy,
-                       "strategy_note": "automatic + GKOMI_CSR_STREAMING (caller's working set exceeds the "
-                                        "Infinity Cache); the matrix carries its srow (Csr::make_srow)"},
+                       "strategy_note": "automatic (0), as Csr::apply through the reference interface passes it: no caller "
+                                        "flag; the library's residency tracker finds > 256 MiB of other CSR applies between "
+                                        "two applies of a copy and selects the nontemporal streams itself; the matrix "
+                                        "carries its srow (Csr::make_srow)"},
         }
         kern_s = ev / args.steps
         achieved = bytes_per_launch / kern_s / 1e9

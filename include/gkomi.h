@@ -626,6 +626,18 @@ int gkomi_trs_solve_plan_f64(gkomi_stream_t s, int64_t n, int64_t nrhs,
                              int64_t b_stride, double* x, int64_t x_stride);
 int gkomi_trs_plan_check_overrun(gkomi_stream_t s, const void* plan,
                                  int* host_flag);
+/* The rule `generate` follows when it chooses between the level plan (1) and the
+ * analysis-free kernel (0) for a factor whose symbolic analysis reported nlevels and
+ * max_deps (out[2], out[3] of gkomi_trs_analyse_symbolic_i32): wide levels, or any
+ * factor of at most 4096 rows with at most 8 dependencies per row -- those are
+ * solved by ONE workgroup with x in LDS and a barrier per level (the reference's
+ * ani4 factors: 170 -> ~30 us per solve) -- take the plan. */
+int64_t gkomi_trs_use_plan(int64_t n, int64_t nlevels, int64_t max_deps);
+/* ... and whether a box-grid factor whose brick analysis found levels_estimate levels and
+ * coarse_levels brick-to-brick hand-offs on its longest path should take the brick plan (1)
+ * or the level plan (0): the cost model of profiles/r02_trs_bricks.md, with the
+ * single-workgroup solve's price per level for factors of at most 4096 rows. */
+int64_t gkomi_trs_prefer_bricks(int64_t n, int64_t levels_estimate, int64_t coarse_levels);
 
 /* ---- the brick plan: a second analysis for factors of grid problems -------------
  * Same place in the reference (LowerTrs/UpperTrs::generate, common_trs_kernels.hip.hpp:61-253),
@@ -872,6 +884,10 @@ int gkomi_diag_poisson3d_7pt_f64_i32(gkomi_stream_t s, int64_t g, int32_t* row_p
                                      int32_t* col_idxs, double* vals);
 int gkomi_diag_poisson3d_7pt_f64_i64(gkomi_stream_t s, int64_t g, int64_t* row_ptrs,
                                      int64_t* col_idxs, double* vals);
+/* Diagnostics: automatic CSR applies of this process whose matrix the library's residency
+ * tracker found evicted from the Infinity Cache (more than 256 MiB of other CSR applies since
+ * its last one) and that therefore read the matrix with nontemporal loads. */
+int64_t gkomi_diag_csr_evicted_applies(void);
 int64_t gkomi_cg_persistent_solves(void);
 /* Process-wide switch of the single-launch CG (what GKOMI_CG_PERSISTENT sets at
  * start-up): 0 = off (every solve runs the three-launch iteration), 1 = on. */

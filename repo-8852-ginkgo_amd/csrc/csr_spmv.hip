@@ -23,6 +23,11 @@
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <atomic>
+#include <mutex>
+
+#include "internal.hpp"
+
 namespace gkomi {
 namespace {
 
@@ -1249,6 +1254,42 @@ bool csr_auto_swizzle(int64_t nrows, int64_t nnz)
     return 12 * nnz + 20 * nrows < (int64_t{288} << 20);
 }
 
+// Is this matrix still in the Infinity Cache?  Only the caller knows its working set (GKOMI_CSR_STREAMING says so),
+// but a Csr::apply through the reference's interface cannot carry that flag.  What the library does know is what ITS
+// OWN SpMVs have streamed since this matrix was applied last: a running byte count over all CSR applies of the process
+// and, per matrix (keyed by its values array), the count at its last apply.  More than the cache in between = evicted for
+// sure -> nontemporal streams (cold 18.3 -> 16.6 us on the 1M-row 5-pt matrix); an unknown matrix or a
+// smaller distance keeps the cached variant.  Other kernels' traffic is not counted: the estimate errs towards "resident".
+std::atomic<int64_t> csr_evicted_applies{0};
+bool csr_probably_evicted(const void* key, int64_t bytes)
+{
+    struct entry {
+        const void* key;
+        uint64_t stamp;
+    };
+    static std::mutex lock;
+    static uint64_t clock = 0;
+    static entry table[64] = {};
+    std::lock_guard<std::mutex> guard(lock);
+    entry* slot = nullptr;
+    entry* oldest = &table[0];
+    for (entry& e : table) {
+        if (e.key == key) slot = &e;
+        if (e.stamp < oldest->stamp) oldest = &e;
+    }
+    bool evicted = false;
+    if (slot != nullptr) {
+        evicted = clock - slot->stamp + static_cast<uint64_t>(bytes) > static_cast<uint64_t>(infinity_cache_bytes);
+    } else {
+        slot = oldest;
+        slot->key = key;
+    }
+    clock += static_cast<uint64_t>(bytes);
+    slot->stamp = clock;
+    if (evicted) csr_evicted_applies.fetch_add(1, std::memory_order_relaxed);
+    return evicted;
+}
+
 }  // namespace gkomi
 
 
@@ -1363,7 +1404,9 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
     if (automatic) {
         // 256 threads, 256 rows, 1536-nonzero tile: fastest measured
         no_swizzle = !csr_auto_swizzle(nrows, nnz);
-        nt = no_swizzle || ((strategy & GKOMI_CSR_STREAMING) != 0);
+        // (the tracker is asked on every automatic apply, also when the answer is not needed: it keeps the byte count)
+        const bool evicted = nnz > 0 && csr_probably_evicted(vals, 12 * nnz + 20 * nrows);
+        nt = no_swizzle || ((strategy & GKOMI_CSR_STREAMING) != 0) || evicted;
         // A matrix that streams from HBM, cut by nonzeros: consecutive tiles on consecutive XCDs (no swizzle) pull
         // the x lines of neighbouring rows into up to three L2s (1.19x the algorithmic traffic on the 256^3 7-point
         // matrix); one contiguous eighth per XCD reads every line once but is 6 % slower there (eight far-apart
@@ -1674,3 +1717,6 @@ extern "C" int gkomi_csr_spmv_f64_i64(gkomi_stream_t stream_, int64_t nrows, int
     return gkomi_csr_spmv_srow_f64_i64(stream_, nrows, ncols, nrhs, nnz, row_ptrs, col_idxs, vals, b, b_stride, c, c_stride,
                                        alpha, beta, strategy, max_row_nnz_hint, nullptr, 0);
 }
+
+/* diagnostics: how many automatic applies of this process found their matrix evicted (csr_probably_evicted) */
+extern "C" int64_t gkomi_diag_csr_evicted_applies(void) { return gkomi::csr_evicted_applies.load(); }

@@ -70,7 +70,7 @@ struct plan_header {
 static_assert(sizeof(plan_header) <= 256, "the plan header has 256 bytes");
 
 struct plan_layout {
-    size_t perm, slice_off, scout, diag, xp, cols, vals, total;
+    size_t perm, slice_off, scout, diag, xp, cols, vals, level_start, total;
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -86,6 +86,8 @@ plan_layout make_plan_layout(int64_t nslices, int64_t entries)
     l.xp = off; off += align_up(sizeof(double) * nslices * slice, 256);
     l.cols = off; off += align_up(sizeof(int32_t) * entries, 256);
     l.vals = off; off += align_up(sizeof(double) * entries, 256);
+    // first position of every level (nlevels + 1 <= rows + 1 entries): the single-workgroup solve of small factors
+    l.level_start = off; off += align_up(sizeof(int32_t) * (nslices * slice + 1), 256);
     l.total = off;
     return l;
 }
@@ -412,6 +414,114 @@ __global__ __launch_bounds__(solve_block) void trs_level_solve_kernel(
     if (gave_up && lane == 0) atomicExch(&hdr->overrun, 1u);  // unsolved rows keep the sentinel NaN
 }
 
+// level_start[l] = first position (level order) of level l, level_start[nlevels] = n; every level 0 .. nlevels - 1 holds a row
+__global__ __launch_bounds__(256) void trs_level_start_kernel(int32_t n, int32_t nlevels, const int32_t* __restrict__ level_sorted,
+                                                             int32_t* __restrict__ level_start)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p == 0) level_start[nlevels] = n;
+    if (p >= n) return;
+    if (p == 0 || level_sorted[p] != level_sorted[p - 1]) level_start[level_sorted[p]] = p;
+}
+
+// ---- small factors: the whole solve in ONE workgroup -----------------------------------------------------------------
+// A factor of a few thousand rows (the reference's own test matrices: ani4, 3081 rows, ~140 levels of ~22 rows) gives the
+// chip-wide kernels nothing to spread: every level is a hand-off through memory (1.2 us each: 170 us per solve).  Here one
+// workgroup of 512 threads owns the factor: x lives in LDS in level order, every thread keeps the dependencies of its
+// (at most R) rows in registers -- loaded once, coalesced, from the plan's SELL-64 slices -- and a level costs the LDS reads
+// of its rows, the division and one workgroup barrier.  Rows of a level are independent; inside a row the subtractions run
+// in storage order and the quotient is the IEEE one: the reference's bits (reference/solver/lower_trs_kernels.cpp:90-120).
+constexpr int small_block = 512;
+constexpr int small_max_rows = 4096;   // 8 positions per thread x up to 8 dependencies each: 192 VGPRs of matrix data
+
+template <int R, int D>
+__global__ __launch_bounds__(small_block) void trs_small_solve_kernel(
+    const plan_header* __restrict__ hdr, const int32_t* __restrict__ perm, const int32_t* __restrict__ slice_off,
+    const double* __restrict__ diag, const int32_t* __restrict__ cols, const double* __restrict__ pvals,
+    const int32_t* __restrict__ level_start, bool unit_diag, const double* __restrict__ b, int64_t b_stride,
+    double* __restrict__ x, int64_t x_stride)
+{
+    __shared__ double xs[R * small_block];
+    __shared__ int32_t ls[R * small_block + 1];
+    const int n = static_cast<int>(hdr->n), nlevels = static_cast<int>(hdr->nlevels);
+    const int tid = threadIdx.x;
+    for (int l = tid; l <= nlevels; l += small_block) ls[l] = level_start[l];
+    int c[R][D];
+    double v[R][D], d[R], sum[R];
+    int row[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = tid + r * small_block;
+        row[r] = -1;
+        d[r] = 1.0;
+        sum[r] = 0.0;
+#pragma unroll
+        for (int e = 0; e < D; ++e) {
+            c[r][e] = -1;
+            v[r][e] = 0.0;
+        }
+        if (p < n) {
+            row[r] = perm[p];
+            const int s = p >> 6, lane = p & 63;
+            const int off = slice_off[s];
+            const int len = (slice_off[s + 1] - off) / slice;
+#pragma unroll
+            for (int e = 0; e < D; ++e) {
+                if (e < len) {
+                    c[r][e] = cols[off + e * slice + lane];
+                    v[r][e] = pvals[off + e * slice + lane];
+                }
+            }
+            d[r] = diag[p];
+            sum[r] = b[row[r] * b_stride];
+        }
+    }
+    __syncthreads();
+    int lo = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const int hi = ls[l + 1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = tid + r * small_block;
+            if (p >= lo && p < hi) {
+                double acc = sum[r];
+#pragma unroll
+                for (int e = 0; e < D; ++e) {
+                    if (c[r][e] >= 0) acc -= v[r][e] * xs[c[r][e]];
+                }
+                const double xr = unit_diag ? acc : acc / d[r];
+                xs[p] = xr;
+                sum[r] = xr;
+            }
+        }
+        lo = hi;
+        // (no global store inside the loop: the barrier would wait for it -- 0.5 us per level instead of 0.1)
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (row[r] >= 0) x[row[r] * x_stride] = sum[r];
+    }
+}
+
+template <int R>
+void launch_small(hipStream_t stream, int64_t max_deps, const plan_header* hdr, const plan_layout& pl, char* p, bool unit_diag,
+                  const double* b, int64_t b_stride, double* x, int64_t x_stride)
+{
+#define GKOMI_SMALL(DEPS)                                                                                                  \
+    hipLaunchKernelGGL((trs_small_solve_kernel<R, DEPS>), dim3(1), dim3(small_block), 0, stream, hdr,                       \
+                       reinterpret_cast<const int32_t*>(p + pl.perm), reinterpret_cast<const int32_t*>(p + pl.slice_off),  \
+                       reinterpret_cast<const double*>(p + pl.diag), reinterpret_cast<const int32_t*>(p + pl.cols),         \
+                       reinterpret_cast<const double*>(p + pl.vals), reinterpret_cast<const int32_t*>(p + pl.level_start),  \
+                       unit_diag, b, b_stride, x, x_stride)
+    if (max_deps <= 4) {
+        GKOMI_SMALL(4);
+    } else {
+        GKOMI_SMALL(8);
+    }
+#undef GKOMI_SMALL
+}
+
 template <bool Lower>
 int analyse_symbolic(hipStream_t stream, int64_t n, const int32_t* row_ptrs, const int32_t* col_idxs,
                      void* workspace, size_t workspace_bytes, int64_t* host_out)
@@ -543,6 +653,11 @@ extern "C" int gkomi_trs_analyse_numeric_f64_i32(gkomi_stream_t s, int64_t n, co
                        tuning("GKOMI_TRS_NEAR", default_scout_near))
     if (lower) GKOMI_FILL(true); else GKOMI_FILL(false);
 #undef GKOMI_FILL
+    err = check_launch();
+    if (err) return err;
+    hipLaunchKernelGGL(trs_level_start_kernel, dim3(static_cast<unsigned>(ceildiv(n, 256))), dim3(256), 0, stream,
+                       static_cast<int32_t>(n), static_cast<int32_t>(nlevels), reinterpret_cast<const int32_t*>(sw + sl.level_sorted),
+                       reinterpret_cast<int32_t*>(p + pl.level_start));
     return check_launch();
 }
 
@@ -558,6 +673,27 @@ extern "C" int gkomi_trs_solve_plan_f64(gkomi_stream_t s, int64_t n, int64_t nrh
     char* p = static_cast<char*>(plan);
     plan_header* hdr = reinterpret_cast<plan_header*>(p);
     hipStream_t stream = to_stream(s);
+    // a factor of a few thousand rows: one workgroup, x in LDS (see trs_small_solve_kernel); GKOMI_TRS_SMALL=0: tuning hook
+    static const bool small_on = [] {
+        const char* e = getenv("GKOMI_TRS_SMALL");
+        return e == nullptr || e[0] != '0';
+    }();
+    if (small_on && n <= small_max_rows && max_deps >= 0 && max_deps <= 8) {
+        for (int64_t j = 0; j < nrhs; ++j) {
+            if (n <= 1 * small_block) {
+                launch_small<1>(stream, max_deps, hdr, pl, p, unit_diag != 0, b + j, b_stride, x + j, x_stride);
+            } else if (n <= 2 * small_block) {
+                launch_small<2>(stream, max_deps, hdr, pl, p, unit_diag != 0, b + j, b_stride, x + j, x_stride);
+            } else if (n <= 4 * small_block) {
+                launch_small<4>(stream, max_deps, hdr, pl, p, unit_diag != 0, b + j, b_stride, x + j, x_stride);
+            } else {
+                launch_small<8>(stream, max_deps, hdr, pl, p, unit_diag != 0, b + j, b_stride, x + j, x_stride);
+            }
+            const int err = check_launch();
+            if (err) return err;
+        }
+        return GKOMI_SUCCESS;
+    }
     const unsigned groups = static_cast<unsigned>(ceildiv(nslices, solve_block / slice));
     const char* env_rounds = getenv("GKOMI_TRS_MAX_ROUNDS");
     const long long max_rounds = env_rounds != nullptr && env_rounds[0] != 0 ? atoll(env_rounds) : default_max_rounds;
@@ -596,4 +732,28 @@ extern "C" int gkomi_trs_plan_check_overrun(gkomi_stream_t s, const void* plan, 
     err = static_cast<int>(hipStreamSynchronize(stream));
     *host_flag = static_cast<int>(h.overrun);
     return err;
+}
+
+
+// Which solve `generate` should prepare for a factor of n rows whose symbolic analysis found nlevels levels and rows of at
+// most max_deps dependencies: 1 = the level plan (gkomi_trs_analyse_numeric + gkomi_trs_solve_plan: level-scheduled
+// waves for wide levels, ONE workgroup with x in LDS for factors of up to 4096 rows), 0 = the analysis-free kernel
+// (chains and narrow bands of large factors: in-workgroup LDS hand-offs).  One rule for the shims, the mirror and
+// gkomi.solvers.
+extern "C" int64_t gkomi_trs_use_plan(int64_t n, int64_t nlevels, int64_t max_deps)
+{
+    if (n <= 0) return 0;
+    if (n <= small_max_rows && max_deps >= 0 && max_deps <= 8) return 1;
+    return n >= 64 * (nlevels > 0 ? nlevels : 1) ? 1 : 0;
+}
+
+// ... and between the brick plan of a box-grid factor (levels_estimate levels, coarse_levels brick-to-brick hand-offs on
+// the longest path: gkomi_trs_bricks_levels_estimate / info[1]) and the level plan: us per level inside bricks 0.17, per
+// hand-off 5.0, per level of the level plan 1.7 (profiles/r02_trs_bricks.md) -- or 0.2 when the factor is small enough for
+// the single-workgroup solve (profiles/r04_trs_small.log).
+extern "C" int64_t gkomi_trs_prefer_bricks(int64_t n, int64_t levels_estimate, int64_t coarse_levels)
+{
+    if (levels_estimate <= 16) return 0;
+    const double per_level = n <= small_max_rows ? 0.2 : 1.7;
+    return 0.17 * levels_estimate + 5.0 * coarse_levels < per_level * levels_estimate ? 1 : 0;
 }

@@ -404,7 +404,8 @@ def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True, brick
     """preconditioner::Ilu over given CSR factors L = (row_ptrs, col_idxs, vals), U likewise.
     analyse: LowerTrs / UpperTrs::generate -- the dependency analysis of both factors (True / False / "force");
     a factor of a grid problem gets the brick plan (bricks=True; csrc/trs_bricks.hip), one whose levels are
-    wide enough the level-scheduled kernel, anything else keeps the analysis-free solve.
+    wide enough the level-scheduled kernel, a small one (<= 4096 rows) the single-workgroup solve of the same plan,
+    anything else keeps the analysis-free solve.
     brick_rows: rows per brick of the brick plan (0: the library's default); bricks="force" takes the
     brick plan whenever the factor admits one, whatever the cost model says.
     The brick analysis runs on the device; a factor that takes the brick plan skips the level analysis (its
@@ -427,13 +428,13 @@ def ilu_from_factors(gk, n, L, U, nrhs=1, l_unit_diag=False, analyse=True, brick
             if bk is not None:
                 nlevels = bk.levels_estimate
                 # pipelined: about one step per level of the factor
-                if nlevels > 16 and (bricks == "force" or TRS_BRICK_STEP_US * nlevels + TRS_BRICK_HOP_US * bk.coarse_levels
-                                     < TRS_LEVEL_US * nlevels):
+                if nlevels > 16 and (bricks == "force" or gk.trs_prefer_bricks(n, nlevels, bk.coarse_levels)):
                     brick_plans[i] = bk
                     continue
                 del bk
             plan = TrsPlan(gk, n, f[0], f[1], f[2], lower)
-            if analyse == "force" or n >= TRS_PLAN_MIN_ROWS_PER_LEVEL * max(plan.nlevels, 1):
+            # wide levels, or a small factor (one workgroup, x in LDS): gkomi_trs_use_plan, the rule of the shims and the mirror
+            if analyse == "force" or gk.trs_use_plan(n, plan.nlevels, plan.max_deps):
                 plans[i] = plan
     pl, pu = plans
     bl, bu = brick_plans

@@ -2283,7 +2283,7 @@ protected:
                 int64_t info[8] = {};
                 GKOMI_CALL(gkomi_trs_bricks_info(bricks_, info));
                 const int64_t levels = gkomi_trs_bricks_levels_estimate(bricks_);
-                if (levels > 16 && 0.17 * levels + 5.0 * info[1] < 1.7 * levels) {  // us per level / per brick level (profiles/r02_trs_bricks.md) vs the level plan
+                if (gkomi_trs_prefer_bricks(n, levels, info[1]) != 0) {  // the cost model of profiles/r02_trs_bricks.md (+ the single-workgroup solve of small factors)
                     nlevels_ = levels;
                     plan_.resize_and_reset(gkomi_trs_bricks_plan_bytes(bricks_));
                     GKOMI_CALL(gkomi_trs_bricks_numeric_f64_i32(nullptr, bricks_, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(), plan_.get_data(),
@@ -2300,7 +2300,7 @@ protected:
                                                   symbolic.get_num_elems(), out));
         nslices_ = out[0]; entries_ = out[1]; nlevels_ = out[2]; max_deps_ = out[3];
         // wide levels: level-scheduled; chains and narrow bands: the analysis-free kernel's in-workgroup hand-offs
-        planned_ = n > 0 && n >= 64 * std::max<int64_t>(nlevels_, 1);
+        planned_ = gkomi_trs_use_plan(n, nlevels_, max_deps_) != 0;
         if (planned_) {
             plan_.resize_and_reset(gkomi_trs_plan_bytes(nslices_, entries_));
             GKOMI_CALL(gkomi_trs_analyse_numeric_f64_i32(nullptr, n, csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_const_values(), Lower ? 1 : 0,

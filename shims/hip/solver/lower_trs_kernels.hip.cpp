@@ -42,7 +42,7 @@ void generate(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double,
         int64_t info[8] = {};
         if (st->bricks != nullptr) GKOMI_CALL(gkomi_trs_bricks_info(st->bricks, info));
         const int64_t levels = st->bricks != nullptr ? gkomi_trs_bricks_levels_estimate(st->bricks) : 0;
-        if (st->bricks != nullptr && levels > 16 && 0.17 * levels + 5.0 * info[1] < 1.7 * levels) {
+        if (st->bricks != nullptr && gkomi_trs_prefer_bricks(n, levels, info[1]) != 0) {
             st->nlevels = levels;
             st->plan.resize_and_reset(gkomi_trs_bricks_plan_bytes(st->bricks));
             GKOMI_CALL(gkomi_trs_bricks_numeric_f64_i32(GKOMI_NULL_STREAM, st->bricks, matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(),
@@ -58,8 +58,9 @@ void generate(std::shared_ptr<const HipExecutor> exec, const matrix::Csr<double,
     GKOMI_CALL(gkomi_trs_analyse_symbolic_i32(GKOMI_NULL_STREAM, n, matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(), /*lower=*/1,
                                               st->symbolic.get_data(), st->symbolic.get_num_elems(), out));
     st->nslices = out[0]; st->entries = out[1]; st->nlevels = out[2]; st->max_deps = out[3];
-    // wide levels: the level-scheduled solve; chains and narrow bands: the in-workgroup hand-offs of the other kernel
-    st->planned = n >= 64 * (st->nlevels > 0 ? st->nlevels : 1);
+    // wide levels: the level-scheduled solve; small factors: one workgroup with x in LDS; chains and narrow bands of large
+    // factors: the in-workgroup hand-offs of the other kernel (gkomi_trs_use_plan)
+    st->planned = gkomi_trs_use_plan(n, st->nlevels, st->max_deps) != 0;
     if (st->planned) {
         st->plan.resize_and_reset(gkomi_trs_plan_bytes(st->nslices, st->entries));
         GKOMI_CALL(gkomi_trs_analyse_numeric_f64_i32(GKOMI_NULL_STREAM, n, matrix->get_const_row_ptrs(), matrix->get_const_col_idxs(),

@@ -177,3 +177,30 @@ def test_full_size_p2_bit_exact_and_properties(gk, oracle):
     assert np.all(ones[interior.ravel()] == 0.0)          # A 1 = 0 away from the boundary
     again = host(csr_apply_srow(gk, A, dev(x), srow, tile, hint=5))
     assert np.array_equal(got, again)                     # run-to-run deterministic
+
+
+def test_residency_tracker_selects_the_nontemporal_streams_by_itself(gk, oracle):
+    """An automatic apply (no GKOMI_CSR_STREAMING: what Csr::apply through the reference interface passes) reads the
+    matrix with nontemporal loads when more than the 256 MiB Infinity Cache of OTHER CSR applies went by since its last
+    apply -- the library's own byte count (csr_probably_evicted).  The same matrix again and again: never; four 85 MB
+    matrices in rotation: every apply after the first round.  Results are bit-identical either way."""
+    g = 1030
+    n, rp, ci, v = matgen.poisson_2d_5pt(g)
+    x = dev(np.sin(0.01 * np.arange(n)).reshape(n, 1))
+    mats = []
+    for k in range(4):
+        A = DevCsr(n, n, rp, ci, v * (1.0 + k))
+        mats.append((A, make_srow(gk, A, 1536)))
+    expect = np.empty((n, 1))
+    oracle.ref_csr_spmv(n, 1, rp, ci, v, host(x), 1, expect, 1)
+    before = gk.diag_csr_evicted_applies()
+    A, (srow, tile) = mats[0]
+    for _ in range(6):
+        y = csr_apply_srow(gk, A, x, srow, tile, hint=5)
+    assert gk.diag_csr_evicted_applies() == before and np.array_equal(host(y), expect)
+    for rnd in range(3):
+        for A, (srow, tile) in mats:
+            y = csr_apply_srow(gk, A, x, srow, tile, hint=5)
+    assert gk.diag_csr_evicted_applies() - before >= 8          # rounds 2 and 3: every apply
+    y = csr_apply_srow(gk, mats[0][0], x, mats[0][1][0], mats[0][1][1], hint=5)
+    assert np.array_equal(host(y), expect)

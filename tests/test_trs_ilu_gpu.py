@@ -352,7 +352,8 @@ def test_trs_overrun_is_sticky_and_surfaces_as_an_error(gk, oracle, monkeypatch,
     out (level plan), "bricks" asks for bricks of 256 rows and checks there is a hand-off to give up on."""
     import gkomi
     import gkomi.solvers as solvers
-    n, rp, ci, v = matgen.poisson_2d_5pt(48)
+    # (more than 4096 rows: a smaller factor is solved by one workgroup behind barriers and has nothing to give up on)
+    n, rp, ci, v = matgen.poisson_2d_5pt(72)
     f = ilu_util.oracle_par_ilu(oracle, n, rp, ci, v)
     L = tuple(dev(a) for a in f["L"])
     U = tuple(dev(a) for a in f["U"])
@@ -405,3 +406,43 @@ def test_trs_single_brick_has_nothing_to_wait_for(gk, oracle, monkeypatch):
     yd = torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")
     bk.solve(dev(b), yd)
     assert np.array_equal(host(yd), y) and not bk.overrun()
+
+
+@pytest.mark.parametrize("which", ["lower", "upper"])
+@pytest.mark.parametrize("n", [2, 511, 512, 513, 1024, 1025, 2049, 4096, 4097])
+def test_trs_plan_small_factors_one_workgroup(gk, oracle, which, n):
+    """Factors of up to 4096 rows with at most 8 dependencies per row are solved by ONE workgroup (x in LDS, the
+    rows' dependencies in registers, a barrier per level: trs_small_solve_kernel); 1 / 2 / 4 / 8 positions per thread
+    at the sizes around 512, 1024, 2048; 4097 rows take the level-scheduled waves.  Bit-exact either way, two
+    right-hand sides, unit and stored diagonal; gkomi_trs_use_plan sends every one of them to the plan."""
+    rp, ci, v = random_triangular(n, which == "lower", seed=n, max_off=8, band=min(n, 300))
+    rng = np.random.default_rng(n)
+    import gkomi.solvers as solvers
+    plan = solvers.TrsPlan(gk, n, dev(rp), dev(ci), dev(v), which == "lower")
+    assert plan.max_deps <= 8 and bool(gk.trs_use_plan(n, plan.nlevels, plan.max_deps)) == (n <= 4096 or n >= 64 * plan.nlevels)
+    for unit in (False, True):
+        b = rng.standard_normal((n, 2))
+        e = np.zeros_like(b)
+        (oracle.ref_lower_trs_solve if which == "lower" else oracle.ref_upper_trs_solve)(n, 2, rp, ci, v, int(unit), b, 2, e, 2)
+        x = torch.full((n, 2), 777.0, dtype=torch.float64, device="cuda:0")
+        plan.solve(dev(b), x, unit)
+        assert np.array_equal(host(x), e), unit
+    assert not plan.overrun()
+
+
+def test_trs_small_factor_of_the_reference_test_matrix_ani4(gk, oracle):
+    """ILU(0) factors of matrices/test/ani4.mtx (3081 rows, irregular FEM pattern): Ilu::apply through the plan the
+    generate step picks (both factors: the single-workgroup solve), bit-exact against the oracle's two solves."""
+    import gkomi.solvers as solvers
+    kind, n, nc, rows, cols, vals = matgen.read_mtx(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ani4.mtx"))
+    rp, ci, v = matgen.coo_to_csr(n, rows, cols, vals)
+    f = ilu_util.oracle_par_ilu(oracle, n, rp, ci, v)
+    pre = solvers.ilu_from_factors(gk, n, tuple(dev(a) for a in f["L"]), tuple(dev(a) for a in f["U"]))
+    assert pre.l_plan is not None and pre.u_plan is not None and pre.l_bricks is None
+    b = np.sin(0.1 * np.arange(n)).reshape(n, 1) + 2.0
+    y, e = np.zeros_like(b), np.zeros_like(b)
+    oracle.ref_lower_trs_solve(n, 1, *f["L"], 0, b, 1, y, 1)
+    oracle.ref_upper_trs_solve(n, 1, *f["U"], 0, y, 1, e, 1)
+    z = torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")
+    pre.apply(dev(b), z)
+    assert np.array_equal(host(z), e)

@@ -18,8 +18,17 @@ def timed(f, reps=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 
-for name, gen in (("t2_like_permuted_1108", lambda: matgen.t2_like_permuted(1108)), ("diffusion_patch_ordered_1104", lambda: matgen.diffusion_2d_patch_ordered(1104)),
-                  ("poisson_2d_1000 (bricks)", lambda: matgen.poisson_2d_5pt(1000))):
+def ani(name):
+    kind, nr, nc, rows, cols, vals = matgen.read_mtx(os.path.join(ROOT, "tests", "golden", name + ".mtx"))
+    rp, ci, v = matgen.coo_to_csr(nr, rows, cols, vals)
+    return nr, rp, ci, v
+
+CASES = (("ani4 (3081 rows: one workgroup, x in LDS)", lambda: ani("ani4")), ("ani1", lambda: ani("ani1")),
+         ("poisson_2d_60 (3600 rows)", lambda: matgen.poisson_2d_5pt(60)))
+if "--small-only" not in sys.argv:
+    CASES += (("t2_like_permuted_1108", lambda: matgen.t2_like_permuted(1108)), ("diffusion_patch_ordered_1104", lambda: matgen.diffusion_2d_patch_ordered(1104)),
+              ("poisson_2d_1000 (bricks)", lambda: matgen.poisson_2d_5pt(1000)))
+for name, gen in CASES:
     n, rp, ci, v = gen()
     a = [d(rp), d(ci), d(v)]
     torch.cuda.synchronize(); t0 = time.perf_counter()
