@@ -467,10 +467,12 @@ def main():
         ("n1_same_run"), so that each line carries its own anchor."""
         progress(f"P3: building the {args.p3_grid}^3 matrix on one GPU")
         g = args.p3_grid
-        n3, rp3, ci3, v3 = matgen.poisson_3d_7pt(g)
-        nnz3 = int(rp3[-1])
-        a3 = [dev(rp3), dev(ci3), dev(v3)]
-        del rp3, ci3, v3
+        # the matrix is written on the device (gkomi_diag_poisson3d_7pt_f64_i32: row_ptrs in closed form; the same arrays
+        # as tests/matgen.py poisson_3d_7pt, tests/test_csr_i64_gpu.py::test_device_generated_poisson_matrix_equals_the_host_one)
+        n3, nnz3 = g ** 3, 7 * g ** 3 - 6 * g * g
+        a3 = [torch.empty(n3 + 1, dtype=torch.int32, device=device), torch.empty(nnz3, dtype=torch.int32, device=device),
+              torch.empty(nnz3, dtype=torch.float64, device=device)]
+        gk.diag_poisson3d_7pt_f64_i32(stream, g, a3[0], a3[1], a3[2])
         x3 = dev(np.sin(0.01 * np.arange(n3)).reshape(n3, 1))
         y3 = torch.empty((n3, 1), dtype=torch.float64, device=device)
         srow3, tile3 = make_srow(a3[0], n3, nnz3)

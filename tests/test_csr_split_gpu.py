@@ -193,6 +193,10 @@ def test_residency_tracker_selects_the_nontemporal_streams_by_itself(gk, oracle)
         mats.append((A, make_srow(gk, A, 1536)))
     expect = np.empty((n, 1))
     oracle.ref_csr_spmv(n, 1, rp, ci, v, host(x), 1, expect, 1)
+    # (the tracker is keyed by the address of the values: torch hands out addresses that earlier tests' matrices had --
+    # one apply each makes these four known, then the first one is the most recent again)
+    for A, (srow, tile) in mats + mats[:1]:
+        csr_apply_srow(gk, A, x, srow, tile, hint=5)
     before = gk.diag_csr_evicted_applies()
     A, (srow, tile) = mats[0]
     for _ in range(6):

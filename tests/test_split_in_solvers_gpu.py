@@ -83,7 +83,32 @@ def test_fused_drivers_with_srow_agree_with_the_row_cut_kernels(gk, oracle, solv
     one, solutions to 1e-8, true residual (oracle SpMV) at the tolerance of the solve."""
     from gkomi import formats, solvers
     if solver == "cgs" and len(grid) == 2:
-        pytest.skip("CGS stagnates above 1e-10 on the 81 000-row 2-D convection-diffusion problem with either kernel")
+        # CGS stagnates above 1e-10 on the 81 000-row 2-D convection-diffusion problem with either kernel: is that the
+        # algorithm or the backend?  The oracle's CGS (reference kernel sequence, sequential dots) on the same system:
+        # it must stagnate too, and where it stands after the same number of iterations the device must stand as well
+        # (true residuals, oracle SpMV, within two orders of magnitude: CGS's plateau is eps x the largest
+        # intermediate residual, which moves with the rounding of every dot product)
+        n, rp, ci, v = matgen.poisson_2d_5pt(*grid)
+        v = v.copy()
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        v[ci == rows - 1] -= 0.3
+        v[ci == rows] += 0.3
+        b = np.sin(0.1 * np.arange(n)) + 1.0
+        xe = np.zeros(n)
+        ite = oracle.ref_cgs_solve(n, rp, ci, v, b.copy(), xe, 1500, 1e-10, 0)
+        S = formats.Csr.from_host(gk, n, n, rp, ci, v)
+        res = solvers.solve_op(gk, "cgs", S, dev(b), max_iters=1500, reduction=1e-10, fused=True)
+
+        def true_rel(x):
+            r = b.copy().reshape(n, 1)
+            oracle.ref_csr_advanced_spmv(n, 1, -1.0, rp, ci, v, np.ascontiguousarray(x).reshape(n, 1), 1, 1.0, r, 1)
+            return float(np.linalg.norm(r) / np.linalg.norm(b))
+
+        ro, rg = true_rel(xe), true_rel(host(res["x"]))
+        assert (ite >= 1500) == (not res["converged"]), (ite, res["iterations"], ro, rg)
+        assert ro > 1e-10 and rg > 1e-10, (ro, rg)                       # both plateau above the goal
+        assert 1e-2 <= rg / ro <= 1e2, (ro, rg)
+        return
     if len(grid) == 2:
         n, rp, ci, v = matgen.poisson_2d_5pt(*grid)
     else:
