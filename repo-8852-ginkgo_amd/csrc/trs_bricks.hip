@@ -53,6 +53,8 @@ struct gkomi_trs_bricks {
     int64_t nbricks = 0, nsteps = 0, coarse_levels = 0, critical_steps = 0, lds_bytes_max = 0;
     int64_t max_brick_steps = 0, nlevels_fine = 0;
     int64_t levels_estimate = 0;  // levels of the factor if the guessed box geometry holds: sum (extent - 1) + 1 (cost models only)
+    int lexicographic = 1;        // 0: the grid coordinates were recovered from the dependency graph (any monotone numbering)
+    int geometry_failed_width = 0;  // device analysis: the offsets are no divisor chain; widest dependency list (host recovery next)
     std::vector<int32_t> perm;             // plan position -> row
     std::vector<int32_t> inv_local;        // row -> LDS index inside its brick
     std::vector<int32_t> row_rank;         // row -> rank of its brick (topological order)
@@ -212,6 +214,130 @@ inline int analysis_threads()
     return static_cast<int>(std::min(8u, std::max(1u, hw)));
 }
 
+// ---- grid coordinates from the dependency graph --------------------------------------------------------------
+// The divisor-chain test below recognises a box grid only when it is numbered lexicographically.  The factor of a grid
+// problem numbered any other way that keeps "smaller index = earlier" along every axis -- patches / tiles (the locality a
+// FEM or a cache-blocked ordering has), space-filling curves -- has the same dependency graph: every row depends on at most
+// one neighbour per dimension, one step back.  Here the coordinates are read off that graph: walked in dependency order, a
+// row sits at the componentwise maximum of its neighbours' coordinates (interior rows, rows on coordinate planes), or one
+// step further along its single neighbour's axis (rows on the coordinate axes; the children of the origin take the axes
+// in the order they come).  Like the divisor chain this is a guess that is never trusted: every dependency must be exactly
+// one step back along one axis, no two rows may share a cell, the cells must nearly fill their bounding box -- and the brick
+// graph is still built from the actual entries afterwards.  Any failure = this factor is not for the brick plan.
+bool recover_grid_coordinates(int64_t n, bool lower, const std::vector<int32_t>& rp, const std::vector<int32_t>& ci, int width,
+                              std::vector<int32_t>* coord, int64_t* extent, int* dims_out)
+{
+    const int dims = width;  // one dependency per dimension at most
+    if (dims < 1 || dims > 3 || n < 2) return false;
+    for (int k = 0; k < dims; ++k) coord[k].assign(static_cast<size_t>(n), 0);
+    std::vector<int32_t> level(static_cast<size_t>(n), 0);
+    int origin_children = 0;
+    int64_t origins = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t row = lower ? i : n - 1 - i;  // dependency order
+        int32_t parents[3];
+        int np = 0;
+        for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
+            const int64_t col = ci[k];
+            if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
+            if (np == dims) return false;
+            parents[np++] = static_cast<int32_t>(col);
+        }
+        if (np == 0) {
+            if (++origins > 1) return false;  // one corner only
+            continue;
+        }
+        int32_t m[3] = {0, 0, 0};
+        int32_t lvl = 0;
+        for (int j = 0; j < np; ++j) {
+            lvl = std::max(lvl, level[parents[j]] + 1);
+            for (int k = 0; k < dims; ++k) m[k] = std::max(m[k], coord[k][parents[j]]);
+        }
+        const int64_t sum = static_cast<int64_t>(m[0]) + m[1] + m[2];
+        if (sum == lvl - 1 && np == 1) {  // on a coordinate axis: one step further along it
+            int nonzero = 0, axis = -1;
+            for (int k = 0; k < dims; ++k) {
+                if (coord[k][parents[0]] != 0) {
+                    ++nonzero;
+                    axis = k;
+                }
+            }
+            if (nonzero == 0) {
+                if (origin_children >= dims) return false;
+                axis = origin_children++;
+            } else if (nonzero != 1) {
+                return false;
+            }
+            ++m[axis];
+        } else if (sum != lvl) {
+            return false;
+        }
+        for (int j = 0; j < np; ++j) {  // every neighbour exactly one step back along one axis
+            int steps = 0;
+            for (int k = 0; k < dims; ++k) {
+                const int32_t d = m[k] - coord[k][parents[j]];
+                if (d < 0 || d > 1) return false;
+                steps += d;
+            }
+            if (steps != 1) return false;
+        }
+        level[row] = lvl;
+        for (int k = 0; k < dims; ++k) coord[k][row] = m[k];
+    }
+    if (origins != 1) return false;
+    int64_t cells = 1;
+    for (int k = 0; k < dims; ++k) {
+        int32_t mx = 0;
+        for (int64_t row = 0; row < n; ++row) mx = std::max(mx, coord[k][row]);
+        extent[k] = static_cast<int64_t>(mx) + 1;
+        cells *= extent[k];
+        if (cells > 2 * n + 1024) return false;  // the rows must nearly fill their box
+    }
+    std::vector<char> taken(static_cast<size_t>(cells), 0);
+    for (int64_t row = 0; row < n; ++row) {
+        int64_t cell = 0, mul = 1;
+        for (int k = 0; k < dims; ++k) {
+            cell += coord[k][row] * mul;
+            mul *= extent[k];
+        }
+        if (taken[cell]) return false;
+        taken[cell] = 1;
+    }
+    *dims_out = dims;
+    return true;
+}
+
+// ---- bricks of a THIN factor: consecutive pieces of the level order ------------------------------------------------
+// A factor without a grid in it can still have many more levels than a level holds rows: chains, narrow bands, the factors
+// of small unstructured meshes (the reference's ani4: 183 levels of 17 rows).  The level plan pays a memory hand-off per
+// level there, and the bricks' LDS cadence (0.165 us per level) needs only that consecutive levels live in ONE workgroup:
+// rows sorted by (level, row) and cut every brick_rows rows give bricks whose graph is acyclic by construction (a
+// dependency runs from a lower level to a strictly higher one, so never from a later piece to an earlier one).  A piece
+// holds brick_rows / (rows per level) levels: worth it when that is many -- `thin` = at most 64 rows per level on average.
+// level[row] (longest path), order[i] = rows by (level, row); returns the number of levels
+int64_t level_order(int64_t n, bool lower, const std::vector<int32_t>& rp, const std::vector<int32_t>& ci,
+                    std::vector<int32_t>& order)
+{
+    std::vector<int32_t> level(static_cast<size_t>(n), 0);
+    int32_t nlevels = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t row = lower ? i : n - 1 - i;
+        int32_t lvl = 0;
+        for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
+            const int64_t col = ci[k];
+            if (is_dep(lower, col, row) && col >= 0 && col < n) lvl = std::max(lvl, level[col] + 1);
+        }
+        level[row] = lvl;
+        nlevels = std::max(nlevels, lvl + 1);
+    }
+    std::vector<int32_t> start(static_cast<size_t>(nlevels) + 1, 0);
+    for (int64_t row = 0; row < n; ++row) ++start[level[row] + 1];
+    for (int32_t l = 0; l < nlevels; ++l) start[l + 1] += start[l];
+    order.assign(static_cast<size_t>(n), 0);
+    for (int64_t row = 0; row < n; ++row) order[start[level[row]]++] = static_cast<int32_t>(row);
+    return nlevels;
+}
+
 // the whole symbolic analysis; GKOMI_ENOTSUPPORTED = this factor is not for the brick plan
 int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vector<int32_t>& ci,
             int64_t brick_rows, int threads, int mode)
@@ -233,6 +359,7 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
     int64_t offs[max_offsets];
     int noffs = 0;
     int width = 0;
+    bool too_many = false;  // more distinct offsets than a lexicographic box numbering has (a space-filling curve has many)
     {
         struct partial {
             int64_t offs[max_offsets];
@@ -242,54 +369,88 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
         std::vector<partial> part(static_cast<size_t>(nthreads));
         in_parallel(n, 4096, nthreads, [&](int t, int64_t lo, int64_t hi) {
             partial& me = part[t];
-            for (int64_t row = lo; row < hi && !me.too_many; ++row) {
+            for (int64_t row = lo; row < hi; ++row) {  // (the widest row counts also when the offsets are too many)
                 int deps = 0;
                 for (int32_t k = rp[row]; k < rp[row + 1]; ++k) {
                     const int64_t col = ci[k];
                     if (!is_dep(lower, col, row) || col < 0 || col >= n) continue;
                     ++deps;
+                    if (me.too_many) continue;
                     const int64_t d = lower ? row - col : col - row;
                     int j = 0;
                     while (j < me.noffs && me.offs[j] != d) ++j;
                     if (j == me.noffs) {
                         if (me.noffs == max_offsets) {
                             me.too_many = true;
-                            break;
+                        } else {
+                            me.offs[me.noffs++] = d;
                         }
-                        me.offs[me.noffs++] = d;
                     }
                 }
                 me.width = std::max(me.width, deps);
             }
         });
         for (const partial& me : part) {
-            if (me.too_many) return GKOMI_ENOTSUPPORTED;
+            too_many = too_many || me.too_many;
             width = std::max(width, me.width);
-            for (int q = 0; q < me.noffs; ++q) {
+            for (int q = 0; q < me.noffs && !too_many; ++q) {
                 int j = 0;
                 while (j < noffs && offs[j] != me.offs[q]) ++j;
                 if (j == noffs) {
-                    if (noffs == max_offsets) return GKOMI_ENOTSUPPORTED;
+                    if (noffs == max_offsets) {
+                        too_many = true;
+                        break;
+                    }
                     offs[noffs++] = me.offs[q];
                 }
             }
         }
     }
     mark("offsets");
-    if (noffs == 0 || width > max_width) return GKOMI_ENOTSUPPORTED;
+    if ((noffs == 0 && !too_many) || width > max_width) return GKOMI_ENOTSUPPORTED;
     std::sort(offs, offs + noffs);
-    // 2. strides of a lexicographic box numbering: a divisor chain
+    // 2. strides of a lexicographic box numbering: a divisor chain ...
     int64_t stride[max_dims];
-    int dims = 0;
-    stride[dims++] = 1;
-    for (int j = 0; j < noffs; ++j) {
-        if (offs[j] == stride[dims - 1]) continue;
-        if (offs[j] % stride[dims - 1] != 0 || dims == max_dims) return GKOMI_ENOTSUPPORTED;
-        stride[dims++] = offs[j];
-    }
     int64_t extent[max_dims];
-    for (int k = 0; k + 1 < dims; ++k) extent[k] = stride[k + 1] / stride[k];
-    extent[dims - 1] = ceildiv(n, stride[dims - 1]);
+    int dims = 0;
+    bool lexicographic = !too_many;
+    if (lexicographic) {
+        stride[dims++] = 1;
+        for (int j = 0; j < noffs && lexicographic; ++j) {
+            if (offs[j] == stride[dims - 1]) continue;
+            if (offs[j] % stride[dims - 1] != 0 || dims == max_dims) {
+                lexicographic = false;
+            } else {
+                stride[dims++] = offs[j];
+            }
+        }
+    }
+    // ... or any other numbering of a box grid whose graph gives the coordinates away (recover_grid_coordinates)
+    std::vector<int32_t> coord[3];
+    std::vector<int32_t> band_order;  // thin factors: rows by (level, row)
+    bool banded = false;
+    if (lexicographic) {
+        for (int k = 0; k + 1 < dims; ++k) extent[k] = stride[k + 1] / stride[k];
+        extent[dims - 1] = ceildiv(n, stride[dims - 1]);
+    } else {
+        static const bool recover = [] {
+            const char* e = getenv("GKOMI_TRS_RECOVER_GRID");  // =0: lexicographic numberings only (rounds 2-3)
+            return e == nullptr || e[0] != '0';
+        }();
+        if (!recover) return GKOMI_ENOTSUPPORTED;
+        if (width <= 3 && recover_grid_coordinates(n, lower, rp, ci, width, coord, extent, &dims)) {
+            mark("grid coordinates from the graph");
+        } else {
+            // ... or no grid at all, but a thin factor: pieces of the level order (level_order above)
+            const int64_t nlevels = level_order(n, lower, rp, ci, band_order);
+            mark("level order");
+            if (nlevels < 2 || n > 64 * nlevels) return GKOMI_ENOTSUPPORTED;
+            banded = true;
+            dims = 1;
+            extent[0] = nlevels;
+        }
+    }
+    h.lexicographic = lexicographic ? 1 : (banded ? 2 : 0);
     int active = 0;  // dimensions that are more than one point wide
     for (int k = 0; k < dims; ++k) active += extent[k] > 1;
     h.levels_estimate = 1;
@@ -301,7 +462,10 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
     //    shrunk until a brick with its inflow fits LDS
     for (int attempt = 0; attempt < 8; ++attempt, brick_rows = std::max<int64_t>(brick_rows / 2, 8)) {
         int64_t edge[max_dims], nbk[max_dims];
-        if (h.mode == 2 && active >= 3) {
+        if (banded) {
+            edge[0] = 1;  // (unused: the brick map below is a cut of band_order)
+            nbk[0] = ceildiv(n, brick_rows);
+        } else if (h.mode == 2 && active >= 3) {
             // pipelined, three or more dimensions: a level of a box is at most the product of all its edges but
             // the longest -- keep that within the 64 lanes of the compute wave (8 x 8, 4 x 4 x 4) so that every
             // level is ONE step, and spend the rows on the last dimension (measured on the 108^3 factor:
@@ -337,7 +501,7 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
                 remaining = std::max(1.0, remaining / static_cast<double>(edge[k]));
             }
         }
-        if (const char* forced = getenv("GKOMI_TRS_BRICK_EDGES")) {  // tuning: "e0,e1,e2" (tools/trs_bricks_probe.py edges)
+        if (const char* forced = banded ? nullptr : getenv("GKOMI_TRS_BRICK_EDGES")) {  // tuning: "e0,e1,e2" (tools/trs_bricks_probe.py edges)
             int k = 0;
             for (const char* q = forced; *q != 0 && k < dims; ++k) {
                 edge[k] = std::max<int64_t>(1, std::min<int64_t>(extent[k], atoll(q)));
@@ -352,9 +516,28 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
             if (nbricks > (1 << 24)) return GKOMI_ENOTSUPPORTED;
         }
         // a LAYER = the bricks with one coordinate along the last dimension = a contiguous range of
-        // rows: bricks never straddle layers, so layers are analysed side by side
-        const int64_t layer_rows = edge[dims - 1] * stride[dims - 1];
+        // rows: bricks never straddle layers, so layers are analysed side by side.  Recovered coordinates: any
+        // row can be anywhere -- one layer, the passes below that walk rows in dependency order run on one thread.
+        const int64_t layer_rows = lexicographic ? edge[dims - 1] * stride[dims - 1] : n;
         std::vector<int32_t> brick(static_cast<size_t>(n));
+        if (banded) {
+            in_parallel(n, 4096, nthreads, [&](int, int64_t lo, int64_t hi) {
+                for (int64_t i = lo; i < hi; ++i) brick[band_order[i]] = static_cast<int32_t>(i / brick_rows);
+            });
+        } else if (!lexicographic) {
+            int64_t bmul[max_dims];
+            for (int k = 0, m = 1; k < dims; ++k) {
+                bmul[k] = m;
+                m *= static_cast<int>(nbk[k]);
+            }
+            in_parallel(n, 4096, nthreads, [&](int, int64_t lo, int64_t hi) {
+                for (int64_t row = lo; row < hi; ++row) {
+                    int64_t id = 0;
+                    for (int k = 0; k < dims; ++k) id += (coord[k][row] / edge[k]) * bmul[k];
+                    brick[row] = static_cast<int32_t>(id);
+                }
+            });
+        } else {
         in_parallel(n, layer_rows, nthreads, [&](int, int64_t lo, int64_t hi) {
             // coordinates of `lo` by division, then counted up row by row (dimension 0 has stride 1)
             int64_t c[max_dims], within[max_dims], mul[max_dims], id = 0;
@@ -381,6 +564,7 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
                 }
             }
         });
+        }
         mark("brick of every row");
         // 4. the brick graph from the actual entries (never from the guessed geometry), and
         // 6. the level of a row inside its brick (dependencies on other bricks do not count: their
@@ -1054,13 +1238,17 @@ int analyse_device(gkomi_trs_bricks& h, hipStream_t stream, const int32_t* rp, c
     ANA_TRY(check_launch());
     ANA_TRY(hipMemcpyAsync(&head, small.p, sizeof(head), hipMemcpyDeviceToHost, stream));
     ANA_TRY(hipStreamSynchronize(stream));
-    if (head.too_many) return GKOMI_ENOTSUPPORTED;
+    const int width = head.width;
+    // (not a lexicographic box numbering: the caller may still find the grid in the dependency graph, on the host)
+    if (head.too_many) {
+        h.geometry_failed_width = width;
+        return GKOMI_ENOTSUPPORTED;
+    }
     int64_t offs[max_offsets];
     int noffs = 0;
     for (unsigned long long t : head.table) {
         if (t != ana_empty) offs[noffs++] = static_cast<int64_t>(t);
     }
-    const int width = head.width;
     if (noffs == 0 || width > max_width) return GKOMI_ENOTSUPPORTED;
     std::sort(offs, offs + noffs);
     // strides of a lexicographic box numbering: a divisor chain (step 2 of the host analysis)
@@ -1069,7 +1257,10 @@ int analyse_device(gkomi_trs_bricks& h, hipStream_t stream, const int32_t* rp, c
     stride[dims++] = 1;
     for (int j = 0; j < noffs; ++j) {
         if (offs[j] == stride[dims - 1]) continue;
-        if (offs[j] % stride[dims - 1] != 0 || dims == max_dims) return GKOMI_ENOTSUPPORTED;
+        if (offs[j] % stride[dims - 1] != 0 || dims == max_dims) {
+            h.geometry_failed_width = width;
+            return GKOMI_ENOTSUPPORTED;
+        }
         stride[dims++] = offs[j];
     }
     int64_t extent[max_dims];
@@ -2040,12 +2231,31 @@ extern "C" int gkomi_trs_bricks_create_i32(gkomi_stream_t s, int64_t n, const in
         h->n = n;
         h->lower = lower ? 1 : 0;
         err = analyse_device(*h, stream, row_ptrs, col_idxs, brick_rows, threads, mode);
-        if (err != GKOMI_SUCCESS) {
-            delete h;
-            return err;
+        if (err == GKOMI_SUCCESS) {
+            *out = h;
+            return GKOMI_SUCCESS;
         }
-        *out = h;
-        return GKOMI_SUCCESS;
+        // Not a lexicographic numbering, but rows of at most three dependencies: it may be a box grid numbered in
+        // patches / along a curve -- the host analysis reads the coordinates off the dependency graph
+        // (recover_grid_coordinates; the pattern comes to the host for it: set-up, tens of milliseconds per million rows)
+        const int failed_width = err == GKOMI_ENOTSUPPORTED ? h->geometry_failed_width : 0;
+        delete h;
+        if (failed_width < 1 || failed_width > max_width) return err;
+        if (failed_width > 3) {
+            // no grid to recover (more than one dependency per dimension): the host analysis is worth the copy of the
+            // pattern only for a THIN factor (pieces of the level order as bricks) -- ask the level analysis how many
+            // levels there are before anything leaves the device
+            const size_t bytes = gkomi_trs_symbolic_workspace_bytes(n);
+            void* ws = nullptr;
+            if (hipMalloc(&ws, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                return GKOMI_ENOTSUPPORTED;
+            }
+            int64_t sym[4] = {};
+            const int serr = gkomi_trs_analyse_symbolic_i32(s, n, row_ptrs, col_idxs, lower, ws, bytes, sym);
+            (void)hipFree(ws);
+            if (serr != GKOMI_SUCCESS || sym[2] < 2 || n > 64 * sym[2]) return GKOMI_ENOTSUPPORTED;
+        }
     }
     std::vector<int32_t> rp(static_cast<size_t>(n) + 1);
     err = static_cast<int>(hipMemcpyAsync(rp.data(), row_ptrs, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost, stream));

@@ -478,11 +478,16 @@ __global__ __launch_bounds__(small_block) void trs_small_solve_kernel(
         }
     }
     __syncthreads();
+    // (Tried: skipping the workgroup barrier between levels that live in one wave -- LDS executes a wave's instructions in
+    // order -- 12 % slower: the bookkeeping costs every wave more than the barriers it saves.)
+    const int wave_first = (tid & ~63);   // first position of this wave's block in round r: wave_first + r * small_block
     int lo = 0, hi = nlevels > 0 ? ls[1] : 0;
     for (int l = 0; l < nlevels; ++l) {
         const int hi_next = ls[min(l + 2, nlevels)];   // the next level's bound is asked for now, not behind the barrier
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+            const int first = wave_first + r * small_block;
+            if (hi <= first || lo >= first + 64) continue;   // wave-uniform: none of my 64 positions is in this level
             const int p = tid + r * small_block;
             if (p >= lo && p < hi) {
                 // all reads go out together (a padding slot reads cell 0 and is dropped: a branch per slot would put one
@@ -497,9 +502,15 @@ __global__ __launch_bounds__(small_block) void trs_small_solve_kernel(
                 }
                 double acc = xs[p];
                 const double d = ds[p];
+                // the products first (independent), then the subtractions in storage order; a padding slot subtracts
+                // +0.0, which changes nothing (also not a -0.0): no select in the dependent chain
+                double t[D];
 #pragma unroll
-                for (int e = 0; e < D; ++e) acc = has[e] ? acc - v[r][e] * xd[e] : acc;
-                xs[p] = unit_diag ? acc : acc / d;
+                for (int e = 0; e < D; ++e) t[e] = has[e] ? v[r][e] * xd[e] : 0.0;
+#pragma unroll
+                for (int e = 0; e < D; ++e) acc -= t[e];
+                // (acc / 1.0 == acc for every acc: the unit diagonal ParILU stores explicitly costs no division)
+                xs[p] = (unit_diag || d == 1.0) ? acc : acc / d;
             }
         }
         lo = hi;
@@ -764,6 +775,6 @@ extern "C" int64_t gkomi_trs_use_plan(int64_t n, int64_t nlevels, int64_t max_de
 extern "C" int64_t gkomi_trs_prefer_bricks(int64_t n, int64_t levels_estimate, int64_t coarse_levels)
 {
     if (levels_estimate <= 16) return 0;
-    const double per_level = n <= small_max_rows ? 0.2 : 1.7;
+    const double per_level = n <= small_max_rows ? 0.5 : 1.7;   // measured: profiles/r04_trs_small.log
     return 0.17 * levels_estimate + 5.0 * coarse_levels < per_level * levels_estimate ? 1 : 0;
 }

@@ -217,29 +217,54 @@ def test_brick_schedule_is_legal_and_replays_to_the_oracle(gk, oracle, name, mak
         bk.close()
 
 
-def test_brick_analysis_refuses_what_it_cannot_schedule(gk):
+def test_brick_analysis_refuses_what_it_cannot_schedule(gk, oracle):
+    """No grid in the factor: since round 4 a THIN factor (many more levels than rows per level) is still cut into
+    pieces of its level order, anything else is refused.  Whatever comes back must be a legal schedule."""
     rng = np.random.default_rng(3)
-    # random lower triangle: more than 16 distinct offsets
+    # random lower triangle (more than 16 distinct offsets): ~20 levels of ~25 rows -- thin enough for level pieces
     n = 500
     rows = np.repeat(np.arange(n), 3)
     cols = (rows * rng.random(len(rows))).astype(np.int32)
     m = np.unique(np.stack([rows, cols], 1), axis=0)
-    rp = np.zeros(n + 1, np.int32)
-    np.add.at(rp, m[:, 0] + 1, 1)
-    rp = np.cumsum(rp).astype(np.int32)
-    with pytest.raises(Exception):
-        Bricks(gk, n, rp, m[:, 1].astype(np.int32), True)
-    # offsets that are no divisor chain (1, 7, 10)
+    m = np.concatenate([m[m[:, 0] != m[:, 1]], np.stack([np.arange(n), np.arange(n)], 1)])
+    m = m[np.lexsort((m[:, 1], m[:, 0]))]
+    rp, ci, v = matgen.coo_to_csr(n, m[:, 0].astype(np.int32), m[:, 1].astype(np.int32),
+                                  np.where(m[:, 0] == m[:, 1], 3.0, -0.4))
+    b = np.cos(np.arange(n))
+    e = np.zeros((n, 1))
+    oracle.ref_lower_trs_solve(n, 1, rp, ci, v, 0, b.reshape(n, 1).copy(), 1, e, 1)
+    bk = Bricks(gk, n, rp, ci, True, 128)
+    try:
+        assert np.array_equal(replay(bk, n, rp, ci, v, True, False, b), e[:, 0])
+    finally:
+        bk.close()
+    # offsets that are no divisor chain (1, 7, 10): a band, thin -- level pieces, legal
     n = 300
     rp, ci = [0], []
     for r in range(n):
         ci += [c for c in (r - 10, r - 7, r - 1) if c >= 0] + [r]
         rp.append(len(ci))
-    with pytest.raises(Exception):
-        Bricks(gk, n, np.array(rp, np.int32), np.array(ci, np.int32), True)
+    rp, ci = np.array(rp, np.int32), np.array(ci, np.int32)
+    v = np.where(ci == np.repeat(np.arange(n), np.diff(rp)), 2.0, -0.3)
+    b = np.cos(np.arange(n))
+    e = np.zeros((n, 1))
+    oracle.ref_lower_trs_solve(n, 1, rp, ci, v, 0, b.reshape(n, 1).copy(), 1, e, 1)
+    bk = Bricks(gk, n, rp, ci, True, 64)
+    try:
+        assert np.array_equal(replay(bk, n, rp, ci, v, True, False, b), e[:, 0])
+    finally:
+        bk.close()
     # a diagonal matrix has nothing to schedule
     with pytest.raises(Exception):
         Bricks(gk, 100, np.arange(101, dtype=np.int32), np.arange(100, dtype=np.int32), True)
+    # more than 8 dependencies per row: not for the bricks' record layout
+    n = 200
+    r = np.repeat(np.arange(n), 12)
+    c = np.clip(r - np.tile(np.arange(12), n), 0, None)
+    m = np.unique(np.stack([r, c], 1), axis=0)
+    rp, ci, v = matgen.coo_to_csr(n, m[:, 0].astype(np.int32), m[:, 1].astype(np.int32), np.ones(len(m)))
+    with pytest.raises(Exception):
+        Bricks(gk, n, rp, ci, True)
 
 
 def test_brick_analysis_wraparound_band_is_checked_on_the_entries(gk, oracle):
@@ -285,3 +310,161 @@ def test_brick_analysis_is_the_same_on_any_number_of_host_threads(gk, monkeypatc
         assert info == plans[0][1]
         for a, b in zip(arrays, plans[0][0]):
             assert np.array_equal(a, b)
+
+
+def renumber(n, rp, ci, v, new_index):
+    """P A P^T for the numbering new_index[old row], rows and columns sorted"""
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    pr, pc = new_index[rows], new_index[ci]
+    order = np.lexsort((pc, pr))
+    return matgen.coo_to_csr(n, pr[order].astype(np.int32), pc[order].astype(np.int32), v[order])
+
+
+def morton(i, j):
+    code = np.zeros_like(i)
+    for bit in range(12):
+        code |= ((i >> bit) & 1) << (2 * bit + 1)
+        code |= ((j >> bit) & 1) << (2 * bit)
+    return code
+
+
+def grid_numberings():
+    out = {}
+    n, rp, ci, v = matgen.diffusion_2d_patch_ordered(48, patch=(4, 8))          # 2-D, 4 x 8 patches (the thermal2 stand-in's numbering)
+    out["patches_2d"] = (n, rp, ci, v)
+    g = 32
+    n, rp, ci, v = matgen.poisson_2d_5pt(g)
+    i, j = np.divmod(np.arange(n), g)
+    out["morton_2d"] = (n, *renumber(n, rp, ci, v + 0.01 * np.arange(len(v)) % 0.3, np.argsort(np.argsort(morton(i, j)))))
+    g = 12
+    n, rp, ci, v = matgen.poisson_3d_7pt(g)
+    idx = np.arange(n)
+    i, j, k = idx // (g * g), (idx // g) % g, idx % g
+    pi, pj, pk = 2, 3, 4                                                         # 3-D, 2 x 3 x 4 patches
+    new = (((i // pi) * (g // pj) + (j // pj)) * (g // pk) + (k // pk)) * (pi * pj * pk) + ((i % pi) * pj + (j % pj)) * pk + (k % pk)
+    out["patches_3d"] = (n, *renumber(n, rp, ci, v, new))
+    # a lexicographic numbering with its second axis reversed is NOT monotone: must be refused, not mis-scheduled
+    g = 20
+    n, rp, ci, v = matgen.poisson_2d_5pt(g)
+    i, j = np.divmod(np.arange(n), g)
+    out["reversed_axis"] = (n, *renumber(n, rp, ci, v, i * g + (g - 1 - j)))
+    return out
+
+
+NUMBERINGS = grid_numberings()
+
+
+@pytest.mark.parametrize("lower", [True, False], ids=["lower", "upper"])
+@pytest.mark.parametrize("name,brick_rows", [("patches_2d", 256), ("patches_2d", 0), ("morton_2d", 100), ("patches_3d", 216), ("reversed_axis", 64)])
+def test_brick_analysis_recovers_the_grid_of_a_non_lexicographic_numbering(gk, oracle, name, brick_rows, lower):
+    """Round 4: factors of grid problems numbered in patches / along a space-filling curve have no divisor chain of
+    offsets; the host analysis reads the grid coordinates off the dependency graph (recover_grid_coordinates) and cuts
+    bricks from them.  The schedule must be legal and replay to the oracle's bits, blocking and pipelined; a numbering
+    that is monotone along both axes after a reflection (reversed axis) is still a grid walk from ANOTHER corner for one
+    of the two factors -- whatever the analysis decides there (bricks or refusal), it must not mis-schedule."""
+    n, rp, ci, v = NUMBERINGS[name]
+    rp, ci, v = triangle(n, rp, ci, v, lower)
+    b = np.sin(0.37 * np.arange(n)) + 1.5
+    e = np.zeros((n, 1))
+    (oracle.ref_lower_trs_solve if lower else oracle.ref_upper_trs_solve)(n, 1, rp, ci, v, 0, b.reshape(n, 1).copy(), 1, e, 1)
+    try:
+        bk = Bricks(gk, n, rp, ci, lower, brick_rows, 0, 1)
+    except Exception:
+        assert name == "reversed_axis", "a monotone numbering of a box grid must be recognised"
+        return
+    try:
+        if name != "reversed_axis":
+            assert bk.nbricks > 1 and bk.coarse_levels > 1
+        assert np.array_equal(replay(bk, n, rp, ci, v, lower, False, b), e[:, 0])
+    finally:
+        bk.close()
+    bk = Bricks(gk, n, rp, ci, lower, brick_rows, 0, 2)
+    try:
+        for resident in (bk.nbricks, 3):
+            assert np.array_equal(replay_pipelined(bk, n, rp, ci, v, lower, False, b, resident), e[:, 0])
+    finally:
+        bk.close()
+
+
+def test_grid_recovery_can_be_switched_off(gk, monkeypatch):
+    # GKOMI_TRS_RECOVER_GRID is read once per process: only check that the default recognises the patch numbering
+    n, rp, ci, v = NUMBERINGS["patches_2d"]
+    rp, ci, v = triangle(n, rp, ci, v, True)
+    bk = Bricks(gk, n, rp, ci, True, 256, 0, 2)
+    assert bk.nbricks == 9 and bk.coarse_levels == 5      # 48 x 48 cells in 16 x 16 bricks
+    bk.close()
+
+
+def thin_factors():
+    import os
+    out = {}
+    here = os.path.dirname(os.path.abspath(__file__))
+    kind, n, nc, rows, cols, vals = matgen.read_mtx(os.path.join(here, "golden", "ani4.mtx"))
+    rp, ci, v = matgen.coo_to_csr(n, rows, cols, vals)
+    out["ani4"] = (n, rp, ci, v + 0.0)
+    n = 5000                                                     # a chain: every row its own level
+    rows = np.repeat(np.arange(n), 3)
+    cols = rows + np.tile([-1, 0, 1], n)
+    keep = (cols >= 0) & (cols < n)
+    out["tridiagonal"] = (n, *matgen.coo_to_csr(n, rows[keep].astype(np.int32), cols[keep].astype(np.int32),
+                                                np.where(cols[keep] == rows[keep], 2.5, -1.0)))
+    rng = np.random.default_rng(8)                               # a narrow random band: up to 6 dependencies within 9 rows
+    n = 4000
+    r, c = [], []
+    for row in range(n):
+        near = np.arange(max(0, row - 9), min(n, row + 10))
+        pick = rng.choice(near, size=min(len(near), 7), replace=False)
+        for col in set(pick.tolist()) | {row}:
+            r.append(row)
+            c.append(col)
+    order = np.lexsort((c, r))
+    r, c = np.array(r, np.int32)[order], np.array(c, np.int32)[order]
+    out["narrow_band"] = (n, *matgen.coo_to_csr(n, r, c, np.where(r == c, 4.0, 0.3 * np.cos(np.arange(len(r))))))
+    return out
+
+
+THIN = thin_factors()
+
+
+@pytest.mark.parametrize("lower", [True, False], ids=["lower", "upper"])
+@pytest.mark.parametrize("name,brick_rows", [("ani4", 0), ("ani4", 300), ("tridiagonal", 0), ("tridiagonal", 700), ("narrow_band", 0)])
+def test_brick_analysis_cuts_thin_factors_into_pieces_of_the_level_order(gk, oracle, name, brick_rows, lower):
+    """Round 4: a factor with no grid in it but far more levels than rows per level (the reference's ani4 factors: 183 levels
+    of 17 rows; a chain; a narrow band) becomes bricks too -- consecutive pieces of its (level, row) order, acyclic by
+    construction.  Legal schedule, the oracle's bits, blocking and pipelined."""
+    n, rp, ci, v = THIN[name]
+    rp, ci, v = triangle(n, rp, ci, v, lower)
+    b = np.sin(0.37 * np.arange(n)) + 1.5
+    e = np.zeros((n, 1))
+    (oracle.ref_lower_trs_solve if lower else oracle.ref_upper_trs_solve)(n, 1, rp, ci, v, 0, b.reshape(n, 1).copy(), 1, e, 1)
+    bk = Bricks(gk, n, rp, ci, lower, brick_rows, 0, 1)
+    try:
+        assert bk.nbricks >= 2 and bk.coarse_levels == bk.nbricks      # a chain of pieces
+        assert np.array_equal(replay(bk, n, rp, ci, v, lower, False, b), e[:, 0])
+    finally:
+        bk.close()
+    bk = Bricks(gk, n, rp, ci, lower, brick_rows, 0, 2)
+    try:
+        for resident in (bk.nbricks, 2):
+            assert np.array_equal(replay_pipelined(bk, n, rp, ci, v, lower, False, b, resident), e[:, 0])
+    finally:
+        bk.close()
+
+
+def test_brick_analysis_leaves_wide_factors_without_a_grid_to_the_level_plan(gk):
+    # 16 levels of 700 rows, random dependencies on the level before: neither a grid nor thin
+    rng = np.random.default_rng(2)
+    n, per = 16 * 700, 700
+    r, c = [], []
+    for row in range(n):
+        lvl = row // per
+        if lvl > 0:
+            for col in rng.choice(np.arange((lvl - 1) * per, lvl * per), size=3, replace=False):
+                r.append(row)
+                c.append(int(col))
+        r.append(row)
+        c.append(row)
+    order = np.lexsort((c, r))
+    rp, ci, v = matgen.coo_to_csr(n, np.array(r, np.int32)[order], np.array(c, np.int32)[order], np.ones(len(r)))
+    with pytest.raises(Exception):
+        Bricks(gk, n, rp, ci, True)

@@ -239,14 +239,76 @@ def test_device_analysis_equals_host_analysis(gk, case, mode):
 
 
 def test_device_analysis_refuses_what_the_host_analysis_refuses(gk):
-    """a random pattern has no divisor chain of offsets: GKOMI_ENOTSUPPORTED from both"""
+    """16 levels of 700 rows with random dependencies on the level before: no divisor chain of offsets, no grid in the
+    graph, not thin -- GKOMI_ENOTSUPPORTED from the device entry (which asks the host analysis before it gives up)"""
     import ctypes
     import gkomi
-    n = 500
-    rp, ci, v = matgen.random_csr(500, 500, 2, 6, 11)
-    from test_trs_bricks_analysis import triangle
-    trp, tci, tv = triangle(n, rp, ci, v, True)
+    rng = np.random.default_rng(2)
+    n, per = 16 * 700, 700
+    r, c = [], []
+    for row in range(n):
+        lvl = row // per
+        if lvl > 0:
+            for col in rng.choice(np.arange((lvl - 1) * per, lvl * per), size=3, replace=False):
+                r.append(row)
+                c.append(int(col))
+        r.append(row)
+        c.append(row)
+    order = np.lexsort((c, r))
+    trp, tci, tv = matgen.coo_to_csr(n, np.array(r, np.int32)[order], np.array(c, np.int32)[order], np.ones(len(r)))
     h = ctypes.c_void_p(0)
     with pytest.raises(gkomi._lib.GkomiError) as e:
         gk.trs_bricks_create_i32(torch.cuda.current_stream().cuda_stream, n, dev(trp), dev(tci), 1, 0, 0, 2, ctypes.addressof(h))
     assert e.value.code == -2 and not h.value
+
+
+@pytest.mark.parametrize("lower", [True, False], ids=["lower", "upper"])
+@pytest.mark.parametrize("name", ["ani4", "tridiagonal", "narrow_band"])
+def test_bricks_on_thin_factors_without_a_grid(gk, oracle, name, lower):
+    """Round 4: pieces of the level order as bricks (the reference's ani4 factors, a chain, a narrow band with up to 7
+    dependencies per row): device entry -> level count on the device -> host analysis -> the same solve kernels;
+    bit-exact against the oracle, both modes."""
+    from test_trs_bricks_analysis import THIN
+    n, rp, ci, v = THIN[name]
+    rp, ci, v = triangle(n, rp, ci, v, lower)
+    rng = np.random.default_rng(len(name))
+    b = rng.standard_normal((n, 2))
+    for brick_rows, mode in ((0, 2), (400, 2), (400, 1)):
+        x, bk = brick_solve(gk, n, rp, ci, v, lower, False, b, brick_rows, 0, mode)
+        assert bk.nbricks >= 2
+        assert np.array_equal(x, oracle_solve(oracle, n, rp, ci, v, lower, False, b)), (brick_rows, mode)
+
+
+@pytest.mark.parametrize("lower", [True, False], ids=["lower", "upper"])
+@pytest.mark.parametrize("name", ["patches_2d", "morton_2d", "patches_3d"])
+def test_bricks_on_grids_numbered_in_patches_or_along_a_curve(gk, oracle, name, lower):
+    """Round 4: a grid problem whose numbering is not lexicographic -- 4 x 8 patches (the
+    thermal2 stand-in's numbering), Morton order, 2 x 3 x 4 patches in three dimensions -- has no divisor chain of offsets;
+    gkomi_trs_bricks_create_i32 then reads the grid coordinates off the dependency graph on the host and cuts bricks from
+    them.  Same solve kernels, bit-exact against the oracle, both modes, two right-hand sides."""
+    from test_trs_bricks_analysis import NUMBERINGS
+    n, rp, ci, v = NUMBERINGS[name]
+    rng = np.random.default_rng(len(name))
+    rp, ci, v = triangle(n, rp, ci, v * (1.0 + 0.3 * rng.random(len(v))), lower)
+    b = rng.standard_normal((n, 2))
+    for brick_rows, mode in ((0, 2), (150, 2), (150, 1)):
+        x, bk = brick_solve(gk, n, rp, ci, v, lower, False, b, brick_rows, 0, mode)
+        assert bk.nbricks > 1 or brick_rows == 0
+        assert np.array_equal(x, oracle_solve(oracle, n, rp, ci, v, lower, False, b)), (brick_rows, mode)
+
+
+def test_ilu_of_the_patch_ordered_problem_takes_the_brick_plan(gk, oracle):
+    """generate's choice (gkomi.solvers.ilu_from_factors, the rule of the shims and the mirror): the ILU(0) factors of the
+    patch-ordered diffusion problem (config 3's second stand-in at 1/4 size: 280^2) get bricks, and Ilu::apply equals the
+    oracle's two solves bit for bit."""
+    n, rp, ci, v = matgen.diffusion_2d_patch_ordered(280)
+    f = ilu_util.oracle_par_ilu(oracle, n, rp, ci, v)
+    pre = solvers.ilu_from_factors(gk, n, tuple(dev(a) for a in f["L"]), tuple(dev(a) for a in f["U"]))
+    assert pre.l_bricks is not None and pre.u_bricks is not None
+    b = np.sin(0.1 * np.arange(n)).reshape(n, 1) + 2.0
+    y, e = np.zeros_like(b), np.zeros_like(b)
+    oracle.ref_lower_trs_solve(n, 1, *f["L"], 0, b, 1, y, 1)
+    oracle.ref_upper_trs_solve(n, 1, *f["U"], 0, y, 1, e, 1)
+    z = torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")
+    pre.apply(dev(b), z)
+    assert np.array_equal(host(z), e)

@@ -431,18 +431,25 @@ def test_trs_plan_small_factors_one_workgroup(gk, oracle, which, n):
 
 
 def test_trs_small_factor_of_the_reference_test_matrix_ani4(gk, oracle):
-    """ILU(0) factors of matrices/test/ani4.mtx (3081 rows, irregular FEM pattern): Ilu::apply through the plan the
-    generate step picks (both factors: the single-workgroup solve), bit-exact against the oracle's two solves."""
+    """ILU(0) factors of matrices/test/ani4.mtx (3081 rows, irregular FEM pattern, 183 levels of 17 rows): Ilu::apply
+    through the plan the generate step picks -- pieces of the level order as bricks (thin factor), or the single-workgroup
+    solve where the cost model prefers it -- bit-exact against the oracle's two solves; and the single-workgroup solve
+    itself on the same factors."""
     import gkomi.solvers as solvers
     kind, n, nc, rows, cols, vals = matgen.read_mtx(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ani4.mtx"))
     rp, ci, v = matgen.coo_to_csr(n, rows, cols, vals)
     f = ilu_util.oracle_par_ilu(oracle, n, rp, ci, v)
     pre = solvers.ilu_from_factors(gk, n, tuple(dev(a) for a in f["L"]), tuple(dev(a) for a in f["U"]))
-    assert pre.l_plan is not None and pre.u_plan is not None and pre.l_bricks is None
+    assert (pre.l_plan is not None or pre.l_bricks is not None) and (pre.u_plan is not None or pre.u_bricks is not None)
     b = np.sin(0.1 * np.arange(n)).reshape(n, 1) + 2.0
     y, e = np.zeros_like(b), np.zeros_like(b)
     oracle.ref_lower_trs_solve(n, 1, *f["L"], 0, b, 1, y, 1)
     oracle.ref_upper_trs_solve(n, 1, *f["U"], 0, y, 1, e, 1)
     z = torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")
     pre.apply(dev(b), z)
+    assert np.array_equal(host(z), e)
+    pre2 = solvers.ilu_from_factors(gk, n, tuple(dev(a) for a in f["L"]), tuple(dev(a) for a in f["U"]), bricks=False)
+    assert pre2.l_plan is not None and pre2.u_plan is not None       # <= 4096 rows: the single-workgroup solve of the level plan
+    z.zero_()
+    pre2.apply(dev(b), z)
     assert np.array_equal(host(z), e)

@@ -45,6 +45,10 @@ for name, gen in CASES:
         bytes_ = 12 * nnz + 4 * (n + 1) + 16 * n
         print(f"   {'lower' if lower else 'upper'}: nnz {nnz}, levels {pl.nlevels}, rows per level {n / max(pl.nlevels, 1):.0f}, level plan {t_plan:8.1f} us = "
               f"{t_plan / max(pl.nlevels, 1):.2f} us per level, {bytes_ / t_plan / 1e6:.2f} TB/s on SURVEY 8(d) bytes", flush=True)
+    for lower, f, bk in ((True, pre.L, pre.l_bricks), (False, pre.U, pre.u_bricks)):
+        if bk is not None:
+            t_b = timed(lambda: bk.solve(b, x))
+            print(f"   {'lower' if lower else 'upper'}: brick plan {t_b:8.1f} us ({bk.nbricks} bricks, {bk.coarse_levels} brick levels)", flush=True)
     y = torch.zeros_like(b)
     t_apply = timed(lambda: pre.apply(b, y))
     print(f"   Ilu apply (what the solvers call): {t_apply:8.1f} us", flush=True)
