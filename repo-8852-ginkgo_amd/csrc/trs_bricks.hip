@@ -458,9 +458,17 @@ int analyse(gkomi_trs_bricks& h, const std::vector<int32_t>& rp, const std::vect
     // pipelined: the levels of a brick should fit the one compute wave, and a brick about fill a CU's LDS
     // (8 x 8 x 27, 45^2: fewer bricks = fewer hand-offs); else large bricks
     if (brick_rows <= 0) brick_rows = h.mode == 2 ? (active >= 3 ? 1728 : 2025) : 4096;
+    if (banded) {
+        // pieces of the level order: every piece is a hand-off on the only path there is, so as few as LDS allows -- start
+        // from what the records of a piece take (no inflow counted yet) and come down in steps of a fifth, not by halves
+        const int k = width <= 2 ? 2 : width <= 3 ? 3 : width <= 4 ? 4 : 8;
+        const int64_t fit = static_cast<int64_t>(max_lds_bytes - 4096) / (8 * (3 + k) + 4 * (k + 1) + 8);
+        brick_rows = std::min(brick_rows, std::max<int64_t>(fit, 8));
+    }
     // 3. brick edges: about brick_rows rows per brick, near-cubic, an even split of every extent;
     //    shrunk until a brick with its inflow fits LDS
-    for (int attempt = 0; attempt < 8; ++attempt, brick_rows = std::max<int64_t>(brick_rows / 2, 8)) {
+    for (int attempt = 0; attempt < (banded ? 16 : 8);
+         ++attempt, brick_rows = std::max<int64_t>(banded ? brick_rows * 4 / 5 : brick_rows / 2, 8)) {
         int64_t edge[max_dims], nbk[max_dims];
         if (banded) {
             edge[0] = 1;  // (unused: the brick map below is a cut of band_order)
