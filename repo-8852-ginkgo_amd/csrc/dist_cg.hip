@@ -21,6 +21,7 @@
 //         host looks every `check_every` iterations.
 #include "cg_fused.hpp"
 
+#include "internal.hpp"
 #include "sort_scan.hpp"
 
 namespace gkomi {
@@ -245,10 +246,10 @@ dist_layout make_dist_layout(int64_t n, int64_t nl_rows)
     l.p = off; off += vec;
     l.q = off; off += vec;
     l.scalars = off; off += 256;
-    const size_t nb = static_cast<size_t>(csr_spmv_dot_num_partials(static_cast<int>(n)));
     l.part_a = off; off += align_up(sizeof(double) * max_parts, 256);
     l.part_b = off; off += align_up(sizeof(double) * max_parts, 256);
-    l.part_c = off; off += align_up(sizeof(double) * (nb + 1), 256);
+    // the local block's SpMV + dot launch: the row-cut kernel leaves a partial per 256 rows, the nonzero-split one per tile
+    l.part_c = off; off += align_up(sizeof(double) * (spmv_dot_partials_room(n) + 1), 256);
     l.part_d = off; off += align_up(sizeof(double) * (static_cast<size_t>(ceildiv(nl_rows, 256)) + 1), 256);
     l.red_a = off; off += 256;
     l.red_b = off; off += 256;
@@ -334,9 +335,16 @@ extern "C" int gkomi_dist_cg_solve_f64(gkomi_stream_t s, const gkomi_comm* comm,
     GKOMI_TRY(check_launch());
 
     const int g = vec_grid(n);
-    const int nb = csr_spmv_dot_num_partials(static_cast<int>(n));
     const int nd = static_cast<int>(ceildiv(A->nl_rows, 256));
-    const bool swizzle = csr_auto_swizzle(n, A->l_nnz);
+    // the local block is a CSR matrix like any other driver's: with its srow it runs the nonzero-split kernel the
+    // apply runs (csr_spmv.hip), nontemporal when matrix + vectors of an iteration exceed the Infinity Cache
+    sysmat local = make_csr_sysmat(n, A->l_nnz, A->l_row_ptrs, A->l_col_idxs, A->l_vals, GKOMI_CSR_AUTO, A->l_max_row_nnz);
+    local.srow = A->l_srow;
+    local.srow_tile = A->l_srow != nullptr ? A->l_srow_tile : 0;
+    local.note_working_set(static_cast<int64_t>(sizeof(double)) * n * 6);
+    const spmv_dot_plan spmv(local);
+    if (n > 0 && !spmv.fused()) return GKOMI_ENOTSUPPORTED;  // (aligned CSR arrays were checked above)
+    const int nb = spmv.num_partials;
     const double* zz = precond == nullptr ? r : z;
     if (check_every < 1) check_every = 1;
     // partials of r.z and r.r -> {rho, tau^2} in one all-reduce
@@ -365,8 +373,7 @@ extern "C" int gkomi_dist_cg_solve_f64(gkomi_stream_t s, const gkomi_comm* comm,
             // q = A p: halo of p on the wire while the local block runs
             GKOMI_TRY(start_exchange(stream, comm, ctx, A, p));
             if (n > 0) {
-                GKOMI_TRY(csr_spmv_dot_launch(stream, static_cast<int>(n), A->l_nnz, A->l_row_ptrs, A->l_col_idxs,
-                                              A->l_vals, p, q, part_c, &scal->status, swizzle));
+                GKOMI_TRY(spmv.launch(stream, p, q, part_c, &scal->status));
             }
             GKOMI_TRY(nonlocal_part(stream, ctx, A, q, p, nd > 0 ? part_d : nullptr, scal));
             // beta = p.q: local partials (+ what the non-local rows added), all-reduce

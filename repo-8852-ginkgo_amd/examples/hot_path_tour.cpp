@@ -4,6 +4,7 @@
 // place.  Prints "name value" lines that tests/test_cpp_mirror.py checks.
 #include <ginkgo/ginkgo.hpp>
 
+#include <algorithm>
 #include <cmath>
 #include <iostream>
 
@@ -88,6 +89,46 @@ int main()
             A64->apply(two.get(), x.get(), one.get(), y2.get());   // y2 = 2 A x + y2 = 3 A x
             A->apply(two.get(), x.get(), one.get(), y3.get());
             std::cout << "csr_int64_advanced_diff " << diff_norm(exec, y3.get(), y2.get()) << "\n";
+        }
+
+        // long rows whose gathers span 8 MB of b: make_srow's column statistic switches the load-balanced kernel to
+        // column windows (Csr::load_balance and the default strategy alike); results to rounding of the COO kernel's
+        {
+            const int nl = 1 << 20;
+            gko::matrix_data<double, int> dl(gko::dim<2>(nl, nl));
+            unsigned long long state = 12345;
+            auto next = [&] { state = state * 6364136223846793005ull + 1442695040888963407ull; return static_cast<unsigned>(state >> 33); };
+            for (int i = 0; i < nl; ++i) {
+                if (i % 65536 == 7) {
+                    std::vector<int> cs(50000);
+                    for (auto& c : cs) c = static_cast<int>(next() % nl);
+                    std::sort(cs.begin(), cs.end());
+                    cs.erase(std::unique(cs.begin(), cs.end()), cs.end());
+                    for (int c : cs) dl.nonzeros.push_back({i, c, 1.0 + 1e-3 * (c % 97)});
+                } else {
+                    dl.nonzeros.push_back({i, i, 2.0});
+                }
+            }
+            auto xl = vec::create(exec->get_master(), gko::dim<2>(nl, 1));
+            for (int i = 0; i < nl; ++i) xl->at(i) = std::cos(0.001 * i);
+            auto dxl = xl->clone(exec);
+            auto cl = gko::matrix::Coo<double, int>::create(exec);
+            {
+                auto tmp = csr::create(exec);
+                tmp->read(dl);
+                tmp->convert_to(cl.get());
+            }
+            auto yc = vec::create(exec, gko::dim<2>(nl, 1));
+            cl->apply(dxl.get(), yc.get());
+            auto yl = vec::create(exec, gko::dim<2>(nl, 1));
+            double worst = 0.0;
+            for (int which = 0; which < 2; ++which) {
+                auto Al = which ? csr::create(exec, std::make_shared<csr::load_balance>(exec)) : csr::create(exec);
+                Al->read(dl);
+                Al->apply(dxl.get(), yl.get());
+                worst = std::max(worst, diff_norm(exec, yc.get(), yl.get()));
+            }
+            std::cout << "csr_long_rows_diff " << worst << " nnz " << dl.nonzeros.size() << "\n";
         }
 
         // CG + block-Jacobi

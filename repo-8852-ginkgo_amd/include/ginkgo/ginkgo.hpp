@@ -464,6 +464,8 @@ struct matrix_data {
         I column{};
         V value{};
     };
+    matrix_data() = default;
+    explicit matrix_data(dim<2> size_) : size(size_) {}  // include/ginkgo/core/base/matrix_data.hpp:159 (no fill value: empty)
     dim<2> size;
     std::vector<nonzero_type> nonzeros;
     void ensure_row_major_order()
@@ -832,6 +834,13 @@ struct csr_abi<int32> {
     static constexpr auto make_srow = &gkomi_csr_make_srow_i32;
     static constexpr auto max_row_nnz = &gkomi_csr_max_row_nnz_i32;
     static constexpr auto idxs_to_ptrs = &gkomi_convert_idxs_to_ptrs_i32;
+    // the column-pattern statistic of the strategy objects (GKOMI_CSR_COLBLOCK or 0): blocking, once per matrix
+    static int gather_flags(int64_t ncols, int64_t nnz, const int32* col_idxs, double* scratch)
+    {
+        int flags = 0;
+        GKOMI_CALL(gkomi_csr_analyse_gather_i32(nullptr, ncols, nnz, col_idxs, scratch, &flags, nullptr));
+        return flags;
+    }
 };
 template <>
 struct csr_abi<int64> {
@@ -839,6 +848,7 @@ struct csr_abi<int64> {
     static constexpr auto make_srow = &gkomi_csr_make_srow_i64;
     static constexpr auto max_row_nnz = &gkomi_csr_max_row_nnz_i64;
     static constexpr auto idxs_to_ptrs = &gkomi_convert_idxs_to_ptrs_i64;
+    static int gather_flags(int64_t, int64_t, const int64*, double*) { return 0; }  // (column windows: int32 kernels only)
 };
 }  // namespace detail_abi
 
@@ -861,9 +871,18 @@ public:
         int code_;
     };
     struct classical : strategy_type { classical() : strategy_type("classical", GKOMI_CSR_VECTOR) {} };
-    struct load_balance : strategy_type { load_balance(int64_t = 0) : strategy_type("load_balance", GKOMI_CSR_BALANCED) {} };
+    struct load_balance : strategy_type {
+        load_balance(int64_t = 0) : strategy_type("load_balance", GKOMI_CSR_BALANCED) {}
+        // include/ginkgo/core/matrix/csr.hpp:355-372: built from an executor (its warp count sized the reference's srow)
+        template <typename Exec>
+        load_balance(std::shared_ptr<Exec>) : load_balance(int64_t{0}) {}
+    };
     struct merge_path : strategy_type { merge_path() : strategy_type("merge_path", GKOMI_CSR_STREAM) {} };
-    struct automatical : strategy_type { automatical(int64_t = 0) : strategy_type("automatical", GKOMI_CSR_AUTO) {} };
+    struct automatical : strategy_type {
+        automatical(int64_t = 0) : strategy_type("automatical", GKOMI_CSR_AUTO) {}
+        template <typename Exec>
+        automatical(std::shared_ptr<Exec>) : automatical(int64_t{0}) {}  // csr.hpp:571-588
+    };
     // the vendor-library strategy (csr.hpp:299-330): no hipSPARSE behind this backend, the automatic choice serves it
     struct sparselib : strategy_type { sparselib() : strategy_type("sparselib", GKOMI_CSR_AUTO) {} };
     struct cusparse : strategy_type { cusparse() : strategy_type("cusparse", GKOMI_CSR_AUTO) {} };
@@ -872,6 +891,11 @@ public:
                                        std::shared_ptr<strategy_type> strategy = std::make_shared<automatical>())
     {
         return std::unique_ptr<Csr>(new Csr(std::move(exec), size, nnz, std::move(strategy)));
+    }
+    // include/ginkgo/core/matrix/csr.hpp:1036-1039: an empty matrix with a strategy
+    static std::unique_ptr<Csr> create(std::shared_ptr<const Executor> exec, std::shared_ptr<strategy_type> strategy)
+    {
+        return std::unique_ptr<Csr>(new Csr(std::move(exec), dim<2>{}, 0, std::move(strategy)));
     }
     V* get_values() noexcept { return values_.get_data(); }
     const V* get_const_values() const noexcept { return values_.get_const_data(); }
@@ -980,7 +1004,7 @@ protected:
         GKOMI_CALL(detail_abi::csr_abi<I>::spmv_srow(nullptr, size_[0], size_[1], db->cols(), get_num_stored_elements(), get_const_row_ptrs(), get_const_col_idxs(),
                                                  get_const_values(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(),
                                                  alpha ? detail_fmt::dense(alpha)->get_const_values() : nullptr,
-                                                 beta ? detail_fmt::dense(beta)->get_const_values() : nullptr, strategy_->get_code(), max_row_nnz_,
+                                                 beta ? detail_fmt::dense(beta)->get_const_values() : nullptr, strategy_->get_code() | gather_flags_, max_row_nnz_,
                                                  get_num_srow_elements() ? get_const_srow() : nullptr, srow_tile_));
     }
 public:
@@ -1006,6 +1030,14 @@ public:
         } else {
             srow_ = array<I>(exec_, 0);
         }
+        // ... and where the gathers of b go: matrices whose long rows select the load-balanced kernel get its column
+        // windows when a tile's gathers overflow an XCD's L2 (gkomi_csr_analyse_gather_i32; acts on that kernel only)
+        gather_flags_ = 0;
+        const int code = strategy_->get_code() & 0xff;
+        if (nnz >= 2 && (code == GKOMI_CSR_AUTO || code == GKOMI_CSR_BALANCED)) {
+            array<double> scratch(exec_, 2);
+            gather_flags_ = detail_abi::csr_abi<I>::gather_flags(static_cast<int64_t>(size_[1]), nnz, get_const_col_idxs(), scratch.get_data());
+        }
         srow_valid_ = true;
     }
     void invalidate_srow() const { srow_valid_ = false; }
@@ -1017,6 +1049,7 @@ protected:
     mutable int64_t max_row_nnz_{-1};
     mutable array<I> srow_;
     mutable int64_t srow_tile_{0};
+    mutable int gather_flags_{0};
     mutable bool srow_valid_{false};
 };
 

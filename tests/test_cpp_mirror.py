@@ -98,6 +98,9 @@ def test_hot_path_tour(bins):
     assert float(kv["csr_int64_diff"][0]) == 0.0 and int(kv["csr_int64_diff"][2]) > 0
     assert float(kv["csr_int64_advanced_diff"][0]) == 0.0
     assert int(kv["hybrid_diff"][2]) > 0
+    # long rows + wide gathers: the strategy objects' column statistic -> windowed load-balanced kernel; sums of
+    # 50 000 terms of size ~1, two summation orders
+    assert float(kv["csr_long_rows_diff"][0]) < 1e-9 and int(kv["csr_long_rows_diff"][2]) > 700000
     assert kv["cg_jacobi_iters"][2] == "1" and float(kv["cg_jacobi_iters"][4]) < 1e-9
     # adaptive block storage: some blocks reduced, same convergence within a few iterations
     assert kv["cg_adaptive_jacobi_iters"][2] == "1" and int(kv["cg_adaptive_jacobi_iters"][4]) > 0
