@@ -131,12 +131,17 @@ int gkomi_csr_spmv_f64_i32(gkomi_stream_t stream, int64_t nrows, int64_t ncols,
  * :395-459 fills srow with the row each wavefront's share of the nonzeros starts
  * in).  Ours: srow[t] = first row whose row_ptrs entry is >= t * tile, for
  * t = 0 .. nnz / tile + 1 -- the rows that START in every tile of `tile`
- * nonzeros.  Built once per matrix (whenever row_ptrs changes) into a caller-owned
- * device int32 array of gkomi_csr_srow_entries(nnz, tile) entries;
+ * nonzeros -- and, in one more entry behind them, the most rows that start in any
+ * one tile (beyond 2048 the kernel hands the rows behind a tile's first 512 out
+ * by row index: a matrix with long runs of empty rows -- the non-local block of a
+ * distributed matrix, a selection matrix -- does not leave 10^5 rows to one
+ * workgroup).  Built once per matrix (whenever row_ptrs changes) into a caller-owned
+ * device int32 array of gkomi_csr_srow_entries(nnz, tile) entries -- the kernels
+ * read ALL of them, an srow must come from gkomi_csr_make_srow_*;
  * gkomi_csr_srow_tile_for(nnz) is the tile the kernels are tuned for at that size
  * (1536 while the matrix can be Infinity-Cache resident, 2048 / 3072 for matrices
  * that stream from HBM: 300 vs 309 us on the 256^3 7-point matrix;
- * gkomi_csr_srow_tile() = the former).  One small launch, no synchronisation. */
+ * gkomi_csr_srow_tile() = the former).  Two small launches, no synchronisation. */
 int64_t gkomi_csr_srow_tile(void);
 int64_t gkomi_csr_srow_tile_for(int64_t nnz);
 int64_t gkomi_csr_srow_entries(int64_t nnz, int64_t tile);

@@ -35,6 +35,8 @@ constexpr int num_xcd = 8;
 // over-read of the nonzero-split kernel: rows up to split_max_over + 1 entries
 // are summed from LDS alone
 constexpr int split_max_over = 64;
+// most rows that may start in one tile before the nonzero-split kernel hands rows out by index (see the kernel)
+constexpr int split_rows_limit = 2048;
 // load-balanced kernel: row segments longer than this are reduced by a whole wave
 constexpr int balanced_coop_min = 128;
 
@@ -353,8 +355,19 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
     if (Dot && !(GKOMI_DOT_PROBE & 1) && status_has_stopped_uniform(stop_status)) return;
     // the rows that start in this tile (scalar loads, back long before the
     // streaming loads below)
-    const I row_begin = srow[logical];
-    const I row_end = srow[logical + 1];
+    // (the top bit of every srow entry: the matrix is in sparse-rows mode, below)
+    constexpr I srow_mark = static_cast<I>(I{1} << (8 * sizeof(I) - 1));
+    const I srow_first = srow[logical];
+    const I row_begin = srow_first & ~srow_mark;
+    const I row_end = srow[logical + 1] & ~srow_mark;
+    // srow's last entry: the most rows that start in any one tile (gkomi_csr_make_srow).  A tile of a matrix with long
+    // runs of EMPTY rows may own hundreds of thousands of them (the non-local block of a distributed matrix, a selection
+    // matrix): its workgroup would walk them 256 at a time, two dependent loads each -- 1.3 ms on a matrix whose other
+    // tiles take 50 us together.  Beyond split_rows_limit, rows behind the first 2 * Block of their tile are handed
+    // out by ROW INDEX instead (step 5 below): every workgroup looks at an equal share of the rows.  make_srow marks
+    // EVERY entry's top bit then -- no load beyond the two every workgroup needs anyway (reading the statistic itself
+    // here cost the 1M-row matrix's cold apply 1 %: 16.68 -> 16.85 us).
+    const bool sparse_rows = srow_first < 0;
 
     // 1) streaming loads: addresses known from the block index alone.  Branch-
     //    free (a branch per load makes the compiler drain the loads before it):
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
         }
         if (active) c[row * c_stride] = sum;
     }
-    for (I row = row_begin + tid + 2 * Block; row < row_end; row += Block) {
+    for (I row = row_begin + tid + 2 * Block; row < row_end && !sparse_rows; row += Block) {
         double sum = Advanced ? c[row * c_stride] * beta : 0.0;
         const pos_t lo = row_ptrs[row] - t0;
         const pos_t hi = row_ptrs[row + 1] - t0;
@@ -492,6 +505,28 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
         if (Dot) {
             pq += w[row * w_stride] * sum;
             qq += sum * sum;
+        }
+    }
+    // 5) sparse-rows mode: my share of the ROWS; those that are not among the first 2 * Block of the tile they start in
+    //    (row_ptrs[row] / Tile) were left out above and are summed here from memory, left to right like the others
+    if (sparse_rows) {
+        const int64_t share = (static_cast<int64_t>(nrows) + ntiles - 1) / ntiles;
+        const int64_t first = static_cast<int64_t>(logical) * share;
+        const int64_t last = min(first + share, static_cast<int64_t>(nrows));
+        for (int64_t row = first + tid; row < last; row += Block) {
+            const pos_t lo = row_ptrs[row];
+            const pos_t hi = row_ptrs[row + 1];
+            if (row - static_cast<int64_t>(srow[lo / Tile] & ~srow_mark) < 2 * Block) continue;
+            double sum = Advanced ? c[row * c_stride] * beta : 0.0;
+            for (pos_t k = lo; k < hi; ++k) {
+                const double val = Advanced ? alpha * vals[k] : vals[k];
+                sum += val * b[col_idxs[k] * b_stride];
+            }
+            c[row * c_stride] = sum;
+            if (Dot) {
+                pq += w[row * w_stride] * sum;
+                qq += sum * sum;
+            }
         }
     }
     GKOMI_STAMP(3);
@@ -520,6 +555,7 @@ __global__ __launch_bounds__(256) void csr_make_srow_kernel(
 {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (t > ntiles) return;
+    if (t == 0) srow[ntiles + 1] = 0;  // the statistic csr_srow_most_rows_kernel leaves behind the tile starts
     const int64_t target = t * tile;
     I lo = 0, hi = nrows;  // answer in [lo, hi]
     while (lo < hi) {
@@ -533,6 +569,35 @@ __global__ __launch_bounds__(256) void csr_make_srow_kernel(
     srow[t] = lo;
 }
 
+// srow[ntiles + 1] = the most rows that start in one tile (initialised to 0 by the kernel above)
+template <typename I>
+__global__ __launch_bounds__(256) void csr_srow_most_rows_kernel(int64_t ntiles, I* __restrict__ srow)
+{
+    __shared__ long long red[256 / wave_size];
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    long long rows = t < ntiles ? static_cast<long long>(srow[t + 1]) - static_cast<long long>(srow[t]) : 0;
+    for (int d = 1; d < wave_size; d *= 2) rows = max(rows, __shfl_xor(rows, d));
+    if ((threadIdx.x & (wave_size - 1)) == 0) red[threadIdx.x / wave_size] = rows;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / wave_size; ++w) rows = max(rows, red[w]);
+        if (rows > 0) {
+            if (sizeof(I) == 8) {
+                atomicMax(reinterpret_cast<long long*>(srow + ntiles + 1), rows);
+            } else {
+                atomicMax(reinterpret_cast<int*>(srow + ntiles + 1), static_cast<int>(rows));
+            }
+        }
+    }
+}
+
+// ... and beyond split_rows_limit every entry's top bit says so (the kernel learns it from the entries it reads anyway)
+template <typename I>
+__global__ __launch_bounds__(256) void csr_srow_mark_kernel(int64_t ntiles, I* __restrict__ srow)
+{
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (t <= ntiles && srow[ntiles + 1] > split_rows_limit) srow[t] |= static_cast<I>(I{1} << (8 * sizeof(I) - 1));
+}
 
 // ---- several right-hand sides at once ---------------------------------------
 //
@@ -773,9 +838,9 @@ __global__ __launch_bounds__(Block) void csr_balanced_kernel(
     // into it: three scalar loads), else wave 0 searches row_ptrs while the loads fly
     int first, last;
     if (srow != nullptr) {
-        const int s0 = srow[blockIdx.x];
+        const int s0 = srow[blockIdx.x] & 0x7fffffff;  // (top bit: the split kernel's sparse-rows mark)
         first = (s0 < nrows && row_ptrs[s0] == t0) ? s0 : s0 - 1;
-        last = min(srow[blockIdx.x + 1], nrows) - 1;
+        last = min(srow[blockIdx.x + 1] & 0x7fffffff, nrows) - 1;
     } else {
         if (tid < 64) {
             const int f = wave_find_row(row_ptrs, nrows, t0);
@@ -1307,7 +1372,7 @@ extern "C" int64_t gkomi_csr_srow_tile_for(int64_t nnz)
 extern "C" int64_t gkomi_csr_srow_entries(int64_t nnz, int64_t tile)
 {
     if (nnz < 0 || tile <= 0) return 0;
-    return nnz / tile + 2;
+    return nnz / tile + 3;  // tile starts 0 .. nnz / tile + 1, then the most rows starting in one tile
 }
 
 extern "C" int gkomi_csr_make_srow_i32(gkomi_stream_t stream_, int64_t nrows, int64_t nnz,
@@ -1324,6 +1389,10 @@ extern "C" int gkomi_csr_make_srow_i32(gkomi_stream_t stream_, int64_t nrows, in
     hipLaunchKernelGGL(csr_make_srow_kernel<int32_t>, dim3(static_cast<unsigned>(ceildiv(ntiles + 1, 256))),
                        dim3(256), 0, to_stream(stream_), static_cast<int>(nrows), row_ptrs,
                        static_cast<int>(tile), ntiles, srow);
+    hipLaunchKernelGGL(csr_srow_most_rows_kernel<int32_t>, dim3(static_cast<unsigned>(ceildiv(ntiles, 256))), dim3(256), 0,
+                       to_stream(stream_), static_cast<int64_t>(ntiles), srow);
+    hipLaunchKernelGGL(csr_srow_mark_kernel<int32_t>, dim3(static_cast<unsigned>(ceildiv(ntiles + 1, 256))), dim3(256), 0,
+                       to_stream(stream_), static_cast<int64_t>(ntiles), srow);
     return check_launch();
 }
 
@@ -1633,6 +1702,10 @@ extern "C" int gkomi_csr_make_srow_i64(gkomi_stream_t stream_, int64_t nrows, in
     const int64_t ntiles = nnz / tile + 1;
     hipLaunchKernelGGL(csr_make_srow_kernel<int64_t>, dim3(static_cast<unsigned>(ceildiv(ntiles + 1, 256))), dim3(256), 0,
                        to_stream(stream_), nrows, row_ptrs, static_cast<int>(tile), ntiles, srow);
+    hipLaunchKernelGGL(csr_srow_most_rows_kernel<int64_t>, dim3(static_cast<unsigned>(ceildiv(ntiles, 256))), dim3(256), 0,
+                       to_stream(stream_), ntiles, srow);
+    hipLaunchKernelGGL(csr_srow_mark_kernel<int64_t>, dim3(static_cast<unsigned>(ceildiv(ntiles + 1, 256))), dim3(256), 0,
+                       to_stream(stream_), ntiles, srow);
     return check_launch();
 }
 

@@ -88,8 +88,9 @@ def test_make_srow_and_index_conversions_int64(gk):
         ne = int(gk.csr_srow_entries(nnz, tile))
         srow = torch.full((ne,), -1, dtype=torch.int64, device="cuda:0")
         gk.csr_make_srow_i64(stream_ptr(), 3000, nnz, rp64, tile, srow, ne)
-        expect = np.searchsorted(rp, np.arange(ne) * tile, side="left")
-        assert np.array_equal(host(srow), np.minimum(expect, 3000))
+        expect = np.minimum(np.searchsorted(rp, np.arange(ne - 1) * tile, side="left"), 3000)
+        assert np.array_equal(host(srow)[:-1], expect)
+        assert host(srow)[-1] == np.max(np.diff(expect))   # the most rows that start in one tile
     # ptrs -> idxs -> ptrs (reference/components/format_conversion_kernels.cpp:50-95)
     idxs = torch.full((nnz,), -1, dtype=torch.int64, device="cuda:0")
     gk.convert_ptrs_to_idxs_i64(stream_ptr(), rp64, 3000, idxs)

@@ -28,7 +28,13 @@ def check_srow(srow, rp, nnz, tile):
     nrows = len(rp) - 1
     t = np.arange(nnz // tile + 2, dtype=np.int64) * tile
     expect = np.minimum(np.searchsorted(np.asarray(rp[:nrows], np.int64), t, side="left"), nrows)
-    assert np.array_equal(host(srow), expect.astype(np.int32))
+    got = host(srow)
+    # ... behind the tile starts, the most rows that start in one tile; beyond 2048 the kernel hands rows out by
+    # index (sparse-rows mode), which every tile start says in its top bit
+    assert got[-1] == np.max(np.diff(expect))
+    marked = got[-1] > 2048
+    assert np.array_equal(got[:-1] < 0, np.full(len(expect), marked))
+    assert np.array_equal(got[:-1] & 0x7fffffff, expect.astype(np.int32))
 
 
 @pytest.mark.parametrize("tile", TILES)
@@ -93,6 +99,44 @@ def test_short_random_rows_with_empty_rows(gk, oracle, tile, seed):
         assert np.array_equal(got, expect), variant
     # automatic strategy with srow takes the same kernel
     assert np.array_equal(host(csr_apply_srow(gk, A, dev(b), srow, tile)), expect)
+
+
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("advanced", [False, True], ids=["simple", "advanced"])
+def test_long_runs_of_empty_rows(gk, oracle, tile, advanced):
+    """A tile that owns hundreds of thousands of empty rows (the non-local block of a distributed matrix, a
+    selection matrix): the kernel hands rows out by index instead of walking them in one workgroup; same bits."""
+    rng = np.random.default_rng(tile)
+    nrows, ncols = 400003, 9001
+    counts = rng.integers(0, 7, size=nrows)
+    counts[5000:260000] = 0          # one tile owns 255 000 empty rows
+    counts[300000:300900] = 1        # 900 one-entry rows: more than 2 x 256 rows starting in one tile
+    counts[380000:] = 0              # trailing empty rows
+    rp, ci, v = matgen.random_rows_csr(nrows, ncols, counts, 5)
+    b = rng.standard_normal((ncols, 1))
+    c0 = rng.standard_normal((nrows, 1))
+    A = DevCsr(nrows, ncols, rp, ci, v)
+    srow, _ = make_srow(gk, A, tile)
+    check_srow(srow, rp, A.nnz, tile)
+    assert host(srow)[-1] > 2048
+    for variant in ("plain", "nt_noswz"):
+        if advanced:
+            expect = _oracle_apply(oracle, nrows, rp, ci, v, b, c0, 1.25, -0.5)
+            got = host(csr_apply_srow(gk, A, dev(b), srow, tile, dev(c0), 1.25, -0.5, strat(variant)))
+        else:
+            expect = _oracle_apply(oracle, nrows, rp, ci, v, b)
+            got = host(csr_apply_srow(gk, A, dev(b), srow, tile, strategy=strat(variant)))
+        assert np.array_equal(got, expect), variant
+    # and it is fast: the whole matrix is ~1 M nonzeros
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    db = dev(b)
+    out = csr_apply_srow(gk, A, db, srow, tile, strategy=SPLIT)
+    e0.record()
+    for _ in range(10):
+        csr_apply_srow(gk, A, db, srow, tile, out, strategy=SPLIT)
+    e1.record()
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(e1) / 10 < 0.2, "ms per apply"
 
 
 @pytest.mark.parametrize("nnz_target", [2, 3, 1535, 1536, 1537, 3072, 2 * 1536 + 1])
