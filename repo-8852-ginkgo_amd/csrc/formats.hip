@@ -67,35 +67,29 @@ __global__ __launch_bounds__(block) void ell_spmv_kernel(
     for (int64_t row = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x;
          row < nrows; row += step) {
         double result = Advanced ? c[row * c_stride] * beta : 0.0;
-        int64_t i = 0;
-        // 4 columns at a time: all 8 loads + 4 gathers in flight, then the
-        // in-order accumulation
-        for (; i + 4 <= num_stored; i += 4) {
-            double v[4];
-            int32_t col[4];
+        // 8 columns at a time: all 16 loads, then all 8 gathers in flight, then the in-order accumulation.  A batch
+        // that reaches behind the last column repeats it (clamped index: the same lines again, nothing added) --
+        // a remainder loop of one column per two dependent round trips made the 7-column matrix of the 108^3
+        // system 20 % slower than its CSR form (25.0 vs 20.5 us)
+        for (int64_t i = 0; i < num_stored; i += 8) {
+            double v[8];
+            int32_t col[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                v[u] = vals[row + (i + u) * stride];
-                col[u] = col_idxs[row + (i + u) * stride];
+            for (int u = 0; u < 8; ++u) {
+                const int64_t at = row + min(i + u, num_stored - 1) * stride;
+                v[u] = vals[at];
+                col[u] = col_idxs[at];
             }
-            double x[4];
+            double x[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 x[u] = b[max(col[u], 0) * b_stride];  // padding (-1) reads b[0], unused
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (col[u] != -1) {
+            for (int u = 0; u < 8; ++u) {
+                if (i + u < num_stored && col[u] != -1) {
                     result += Advanced ? (alpha * v[u]) * x[u] : v[u] * x[u];
                 }
-            }
-        }
-        for (; i < num_stored; ++i) {
-            const double v = vals[row + i * stride];
-            const int32_t col = col_idxs[row + i * stride];
-            if (col != -1) {
-                const double x = b[col * b_stride];
-                result += Advanced ? (alpha * v) * x : v * x;
             }
         }
         c[row * c_stride] = result;
@@ -146,33 +140,25 @@ __global__ __launch_bounds__(block) void sellp_spmv_kernel(
         const int64_t base =
             static_cast<int64_t>(slice_sets[slice]) * slice_size + local;
         double result = Advanced ? c[row * c_stride] * beta : 0.0;
-        int64_t i = 0;
-        for (; i + 4 <= len; i += 4) {
-            double v[4];
-            int32_t col[4];
+        for (int64_t i = 0; i < len; i += 8) {  // (as the ELL kernel: clamped batches of 8)
+            double v[8];
+            int32_t col[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                v[u] = vals[base + (i + u) * slice_size];
-                col[u] = col_idxs[base + (i + u) * slice_size];
+            for (int u = 0; u < 8; ++u) {
+                const int64_t at = base + min(i + u, len - 1) * slice_size;
+                v[u] = vals[at];
+                col[u] = col_idxs[at];
             }
-            double x[4];
+            double x[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 x[u] = b[max(col[u], 0) * b_stride];  // padding (-1) reads b[0], unused
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (col[u] != -1) {
+            for (int u = 0; u < 8; ++u) {
+                if (i + u < len && col[u] != -1) {
                     result += Advanced ? (alpha * v[u]) * x[u] : v[u] * x[u];
                 }
-            }
-        }
-        for (; i < len; ++i) {
-            const double v = vals[base + i * slice_size];
-            const int32_t col = col_idxs[base + i * slice_size];
-            if (col != -1) {
-                const double x = b[col * b_stride];
-                result += Advanced ? (alpha * v) * x : v * x;
             }
         }
         c[row * c_stride] = result;

@@ -255,6 +255,45 @@ def test_load_balanced_on_skewed_matrices(gk, oracle, advanced, nrhs):
         assert got[0, 0] == (2.0 * c0[0, 0] if advanced else 0.0)  # empty row: just beta*c / 0
 
 
+@pytest.mark.parametrize("with_srow", [False, True], ids=["search", "srow"])
+@pytest.mark.parametrize("advanced", [False, True], ids=["simple", "advanced"])
+def test_load_balanced_with_long_runs_of_empty_rows(gk, oracle, advanced, with_srow):
+    """Long rows AND a run of 300 000 empty rows inside one tile: that tile goes by its nonzeros (a row lookup per
+    position) instead of walking the rows 256 at a time; also an empty run in front of the row that contains a
+    tile's first nonzero, and trailing empty rows."""
+    from gpu_util import csr_apply_srow, make_srow
+    rng = np.random.default_rng(5)
+    n, ncols = 420000, 50000
+    counts = rng.integers(0, 5, size=n)
+    counts[2000:302000] = 0
+    counts[302000] = 9000            # a long row right behind the run
+    counts[310000:311500] = 1        # > 4 x 256 rows starting in one tile, none empty
+    counts[350000] = 4000
+    counts[400000:] = 0
+    rp, ci, v = matgen.random_rows_csr(n, ncols, counts, seed=6)
+    b = rng.standard_normal((ncols, 1))
+    c0 = rng.standard_normal((n, 1))
+    A = DevCsr(n, ncols, rp, ci, v)
+    srow, tile = make_srow(gk, A) if with_srow else (None, 0)
+
+    def run(c=None):
+        if with_srow:
+            return csr_apply_srow(gk, A, dev(b), srow, tile, c, *((-0.5, 2.0) if advanced else (None, None)), 3)
+        return csr_apply(gk, A, dev(b), c, *((-0.5, 2.0) if advanced else (None, None)), STRATEGIES["balanced"])
+    expect = _oracle_apply(oracle, n, rp, ci, v, b, *((c0, -0.5, 2.0) if advanced else ()))
+    got = host(run(dev(c0) if advanced else None))
+    assert matgen.rel_err(got, expect) <= 1e-14
+    assert np.array_equal(got[2000:302000], 2.0 * c0[2000:302000] if advanced else np.zeros((300000, 1)))
+    out = run(dev(c0) if advanced else None)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        run(out)
+    e1.record()
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(e1) / 10 < 0.3, "ms per apply (1.2 ms with the row walk)"
+
+
 @pytest.mark.parametrize("advanced", [False, True], ids=["simple", "advanced"])
 def test_load_balanced_long_rows_are_reduced_by_whole_waves(gk, oracle, advanced):
     """Power-law shape with a 200 k-nonzero row (130 tiles of one row), rows around the
