@@ -1064,6 +1064,24 @@ int gkomi_partition_build_starting_indices(const int64_t* host_range_bounds,
                                            int32_t* host_starting_indices,
                                            int32_t* host_part_sizes,
                                            int64_t* host_num_empty_parts);
+/* partition::has_ordered_parts (reference/distributed/partition_kernels.cpp:139-155):
+ * *host_result = 1 if the part ids of consecutive ranges never decrease, else 0.
+ * Partition::has_connected_parts is num_parts - num_empty_parts == num_ranges
+ * (core/distributed/partition.cpp:120-124; num_empty_parts from
+ * gkomi_partition_build_starting_indices). */
+int gkomi_partition_has_ordered_parts(const int32_t* host_part_ids,
+                                      int64_t num_ranges, int64_t* host_result);
+/* distributed_vector::build_local (reference/distributed/vector_kernels.cpp:47-96, what
+ * Vector::read_distributed runs, core/distributed/vector.cpp:120-170): device COO
+ * input with 64-bit global indices; local(local row, col) = value for every entry
+ * whose row local_part owns; the rest of `local` (row-major, local_stride) is left
+ * as the caller set it.  Partition arrays: device copies of the host metadata. */
+int gkomi_dist_vector_build_local_f64(gkomi_stream_t s, int64_t nnz,
+                                      const int64_t* rows, const int64_t* cols,
+                                      const double* vals, const int64_t* range_bounds,
+                                      const int32_t* part_ids, const int32_t* starts,
+                                      int64_t num_ranges, int32_t local_part,
+                                      double* local, int64_t local_stride);
 /* distributed_matrix::build_local_nonlocal
  * (reference/distributed/matrix_kernels.cpp:49-190) on device-resident COO
  * input with 64-bit global indices; partition arrays are device copies of the

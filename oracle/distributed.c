@@ -140,3 +140,28 @@ ORACLE_API void ref_dist_build_local_nonlocal(
     free(nn_gcol);
     free(uc);
 }
+
+/* partition_kernels.cpp:139-155 has_ordered_parts: 1 if the part ids of consecutive ranges never decrease */
+ORACLE_API i64 ref_partition_has_ordered_parts(const i32* part_ids, i64 num_ranges)
+{
+    for (i64 i = 1; i < num_ranges; ++i) {
+        if (part_ids[i] < part_ids[i - 1]) return 0;
+    }
+    return 1;
+}
+
+/* reference/distributed/vector_kernels.cpp:47-96 build_local: local(local row, col) = value for the entries whose row
+ * local_part owns, in input order (a later entry of the same position overwrites an earlier one); `local` is
+ * row-major with `stride`, the caller has filled it (the reference's callers: with zeros) */
+ORACLE_API void ref_dist_vector_build_local(i64 nnz, const i64* rows, const i64* cols, const double* vals,
+                                            const i64* bounds, const i32* part_ids, const i32* starts,
+                                            i64 num_ranges, i32 local_part, double* local, i64 stride)
+{
+    i64 hint = 0;
+    for (i64 i = 0; i < nnz; ++i) {
+        hint = find_range(rows[i], bounds, num_ranges, hint);
+        if (part_ids[hint] != local_part) continue;
+        const i64 lrow = (rows[i] - bounds[hint]) + starts[hint];
+        local[lrow * stride + cols[i]] = vals[i];
+    }
+}

@@ -154,6 +154,21 @@ __global__ __launch_bounds__(block) void gather_info_kernel(
     }
 }
 
+// distributed_vector::build_local: the entries whose row this part owns, scattered into the dense local block
+// (common/cuda_hip/distributed/vector_kernels.hpp.inc:33-98 does it with thrust::upper_bound + scatter_if)
+__global__ __launch_bounds__(block) void vector_build_local_kernel(
+    int64_t nnz, const int64_t* __restrict__ rows, const int64_t* __restrict__ cols, const double* __restrict__ vals,
+    partition_view rp, int32_t local_part, double* __restrict__ local, int64_t stride)
+{
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; i < nnz;
+         i += static_cast<int64_t>(gridDim.x) * block) {
+        const int64_t rr = find_range(rows[i], rp);
+        if (rp.part_ids[rr] != local_part) continue;
+        const int64_t lrow = (rows[i] - rp.bounds[rr]) + rp.starts[rr];
+        local[lrow * stride + cols[i]] = vals[i];
+    }
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct dist_layout {
@@ -252,6 +267,45 @@ extern "C" int gkomi_partition_build_starting_indices(const int64_t* host_range_
         *host_num_empty_parts = std::count(host_part_sizes, host_part_sizes + num_parts, 0);
     }
     return GKOMI_SUCCESS;
+}
+
+// partition::has_ordered_parts (reference/distributed/partition_kernels.cpp:139-155): the part ids of consecutive
+// ranges never decrease.  (Partition::has_ordered_parts asks it only of partitions whose parts are connected --
+// num_parts - num_empty_parts == num_ranges, core/distributed/partition.cpp:120-138.)
+extern "C" int gkomi_partition_has_ordered_parts(const int32_t* host_part_ids, int64_t num_ranges, int64_t* host_result)
+{
+    if (num_ranges < 0 || host_result == nullptr || (num_ranges > 0 && host_part_ids == nullptr)) return GKOMI_EINVAL;
+    *host_result = 1;
+    for (int64_t i = 1; i < num_ranges; ++i) {
+        if (host_part_ids[i] < host_part_ids[i - 1]) {
+            *host_result = 0;
+            break;
+        }
+    }
+    return GKOMI_SUCCESS;
+}
+
+// distributed_vector::build_local (reference/distributed/vector_kernels.cpp:47-96; Vector::read_distributed,
+// core/distributed/vector.cpp:120-170): local(local row of rows[i], cols[i]) = vals[i] for the entries of
+// local_part; everything else of `local` is left as the caller set it (the reference fills it with zeros first).
+// Device arrays; the partition arrays are device copies of the host metadata as for build_local_nonlocal.
+// Entries with the same (row, column): one of them wins (the reference's sequential loop keeps the last, its
+// GPU scatter_if any).
+extern "C" int gkomi_dist_vector_build_local_f64(gkomi_stream_t s, int64_t nnz, const int64_t* rows, const int64_t* cols,
+                                                 const double* vals, const int64_t* range_bounds, const int32_t* part_ids,
+                                                 const int32_t* starts, int64_t num_ranges, int32_t local_part,
+                                                 double* local, int64_t local_stride)
+{
+    if (nnz < 0 || num_ranges < 0 || local_stride < 0) return GKOMI_EINVAL;
+    if (nnz == 0) return GKOMI_SUCCESS;
+    if (rows == nullptr || cols == nullptr || vals == nullptr || local == nullptr || range_bounds == nullptr ||
+        part_ids == nullptr || starts == nullptr) {
+        return GKOMI_EINVAL;
+    }
+    const partition_view rp{range_bounds, part_ids, starts, num_ranges};
+    hipLaunchKernelGGL(vector_build_local_kernel, dim3(grid_for(nnz, block)), dim3(block), 0, to_stream(s), nnz, rows, cols,
+                       vals, rp, local_part, local, local_stride);
+    return check_launch();
 }
 
 // ---- build_local_nonlocal: two phases, because the caller owns the outputs ---------

@@ -26,7 +26,7 @@ class Partition:
     """Host-side partition metadata (O(#ranges)), as
     experimental::distributed::Partition keeps it."""
 
-    def __init__(self, range_bounds, part_ids, starts, part_sizes):
+    def __init__(self, range_bounds, part_ids, starts, part_sizes, gk=None, num_empty_parts=None):
         self.range_bounds = np.ascontiguousarray(range_bounds, np.int64)
         self.part_ids = np.ascontiguousarray(part_ids, np.int32)
         self.starts = np.ascontiguousarray(starts, np.int32)
@@ -34,14 +34,40 @@ class Partition:
         self.num_parts = len(self.part_sizes)
         self.num_ranges = len(self.part_ids)
         self.size = int(self.range_bounds[-1])
+        self.num_empty_parts = int(np.count_nonzero(self.part_sizes == 0)) if num_empty_parts is None else int(num_empty_parts)
+        self._gk = gk
+
+    def has_connected_parts(self):
+        """every part is one range (core/distributed/partition.cpp:120-124)"""
+        return self.num_parts - self.num_empty_parts == self.num_ranges
+
+    def has_ordered_parts(self):
+        """connected, and the parts follow each other in ascending order (partition.cpp:128-138 ->
+        partition::has_ordered_parts, reference/distributed/partition_kernels.cpp:139-155)"""
+        if not self.has_connected_parts():
+            return False
+        out = ctypes.c_int64(0)
+        self._gk.partition_has_ordered_parts(self.part_ids, self.num_ranges, ctypes.addressof(out))
+        return bool(out.value)
 
     @staticmethod
     def _finish(gk, bounds, ids, num_parts):
         nr = len(ids)
-        starts = np.zeros(nr, np.int32)
-        sizes = np.zeros(num_parts, np.int32)
-        gk.partition_build_starting_indices(bounds, ids, nr, num_parts, starts, sizes, None)
-        return Partition(bounds, ids, starts, sizes)
+        starts = np.zeros(max(nr, 1), np.int32)
+        sizes = np.zeros(max(num_parts, 1), np.int32)
+        empty = ctypes.c_int64(0)
+        gk.partition_build_starting_indices(bounds, ids, nr, num_parts, starts, sizes, ctypes.addressof(empty))
+        return Partition(bounds, ids, starts[:nr], sizes[:num_parts], gk, empty.value)
+
+    @staticmethod
+    def build_from_contiguous(gk, ranges):
+        """one range per part: ranges[p] .. ranges[p + 1] (Partition::build_from_contiguous, partition.cpp:76-95)"""
+        ranges = np.ascontiguousarray(ranges, np.int64)
+        num_parts = len(ranges) - 1
+        bounds = np.zeros(num_parts + 1, np.int64)
+        ids = np.zeros(max(num_parts, 1), np.int32)
+        gk.partition_build_from_contiguous(num_parts, ranges, bounds, ids)
+        return Partition._finish(gk, bounds, ids[:num_parts], num_parts)
 
     @staticmethod
     def build_from_global_size_uniform(gk, num_parts, global_size):
@@ -102,6 +128,18 @@ class GpuOps:
                                           out["l_vals"], out["nl_rows"], out["nl_cols"], out["nl_vals"],
                                           out["gather_idxs"], out["recv_sizes"], out["non_local_to_global"])
         return out
+
+    def vector_build_local(self, rows, cols, vals, partition, local_part, ncols):
+        """distributed_vector::build_local (what Vector::read_distributed runs): the dense local block of
+        `local_part`, zero where the input has no entry"""
+        nloc = int(partition.part_sizes[local_part])
+        local = torch.zeros((nloc, ncols), dtype=torch.float64, device=self.device)
+        nnz = int(rows.numel())
+        if nnz:
+            rb, rid, rst = self.tensor(partition.range_bounds), self.tensor(partition.part_ids), self.tensor(partition.starts)
+            self.gk.dist_vector_build_local_f64(self.stream(), nnz, rows, cols, vals, rb, rid, rst, partition.num_ranges,
+                                                local_part, local, ncols)
+        return local
 
     def coo_to_csr(self, nrows, row_idxs, nnz):
         # Csr::read(device_matrix_data): convert_idxs_to_ptrs (core/matrix/csr.cpp:453-470)

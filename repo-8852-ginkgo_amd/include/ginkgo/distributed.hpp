@@ -240,11 +240,27 @@ public:
     size_type get_size() const { return static_cast<size_type>(bounds_.back()); }
     size_type get_num_ranges() const { return part_ids_.size(); }
     comm_index_type get_num_parts() const { return static_cast<comm_index_type>(part_sizes_.size()); }
-    const GlobalIndexType* get_range_bounds() const { return bounds_.data(); }
-    const comm_index_type* get_part_ids() const { return part_ids_.data(); }
-    const LocalIndexType* get_range_starting_indices() const { return starts_.data(); }
-    const LocalIndexType* get_part_sizes() const { return part_sizes_.data(); }
+    // As in the reference the arrays live on the partition's executor (partition.hpp:300-340): device pointers for a
+    // partition built on a HipExecutor -- what the kernels (build_local_nonlocal, build_local) take --, host
+    // pointers for one built on exec->get_master().  host_*(): the host copies this mirror's own set-up code reads.
+    const GlobalIndexType* get_range_bounds() const { return exec_->is_device() ? d_bounds_.get_const_data() : bounds_.data(); }
+    const comm_index_type* get_part_ids() const { return exec_->is_device() ? d_part_ids_.get_const_data() : part_ids_.data(); }
+    const LocalIndexType* get_range_starting_indices() const { return exec_->is_device() ? d_starts_.get_const_data() : starts_.data(); }
+    const LocalIndexType* get_part_sizes() const { return exec_->is_device() ? d_part_sizes_.get_const_data() : part_sizes_.data(); }
+    const GlobalIndexType* host_range_bounds() const { return bounds_.data(); }
+    const comm_index_type* host_part_ids() const { return part_ids_.data(); }
+    const LocalIndexType* host_range_starting_indices() const { return starts_.data(); }
     LocalIndexType get_part_size(comm_index_type part) const { return part_sizes_[part]; }
+    comm_index_type get_num_empty_parts() const { return static_cast<comm_index_type>(num_empty_parts_); }
+    // core/distributed/partition.cpp:120-138
+    bool has_connected_parts() const { return static_cast<size_type>(get_num_parts() - get_num_empty_parts()) == get_num_ranges(); }
+    bool has_ordered_parts() const
+    {
+        if (!has_connected_parts()) return false;
+        int64_t ordered = 0;
+        GKOMI_CALL(gkomi_partition_has_ordered_parts(part_ids_.data(), static_cast<int64_t>(part_ids_.size()), &ordered));
+        return ordered != 0;
+    }
     std::shared_ptr<const Executor> get_executor() const { return exec_; }
 private:
     explicit Partition(std::shared_ptr<const Executor> exec) : exec_(std::move(exec)) {}
@@ -253,11 +269,26 @@ private:
         starts_.resize(part_ids_.size());
         part_sizes_.resize(num_parts);
         GKOMI_CALL(gkomi_partition_build_starting_indices(bounds_.data(), part_ids_.data(), static_cast<int64_t>(part_ids_.size()), num_parts,
-                                                          starts_.data(), part_sizes_.data(), nullptr));
+                                                          starts_.data(), part_sizes_.data(), &num_empty_parts_));
+        if (exec_->is_device()) {
+            auto host = exec_->get_master();
+            auto up = [&](auto& dst, const auto& src) {
+                using T = typename std::decay<decltype(src)>::type::value_type;
+                dst = array<T>(exec_, std::max<size_type>(src.size(), 1));
+                if (!src.empty()) exec_->copy_from(host.get(), src.size(), src.data(), dst.get_data());
+            };
+            up(d_bounds_, bounds_);
+            up(d_part_ids_, part_ids_);
+            up(d_starts_, starts_);
+            up(d_part_sizes_, part_sizes_);
+        }
     }
     std::shared_ptr<const Executor> exec_;
     std::vector<int64_t> bounds_;
     std::vector<int32_t> part_ids_, starts_, part_sizes_;
+    array<int64_t> d_bounds_;
+    array<int32_t> d_part_ids_, d_starts_, d_part_sizes_;
+    int64_t num_empty_parts_{0};
     static_assert(std::is_same<GlobalIndexType, int64>::value && std::is_same<LocalIndexType, int32>::value,
                   "this backend instantiates Partition<int32, int64>");
 };
@@ -273,7 +304,7 @@ inline size_type own_range(const PartitionType* partition, int rank, const char*
     if (nr != static_cast<size_type>(partition->get_num_parts())) GKO_NOT_SUPPORTED(what);
     size_type own = nr;
     for (size_type i = 0; i < nr; ++i) {
-        if (partition->get_part_ids()[i] == rank) {
+        if (partition->host_part_ids()[i] == rank) {
             if (own != nr) GKO_NOT_SUPPORTED(what);
             own = i;
         }
@@ -293,23 +324,53 @@ public:
     {
         return std::unique_ptr<Vector>(new Vector(std::move(exec), comm, global_size, local_size));
     }
-    // Vector::read_distributed (core/distributed/vector.cpp:120-170): keeps the rows this rank owns
+    // Vector::read_distributed (core/distributed/vector.cpp:120-170): keeps the rows this rank owns -- any partition
+    // (several ranges per part, parts in any order); the entries go to the device as they are and
+    // distributed_vector::build_local scatters the local ones (gkomi_dist_vector_build_local_f64)
     template <typename GlobalIndexType>
     void read_distributed(const matrix_data<ValueType, GlobalIndexType>& data, const Partition<int32, GlobalIndexType>* partition)
     {
         const int rank = comm_.rank();
-        // ranges map to parts through part_ids (reference/distributed/partition_kernels.cpp:42-95): this
-        // rank's rows are those of the range whose part id is the rank, not of range number `rank`
-        const auto own = detail::own_range(partition, rank, "Vector::read_distributed: one contiguous range per part");
-        const auto lo = partition->get_range_bounds()[own], hi = partition->get_range_bounds()[own + 1];
-        const size_type nloc = static_cast<size_type>(hi - lo), ncols = data.size[1];
-        std::vector<ValueType> host(nloc * ncols, ValueType{});
-        for (const auto& e : data.nonzeros) {
-            if (e.row >= lo && e.row < hi) host[static_cast<size_type>(e.row - lo) * ncols + static_cast<size_type>(e.column)] = e.value;
-        }
+        const size_type nloc = static_cast<size_type>(partition->get_part_size(rank)), ncols = data.size[1];
+        const size_type nnz = data.nonzeros.size(), nr = partition->get_num_ranges();
         local_ = local_vector_type::create(exec_, dim<2>(nloc, ncols));
-        exec_->copy_from(exec_->get_master().get(), host.size(), host.data(), local_->get_values());
+        local_->fill(ValueType{});
         set_size(dim<2>(data.size[0], ncols));
+        if (nnz == 0 || nloc == 0) return;
+        if (!exec_->is_device()) {
+            // staging on a host executor (the example's flow: read on the host, clone to the device): the same
+            // map, entry by entry
+            const auto* bounds = partition->host_range_bounds();
+            for (const auto& e : data.nonzeros) {
+                const size_type r = static_cast<size_type>(std::upper_bound(bounds + 1, bounds + nr + 1, e.row) - (bounds + 1));
+                if (r < nr && partition->host_part_ids()[r] == rank) {
+                    local_->at(static_cast<size_type>(e.row - bounds[r]) + partition->host_range_starting_indices()[r], static_cast<size_type>(e.column)) = e.value;
+                }
+            }
+            return;
+        }
+        std::vector<int64_t> rows(nnz), cols(nnz);
+        std::vector<ValueType> vals(nnz);
+        for (size_type i = 0; i < nnz; ++i) {
+            rows[i] = data.nonzeros[i].row;
+            cols[i] = data.nonzeros[i].column;
+            vals[i] = data.nonzeros[i].value;
+        }
+        auto host = exec_->get_master();
+        array<int64_t> d_rows(exec_, nnz), d_cols(exec_, nnz), d_bounds(exec_, nr + 1);
+        array<ValueType> d_vals(exec_, nnz);
+        array<int32_t> d_ids(exec_, nr), d_starts(exec_, nr);
+        exec_->copy_from(host.get(), nnz, rows.data(), d_rows.get_data());
+        exec_->copy_from(host.get(), nnz, cols.data(), d_cols.get_data());
+        exec_->copy_from(host.get(), nnz, vals.data(), d_vals.get_data());
+        exec_->copy_from(host.get(), nr + 1, reinterpret_cast<const int64_t*>(partition->host_range_bounds()), d_bounds.get_data());
+        exec_->copy_from(host.get(), nr, partition->host_part_ids(), d_ids.get_data());
+        exec_->copy_from(host.get(), nr, partition->host_range_starting_indices(), d_starts.get_data());
+        GKOMI_CALL(gkomi_dist_vector_build_local_f64(nullptr, static_cast<int64_t>(nnz), d_rows.get_const_data(), d_cols.get_const_data(),
+                                                     d_vals.get_const_data(), d_bounds.get_const_data(), d_ids.get_const_data(),
+                                                     d_starts.get_const_data(), static_cast<int64_t>(nr), rank, local_->get_values(),
+                                                     static_cast<int64_t>(local_->get_stride())));
+        GKOMI_CALL(gkomi_synchronize(nullptr));  // the staging arrays go out of scope
     }
     void copy_from(const Vector* other)
     {
@@ -389,7 +450,7 @@ public:
         // ranges map to parts through part_ids (reference/distributed/partition_kernels.cpp:42-95): this
         // rank's rows are those of the range whose part id is the rank, not of range number `rank`
         const auto own = detail::own_range(partition, rank, "Matrix::read_distributed: one contiguous range per part");
-        const auto lo = partition->get_range_bounds()[own], hi = partition->get_range_bounds()[own + 1];
+        const auto lo = partition->host_range_bounds()[own], hi = partition->host_range_bounds()[own + 1];
         staged_.rows.clear(); staged_.cols.clear(); staged_.vals.clear();
         auto sorted = data;
         sorted.ensure_row_major_order();
@@ -398,9 +459,9 @@ public:
                 staged_.rows.push_back(e.row); staged_.cols.push_back(e.column); staged_.vals.push_back(e.value);
             }
         }
-        staged_.bounds.assign(partition->get_range_bounds(), partition->get_range_bounds() + partition->get_num_ranges() + 1);
-        staged_.part_ids.assign(partition->get_part_ids(), partition->get_part_ids() + partition->get_num_ranges());
-        staged_.starts.assign(partition->get_range_starting_indices(), partition->get_range_starting_indices() + partition->get_num_ranges());
+        staged_.bounds.assign(partition->host_range_bounds(), partition->host_range_bounds() + partition->get_num_ranges() + 1);
+        staged_.part_ids.assign(partition->host_part_ids(), partition->host_part_ids() + partition->get_num_ranges());
+        staged_.starts.assign(partition->host_range_starting_indices(), partition->host_range_starting_indices() + partition->get_num_ranges());
         staged_.num_parts = partition->get_num_parts();
         staged_.n_local = static_cast<int64_t>(hi - lo);
         staged_.valid = true;

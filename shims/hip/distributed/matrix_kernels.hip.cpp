@@ -74,7 +74,34 @@ void build_starting_indices(std::shared_ptr<const HipExecutor> exec, const int64
     exec->copy_from(host.get(), static_cast<size_type>(num_parts), part_sizes.data(), sizes);
 }
 
+// core/distributed/partition_kernels.hpp GKO_DECLARE_PARTITION_IS_ORDERED (reference/distributed/partition_kernels.cpp:139-155)
+void has_ordered_parts(std::shared_ptr<const HipExecutor> exec, const experimental::distributed::Partition<int32, int64>* partition, bool* result)
+{
+    const auto num_ranges = partition->get_num_ranges();
+    std::vector<int32_t> parts(num_ranges);
+    exec->get_master()->copy_from(exec.get(), num_ranges, partition->get_part_ids(), parts.data());
+    int64_t ordered = 0;
+    GKOMI_CALL(gkomi_partition_has_ordered_parts(parts.data(), static_cast<int64_t>(num_ranges), &ordered));
+    *result = ordered != 0;
+}
+
 }  // namespace partition
+
+namespace distributed_vector {
+
+// core/distributed/vector_kernels.hpp GKO_DECLARE_DISTRIBUTED_VECTOR_BUILD_LOCAL (reference/distributed/vector_kernels.cpp:47-96)
+void build_local(std::shared_ptr<const HipExecutor> exec, const device_matrix_data<double, int64>& input,
+                 const experimental::distributed::Partition<int32, int64>* partition, experimental::distributed::comm_index_type local_part,
+                 matrix::Dense<double>* local_mtx)
+{
+    GKOMI_CALL(gkomi_dist_vector_build_local_f64(
+        GKOMI_NULL_STREAM, static_cast<int64_t>(input.get_num_elems()), reinterpret_cast<const int64_t*>(input.get_const_row_idxs()),
+        reinterpret_cast<const int64_t*>(input.get_const_col_idxs()), input.get_const_values(),
+        reinterpret_cast<const int64_t*>(partition->get_range_bounds()), partition->get_part_ids(), partition->get_range_starting_indices(),
+        static_cast<int64_t>(partition->get_num_ranges()), local_part, local_mtx->get_values(), static_cast<int64_t>(local_mtx->get_stride())));
+}
+
+}  // namespace distributed_vector
 }  // namespace hip
 }  // namespace kernels
 }  // namespace gko

@@ -2,10 +2,8 @@
 // coo::spmv2, prefix_sum<int32>, fcg::step_1): every kernel INTEGRATION.md's table binds, each against the mirror's own
 // apply or a closed-form answer.  Prints one "ran <namespace>::<kernel> ok|WRONG" line per kernel
 // (tests/test_cpp_mirror.py compares the list with INTEGRATION.md) and returns the number of wrong ones.
-//
-// One binding cannot run against the mirror: distributed_matrix::build_local_nonlocal reads the Partition's arrays as
-// DEVICE pointers (they live on the executor in a reference tree, partition.hpp:300-340); the mirror's Partition keeps
-// them on the host.  Its C entry points run in tests/test_distributed_native_gpu.py; here it stays compile-only.
+// (The distributed bindings read the Partition's arrays as DEVICE pointers -- they live on the partition's executor in
+// a reference tree, partition.hpp:300-340, and in the mirror since round 4.)
 #include "prelude_mirror.hpp"
 #include <cmath>
 #include <cstdio>
@@ -136,6 +134,17 @@ void solve(std::shared_ptr<const HipExecutor>, const Mtx*, const solver::SolveSt
 namespace partition {
 void build_starting_indices(std::shared_ptr<const HipExecutor>, const int64*, const int*, size_type, experimental::distributed::comm_index_type,
                             experimental::distributed::comm_index_type&, int32*, int32*);
+void has_ordered_parts(std::shared_ptr<const HipExecutor>, const experimental::distributed::Partition<int32, int64>*, bool*);
+}
+namespace distributed_vector {
+void build_local(std::shared_ptr<const HipExecutor>, const device_matrix_data<double, int64>&, const experimental::distributed::Partition<int32, int64>*,
+                 experimental::distributed::comm_index_type, Vec*);
+}
+namespace distributed_matrix {
+void build_local_nonlocal(std::shared_ptr<const HipExecutor>, const device_matrix_data<double, int64>&, const experimental::distributed::Partition<int32, int64>*,
+                          const experimental::distributed::Partition<int32, int64>*, experimental::distributed::comm_index_type, array<int32>&, array<int32>&,
+                          array<double>&, array<int32>&, array<int32>&, array<double>&, array<int32>&, array<experimental::distributed::comm_index_type>&,
+                          array<int64>&);
 }
 }}}
 
@@ -779,6 +788,44 @@ int main()
         experimental::distributed::comm_index_type empty = -1;
         k::partition::build_starting_indices(hip, doff.get_const_data(), dparts.get_const_data(), 4, 4, empty, starts.get_data(), sizes.get_data());
         ran("partition::build_starting_indices", starts.to_host() == std::vector<int32>({0, 0, 10, 0}) && sizes.to_host() == std::vector<int32>({20, 15, 25, 0}) && empty == 1);
+    }
+    // ---- the distributed set-up kernels on a Partition whose arrays live on the device --------------------------------------
+    {
+        using part_t = experimental::distributed::Partition<int32, int64>;
+        // reference/test/distributed/matrix_kernels.cpp:301-330 (BuildsLocalNonLocalMixed), part 1
+        array<int> mapping(hip, {1, 2, 0, 0, 2, 1});
+        auto partition = part_t::build_from_mapping(hip, mapping, 3);
+        std::vector<int64> rows = {0, 0, 0, 0, 1, 1, 1, 2, 3, 3, 4, 4, 5, 5}, cols = {0, 1, 3, 5, 1, 4, 5, 3, 1, 2, 3, 4, 0, 2};
+        std::vector<double> vals = {11, 1, 2, 12, 13, 14, 5, 15, 6, 16, 7, 17, 18, 8};
+        device_matrix_data<double, int64> input(dim<2>(6, 6), array<int64>(hip, rows.begin(), rows.end()), array<int64>(hip, cols.begin(), cols.end()),
+                                                array<double>(hip, vals.begin(), vals.end()));
+        array<int32> lr(hip), lc(hip), nr(hip), nc(hip), gather(hip);
+        array<double> lv(hip), nv(hip);
+        array<experimental::distributed::comm_index_type> recv(hip, 3);
+        array<int64> n2g(hip);
+        k::distributed_matrix::build_local_nonlocal(hip, input, partition.get(), partition.get(), 1, lr, lc, lv, nr, nc, nv, gather, recv, n2g);
+        ran("distributed_matrix::build_local_nonlocal",
+            lr.to_host() == std::vector<int32>({0, 0, 1}) && lc.to_host() == std::vector<int32>({0, 1, 0}) && lv.to_host() == std::vector<double>({11, 12, 18}) &&
+                nr.to_host() == std::vector<int32>({0, 0, 1}) && nc.to_host() == std::vector<int32>({2, 1, 0}) && nv.to_host() == std::vector<double>({1, 2, 8}) &&
+                gather.to_host() == std::vector<int32>({0, 1, 0}) && recv.to_host() == std::vector<int32>({2, 0, 1}) && n2g.to_host() == std::vector<int64>({2, 3, 1}));
+        // reference/test/distributed/vector_kernels.cpp:137-152 (BuildsLocal), part 2
+        std::vector<int64> vr = {0, 0, 1, 1, 2, 3, 4, 5}, vc = {0, 1, 2, 3, 4, 5, 6, 7};
+        std::vector<double> vv = {1, 2, 3, 4, 5, 6, 7, 8};
+        device_matrix_data<double, int64> vin(dim<2>(6, 8), array<int64>(hip, vr.begin(), vr.end()), array<int64>(hip, vc.begin(), vc.end()),
+                                              array<double>(hip, vv.begin(), vv.end()));
+        auto local = Vec::create(hip, dim<2>(2, 8));
+        local->fill(0.0);
+        k::distributed_vector::build_local(hip, vin, partition.get(), 2, local.get());
+        auto hl = local->clone(hip->get_master());
+        bool ok = true;
+        const double expect[2][8] = {{0, 0, 3, 4, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 7, 0}};
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 8; ++j) ok = ok && hl->at(i, j) == expect[i][j];
+        ran("distributed_vector::build_local", ok);
+        // reference/test/distributed/partition_kernels.cpp:246-295: {1, 1, 0, 0, 2} is connected but not ordered, {0, 1, 1, 2, 2} ordered
+        bool unordered = true, ordered = false;
+        k::partition::has_ordered_parts(hip, part_t::build_from_mapping(hip, array<int>(hip, {1, 1, 0, 0, 2}), 3).get(), &unordered);
+        k::partition::has_ordered_parts(hip, part_t::build_from_mapping(hip, array<int>(hip, {0, 1, 1, 2, 2}), 3).get(), &ordered);
+        ran("partition::has_ordered_parts", !unordered && ordered);
     }
     std::printf("wrong: %d\n", wrong);
     return wrong;

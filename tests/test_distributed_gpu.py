@@ -20,11 +20,11 @@ pytestmark = pytest.mark.gpu
 G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "distributed.json")))
 
 
-def gpu_build(gk, rows, cols, vals, partition, part):
+def gpu_build(gk, rows, cols, vals, partition, part, col_partition=None):
     ops = gd.GpuOps(gk, "cuda:0")
-    z = np.zeros(0)
     return ops.build_local_nonlocal(ops.tensor(np.array(rows, np.int64)), ops.tensor(np.array(cols, np.int64)),
-                                    ops.tensor(np.array(vals, np.float64)), partition, partition, part)
+                                    ops.tensor(np.array(vals, np.float64)), partition,
+                                    partition if col_partition is None else col_partition, part)
 
 
 def check_against(o, sz, g):
@@ -41,12 +41,59 @@ def check_against(o, sz, g):
 def test_build_local_nonlocal_known_answers(gk, oracle, case):
     part = gd.Partition.build_from_mapping(gk, case["mapping"], case["num_parts"])
     meta = oracle_partition_from_mapping(oracle, case["mapping"], case["num_parts"])
+    cpart = cmeta = None
+    if "col_mapping" in case:   # a column partition of its own (matrix_kernels.cpp:333-513)
+        cpart = gd.Partition.build_from_mapping(gk, case["col_mapping"], case["num_parts"])
+        cmeta = oracle_partition_from_mapping(oracle, case["col_mapping"], case["num_parts"])
+    for p in range(case["num_parts"]):
+        g = gpu_build(gk, case["rows"], case["cols"], case["vals"], part, p, cpart)
+        o, sz = oracle_build(oracle, case["rows"], case["cols"], case["vals"], meta, case["num_parts"], p, cmeta)
+        check_against(o, sz, g)
+        for key, field in (("local", "l_"), ("non_local", "nl_")):
+            n = int(sz[0] if key == "local" else sz[1])
+            for what in ("rows", "cols", "vals"):
+                assert list(host(g[field + what])[:n]) == case[key][p][what], (key, what)
+        assert list(host(g["gather_idxs"])[:sz[2]]) == case["gather_idxs"][p]
+        assert list(host(g["recv_sizes"])) == case["recv_sizes"][p]
+
+
+@pytest.mark.parametrize("case", G["ghost_maps"], ids=lambda c: c["name"])
+def test_ghost_maps(gk, case):
+    part = gd.Partition.build_from_mapping(gk, case["mapping"], case["num_parts"])
     for p in range(case["num_parts"]):
         g = gpu_build(gk, case["rows"], case["cols"], case["vals"], part, p)
-        o, sz = oracle_build(oracle, case["rows"], case["cols"], case["vals"], meta, case["num_parts"], p)
-        check_against(o, sz, g)
-        assert list(host(g["l_vals"])[:sz[0]]) == case["local"][p]["vals"]
-        assert list(host(g["gather_idxs"])[:sz[2]]) == case["gather_idxs"][p]
+        assert list(host(g["non_local_to_global"])[:g["num_unique"]]) == case["non_local_to_global"][p]
+
+
+@pytest.mark.parametrize("case", G["vector_build_local"], ids=lambda c: c["name"])
+def test_vector_build_local_known_answers(gk, case):
+    """distributed_vector::build_local (reference/test/distributed/vector_kernels.cpp:105-152)"""
+    ops = gd.GpuOps(gk, "cuda:0")
+    part = gd.Partition.build_from_mapping(gk, case["mapping"], case["num_parts"])
+    rows, cols = ops.tensor(np.array(case["rows"], np.int64)), ops.tensor(np.array(case["cols"], np.int64))
+    vals = ops.tensor(np.array(case["vals"], np.float64))
+    for p in range(case["num_parts"]):
+        got = host(ops.vector_build_local(rows, cols, vals, part, p, case["size"][1]))
+        assert np.array_equal(got, np.array(case["local"][p], np.float64).reshape(got.shape))
+
+
+@pytest.mark.parametrize("seed,n,ncols,nparts", [(1, 300, 3, 4), (2, 20000, 5, 7)])
+def test_vector_build_local_random_partitions(gk, oracle, seed, n, ncols, nparts):
+    from test_oracle_distributed import oracle_vector_build_local
+    rng = np.random.default_rng(seed)
+    mapping = np.repeat(rng.integers(0, nparts, size=n // 5 + 1), 5)[:n].astype(np.int32)
+    # distinct positions in random order (duplicates: any of them may win on the device)
+    flat = rng.permutation(n * ncols)[: (n * ncols) // 2]
+    case = dict(size=[n, ncols], rows=(flat // ncols).tolist(), cols=(flat % ncols).tolist(),
+                vals=rng.standard_normal(len(flat)).tolist())
+    ops = gd.GpuOps(gk, "cuda:0")
+    part = gd.Partition.build_from_mapping(gk, mapping, nparts)
+    meta = oracle_partition_from_mapping(oracle, mapping, nparts)
+    rows, cols = ops.tensor(np.array(case["rows"], np.int64)), ops.tensor(np.array(case["cols"], np.int64))
+    vals = ops.tensor(np.array(case["vals"], np.float64))
+    for p in range(nparts):
+        got = host(ops.vector_build_local(rows, cols, vals, part, p, ncols))
+        assert np.array_equal(got, oracle_vector_build_local(oracle, case, meta, p))
 
 
 @pytest.mark.parametrize("seed,n,nparts", [(1, 200, 3), (2, 5000, 8), (3, 777, 5)])
