@@ -323,3 +323,29 @@ def test_full_size_p2_formats(gk, oracle):
     gk.hybrid_spmv_f64_i32(s, n, n, 1, 4, n, h["ell_cols"], h["ell_vals"], h["coo_nnz"], h["coo_rows"], h["coo_cols"],
                            h["coo_vals"], xd, 1, c, 1, None, None)
     assert matgen.rel_err(host(c), e) <= 1e-15
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_format_conversion_known_answers(gk, bits):
+    """reference/test/components/format_conversion_kernels.cpp:62-128, both index types, through the C ABI"""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "formats.json")))["format_conversion"]
+    npt, tt = (np.int32, torch.int32) if bits == 32 else (np.int64, torch.int64)
+    sfx = "_i32" if bits == 32 else "_i64"
+    ptrs = dev(np.array(g["ptrs"], npt))
+    idxs = torch.full((5,), -1, dtype=tt, device="cuda:0")
+    getattr(gk, "convert_ptrs_to_idxs" + sfx)(stream_ptr(), ptrs, 4, idxs)
+    assert list(host(idxs)) == g["idxs_of_ptrs"]
+    sizes = torch.full((4,), 99, dtype=torch.int64, device="cuda:0")
+    getattr(gk, "convert_ptrs_to_sizes" + sfx)(stream_ptr(), ptrs, 4, sizes)
+    assert list(host(sizes)) == g["sizes_of_ptrs"]
+    nb = gk.prefix_sum_workspace_bytes(g["empty_num_blocks"] + 1)
+    ws = torch.empty(max(nb, 8), dtype=torch.uint8, device="cuda:0")
+    out = torch.full((6,), -1, dtype=tt, device="cuda:0")
+    getattr(gk, "convert_idxs_to_ptrs" + sfx)(stream_ptr(), dev(np.array(g["idxs"], npt)), 6, g["num_blocks"], out, ws, nb)
+    assert list(host(out)) == g["ptrs_of_idxs"]
+    out = torch.full((g["empty_num_blocks"] + 1,), -1, dtype=tt, device="cuda:0")
+    getattr(gk, "convert_idxs_to_ptrs" + sfx)(stream_ptr(), torch.zeros(1, dtype=tt, device="cuda:0"), 0, g["empty_num_blocks"], out, ws, nb)
+    assert not host(out).any()
+    getattr(gk, "convert_ptrs_to_idxs" + sfx)(stream_ptr(), torch.zeros(10, dtype=tt, device="cuda:0"), 9, None)   # empty: must not fault
+    torch.cuda.synchronize()

@@ -120,3 +120,22 @@ def _apply_all_formats(oracle, case):
 def test_applies_known_answers(oracle, case):
     for name, got in _apply_all_formats(oracle, case):
         assert np.array_equal(got, np.array(case["expect"])), name
+
+
+def test_format_conversion_known_answers(oracle):
+    """reference/test/components/format_conversion_kernels.cpp:62-128"""
+    g = G["format_conversion"]
+    ptrs = np.array(g["ptrs"], np.int32)
+    idxs = np.full(5, -1, np.int32)
+    oracle.ref_convert_ptrs_to_idxs(ptrs, 4, idxs)
+    assert list(idxs) == g["idxs_of_ptrs"]
+    sizes = np.full(4, 99, np.uint64)
+    oracle.ref_convert_ptrs_to_sizes(ptrs, 4, sizes)
+    assert list(sizes) == g["sizes_of_ptrs"]
+    out = np.full(6, -1, np.int32)
+    oracle.ref_convert_idxs_to_ptrs(np.array(g["idxs"], np.int32), 6, g["num_blocks"], out)
+    assert list(out) == g["ptrs_of_idxs"]
+    out = np.full(g["empty_num_blocks"] + 1, -1, np.int32)   # ConvertsEmptyIdxsToPtrs
+    oracle.ref_convert_idxs_to_ptrs(np.zeros(1, np.int32), 0, g["empty_num_blocks"], out)
+    assert not out.any()
+    oracle.ref_convert_ptrs_to_idxs(np.zeros(10, np.int32), 9, np.zeros(1, np.int32))   # ConvertsEmptyPtrsToIdxs: no write

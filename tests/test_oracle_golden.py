@@ -167,3 +167,34 @@ def test_stop_kernels(oracle):
     assert list(st) == [0xC2, 5, 0xC2]
     oracle.ref_implicit_residual_norm(3, np.array([0.25, 0.25, 0.25]), np.ones(3), 0.6, 3, 0, st, flags)
     assert list(st) == [0xC2, 5, 0xC2] and list(flags) == [1, 1]
+
+
+def _dense_to_csr(dense):
+    a = np.array(dense, np.float64)
+    rp = np.zeros(a.shape[0] + 1, np.int32)
+    np.cumsum((a != 0).sum(1), out=rp[1:])
+    ci = np.concatenate([np.nonzero(r)[0] for r in a]).astype(np.int32)
+    return a.shape, rp, ci, a[a != 0]
+
+
+def test_csr_utility_known_answers(oracle):
+    """csr::transpose, is_sorted_by_column_index, sort_by_column_index, extract_diagonal of the oracle against the
+    reference's own small cases (reference/test/matrix/csr_kernels.cpp:1044-1076, 1299-1344)"""
+    u = load("formats.json")["csr_utilities"]
+    for t in u["transposes"]:
+        (nr, nc), rp, ci, v = _dense_to_csr(t["dense"])
+        trp, tc, tv = np.zeros(nc + 1, np.int32), np.zeros(len(ci), np.int32), np.zeros(len(ci))
+        oracle.ref_csr_transpose(nr, nc, rp, ci, v, trp, tc, tv)
+        (_, _), erp, ec, ev = _dense_to_csr(t["expect"])
+        assert np.array_equal(trp, erp) and np.array_equal(tc, ec) and np.array_equal(tv, ev), t["name"]
+    s, un = u["mtx3_sorted"], u["mtx3_unsorted"]
+    rp = np.array(s["row_ptrs"], np.int32)
+    assert oracle.ref_csr_is_sorted_by_column_index(3, rp, np.array(s["col_idxs"], np.int32)) == 1
+    assert oracle.ref_csr_is_sorted_by_column_index(3, rp, np.array(un["col_idxs"], np.int32)) == 0
+    for m in (s, un):   # SortSortedMatrix / SortUnsortedMatrix
+        c, v = np.array(m["col_idxs"], np.int32), np.array(m["vals"], np.float64)
+        oracle.ref_csr_sort_by_column_index(3, rp, c, v)
+        assert list(c) == s["col_idxs"] and list(v) == s["vals"]
+    diag = np.full(3, -1.0)
+    oracle.ref_csr_extract_diagonal(3, rp, np.array(un["col_idxs"], np.int32), np.array(un["vals"], np.float64), diag)
+    assert list(diag) == u["mtx3_diagonal"]

@@ -220,6 +220,38 @@ def test_sort_by_column_index_and_is_sorted(gk, oracle):
     assert flag.value == 1
 
 
+def test_csr_utilities_known_answers(gk):
+    """the reference's own small cases (reference/test/matrix/csr_kernels.cpp:1044-1076, 1299-1344; fixture
+    tests/golden/formats.json csr_utilities) through the C ABI: transpose, is_sorted, sort, extract_diagonal"""
+    import ctypes, json, os
+    from test_oracle_golden import _dense_to_csr
+    u = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "formats.json")))["csr_utilities"]
+    for t in u["transposes"]:
+        (nr, nc), rp, ci, v = _dense_to_csr(t["dense"])
+        nnz = len(ci)
+        nb = gk.csr_transpose_workspace_bytes(nc)
+        ws = torch.empty(max(nb, 8), dtype=torch.uint8, device="cuda:0")
+        trp = torch.zeros(nc + 1, dtype=torch.int32, device="cuda:0")
+        tc = torch.zeros(nnz, dtype=torch.int32, device="cuda:0")
+        tv = torch.zeros(nnz, dtype=torch.float64, device="cuda:0")
+        gk.csr_transpose_f64_i32(stream_ptr(), nr, nc, nnz, dev(rp), dev(ci), dev(v), trp, tc, tv, ws, nb)
+        (_, _), erp, ec, ev = _dense_to_csr(t["expect"])
+        assert np.array_equal(host(trp), erp) and np.array_equal(host(tc), ec) and np.array_equal(host(tv), ev), t["name"]
+    s, un = u["mtx3_sorted"], u["mtx3_unsorted"]
+    rp = dev(np.array(s["row_ptrs"], np.int32))
+    ws = torch.zeros(8, dtype=torch.uint8, device="cuda:0")
+    flag = ctypes.c_int(-1)
+    for m, expect in ((s, 1), (un, 0)):
+        gk.csr_is_sorted_by_column_index_i32(stream_ptr(), 3, rp, dev(np.array(m["col_idxs"], np.int32)), ws, 8, ctypes.addressof(flag))
+        assert flag.value == expect
+        c, v = dev(np.array(m["col_idxs"], np.int32)), dev(np.array(m["vals"], np.float64))
+        gk.csr_sort_by_column_index_f64_i32(stream_ptr(), 3, rp, c, v)
+        assert list(host(c)) == s["col_idxs"] and list(host(v)) == s["vals"]
+    diag = torch.full((3,), -1.0, dtype=torch.float64, device="cuda:0")
+    gk.csr_extract_diagonal_f64_i32(stream_ptr(), 3, rp, dev(np.array(un["col_idxs"], np.int32)), dev(np.array(un["vals"], np.float64)), diag)
+    assert list(host(diag)) == u["mtx3_diagonal"]
+
+
 # ---- analysed solves: LowerTrs / UpperTrs::generate + apply (csrc/trs_levels.hip) ----------
 
 def trs_plan(gk, which, n, rp, ci, v, unit, b, check=None):
