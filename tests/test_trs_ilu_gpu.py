@@ -142,6 +142,38 @@ def test_add_diagonal_known_answers(gk, case):
     assert list(host(nc)) == case["expect_col_idxs"] and list(host(nv)) == case["expect_vals"]
 
 
+def test_par_ilu_kernel_known_answers(gk):
+    """reference/test/factorization/par_ilu_kernels.cpp:306-446 through the C ABI: initialize_row_ptrs_l_u,
+    initialize_l_u, compute_l_u_factors on mtx_small (sweeps until the exact factors: the device sweep is
+    asynchronous, the reference's sequential one is exact after one), and the zero-matrix variants"""
+    k = G["par_ilu"]["kernels"]
+    n = 3
+    rp, ci, v = matgen.dense_to_csr(np.array(k["A"], np.float64))
+    s = stream_ptr()
+    sb = gk.prefix_sum_workspace_bytes(n + 1)
+    sws = torch.empty(max(sb, 8), dtype=torch.uint8, device="cuda:0")
+    lrp = torch.zeros(n + 1, dtype=torch.int32, device="cuda:0")
+    urp = torch.zeros(n + 1, dtype=torch.int32, device="cuda:0")
+    gk.factorization_initialize_row_ptrs_l_u_i32(s, n, dev(rp), dev(ci), lrp, urp, sws, sb)
+    assert list(host(lrp)) == k["l_row_ptrs"] and list(host(urp)) == k["u_row_ptrs"]
+    lc, uc = (torch.zeros(6, dtype=torch.int32, device="cuda:0") for _ in range(2))
+    lv, uv = (torch.zeros(6, dtype=torch.float64, device="cuda:0") for _ in range(2))
+    gk.factorization_initialize_l_u_f64_i32(s, n, dev(rp), dev(ci), dev(v), lrp, lc, lv, urp, uc, uv)
+    assert np.array_equal(ilu_util.csr_to_dense(n, n, host(lrp), host(lc), host(lv)), np.array(k["L_init"], np.float64))
+    assert np.array_equal(ilu_util.csr_to_dense(n, n, host(urp), host(uc), host(uv)), np.array(k["U_init"], np.float64))
+    f = ilu_util.gpu_par_ilu(gk, torch, n, dev(rp), dev(ci), dev(v), iterations=5)
+    assert matgen.rel_err(ilu_util.csr_to_dense(n, n, *(host(t) for t in f["L"])), k["L_after_one_sweep"]) <= k["tol"]
+    assert matgen.rel_err(ilu_util.csr_to_dense(n, n, *(host(t) for t in f["U"])), k["U_after_one_sweep"]) <= k["tol"]
+    z = k["zero_matrix"]
+    zrp = torch.zeros(n + 1, dtype=torch.int32, device="cuda:0")
+    one = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    lrp.copy_(dev(np.array(z["l_row_ptrs"], np.int32)))
+    urp.copy_(dev(np.array(z["u_row_ptrs"], np.int32)))
+    gk.factorization_initialize_l_u_f64_i32(s, n, zrp, one, torch.zeros(1, dtype=torch.float64, device="cuda:0"), lrp, lc, lv, urp, uc, uv)
+    assert np.array_equal(ilu_util.csr_to_dense(n, n, host(lrp), host(lc)[:3], host(lv)[:3]), np.eye(n))
+    assert np.array_equal(ilu_util.csr_to_dense(n, n, host(urp), host(uc)[:3], host(uv)[:3]), np.eye(n))
+
+
 @pytest.mark.parametrize("case", G["par_ilu"]["cases"], ids=lambda c: c["name"])
 def test_par_ilu_known_factors(gk, case):
     a = np.array(case["A"], np.float64)
