@@ -295,24 +295,6 @@ private:
 
 
 // include/ginkgo/core/distributed/vector.hpp: the local rows of a global vector
-namespace detail {
-// index of the one range that belongs to `rank`; refuses partitions with several ranges per part
-template <typename PartitionType>
-inline size_type own_range(const PartitionType* partition, int rank, const char* what)
-{
-    const size_type nr = partition->get_num_ranges();
-    if (nr != static_cast<size_type>(partition->get_num_parts())) GKO_NOT_SUPPORTED(what);
-    size_type own = nr;
-    for (size_type i = 0; i < nr; ++i) {
-        if (partition->host_part_ids()[i] == rank) {
-            if (own != nr) GKO_NOT_SUPPORTED(what);
-            own = i;
-        }
-    }
-    if (own == nr) GKO_NOT_SUPPORTED(what);
-    return own;
-}
-}  // namespace detail
 
 template <typename ValueType = double>
 class Vector : public LinOp {
@@ -331,6 +313,9 @@ public:
     void read_distributed(const matrix_data<ValueType, GlobalIndexType>& data, const Partition<int32, GlobalIndexType>* partition)
     {
         const int rank = comm_.rank();
+        if (comm_.size() != partition->get_num_parts()) {  // core/distributed/vector.cpp:172
+            throw BadDimension(__FILE__, __LINE__, "Vector::read_distributed: one part per rank");
+        }
         const size_type nloc = static_cast<size_type>(partition->get_part_size(rank)), ncols = data.size[1];
         const size_type nnz = data.nonzeros.size(), nr = partition->get_num_ranges();
         local_ = local_vector_type::create(exec_, dim<2>(nloc, ncols));
@@ -447,23 +432,33 @@ public:
     void read_distributed(const matrix_data<ValueType, GlobalIndexType>& data, const Partition<LocalIndexType, GlobalIndexType>* partition)
     {
         const int rank = comm_.rank();
-        // ranges map to parts through part_ids (reference/distributed/partition_kernels.cpp:42-95): this
-        // rank's rows are those of the range whose part id is the rank, not of range number `rank`
-        const auto own = detail::own_range(partition, rank, "Matrix::read_distributed: one contiguous range per part");
-        const auto lo = partition->host_range_bounds()[own], hi = partition->host_range_bounds()[own + 1];
+        // core/distributed/matrix.cpp:148-151
+        if (static_cast<size_type>(data.size[0]) != partition->get_size() || comm_.size() != partition->get_num_parts()) {
+            throw BadDimension(__FILE__, __LINE__, "Matrix::read_distributed: the partition must cover the rows and have one part per rank");
+        }
+        // ranges map to parts through part_ids (reference/distributed/partition_kernels.cpp:42-95): this rank's rows
+        // are those of EVERY range whose part id is the rank (a part may own several ranges, in any order); entries of
+        // other parts are dropped here, the device kernel (build_local_nonlocal) maps the rest to local indices
+        const auto* rb = partition->host_range_bounds();
+        const size_type nr = partition->get_num_ranges();
         staged_.rows.clear(); staged_.cols.clear(); staged_.vals.clear();
         auto sorted = data;
         sorted.ensure_row_major_order();
+        size_type hint = 0;
         for (const auto& e : sorted.nonzeros) {
-            if (e.row >= lo && e.row < hi) {
+            if (!(nr > 0 && rb[hint] <= e.row && e.row < rb[hint + 1])) {
+                hint = static_cast<size_type>(std::upper_bound(rb + 1, rb + nr + 1, e.row) - (rb + 1));
+            }
+            if (hint < nr && partition->host_part_ids()[hint] == rank) {
                 staged_.rows.push_back(e.row); staged_.cols.push_back(e.column); staged_.vals.push_back(e.value);
             }
+            if (hint >= nr) hint = 0;
         }
         staged_.bounds.assign(partition->host_range_bounds(), partition->host_range_bounds() + partition->get_num_ranges() + 1);
         staged_.part_ids.assign(partition->host_part_ids(), partition->host_part_ids() + partition->get_num_ranges());
         staged_.starts.assign(partition->host_range_starting_indices(), partition->host_range_starting_indices() + partition->get_num_ranges());
         staged_.num_parts = partition->get_num_parts();
-        staged_.n_local = static_cast<int64_t>(hi - lo);
+        staged_.n_local = static_cast<int64_t>(partition->get_part_size(rank));
         staged_.valid = true;
         set_size(data.size);
         if (exec_->is_device()) build_on_device();
