@@ -210,6 +210,43 @@ int gkomi_csr_analyse_gather_i32(gkomi_stream_t stream, int64_t ncols, int64_t n
                                  const int32_t* col_idxs, double* scratch,
                                  int* host_flags, int64_t* host_footprint_bytes);
 
+/* ---- column-partitioned copy: an analysis-based CSR strategy for scattered columns --
+ * Role: the reference's `sparselib` strategy (hipSPARSE csrmv behind an analysis,
+ * hip/matrix/csr_kernels.hip.cpp:293-330) -- a second representation built once per
+ * matrix that makes the SpMV faster; opt-in.  The matrix is stored once more as a CSR of
+ * nb * nrows VIRTUAL rows (virtual row k * nrows + r = row r's nonzeros in column block
+ * k of nb, in their order), so that the workgroups resident at any moment gather from
+ * ONE <= 2 MiB slice of b (it stays in every XCD's L2); the library's CSR kernels run on
+ * the virtual matrix and a small kernel adds each row's nb partial sums in block order
+ * (csrc/csr_colpart.hip; uniform random 16 per row on 1 M columns 171 -> ~110 us,
+ * power-law rows 126 -> ~96 us).  Tolerance parity like load_balance (the groups of a
+ * row are added in another association), one right-hand side.
+ *   blocks_for  nb for a matrix of this shape, 0 = does not pay (b within one L2, b
+ *               beyond 16 MB, fewer than ~6 nonzeros per row)
+ *   create      blocking set-up into `plan` (device memory, gkomi_csr_colpart_plan_bytes
+ *               bytes, 16-B aligned, owned by the caller while the handle lives);
+ *               nb in {2, 4, 8}
+ *   refresh     the matrix's VALUES changed (same pattern): gathers them again -- the
+ *               copy knows nothing of writes through Csr::get_values()
+ *   spmv        c = A b (alpha = beta = NULL) or c = alpha A b + beta c
+ *   info        out[4] = { nb, virtual rows, longest virtual row, srow tile } */
+typedef struct gkomi_csr_colpart gkomi_csr_colpart;
+int64_t gkomi_csr_colpart_blocks_for(int64_t nrows, int64_t ncols, int64_t nnz);
+size_t gkomi_csr_colpart_plan_bytes(int64_t nrows, int64_t nnz, int64_t nb);
+int gkomi_csr_colpart_create_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                                     int64_t nnz, const int32_t* row_ptrs,
+                                     const int32_t* col_idxs, const double* vals,
+                                     int64_t nb, void* plan, size_t plan_bytes,
+                                     gkomi_csr_colpart** out);
+int gkomi_csr_colpart_refresh_f64(gkomi_stream_t s, gkomi_csr_colpart* h,
+                                  const double* vals);
+int gkomi_csr_colpart_spmv_f64(gkomi_stream_t s, const gkomi_csr_colpart* h,
+                               const double* b, int64_t b_stride, double* c,
+                               int64_t c_stride, const double* alpha,
+                               const double* beta);
+int gkomi_csr_colpart_info(const gkomi_csr_colpart* h, int64_t* out);
+void gkomi_csr_colpart_destroy(gkomi_csr_colpart* h);
+
 /* ell::compute_max_row_nnz analogue on a CSR row_ptrs array
  * (reference/matrix/ell_kernels.cpp:159-170 / csr strategy statistics).
  * result: device int32[1]. */

@@ -1,0 +1,255 @@
+// Column-partitioned copy of a CSR matrix whose gathers of b are scattered (uniformly random / power-law column
+// patterns on up to ~2 M columns): an analysis-based strategy like the reference's `sparselib` (hipSPARSE with its
+// analysis step, hip/matrix/csr_kernels.hip.cpp:293-330), opt-in, for csr::spmv / advanced_spmv on one column.
+//
+// Why: with scattered columns half the gathers of b miss the XCD's 4 MiB L2 and every miss moves a 128-B line over
+// the fabric for 8 useful bytes -- the fabric, not HBM, bounds the SpMV (profiles/r04_gather_pmc.md: 1.2-1.5 TB/s of
+// algorithmic bytes whatever the format).  Here the matrix is stored once more as a CSR of nb * n VIRTUAL rows:
+// virtual row k * n + r holds row r's nonzeros whose columns lie in block k of nb equal column blocks, in their
+// original order.  The ~2000 workgroups resident at any moment work on consecutive tiles of that matrix, i.e. on ONE
+// column block: all eight L2s hold the same <= 2 MiB slice of b and the gathers hit.  The library's own kernels run
+// on the virtual matrix (nonzero-split / load-balanced, csr_spmv.hip; runs of empty virtual rows: its sparse-rows
+// mode), into nb * n partial sums; a second small kernel adds the nb partial sums of every row in block order and
+// applies alpha / beta.  Measured (tools/colpart_probe.py, profiles/r04_colpart_probe.md): uniform random 16 per row
+// on 1 M columns 171 -> ~110 us, power-law rows 126 -> ~96 us; bound by L2 requests then (one per gather).
+//
+// Results: every (row, block) group is added left to right, the groups of a row in block order -- a different
+// association than the reference's one left-to-right sum: tolerance parity like `load_balance`, not bit-exactness.
+// The copy holds VALUES: gkomi_csr_colpart_refresh_f64 re-gathers them after the matrix's values changed (the
+// pattern may not change without a new plan).
+#include "common.hpp"
+
+#include "sort_scan.hpp"
+
+namespace gkomi {
+namespace {
+
+constexpr int block = 256;
+constexpr uint32_t colpart_magic = 0x43504c54u;  // "CPLT"
+
+struct device_buffer {
+    void* p = nullptr;
+    ~device_buffer()
+    {
+        if (p != nullptr) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) { return static_cast<int>(hipMalloc(&p, bytes > 0 ? bytes : 8)); }
+    template <typename T>
+    T* as() const
+    {
+        return static_cast<T*>(p);
+    }
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct colpart_layout {
+    size_t row_ptrs, cols, vals, perm, srow, partial, total;
+};
+
+colpart_layout make_layout(int64_t nrows, int64_t nnz, int64_t nb, int64_t tile)
+{
+    colpart_layout l{};
+    const size_t vrows = static_cast<size_t>(nb * nrows);
+    size_t off = 0;
+    l.vals = off; off += align_up(sizeof(double) * static_cast<size_t>(nnz + 2), 256);
+    l.partial = off; off += align_up(sizeof(double) * (vrows + 1), 256);
+    l.cols = off; off += align_up(sizeof(int32_t) * static_cast<size_t>(nnz + 2), 256);
+    l.perm = off; off += align_up(sizeof(uint32_t) * static_cast<size_t>(nnz + 2), 256);
+    l.row_ptrs = off; off += align_up(sizeof(int32_t) * (vrows + 1), 256);
+    l.srow = off; off += align_up(sizeof(int32_t) * static_cast<size_t>(gkomi_csr_srow_entries(nnz, tile)), 256);
+    l.total = off;
+    return l;
+}
+
+// key = block of the column * n + row: virtual row of the nonzero
+__global__ __launch_bounds__(block) void colpart_keys_kernel(int64_t nnz, const int32_t* __restrict__ rows,
+                                                             const int32_t* __restrict__ cols, int32_t width, int64_t n,
+                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ ids)
+{
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; i < nnz; i += static_cast<int64_t>(gridDim.x) * block) {
+        keys[i] = static_cast<uint32_t>(static_cast<int64_t>(cols[i] / width) * n + rows[i]);
+        ids[i] = static_cast<uint32_t>(i);
+    }
+}
+
+__global__ __launch_bounds__(block) void colpart_gather_kernel(int64_t nnz, const uint32_t* __restrict__ perm,
+                                                               const int32_t* __restrict__ cols, const double* __restrict__ vals,
+                                                               int32_t* __restrict__ v_cols, double* __restrict__ v_vals)
+{
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; i < nnz; i += static_cast<int64_t>(gridDim.x) * block) {
+        const uint32_t src = perm[i];
+        if (v_cols != nullptr) v_cols[i] = cols[src];
+        v_vals[i] = vals[src];
+    }
+}
+
+// c[r] = [beta c[r] +] [alpha] (part[r] + part[n + r] + ... ), blocks in order
+template <int NB>
+__global__ __launch_bounds__(block) void colpart_reduce_kernel(int64_t n, const double* __restrict__ part, double* __restrict__ c,
+                                                               int64_t c_stride, const double* __restrict__ alpha_p,
+                                                               const double* __restrict__ beta_p)
+{
+    const double alpha = alpha_p != nullptr ? alpha_p[0] : 1.0;
+    const double beta = beta_p != nullptr ? beta_p[0] : 0.0;
+    for (int64_t r = blockIdx.x * static_cast<int64_t>(block) + threadIdx.x; r < n; r += static_cast<int64_t>(gridDim.x) * block) {
+        double p[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) p[k] = part[k * n + r];
+        double sum = p[0];
+#pragma unroll
+        for (int k = 1; k < NB; ++k) sum += p[k];
+        double* dst = c + r * c_stride;
+        if (alpha_p != nullptr) {
+            *dst = beta * *dst + alpha * sum;  // (the partial sums carry no alpha: one rounding more than (alpha val) b)
+        } else {
+            *dst = sum;
+        }
+    }
+}
+
+}  // namespace
+}  // namespace gkomi
+
+using namespace gkomi;
+
+struct gkomi_csr_colpart {
+    uint32_t magic = colpart_magic;
+    int64_t nrows = 0, ncols = 0, nnz = 0, nb = 0, tile = 0, max_row_nnz = -1;
+    char* plan = nullptr;
+    colpart_layout l{};
+};
+
+// Blocks for a matrix of this shape, 0 = this strategy does not pay: b must span more than an L2 keeps (else the
+// plain kernels' gathers hit already) and at most 8 slices of 2 MiB (beyond that nearly every (row, block) group is
+// a single nonzero and the partial sums cost more than the fabric reads they save); rows of at least ~6 nonzeros on
+// average for the same reason.
+extern "C" int64_t gkomi_csr_colpart_blocks_for(int64_t nrows, int64_t ncols, int64_t nnz)
+{
+    if (nrows <= 0 || ncols <= 0 || nnz <= 0) return 0;
+    const int64_t slice = int64_t{2} << 20;
+    const int64_t b_bytes = 8 * ncols;
+    if (b_bytes <= (int64_t{3} << 20) || b_bytes > 8 * slice) return 0;
+    if (nnz < 6 * nrows || nnz < (int64_t{1} << 20)) return 0;
+    int64_t nb = 2;
+    while (nb < 8 && b_bytes > nb * slice) nb *= 2;
+    if (nb * nrows > INT32_MAX - 4096) return 0;
+    return nb;
+}
+
+extern "C" size_t gkomi_csr_colpart_plan_bytes(int64_t nrows, int64_t nnz, int64_t nb)
+{
+    if (nrows < 0 || nnz < 0 || nb < 1 || nb > 8) return 0;
+    return make_layout(nrows, nnz, nb, gkomi_csr_srow_tile_for(nnz)).total;
+}
+
+extern "C" void gkomi_csr_colpart_destroy(gkomi_csr_colpart* h) { delete h; }
+
+// Blocking (set-up): sorts the nonzeros by virtual row, builds the virtual CSR, its srow and row statistic in `plan`
+// (device memory, gkomi_csr_colpart_plan_bytes; owned by the caller, as long as the handle lives).
+extern "C" int gkomi_csr_colpart_create_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols, int64_t nnz,
+                                                const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
+                                                int64_t nb, void* plan, size_t plan_bytes, gkomi_csr_colpart** out)
+{
+    if (out == nullptr) return GKOMI_EINVAL;
+    *out = nullptr;
+    if (nrows <= 0 || ncols <= 0 || nnz < 2 || (nb != 2 && nb != 4 && nb != 8) || plan == nullptr) return GKOMI_EINVAL;
+    if (nb * nrows > INT32_MAX - 4096 || nnz > INT32_MAX - 8192 || ncols > INT32_MAX - 4096) return GKOMI_ENOTSUPPORTED;
+    const int64_t tile = gkomi_csr_srow_tile_for(nnz);
+    const colpart_layout l = make_layout(nrows, nnz, nb, tile);
+    if (plan_bytes < l.total || reinterpret_cast<uintptr_t>(plan) % 16 != 0) return GKOMI_EWORKSPACE;
+    hipStream_t stream = to_stream(s);
+    char* base = static_cast<char*>(plan);
+    const int64_t vrows = nb * nrows;
+    const int32_t width = static_cast<int32_t>(ceildiv(ncols, nb));
+    int end_bit = 1;
+    while ((int64_t{1} << end_bit) < vrows) ++end_bit;
+    device_buffer rows, keys, ids, sorted, sort_ws, scan_ws, stat;
+    const size_t sort_bytes = radix_sort_workspace_bytes(nnz, sizeof(uint32_t), true);
+    const size_t scan_bytes = gkomi_prefix_sum_workspace_bytes(vrows + 1) + 8;
+    int err = rows.alloc(sizeof(int32_t) * nnz);
+    if (!err) err = keys.alloc(sizeof(uint32_t) * nnz);
+    if (!err) err = ids.alloc(sizeof(uint32_t) * nnz);
+    if (!err) err = sorted.alloc(sizeof(uint32_t) * nnz);
+    if (!err) err = sort_ws.alloc(sort_bytes);
+    if (!err) err = scan_ws.alloc(scan_bytes);
+    if (!err) err = stat.alloc(sizeof(int32_t));
+    if (err) return err;
+    err = gkomi_convert_ptrs_to_idxs_i32(s, row_ptrs, nrows, rows.as<int32_t>());
+    if (err) return err;
+    hipLaunchKernelGGL(colpart_keys_kernel, dim3(grid_for(nnz, block)), dim3(block), 0, stream, nnz, rows.as<int32_t>(), col_idxs, width,
+                       nrows, keys.as<uint32_t>(), ids.as<uint32_t>());
+    uint32_t* perm = reinterpret_cast<uint32_t*>(base + l.perm);
+    err = radix_sort_u32(stream, nnz, keys.as<uint32_t>(), sorted.as<uint32_t>(), ids.as<uint32_t>(), perm, end_bit, sort_ws.p, sort_bytes);
+    if (err) return err;
+    int32_t* v_rp = reinterpret_cast<int32_t*>(base + l.row_ptrs);
+    err = gkomi_convert_idxs_to_ptrs_i32(s, sorted.as<int32_t>(), nnz, vrows, v_rp, scan_ws.p, scan_bytes);
+    if (err) return err;
+    int32_t* v_cols = reinterpret_cast<int32_t*>(base + l.cols);
+    double* v_vals = reinterpret_cast<double*>(base + l.vals);
+    hipLaunchKernelGGL(colpart_gather_kernel, dim3(grid_for(nnz, block)), dim3(block), 0, stream, nnz, perm, col_idxs, vals, v_cols, v_vals);
+    int32_t* srow = reinterpret_cast<int32_t*>(base + l.srow);
+    err = gkomi_csr_make_srow_i32(s, vrows, nnz, v_rp, tile, srow, gkomi_csr_srow_entries(nnz, tile));
+    if (err) return err;
+    err = gkomi_csr_max_row_nnz_i32(s, vrows, v_rp, stat.as<int32_t>());
+    if (err) return err;
+    int32_t longest = 0;
+    err = static_cast<int>(hipMemcpyAsync(&longest, stat.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    if (!err) err = static_cast<int>(hipStreamSynchronize(stream));
+    if (err) return err;
+    err = check_launch();
+    if (err) return err;
+    gkomi_csr_colpart* h = new gkomi_csr_colpart;
+    h->nrows = nrows; h->ncols = ncols; h->nnz = nnz; h->nb = nb; h->tile = tile; h->max_row_nnz = longest;
+    h->plan = base;
+    h->l = l;
+    *out = h;
+    return GKOMI_SUCCESS;
+}
+
+// the matrix's values changed (same pattern): gather them again
+extern "C" int gkomi_csr_colpart_refresh_f64(gkomi_stream_t s, gkomi_csr_colpart* h, const double* vals)
+{
+    if (h == nullptr || h->magic != colpart_magic || vals == nullptr) return GKOMI_EINVAL;
+    hipLaunchKernelGGL(colpart_gather_kernel, dim3(grid_for(h->nnz, block)), dim3(block), 0, to_stream(s), h->nnz,
+                       reinterpret_cast<const uint32_t*>(h->plan + h->l.perm), static_cast<const int32_t*>(nullptr), vals,
+                       static_cast<int32_t*>(nullptr), reinterpret_cast<double*>(h->plan + h->l.vals));
+    return check_launch();
+}
+
+// c = A b  (alpha == beta == NULL)  or  c = alpha A b + beta c; one column (b, c: leading dimensions in elements)
+extern "C" int gkomi_csr_colpart_spmv_f64(gkomi_stream_t s, const gkomi_csr_colpart* h, const double* b, int64_t b_stride, double* c,
+                                          int64_t c_stride, const double* alpha, const double* beta)
+{
+    if (h == nullptr || h->magic != colpart_magic || b == nullptr || c == nullptr) return GKOMI_EINVAL;
+    if ((alpha == nullptr) != (beta == nullptr) || b_stride < 1 || c_stride < 1) return GKOMI_EINVAL;
+    const char* base = h->plan;
+    double* partial = reinterpret_cast<double*>(h->plan + h->l.partial);
+    int err = gkomi_csr_spmv_srow_f64_i32(s, h->nb * h->nrows, h->ncols, 1, h->nnz, reinterpret_cast<const int32_t*>(base + h->l.row_ptrs),
+                                          reinterpret_cast<const int32_t*>(base + h->l.cols), reinterpret_cast<const double*>(base + h->l.vals), b,
+                                          b_stride, partial, 1, nullptr, nullptr, GKOMI_CSR_AUTO, h->max_row_nnz,
+                                          reinterpret_cast<const int32_t*>(base + h->l.srow), h->tile);
+    if (err) return err;
+    const dim3 grid(grid_for(h->nrows, block));
+    hipStream_t stream = to_stream(s);
+#define GKOMI_REDUCE(NB) \
+    hipLaunchKernelGGL(colpart_reduce_kernel<NB>, grid, dim3(block), 0, stream, h->nrows, partial, c, c_stride, alpha, beta)
+    if (h->nb == 2) {
+        GKOMI_REDUCE(2);
+    } else if (h->nb == 4) {
+        GKOMI_REDUCE(4);
+    } else if (h->nb == 8) {
+        GKOMI_REDUCE(8);
+    } else {
+        return GKOMI_ENOTSUPPORTED;
+    }
+#undef GKOMI_REDUCE
+    return check_launch();
+}
+
+extern "C" int gkomi_csr_colpart_info(const gkomi_csr_colpart* h, int64_t* out)
+{
+    if (h == nullptr || h->magic != colpart_magic || out == nullptr) return GKOMI_EINVAL;
+    out[0] = h->nb; out[1] = h->nb * h->nrows; out[2] = h->max_row_nnz; out[3] = h->tile;
+    return GKOMI_SUCCESS;
+}

@@ -69,6 +69,14 @@ class Csr:
         self.srow_tile = 0
         self._gather_flags = None
         self.gather_footprint = None
+        self._colpart = None       # (handle, plan tensor) of the column-partitioned copy, False = not worthwhile
+
+    def __del__(self):
+        if getattr(self, "_colpart", None):
+            try:
+                self.gk.csr_colpart_destroy(self._colpart[0])
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass
 
     @classmethod
     def from_host(cls, gk, nrows, ncols, row_ptrs, col_idxs, vals, device="cuda:0", strategy=0, split=True):
@@ -137,18 +145,52 @@ class Csr:
                 self._gather_flags, self.gather_footprint = int(flags.value), int(foot.value)
         return self._gather_flags
 
+    PARTITIONED = 1 << 29   # strategy bit of this mirror: apply through the column-partitioned copy ("csrp")
+
+    def colpart(self, nb=None):
+        """The column-partitioned copy (gkomi_csr_colpart_*, the analysis of the "csrp" strategy): built once, like
+        srow; None when the shape does not pay (gkomi_csr_colpart_blocks_for) and no block count is forced.  The copy
+        holds VALUES: call values_changed() after writing to self.vals."""
+        if self._colpart is None:
+            gk = self.gk
+            if nb is None:
+                # the shape must fit (blocks_for) AND the column pattern must be scattered (the one-time gather statistic:
+                # a stencil or banded matrix gathers from L2 already and would only pay for the partial sums)
+                self.gather_flags()
+                scattered = (self.gather_footprint or 0) > (3 << 20)   # a tile's gathers range over more of b than an L2 keeps
+                nb = int(gk.csr_colpart_blocks_for(self.nrows, self.ncols, self.nnz)) if scattered else 0
+            nb = int(nb)
+            if nb == 0:
+                self._colpart = False
+            else:
+                nbytes = int(gk.csr_colpart_plan_bytes(self.nrows, self.nnz, nb))
+                plan = torch.empty(nbytes, dtype=U8, device=self.vals.device)
+                h = ctypes.c_void_p(0)
+                gk.csr_colpart_create_f64_i32(_stream(self.vals), self.nrows, self.ncols, self.nnz, self.row_ptrs, self.col_idxs,
+                                              self.vals, nb, plan, nbytes, ctypes.addressof(h))
+                self._colpart = (h.value, plan)
+        return self._colpart or None
+
+    def values_changed(self):
+        if self._colpart:
+            self.gk.csr_colpart_refresh_f64(_stream(self.vals), self._colpart[0], self.vals)
+
     def apply(self, b, x, alpha=None, beta=None):
         dv = self.vals.device
+        if (self.strategy & self.PARTITIONED) and b.shape[1] == 1 and self.colpart() is not None:
+            self.gk.csr_colpart_spmv_f64(_stream(self.vals), self._colpart[0], b, b.stride(0), x, x.stride(0),
+                                         _scalar(dv, alpha), _scalar(dv, beta))
+            return x
         self.gk.csr_spmv_srow_f64_i32(_stream(self.vals), self.nrows, self.ncols, b.shape[1], self.nnz, self.row_ptrs,
                                       self.col_idxs, self.vals, b, b.stride(0), x, x.stride(0), _scalar(dv, alpha),
-                                      _scalar(dv, beta), (self.strategy & ~(1 << 30)) | self.gather_flags(), self.max_row_nnz(),
+                                      _scalar(dv, beta), (self.strategy & ~(3 << 29)) | self.gather_flags(), self.max_row_nnz(),
                                       self.srow(), self.srow_tile)
         return x
 
     def callback(self):
         srow = self.srow()
         ctx = CsrCtx(self.nrows, self.ncols, self.nnz, self.row_ptrs.data_ptr(), self.col_idxs.data_ptr(),
-                     self.vals.data_ptr(), self.strategy & ~(1 << 30), self.max_row_nnz(),
+                     self.vals.data_ptr(), self.strategy & ~(3 << 29), self.max_row_nnz(),
                      srow.data_ptr() if srow is not None else None, self.srow_tile)
         return MatrixCallback(self.gk, "gkomi_csr_matrix_apply_cb", ctx, self)
 
@@ -161,7 +203,8 @@ class Csr:
     # "csrm" = merge_path, "csrc" = classical, "csrs" = sparselib (served by the automatic
     # kernel here, like Csr::sparselib in the C++ mirror); GKOMI_CSR_* codes of include/gkomi.h
     CSR_STRATEGIES = {"csr": 0, "csrs": 0, "csrm": 1, "csrc": 2, "csri": 3, "csri_serial": 3 | (1 << 8),
-                      "csr_1pass": 0 | (1 << 30), "csri_1pass": 3 | (1 << 30)}   # bit 30: no column-pattern analysis (A/B)
+                      "csr_1pass": 0 | (1 << 30), "csri_1pass": 3 | (1 << 30),   # bit 30: no column-pattern analysis (A/B)
+                      "csrp": 0 | (1 << 29)}   # bit 29: the column-partitioned copy where it pays (else the automatic kernels)
 
     def to(self, fmt, **kw):
         if fmt in self.CSR_STRATEGIES:

@@ -835,11 +835,22 @@ struct csr_abi<int32> {
     static constexpr auto max_row_nnz = &gkomi_csr_max_row_nnz_i32;
     static constexpr auto idxs_to_ptrs = &gkomi_convert_idxs_to_ptrs_i32;
     // the column-pattern statistic of the strategy objects (GKOMI_CSR_COLBLOCK or 0): blocking, once per matrix
-    static int gather_flags(int64_t ncols, int64_t nnz, const int32* col_idxs, double* scratch)
+    static int gather_flags(int64_t ncols, int64_t nnz, const int32* col_idxs, double* scratch, int64_t* footprint)
     {
         int flags = 0;
-        GKOMI_CALL(gkomi_csr_analyse_gather_i32(nullptr, ncols, nnz, col_idxs, scratch, &flags, nullptr));
+        GKOMI_CALL(gkomi_csr_analyse_gather_i32(nullptr, ncols, nnz, col_idxs, scratch, &flags, footprint));
         return flags;
+    }
+    // the column-partitioned copy of the "gkomi_partitioned" strategy (gkomi_csr_colpart_*): nullptr = does not pay
+    static gkomi_csr_colpart* colpart_create(std::shared_ptr<const Executor> exec, int64_t nrows, int64_t ncols, int64_t nnz, const int32* rp,
+                                             const int32* ci, const double* v, array<char>& plan)
+    {
+        const int64_t nb = gkomi_csr_colpart_blocks_for(nrows, ncols, nnz);
+        if (nb == 0) return nullptr;
+        plan = array<char>(exec, gkomi_csr_colpart_plan_bytes(nrows, nnz, nb));
+        gkomi_csr_colpart* h = nullptr;
+        GKOMI_CALL(gkomi_csr_colpart_create_f64_i32(nullptr, nrows, ncols, nnz, rp, ci, v, nb, plan.get_data(), plan.get_num_elems(), &h));
+        return h;
     }
 };
 template <>
@@ -848,7 +859,16 @@ struct csr_abi<int64> {
     static constexpr auto make_srow = &gkomi_csr_make_srow_i64;
     static constexpr auto max_row_nnz = &gkomi_csr_max_row_nnz_i64;
     static constexpr auto idxs_to_ptrs = &gkomi_convert_idxs_to_ptrs_i64;
-    static int gather_flags(int64_t, int64_t, const int64*, double*) { return 0; }  // (column windows: int32 kernels only)
+    static int gather_flags(int64_t, int64_t, const int64*, double*, int64_t* footprint)  // (column windows: int32 kernels only)
+    {
+        *footprint = 0;
+        return 0;
+    }
+    static gkomi_csr_colpart* colpart_create(std::shared_ptr<const Executor>, int64_t, int64_t, int64_t, const int64*, const int64*, const double*,
+                                             array<char>&)
+    {
+        return nullptr;
+    }
 };
 }  // namespace detail_abi
 
@@ -885,6 +905,12 @@ public:
     };
     // the vendor-library strategy (csr.hpp:299-330): no hipSPARSE behind this backend, the automatic choice serves it
     struct sparselib : strategy_type { sparselib() : strategy_type("sparselib", GKOMI_CSR_AUTO) {} };
+    // An analysis-based strategy of this backend (the role hipSPARSE's analysis plays behind `sparselib` in the reference):
+    // the matrix keeps a column-partitioned COPY (gkomi_csr_colpart_*, csrc/csr_colpart.hip) when its column pattern is
+    // scattered and its shape fits, and applies one-column products through it (1.3-1.6 x on uniformly random / power-law
+    // patterns of ~1 M columns; tolerance parity like load_balance); otherwise the automatic kernels.  The copy holds
+    // values: it is re-gathered after get_values() (non-const) was asked for.
+    struct gkomi_partitioned : strategy_type { gkomi_partitioned() : strategy_type("gkomi_partitioned", GKOMI_CSR_AUTO) {} };
     struct cusparse : strategy_type { cusparse() : strategy_type("cusparse", GKOMI_CSR_AUTO) {} };
 
     static std::unique_ptr<Csr> create(std::shared_ptr<const Executor> exec, const dim<2>& size = dim<2>{}, size_type nnz = 0,
@@ -897,7 +923,7 @@ public:
     {
         return std::unique_ptr<Csr>(new Csr(std::move(exec), dim<2>{}, 0, std::move(strategy)));
     }
-    V* get_values() noexcept { return values_.get_data(); }
+    V* get_values() noexcept { colpart_dirty_ = true; return values_.get_data(); }
     const V* get_const_values() const noexcept { return values_.get_const_data(); }
     I* get_col_idxs() noexcept { return col_idxs_.get_data(); }
     const I* get_const_col_idxs() const noexcept { return col_idxs_.get_const_data(); }
@@ -1001,6 +1027,16 @@ protected:
         detail::require_device(exec_, "csr::spmv");
         auto db = detail_fmt::dense(b); auto dx = detail_fmt::dense(x);
         make_srow();
+        if (colpart_ && db->cols() == 1) {
+            if (colpart_dirty_) {
+                GKOMI_CALL(gkomi_csr_colpart_refresh_f64(nullptr, colpart_.get(), get_const_values()));
+                colpart_dirty_ = false;
+            }
+            GKOMI_CALL(gkomi_csr_colpart_spmv_f64(nullptr, colpart_.get(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(),
+                                                  alpha ? detail_fmt::dense(alpha)->get_const_values() : nullptr,
+                                                  beta ? detail_fmt::dense(beta)->get_const_values() : nullptr));
+            return;
+        }
         GKOMI_CALL(detail_abi::csr_abi<I>::spmv_srow(nullptr, size_[0], size_[1], db->cols(), get_num_stored_elements(), get_const_row_ptrs(), get_const_col_idxs(),
                                                  get_const_values(), db->get_const_values(), db->get_stride(), dx->get_values(), dx->get_stride(),
                                                  alpha ? detail_fmt::dense(alpha)->get_const_values() : nullptr,
@@ -1033,13 +1069,22 @@ public:
         // ... and where the gathers of b go: matrices whose long rows select the load-balanced kernel get its column
         // windows when a tile's gathers overflow an XCD's L2 (gkomi_csr_analyse_gather_i32; acts on that kernel only)
         gather_flags_ = 0;
+        gather_footprint_ = 0;
         const int code = strategy_->get_code() & 0xff;
         if (nnz >= 2 && (code == GKOMI_CSR_AUTO || code == GKOMI_CSR_BALANCED)) {
             array<double> scratch(exec_, 2);
-            gather_flags_ = detail_abi::csr_abi<I>::gather_flags(static_cast<int64_t>(size_[1]), nnz, get_const_col_idxs(), scratch.get_data());
+            gather_flags_ = detail_abi::csr_abi<I>::gather_flags(static_cast<int64_t>(size_[1]), nnz, get_const_col_idxs(), scratch.get_data(), &gather_footprint_);
+        }
+        // the analysis of the gkomi_partitioned strategy: a scattered column pattern (the statistic above) on a shape that fits
+        colpart_.reset();
+        if (strategy_->get_name() == "gkomi_partitioned" && gather_footprint_ > (int64_t{3} << 20)) {  // gathers beyond an L2
+            colpart_.reset(detail_abi::csr_abi<I>::colpart_create(exec_, static_cast<int64_t>(size_[0]), static_cast<int64_t>(size_[1]), nnz, get_const_row_ptrs(),
+                                                                  get_const_col_idxs(), get_const_values(), colpart_plan_));
+            colpart_dirty_ = false;
         }
         srow_valid_ = true;
     }
+    bool has_partitioned_copy() const noexcept { return static_cast<bool>(colpart_); }
     void invalidate_srow() const { srow_valid_ = false; }
 protected:
     array<V> values_;
@@ -1050,7 +1095,14 @@ protected:
     mutable array<I> srow_;
     mutable int64_t srow_tile_{0};
     mutable int gather_flags_{0};
+    mutable int64_t gather_footprint_{0};
     mutable bool srow_valid_{false};
+    struct colpart_deleter {
+        void operator()(gkomi_csr_colpart* h) const { gkomi_csr_colpart_destroy(h); }
+    };
+    mutable std::unique_ptr<gkomi_csr_colpart, colpart_deleter> colpart_;
+    mutable array<char> colpart_plan_;
+    mutable bool colpart_dirty_{false};
 };
 
 // core/matrix/csr_builder.hpp:47-83: intrusive access to a Csr's arrays for kernels that rebuild them

@@ -35,7 +35,9 @@ def test_no_torch_types_in_abi():
                              # plain C records of the ABI itself (pointers and sizes, declared in gkomi.h)
                              "gkomi_comm", "gkomi_dist_matrix", "gkomi_dist_ctx",
                              # opaque handle (host-side analysis result, like the reference's SolveStruct)
-                             "gkomi_trs_bricks"), (name, ctype)
+                             "gkomi_trs_bricks",
+                             # opaque handle of the column-partitioned CSR copy (sizes + offsets into the caller's plan)
+                             "gkomi_csr_colpart"), (name, ctype)
 
 
 def test_version_and_error_strings(gk):

@@ -101,6 +101,10 @@ def test_hot_path_tour(bins):
     # long rows + wide gathers: the strategy objects' column statistic -> windowed load-balanced kernel; sums of
     # 50 000 terms of size ~1, two summation orders
     assert float(kv["csr_long_rows_diff"][0]) < 1e-9 and int(kv["csr_long_rows_diff"][2]) > 700000
+    # Csr::gkomi_partitioned: the column-partitioned copy exists for the scattered pattern, same product to rounding
+    # (sums of 8 terms of size ~1 over 600 000 rows), also after new values went in through get_values()
+    p = kv["csr_partitioned_diff"]
+    assert float(p[0]) < 1e-10 and p[2] == "1" and float(p[4]) < 1e-10 and p[6] == "0"
     assert kv["cg_jacobi_iters"][2] == "1" and float(kv["cg_jacobi_iters"][4]) < 1e-9
     # adaptive block storage: some blocks reduced, same convergence within a few iterations
     assert kv["cg_adaptive_jacobi_iters"][2] == "1" and int(kv["cg_adaptive_jacobi_iters"][4]) > 0

@@ -82,7 +82,7 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--formats", default="csr,coo,ell,sellp,hybrid",
                     help="as benchmark/utils/formats.hpp: csr (automatical), csri (load_balance), csrm (merge_path), "
-                         "csrc (classical), csrs, coo, ell, sellp, hybrid; csri_serial = load_balance with every row "
+                         "csrc (classical), csrs, coo, ell, sellp, hybrid; csrp = column-partitioned copy where it pays (gkomi_csr_colpart_*); csri_serial = load_balance with every row "
                          "segment added by one thread (the kernel of rounds 1-3, for A/B timings)")
     ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=2)
