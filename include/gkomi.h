@@ -246,6 +246,13 @@ int gkomi_csr_colpart_spmv_f64(gkomi_stream_t s, const gkomi_csr_colpart* h,
                                const double* beta);
 int gkomi_csr_colpart_info(const gkomi_csr_colpart* h, int64_t* out);
 void gkomi_csr_colpart_destroy(gkomi_csr_colpart* h);
+/* the copy as the system matrix of the *_solve_op_f64 drivers (a gkomi_matrix_apply_fn,
+ * declared below; ctx = the handle): a solve holds its matrix const, the one place where
+ * the copy cannot go stale */
+int gkomi_csr_colpart_matrix_apply_cb(void* ctx, gkomi_stream_t s, int64_t nrhs,
+                                      const double* alpha, const double* b,
+                                      int64_t b_stride, const double* beta, double* c,
+                                      int64_t c_stride);
 
 /* ell::compute_max_row_nnz analogue on a CSR row_ptrs array
  * (reference/matrix/ell_kernels.cpp:159-170 / csr strategy statistics).

@@ -247,6 +247,20 @@ extern "C" int gkomi_csr_colpart_spmv_f64(gkomi_stream_t s, const gkomi_csr_colp
     return check_launch();
 }
 
+// the copy as a system matrix of the *_solve_op_f64 drivers (gkomi_matrix_apply_fn; ctx = the handle): the matrix is
+// const while a solve runs, which is the one place where the copy cannot go stale.  Column by column.
+extern "C" int gkomi_csr_colpart_matrix_apply_cb(void* ctx, gkomi_stream_t s, int64_t nrhs, const double* alpha, const double* b,
+                                                 int64_t b_stride, const double* beta, double* c, int64_t c_stride)
+{
+    const gkomi_csr_colpart* h = static_cast<const gkomi_csr_colpart*>(ctx);
+    if (h == nullptr || h->magic != colpart_magic || nrhs < 0) return GKOMI_EINVAL;
+    for (int64_t j = 0; j < nrhs; ++j) {
+        const int err = gkomi_csr_colpart_spmv_f64(s, h, b + j, b_stride, c + j, c_stride, alpha, beta);
+        if (err) return err;
+    }
+    return GKOMI_SUCCESS;
+}
+
 extern "C" int gkomi_csr_colpart_info(const gkomi_csr_colpart* h, int64_t* out)
 {
     if (h == nullptr || h->magic != colpart_magic || out == nullptr) return GKOMI_EINVAL;

@@ -188,6 +188,12 @@ class Csr:
         return x
 
     def callback(self):
+        if (self.strategy & self.PARTITIONED) and self.colpart() is not None:
+            # the copy as the system matrix of the solver drivers (the matrix is const while a solve runs)
+            cb = MatrixCallback.__new__(MatrixCallback)
+            cb.fn = ctypes.cast(getattr(self.gk._cdll, "gkomi_csr_colpart_matrix_apply_cb"), ctypes.c_void_p).value
+            cb.ctx, cb.ctx_ptr, cb.owner = None, self._colpart[0], self
+            return cb
         srow = self.srow()
         ctx = CsrCtx(self.nrows, self.ncols, self.nnz, self.row_ptrs.data_ptr(), self.col_idxs.data_ptr(),
                      self.vals.data_ptr(), self.strategy & ~(3 << 29), self.max_row_nnz(),

@@ -124,3 +124,30 @@ def test_create_rejects_bad_arguments(gk):
     with pytest.raises(GkomiError):   # plan too small
         gk.csr_colpart_create_f64_i32(stream_ptr(), 100, 100, len(v), dev(rp), dev(ci), dev(v), 4, plan, 64, ctypes.addressof(h))
     assert h.value is None
+
+
+@pytest.mark.parametrize("solver", ["gmres", "bicgstab"])
+def test_solver_drivers_take_the_copy_as_system_matrix(gk, solver):
+    """gkomi_csr_colpart_matrix_apply_cb behind the *_solve_op_f64 drivers (a solve holds its matrix const: the copy
+    cannot go stale there): same convergence as with the plain CSR matrix, same solution to the solve's tolerance"""
+    from gkomi import solvers
+    n = 500000
+    rng = np.random.default_rng(12)
+    rp, ci, v = matgen.random_rows_csr(n, n, np.full(n, 8), 13)
+    v = 0.1 * rng.standard_normal(len(v))
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    v[rows == ci] = 0.0
+    # a strongly diagonally dominant nonsymmetric system: add 2 to the diagonal through one more CSR entry per row
+    rp2 = rp + np.arange(n + 1, dtype=rp.dtype)
+    ci2 = np.insert(ci, rp[1:], np.arange(n)).astype(np.int32)   # (appended at the row's end: unsorted rows are fine)
+    v2 = np.insert(v, rp[1:], 2.0)
+    b = dev(rng.standard_normal((n, 1)))
+    out = {}
+    for name in ("csr", "csrp"):
+        M = formats.Csr.from_host(gk, n, n, rp2, ci2, v2, strategy=formats.Csr.CSR_STRATEGIES[name])
+        if name == "csrp":
+            assert M.colpart() is not None
+        out[name] = solvers.solve_op(gk, solver, M, b, max_iters=200, reduction=1e-10, krylov_dim=30)
+        assert out[name]["converged"]
+    assert abs(out["csr"]["iterations"] - out["csrp"]["iterations"]) <= 1
+    assert matgen.rel_err(host(out["csrp"]["x"]), host(out["csr"]["x"])) <= 1e-8
