@@ -117,6 +117,22 @@ int main()
         CHECK(p->get_num_parts() == 3 && p->get_size() == 10);
         CHECK(p->get_range_bounds()[0] == 0 && p->get_range_bounds()[1] == 4 && p->get_range_bounds()[2] == 7 && p->get_range_bounds()[3] == 10);
         CHECK(p->get_part_size(0) == 4 && p->get_part_size(2) == 3 && p2->get_part_size(1) == 3);
+        // reference/test/distributed/partition_kernels.cpp:88-135, 226-295: mapping with empty parts, connected / ordered
+        {
+            auto pm = part::build_from_mapping(ref, gko::array<int>(ref, {3, 3, 0, 1, 1, 3, 0, 0, 1, 0, 1, 1, 1, 3, 3, 0}), 5);
+            CHECK(pm->get_num_ranges() == 10 && pm->get_num_parts() == 5 && pm->get_num_empty_parts() == 2 && pm->get_size() == 16);
+            const gko::int32 sizes[5] = {5, 6, 0, 5, 0}, starts[10] = {0, 0, 0, 2, 1, 2, 3, 3, 3, 4};
+            for (int i = 0; i < 5; ++i) CHECK(pm->get_part_sizes()[i] == sizes[i]);
+            for (int i = 0; i < 10; ++i) CHECK(pm->get_range_starting_indices()[i] == starts[i]);
+            CHECK(!pm->has_connected_parts() && !pm->has_ordered_parts());
+            auto unordered = part::build_from_mapping(ref, gko::array<int>(ref, {1, 1, 0, 0, 2}), 3);
+            CHECK(unordered->has_connected_parts() && !unordered->has_ordered_parts());
+            auto ordered = part::build_from_mapping(ref, gko::array<int>(ref, {0, 2, 2, 5, 5}), 6);
+            CHECK(ordered->has_connected_parts() && ordered->has_ordered_parts());
+            auto ranges = part::build_from_contiguous(ref, std::vector<int64_t>{0, 5, 5, 7, 9, 10});
+            // (an empty part still has its range here: 5 - 1 != 5 ranges, "not connected" by partition.cpp:120-124)
+            CHECK(ranges->get_num_empty_parts() == 1 && ranges->get_part_size(2) == 2 && !ranges->has_connected_parts());
+        }
         gko::stop::criterion_settings st;
         gko::stop::Combined::build()
             .with_criteria(gko::stop::Iteration::build().with_max_iters(17u).on(ref),
