@@ -218,14 +218,16 @@ int gkomi_csr_analyse_gather_i32(gkomi_stream_t stream, int64_t ncols, int64_t n
  * k of nb, in their order), so that the workgroups resident at any moment gather from
  * ONE <= 2 MiB slice of b (it stays in every XCD's L2); the library's CSR kernels run on
  * the virtual matrix and a small kernel adds each row's nb partial sums in block order
- * (csrc/csr_colpart.hip; uniform random 16 per row on 1 M columns 171 -> ~110 us,
- * power-law rows 126 -> ~96 us).  Tolerance parity like load_balance (the groups of a
+ * (csrc/csr_colpart.hip; uniform random 16 per row on 1 M columns 172 -> 105 us,
+ * power-law rows 126 -> 101 us).  Tolerance parity like load_balance (the groups of a
  * row are added in another association), one right-hand side.
  *   blocks_for  nb for a matrix of this shape, 0 = does not pay (b within one L2, b
  *               beyond 16 MB, fewer than ~6 nonzeros per row)
  *   create      blocking set-up into `plan` (device memory, gkomi_csr_colpart_plan_bytes
  *               bytes, 16-B aligned, owned by the caller while the handle lives);
- *               nb in {2, 4, 8}
+ *               nb in {2, 4, 8}, or 0: the analysis builds blocks_for's count and half
+ *               of it, times a few applies of each and keeps the faster (plan_bytes
+ *               with nb = 0 is the room of the largest)
  *   refresh     the matrix's VALUES changed (same pattern): gathers them again -- the
  *               copy knows nothing of writes through Csr::get_values()
  *   spmv        c = A b (alpha = beta = NULL) or c = alpha A b + beta c

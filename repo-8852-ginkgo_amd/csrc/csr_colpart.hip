@@ -11,7 +11,7 @@
 // on the virtual matrix (nonzero-split / load-balanced, csr_spmv.hip; runs of empty virtual rows: its sparse-rows
 // mode), into nb * n partial sums; a second small kernel adds the nb partial sums of every row in block order and
 // applies alpha / beta.  Measured (tools/colpart_probe.py, profiles/r04_colpart_probe.md): uniform random 16 per row
-// on 1 M columns 171 -> ~110 us, power-law rows 126 -> ~96 us; bound by L2 requests then (one per gather).
+// on 1 M columns 172 -> 105 us, power-law rows 126 -> 101 us; bound by L2 requests then (one per gather).
 //
 // Results: every (row, block) group is added left to right, the groups of a row in block order -- a different
 // association than the reference's one left-to-right sum: tolerance parity like `load_balance`, not bit-exactness.
@@ -139,27 +139,22 @@ extern "C" int64_t gkomi_csr_colpart_blocks_for(int64_t nrows, int64_t ncols, in
 
 extern "C" size_t gkomi_csr_colpart_plan_bytes(int64_t nrows, int64_t nnz, int64_t nb)
 {
-    if (nrows < 0 || nnz < 0 || nb < 1 || nb > 8) return 0;
-    return make_layout(nrows, nnz, nb, gkomi_csr_srow_tile_for(nnz)).total;
+    if (nrows < 0 || nnz < 0 || nb < 0 || nb > 8) return 0;
+    // nb = 0 (the analysis chooses): room for the largest candidate
+    return make_layout(nrows, nnz, nb == 0 ? 8 : nb, gkomi_csr_srow_tile_for(nnz)).total;
 }
 
 extern "C" void gkomi_csr_colpart_destroy(gkomi_csr_colpart* h) { delete h; }
 
-// Blocking (set-up): sorts the nonzeros by virtual row, builds the virtual CSR, its srow and row statistic in `plan`
-// (device memory, gkomi_csr_colpart_plan_bytes; owned by the caller, as long as the handle lives).
-extern "C" int gkomi_csr_colpart_create_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols, int64_t nnz,
-                                                const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
-                                                int64_t nb, void* plan, size_t plan_bytes, gkomi_csr_colpart** out)
+namespace {
+
+// builds the copy with nb blocks into `plan` (blocking) and fills *h
+int build_into(gkomi_stream_t s, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t* row_ptrs, const int32_t* col_idxs,
+               const double* vals, int64_t nb, char* base, gkomi_csr_colpart* h)
 {
-    if (out == nullptr) return GKOMI_EINVAL;
-    *out = nullptr;
-    if (nrows <= 0 || ncols <= 0 || nnz < 2 || (nb != 2 && nb != 4 && nb != 8) || plan == nullptr) return GKOMI_EINVAL;
-    if (nb * nrows > INT32_MAX - 4096 || nnz > INT32_MAX - 8192 || ncols > INT32_MAX - 4096) return GKOMI_ENOTSUPPORTED;
     const int64_t tile = gkomi_csr_srow_tile_for(nnz);
     const colpart_layout l = make_layout(nrows, nnz, nb, tile);
-    if (plan_bytes < l.total || reinterpret_cast<uintptr_t>(plan) % 16 != 0) return GKOMI_EWORKSPACE;
     hipStream_t stream = to_stream(s);
-    char* base = static_cast<char*>(plan);
     const int64_t vrows = nb * nrows;
     const int32_t width = static_cast<int32_t>(ceildiv(ncols, nb));
     int end_bit = 1;
@@ -199,11 +194,80 @@ extern "C" int gkomi_csr_colpart_create_f64_i32(gkomi_stream_t s, int64_t nrows,
     if (err) return err;
     err = check_launch();
     if (err) return err;
-    gkomi_csr_colpart* h = new gkomi_csr_colpart;
     h->nrows = nrows; h->ncols = ncols; h->nnz = nnz; h->nb = nb; h->tile = tile; h->max_row_nnz = longest;
     h->plan = base;
     h->l = l;
-    *out = h;
+    return GKOMI_SUCCESS;
+}
+
+// microseconds per apply of the copy in *h (a few launches on `stream`, b = zeros: the gathers go where they go)
+int time_apply(hipStream_t stream, const gkomi_csr_colpart* h, const double* b, double* c, double* us)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int err = static_cast<int>(hipEventCreate(&e0));
+    if (!err) err = static_cast<int>(hipEventCreate(&e1));
+    constexpr int warm = 2, reps = 5;
+    for (int i = 0; !err && i < warm + reps; ++i) {
+        if (i == warm) err = static_cast<int>(hipEventRecord(e0, stream));
+        if (!err) err = gkomi_csr_colpart_spmv_f64(reinterpret_cast<gkomi_stream_t>(stream), h, b, 1, c, 1, nullptr, nullptr);
+    }
+    if (!err) err = static_cast<int>(hipEventRecord(e1, stream));
+    if (!err) err = static_cast<int>(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    if (!err) err = static_cast<int>(hipEventElapsedTime(&ms, e0, e1));
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    *us = 1e3 * ms / reps;
+    return err;
+}
+
+}  // namespace
+
+// Blocking (set-up): sorts the nonzeros by virtual row, builds the virtual CSR, its srow and row statistic in `plan`
+// (device memory, gkomi_csr_colpart_plan_bytes; owned by the caller, as long as the handle lives).  nb = 0: the
+// analysis chooses -- it builds the copy with gkomi_csr_colpart_blocks_for's count and with half of it, times a few
+// applies of each and keeps the faster one (uniformly random columns on 8 MB of b: 2 blocks of 4 MB beat 4 of 2 MB,
+// 106 vs 115 us; power-law rows the other way round, 149 vs 96 us: profiles/r04_colpart_probe.md).
+extern "C" int gkomi_csr_colpart_create_f64_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols, int64_t nnz,
+                                                const int32_t* row_ptrs, const int32_t* col_idxs, const double* vals,
+                                                int64_t nb, void* plan, size_t plan_bytes, gkomi_csr_colpart** out)
+{
+    if (out == nullptr) return GKOMI_EINVAL;
+    *out = nullptr;
+    if (nrows <= 0 || ncols <= 0 || nnz < 2 || (nb != 0 && nb != 2 && nb != 4 && nb != 8) || plan == nullptr) return GKOMI_EINVAL;
+    if (nnz > INT32_MAX - 8192 || ncols > INT32_MAX - 4096) return GKOMI_ENOTSUPPORTED;
+    int64_t candidates[2] = {nb, 0};
+    if (nb == 0) {
+        candidates[0] = gkomi_csr_colpart_blocks_for(nrows, ncols, nnz);
+        if (candidates[0] == 0) return GKOMI_ENOTSUPPORTED;
+        candidates[1] = candidates[0] > 2 ? candidates[0] / 2 : 0;
+    }
+    if (candidates[0] * nrows > INT32_MAX - 4096) return GKOMI_ENOTSUPPORTED;
+    if (plan_bytes < gkomi_csr_colpart_plan_bytes(nrows, nnz, nb) || reinterpret_cast<uintptr_t>(plan) % 16 != 0) return GKOMI_EWORKSPACE;
+    char* base = static_cast<char*>(plan);
+    gkomi_csr_colpart built{};
+    int err = build_into(s, nrows, ncols, nnz, row_ptrs, col_idxs, vals, candidates[0], base, &built);
+    if (err) return err;
+    if (candidates[1] != 0) {
+        hipStream_t stream = to_stream(s);
+        device_buffer bvec, cvec;
+        err = bvec.alloc(sizeof(double) * ncols);
+        if (!err) err = cvec.alloc(sizeof(double) * nrows);
+        if (!err) err = static_cast<int>(hipMemsetAsync(bvec.p, 0, sizeof(double) * ncols, stream));
+        double t_first = 0.0, t_second = 0.0;
+        if (!err) err = time_apply(stream, &built, bvec.as<double>(), cvec.as<double>(), &t_first);
+        gkomi_csr_colpart other{};
+        if (!err) err = build_into(s, nrows, ncols, nnz, row_ptrs, col_idxs, vals, candidates[1], base, &other);
+        if (!err) err = time_apply(stream, &other, bvec.as<double>(), cvec.as<double>(), &t_second);
+        if (err) return err;
+        if (t_second < t_first) {
+            built = other;
+        } else {  // the first one was faster: once more
+            err = build_into(s, nrows, ncols, nnz, row_ptrs, col_idxs, vals, candidates[0], base, &built);
+            if (err) return err;
+        }
+    }
+    *out = new gkomi_csr_colpart(built);
     return GKOMI_SUCCESS;
 }
 

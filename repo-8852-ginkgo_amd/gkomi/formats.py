@@ -153,7 +153,8 @@ class Csr:
         holds VALUES: call values_changed() after writing to self.vals."""
         if self._colpart is None:
             gk = self.gk
-            if nb is None:
+            auto = nb is None
+            if auto:
                 # the shape must fit (blocks_for) AND the column pattern must be scattered (the one-time gather statistic:
                 # a stencil or banded matrix gathers from L2 already and would only pay for the partial sums)
                 self.gather_flags()
@@ -163,11 +164,12 @@ class Csr:
             if nb == 0:
                 self._colpart = False
             else:
-                nbytes = int(gk.csr_colpart_plan_bytes(self.nrows, self.nnz, nb))
+                ask = 0 if auto else nb     # 0: the analysis times blocks_for's count and half of it, keeps the faster
+                nbytes = int(gk.csr_colpart_plan_bytes(self.nrows, self.nnz, ask))
                 plan = torch.empty(nbytes, dtype=U8, device=self.vals.device)
                 h = ctypes.c_void_p(0)
                 gk.csr_colpart_create_f64_i32(_stream(self.vals), self.nrows, self.ncols, self.nnz, self.row_ptrs, self.col_idxs,
-                                              self.vals, nb, plan, nbytes, ctypes.addressof(h))
+                                              self.vals, ask, plan, nbytes, ctypes.addressof(h))
                 self._colpart = (h.value, plan)
         return self._colpart or None
 

@@ -845,11 +845,10 @@ struct csr_abi<int32> {
     static gkomi_csr_colpart* colpart_create(std::shared_ptr<const Executor> exec, int64_t nrows, int64_t ncols, int64_t nnz, const int32* rp,
                                              const int32* ci, const double* v, array<char>& plan)
     {
-        const int64_t nb = gkomi_csr_colpart_blocks_for(nrows, ncols, nnz);
-        if (nb == 0) return nullptr;
-        plan = array<char>(exec, gkomi_csr_colpart_plan_bytes(nrows, nnz, nb));
-        gkomi_csr_colpart* h = nullptr;
-        GKOMI_CALL(gkomi_csr_colpart_create_f64_i32(nullptr, nrows, ncols, nnz, rp, ci, v, nb, plan.get_data(), plan.get_num_elems(), &h));
+        if (gkomi_csr_colpart_blocks_for(nrows, ncols, nnz) == 0) return nullptr;
+        plan = array<char>(exec, gkomi_csr_colpart_plan_bytes(nrows, nnz, 0));
+        gkomi_csr_colpart* h = nullptr;  // (0 blocks: the analysis times two block counts and keeps the faster)
+        GKOMI_CALL(gkomi_csr_colpart_create_f64_i32(nullptr, nrows, ncols, nnz, rp, ci, v, 0, plan.get_data(), plan.get_num_elems(), &h));
         return h;
     }
 };

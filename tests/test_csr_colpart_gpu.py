@@ -87,6 +87,9 @@ def test_policy_and_refresh(gk, oracle):
     rp, ci, v = matgen.random_rows_csr(n, ncols, rng.integers(6, 12, size=n), 2)
     M = formats.Csr.from_host(gk, n, ncols, rp, ci, v, strategy=formats.Csr.CSR_STRATEGIES["csrp"])
     assert M.colpart() is not None and gk.csr_colpart_blocks_for(n, ncols, M.nnz) == 4
+    info = (ctypes.c_int64 * 4)()
+    gk.csr_colpart_info(M._colpart[0], ctypes.addressof(info))
+    assert info[0] in (2, 4) and info[1] == info[0] * n     # the analysis timed both and kept one
     b2 = rng.standard_normal((ncols, 3))
     bd, cd = dev(b2), torch.zeros((n, 2), dtype=torch.float64, device="cuda:0")
     M.apply(bd[:, 1:2], cd[:, 0:1])            # strides 3 and 2
