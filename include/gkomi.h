@@ -226,8 +226,10 @@ int gkomi_csr_analyse_gather_i32(gkomi_stream_t stream, int64_t ncols, int64_t n
  *   create      blocking set-up into `plan` (device memory, gkomi_csr_colpart_plan_bytes
  *               bytes, 16-B aligned, owned by the caller while the handle lives);
  *               nb in {2, 4, 8}, or 0: the analysis builds blocks_for's count and half
- *               of it, times a few applies of each and keeps the faster (plan_bytes
- *               with nb = 0 is the room of the largest)
+ *               of it, times a few applies of each and of the matrix's own automatic
+ *               kernel, and keeps the faster copy -- or none (GKOMI_ENOTSUPPORTED, *out =
+ *               NULL) when it does not beat that kernel by 10 % (plan_bytes with nb = 0
+ *               is the room of the largest)
  *   refresh     the matrix's VALUES changed (same pattern): gathers them again -- the
  *               copy knows nothing of writes through Csr::get_values()
  *   spmv        c = A b (alpha = beta = NULL) or c = alpha A b + beta c

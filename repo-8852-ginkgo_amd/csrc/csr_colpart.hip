@@ -21,6 +21,8 @@
 
 #include "sort_scan.hpp"
 
+#include <algorithm>
+
 namespace gkomi {
 namespace {
 
@@ -248,21 +250,52 @@ extern "C" int gkomi_csr_colpart_create_f64_i32(gkomi_stream_t s, int64_t nrows,
     gkomi_csr_colpart built{};
     int err = build_into(s, nrows, ncols, nnz, row_ptrs, col_idxs, vals, candidates[0], base, &built);
     if (err) return err;
-    if (candidates[1] != 0) {
+    if (nb == 0) {
         hipStream_t stream = to_stream(s);
-        device_buffer bvec, cvec;
+        device_buffer bvec, cvec, stat;
         err = bvec.alloc(sizeof(double) * ncols);
         if (!err) err = cvec.alloc(sizeof(double) * nrows);
+        if (!err) err = stat.alloc(sizeof(int32_t));
         if (!err) err = static_cast<int>(hipMemsetAsync(bvec.p, 0, sizeof(double) * ncols, stream));
-        double t_first = 0.0, t_second = 0.0;
+        double t_first = 0.0, t_second = 1e30, t_plain = 0.0;
         if (!err) err = time_apply(stream, &built, bvec.as<double>(), cvec.as<double>(), &t_first);
+        // ... and what the copy has to beat: the automatic kernel on the matrix itself (with its row statistic and the
+        // column-window flag, as the strategy objects would pass them)
+        int32_t longest = 0;
+        if (!err) err = gkomi_csr_max_row_nnz_i32(s, nrows, row_ptrs, stat.as<int32_t>());
+        if (!err) err = static_cast<int>(hipMemcpyAsync(&longest, stat.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        if (!err) err = static_cast<int>(hipStreamSynchronize(stream));
+        {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (!err) err = static_cast<int>(hipEventCreate(&e0));
+            if (!err) err = static_cast<int>(hipEventCreate(&e1));
+            constexpr int warm = 2, reps = 5;
+            for (int i = 0; !err && i < warm + reps; ++i) {
+                if (i == warm) err = static_cast<int>(hipEventRecord(e0, stream));
+                if (!err) {
+                    err = gkomi_csr_spmv_f64_i32(s, nrows, ncols, 1, nnz, row_ptrs, col_idxs, vals, bvec.as<double>(), 1, cvec.as<double>(), 1,
+                                                 nullptr, nullptr, GKOMI_CSR_AUTO | GKOMI_CSR_COLBLOCK, longest);
+                }
+            }
+            if (!err) err = static_cast<int>(hipEventRecord(e1, stream));
+            if (!err) err = static_cast<int>(hipEventSynchronize(e1));
+            float ms = 0.0f;
+            if (!err) err = static_cast<int>(hipEventElapsedTime(&ms, e0, e1));
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            t_plain = 1e3 * ms / reps;
+        }
         gkomi_csr_colpart other{};
-        if (!err) err = build_into(s, nrows, ncols, nnz, row_ptrs, col_idxs, vals, candidates[1], base, &other);
-        if (!err) err = time_apply(stream, &other, bvec.as<double>(), cvec.as<double>(), &t_second);
+        if (!err && candidates[1] != 0) {
+            err = build_into(s, nrows, ncols, nnz, row_ptrs, col_idxs, vals, candidates[1], base, &other);
+            if (!err) err = time_apply(stream, &other, bvec.as<double>(), cvec.as<double>(), &t_second);
+        }
         if (err) return err;
+        // a copy that does not beat the matrix's own kernel by 10 % is not worth its memory and its refresh contract
+        if (std::min(t_first, t_second) > 0.9 * t_plain) return GKOMI_ENOTSUPPORTED;
         if (t_second < t_first) {
             built = other;
-        } else {  // the first one was faster: once more
+        } else if (candidates[1] != 0) {  // the first one was faster: once more
             err = build_into(s, nrows, ncols, nnz, row_ptrs, col_idxs, vals, candidates[0], base, &built);
             if (err) return err;
         }

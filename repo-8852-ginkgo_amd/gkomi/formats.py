@@ -168,8 +168,14 @@ class Csr:
                 nbytes = int(gk.csr_colpart_plan_bytes(self.nrows, self.nnz, ask))
                 plan = torch.empty(nbytes, dtype=U8, device=self.vals.device)
                 h = ctypes.c_void_p(0)
-                gk.csr_colpart_create_f64_i32(_stream(self.vals), self.nrows, self.ncols, self.nnz, self.row_ptrs, self.col_idxs,
-                                              self.vals, ask, plan, nbytes, ctypes.addressof(h))
+                try:
+                    gk.csr_colpart_create_f64_i32(_stream(self.vals), self.nrows, self.ncols, self.nnz, self.row_ptrs, self.col_idxs,
+                                                  self.vals, ask, plan, nbytes, ctypes.addressof(h))
+                except GkomiError as e:   # the analysis timed the copy against the matrix's own kernel: it does not pay
+                    if e.code != ENOTSUPPORTED or not auto:
+                        raise
+                    self._colpart = False
+                    return None
                 self._colpart = (h.value, plan)
         return self._colpart or None
 

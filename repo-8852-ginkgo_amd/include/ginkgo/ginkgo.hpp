@@ -848,7 +848,12 @@ struct csr_abi<int32> {
         if (gkomi_csr_colpart_blocks_for(nrows, ncols, nnz) == 0) return nullptr;
         plan = array<char>(exec, gkomi_csr_colpart_plan_bytes(nrows, nnz, 0));
         gkomi_csr_colpart* h = nullptr;  // (0 blocks: the analysis times two block counts and keeps the faster)
-        GKOMI_CALL(gkomi_csr_colpart_create_f64_i32(nullptr, nrows, ncols, nnz, rp, ci, v, 0, plan.get_data(), plan.get_num_elems(), &h));
+        const int rc = gkomi_csr_colpart_create_f64_i32(nullptr, nrows, ncols, nnz, rp, ci, v, 0, plan.get_data(), plan.get_num_elems(), &h);
+        if (rc == GKOMI_ENOTSUPPORTED) {  // timed against the matrix's own kernel: the copy does not pay
+            plan = array<char>(exec, 0);
+            return nullptr;
+        }
+        GKOMI_CALL(rc);
         return h;
     }
 };

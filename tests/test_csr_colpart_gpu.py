@@ -149,8 +149,31 @@ def test_solver_drivers_take_the_copy_as_system_matrix(gk, solver):
     for name in ("csr", "csrp"):
         M = formats.Csr.from_host(gk, n, n, rp2, ci2, v2, strategy=formats.Csr.CSR_STRATEGIES[name])
         if name == "csrp":
-            assert M.colpart() is not None
+            assert M.colpart(2) is not None    # forced: with 4 MB of b the timed analysis may decline the copy
         out[name] = solvers.solve_op(gk, solver, M, b, max_iters=200, reduction=1e-10, krylov_dim=30)
         assert out[name]["converged"]
     assert abs(out["csr"]["iterations"] - out["csrp"]["iterations"]) <= 1
     assert matgen.rel_err(host(out["csrp"]["x"]), host(out["csr"]["x"])) <= 1e-8
+
+
+def test_analysis_declines_where_the_copy_does_not_pay(gk, oracle):
+    """A scattered pattern with few nonzeros per row (the T2-like randomly permuted 2-D matrix, ~5 per row on 1.2 M
+    columns: blocks_for says 0; forced through a shape that passes blocks_for, the timed analysis decides): whatever it
+    decides, the strategy's apply is the matrix's product"""
+    n, rp, ci, v = matgen.t2_like_permuted(1108)
+    M = formats.Csr.from_host(gk, n, n, rp, ci, v, strategy=formats.Csr.CSR_STRATEGIES["csrp"])
+    rng = np.random.default_rng(4)
+    b = rng.standard_normal((n, 1))
+    got = host(M.apply(dev(b), torch.zeros((n, 1), dtype=torch.float64, device="cuda:0")))
+    expect = _oracle_apply(oracle, n, rp, ci, v, b)
+    if M.colpart() is None:
+        assert np.array_equal(got, expect)       # the automatic kernel: the reference's bits
+    else:
+        assert matgen.rel_err(got, expect) <= 1e-14
+    # 6-7 per row, uniformly random on 600 k columns: passes the shape test; the analysis times it
+    rp, ci, v = matgen.random_rows_csr(600000, 600000, rng.integers(6, 8, size=600000), 21)
+    S = formats.Csr.from_host(gk, 600000, 600000, rp, ci, v, strategy=formats.Csr.CSR_STRATEGIES["csrp"])
+    b = rng.standard_normal((600000, 1))
+    got = host(S.apply(dev(b), torch.zeros((600000, 1), dtype=torch.float64, device="cuda:0")))
+    assert matgen.rel_err(got, _oracle_apply(oracle, 600000, rp, ci, v, b)) <= 1e-14
+    print("copy built for 6-7 per row:", S.colpart() is not None)
