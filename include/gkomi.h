@@ -221,8 +221,10 @@ int gkomi_csr_analyse_gather_i32(gkomi_stream_t stream, int64_t ncols, int64_t n
  * (csrc/csr_colpart.hip; uniform random 16 per row on 1 M columns 172 -> 105 us,
  * power-law rows 126 -> 101 us).  Tolerance parity like load_balance (the groups of a
  * row are added in another association), one right-hand side.
- *   blocks_for  nb for a matrix of this shape, 0 = does not pay (b within one L2, b
- *               beyond 16 MB, fewer than ~6 nonzeros per row)
+ *   blocks_for  nb for a matrix of this shape, 0 = cannot pay (b within one L2, fewer
+ *               than 4 nonzeros per row, slices beyond 6 MiB); slices of ~2 MiB but at
+ *               most half the average row length blocks; whether it DOES pay, create's
+ *               timed analysis decides
  *   create      blocking set-up into `plan` (device memory, gkomi_csr_colpart_plan_bytes
  *               bytes, 16-B aligned, owned by the caller while the handle lives);
  *               nb in {2, 4, 8}, or 0: the analysis builds blocks_for's count and half

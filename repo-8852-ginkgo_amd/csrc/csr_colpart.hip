@@ -122,19 +122,24 @@ struct gkomi_csr_colpart {
     colpart_layout l{};
 };
 
-// Blocks for a matrix of this shape, 0 = this strategy does not pay: b must span more than an L2 keeps (else the
-// plain kernels' gathers hit already) and at most 8 slices of 2 MiB (beyond that nearly every (row, block) group is
-// a single nonzero and the partial sums cost more than the fabric reads they save); rows of at least ~6 nonzeros on
-// average for the same reason.
+// Blocks for a matrix of this shape, 0 = this strategy cannot pay (whether it DOES pay, the timed analysis of
+// gkomi_csr_colpart_create decides): b must span more than an L2 keeps (else the plain kernels' gathers hit already);
+// slices of ~2 MiB, but no more blocks than half the average row length -- a (row, block) group of one nonzero costs
+// a row pointer and a partial sum of its own (3 M rows of 8 on 24 MB of b: 4 blocks 251 us, 8 blocks 472, plain
+// kernel 385) -- and slices of at most 6 MiB (tools/colpart_big_probe.py: 4 M rows of 16 on 32 MB of b, 8 blocks of
+// 3.8 MiB 561 us vs 1058 plain; 4 blocks of 7.6 MiB 711).
 extern "C" int64_t gkomi_csr_colpart_blocks_for(int64_t nrows, int64_t ncols, int64_t nnz)
 {
     if (nrows <= 0 || ncols <= 0 || nnz <= 0) return 0;
-    const int64_t slice = int64_t{2} << 20;
+    const int64_t mib = int64_t{1} << 20;
     const int64_t b_bytes = 8 * ncols;
-    if (b_bytes <= (int64_t{3} << 20) || b_bytes > 8 * slice) return 0;
-    if (nnz < 6 * nrows || nnz < (int64_t{1} << 20)) return 0;
-    int64_t nb = 2;
-    while (nb < 8 && b_bytes > nb * slice) nb *= 2;
+    if (b_bytes <= 3 * mib || nnz < 4 * nrows || nnz < mib) return 0;
+    int64_t by_density = 2;
+    while (by_density < 8 && 4 * by_density * nrows <= nnz) by_density *= 2;  // at most half the average row length
+    int64_t by_slice = 2;
+    while (by_slice < 8 && b_bytes > by_slice * 2 * mib) by_slice *= 2;
+    const int64_t nb = std::min(by_density, by_slice);
+    if (b_bytes > nb * 6 * mib) return 0;
     if (nb * nrows > INT32_MAX - 4096) return 0;
     return nb;
 }

@@ -80,8 +80,11 @@ def test_policy_and_refresh(gk, oracle):
     assert gk.csr_colpart_blocks_for(1000000, 1000000, 16000000) == 4
     assert gk.csr_colpart_blocks_for(1000000, 300000, 16000000) == 0       # b within an L2
     assert gk.csr_colpart_blocks_for(1000000, 1500000, 16000000) == 8
-    assert gk.csr_colpart_blocks_for(4000000, 4000000, 64000000) == 0      # b beyond 16 MB
-    assert gk.csr_colpart_blocks_for(1000000, 1000000, 5000000) == 0       # 5 nonzeros per row
+    assert gk.csr_colpart_blocks_for(4000000, 4000000, 64000000) == 8      # 32 MB of b: 8 slices of 4 MB
+    assert gk.csr_colpart_blocks_for(9000000, 9000000, 144000000) == 0     # 72 MB of b: slices beyond 6 MiB
+    assert gk.csr_colpart_blocks_for(3000000, 3000000, 24000000) == 4      # 8 per row: no more than 4 blocks
+    assert gk.csr_colpart_blocks_for(1000000, 1000000, 5000000) == 2       # 5 per row: 2 blocks (the timing decides)
+    assert gk.csr_colpart_blocks_for(1000000, 1000000, 3000000) == 0       # 3 per row
     n = ncols = 600000
     rng = np.random.default_rng(1)
     rp, ci, v = matgen.random_rows_csr(n, ncols, rng.integers(6, 12, size=n), 2)
