@@ -222,8 +222,8 @@ int gkomi_csr_analyse_gather_i32(gkomi_stream_t stream, int64_t ncols, int64_t n
  * power-law rows 126 -> 101 us).  Tolerance parity like load_balance (the groups of a
  * row are added in another association), one right-hand side.
  *   blocks_for  nb for a matrix of this shape, 0 = cannot pay (b within one L2, fewer
- *               than 4 nonzeros per row, slices beyond 6 MiB); slices of ~2 MiB but at
- *               most half the average row length blocks; whether it DOES pay, create's
+ *               than 4 nonzeros per row, slices beyond 6 MiB); slices of ~2 MiB but no
+ *               more blocks than leave 1.25 nonzeros per (row, block) group; whether it DOES pay, create's
  *               timed analysis decides
  *   create      blocking set-up into `plan` (device memory, gkomi_csr_colpart_plan_bytes
  *               bytes, 16-B aligned, owned by the caller while the handle lives);

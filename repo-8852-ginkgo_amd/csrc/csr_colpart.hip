@@ -124,9 +124,9 @@ struct gkomi_csr_colpart {
 
 // Blocks for a matrix of this shape, 0 = this strategy cannot pay (whether it DOES pay, the timed analysis of
 // gkomi_csr_colpart_create decides): b must span more than an L2 keeps (else the plain kernels' gathers hit already);
-// slices of ~2 MiB, but no more blocks than half the average row length -- a (row, block) group of one nonzero costs
-// a row pointer and a partial sum of its own (3 M rows of 8 on 24 MB of b: 4 blocks 251 us, 8 blocks 472, plain
-// kernel 385) -- and slices of at most 6 MiB (tools/colpart_big_probe.py: 4 M rows of 16 on 32 MB of b, 8 blocks of
+// slices of ~2 MiB, but no more blocks than leave 1.25 nonzeros per (row, block) group on average -- a group of one
+// nonzero costs a row pointer and a partial sum of its own (3 M rows of 8 on 24 MB of b: 4 blocks 251 us, 8 blocks 472,
+// plain kernel 385; the T2-like permuted matrix of 5 per row: 4 blocks 54.5 us, 2 blocks 58, plain 67) -- and slices of at most 6 MiB (tools/colpart_big_probe.py: 4 M rows of 16 on 32 MB of b, 8 blocks of
 // 3.8 MiB 561 us vs 1058 plain; 4 blocks of 7.6 MiB 711).
 extern "C" int64_t gkomi_csr_colpart_blocks_for(int64_t nrows, int64_t ncols, int64_t nnz)
 {
@@ -135,7 +135,7 @@ extern "C" int64_t gkomi_csr_colpart_blocks_for(int64_t nrows, int64_t ncols, in
     const int64_t b_bytes = 8 * ncols;
     if (b_bytes <= 3 * mib || nnz < 4 * nrows || nnz < mib) return 0;
     int64_t by_density = 2;
-    while (by_density < 8 && 4 * by_density * nrows <= nnz) by_density *= 2;  // at most half the average row length
+    while (by_density < 8 && 5 * by_density * nrows <= 2 * nnz) by_density *= 2;  // groups of >= 1.25 nonzeros on average
     int64_t by_slice = 2;
     while (by_slice < 8 && b_bytes > by_slice * 2 * mib) by_slice *= 2;
     const int64_t nb = std::min(by_density, by_slice);

@@ -83,7 +83,8 @@ def test_policy_and_refresh(gk, oracle):
     assert gk.csr_colpart_blocks_for(4000000, 4000000, 64000000) == 8      # 32 MB of b: 8 slices of 4 MB
     assert gk.csr_colpart_blocks_for(9000000, 9000000, 144000000) == 0     # 72 MB of b: slices beyond 6 MiB
     assert gk.csr_colpart_blocks_for(3000000, 3000000, 24000000) == 4      # 8 per row: no more than 4 blocks
-    assert gk.csr_colpart_blocks_for(1000000, 1000000, 5000000) == 2       # 5 per row: 2 blocks (the timing decides)
+    assert gk.csr_colpart_blocks_for(1000000, 1000000, 5000000) == 4       # 5 per row: groups of 1.25 (the timing decides)
+    assert gk.csr_colpart_blocks_for(1000000, 1000000, 4000000) == 2       # 4 per row
     assert gk.csr_colpart_blocks_for(1000000, 1000000, 3000000) == 0       # 3 per row
     n = ncols = 600000
     rng = np.random.default_rng(1)
