@@ -234,7 +234,8 @@ int gkomi_csr_analyse_gather_i32(gkomi_stream_t stream, int64_t ncols, int64_t n
  *               is the room of the largest)
  *   refresh     the matrix's VALUES changed (same pattern): gathers them again -- the
  *               copy knows nothing of writes through Csr::get_values()
- *   spmv        c = A b (alpha = beta = NULL) or c = alpha A b + beta c
+ *   spmv        c = A b (alpha = beta = NULL) or c = alpha A b + beta c; the partial sums
+ *               live in the plan: a handle applies on one stream at a time
  *   info        out[4] = { nb, virtual rows, longest virtual row, srow tile } */
 typedef struct gkomi_csr_colpart gkomi_csr_colpart;
 int64_t gkomi_csr_colpart_blocks_for(int64_t nrows, int64_t ncols, int64_t nnz);
