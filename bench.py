@@ -36,6 +36,7 @@ benchmark/utils/general.hpp:96-117; at least 3, at most 400 regions); best and a
 statistics are reported next to it.
 """
 import argparse
+import ctypes
 import json
 import os
 import statistics
@@ -88,6 +89,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--p3-grid", type=int, default=256, help="grid of the 3-D problem (256 = BASELINE config 5)")
     ap.add_argument("--no-config3", action="store_true")
+    ap.add_argument("--no-irregular", action="store_true",
+                    help="skip the scattered-column classes (uniform random / power-law rows, 1 M rows: SuiteSparse's graph-like class)")
     ap.add_argument("--min-region-seconds", type=float, default=0.05,
                     help="floor on the total length of the timed regions of K steps each (more regions, never more steps)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -761,6 +764,46 @@ def main():
                 out["config3"] = c3
             except Exception as e:  # noqa: BLE001 - an extra entry, never allowed to take the headline down
                 out["config3"] = {"error": repr(e)}
+
+        if not args.no_irregular:
+            # north_star names SuiteSparse; its graph-like matrices are this class (no files offline: stand-ins of
+            # tools/spmv_classes.json): the automatic CSR strategy and the opt-in column-partitioned copy (csrp)
+            try:
+                progress("scattered-column classes (uniform random, power-law rows)")
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import benchmark_spmv as bs
+                irr = {"note": "1 M x 1 M, same matrix every step (benchmark/spmv methodology); bytes = 12 nnz + 4 (n + 1) + 16 n; "
+                               "csrp = gkomi_csr_colpart_* (opt-in analysis-based strategy, tolerance parity)"}
+                for key, case in (("uniform_random_16_per_row", {"random": "uniform", "rows": 1000000, "nnz_per_row": 16}),
+                                  ("powerlaw_rows", {"random": "powerlaw", "rows": 1000000, "nnz_per_row": 8})):
+                    Mi = bs.random_matrix(gk, case, 42)
+                    bi = dev(np.cos(0.001 * np.arange(Mi.ncols)).reshape(-1, 1))
+                    yi = torch.zeros((Mi.nrows, 1), dtype=torch.float64, device=device)
+                    ent = {"nnz": Mi.nnz}
+                    ref_y = None
+                    for fmt in ("csr", "csrp"):
+                        Mf = Mi.to(fmt)
+                        Mf.apply(bi, yi)
+                        if fmt == "csr":
+                            ref_y = yi.clone()
+                        else:
+                            ent["csrp_blocks"] = None
+                            if Mf.colpart() is not None:
+                                info = (ctypes.c_int64 * 4)()
+                                gk.csr_colpart_info(Mf._colpart[0], ctypes.addressof(info))
+                                ent["csrp_blocks"] = int(info[0])
+                            ent["csrp_max_rel_diff_vs_csr"] = float(((yi - ref_y).abs().max() / ref_y.abs().max()).item())
+                        (_, evi), _ = timed_region(lambda i: Mf.apply(bi, yi), 40)
+                        byts = 12 * Mi.nnz + 4 * (Mi.nrows + 1) + 16 * Mi.nrows
+                        ent[fmt] = {"us": round(evi / 40 * 1e6, 1), "gbs": round(byts * 40 / evi / 1e9, 1),
+                                    "frac_of_8tbs": round(byts * 40 / evi / 1e9 / HBM_PEAK_GBS, 4)}
+                        del Mf
+                    irr[key] = ent
+                    del Mi, bi, yi, ref_y
+                    torch.cuda.empty_cache()
+                out["irregular"] = irr
+            except Exception as e:  # noqa: BLE001 - an extra entry, never allowed to take the headline down
+                out["irregular"] = {"error": repr(e)}
 
         if not args.no_cpu_baseline:
             progress("CPU baseline (3 child processes)")
