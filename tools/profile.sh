@@ -9,7 +9,9 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-p3 --no-config3 --steps 200 --warmup 20"
+# (the legs that run the SAME kernel template on other matrices -- P3, config 3, the scattered-column classes -- are left out:
+# per-kernel means would mix them with the headline matrix)
+ARGS="--no-cpu-baseline --no-p3 --no-config3 --no-irregular --steps 200 --warmup 20"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS --no-cg --no-config4 > $OUT/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $ARGS --no-cg --no-config4 > $OUT/pmc_write.log 2>&1 || exit 1
