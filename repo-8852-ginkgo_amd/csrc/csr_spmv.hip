@@ -21,6 +21,8 @@
 // from L2) + 8 = 80 B.
 #include "common.hpp"
 
+#include <type_traits>
+
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include <atomic>
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(Block) void csr_split_kernel(
     // the rows that start in this tile (scalar loads, back long before the
     // streaming loads below)
     // (the top bit of every srow entry: the matrix is in sparse-rows mode, below)
-    constexpr I srow_mark = static_cast<I>(I{1} << (8 * sizeof(I) - 1));
+    constexpr I srow_mark = static_cast<I>(static_cast<typename std::make_unsigned<I>::type>(1) << (8 * sizeof(I) - 1));
     const I srow_first = srow[logical];
     const I row_begin = srow_first & ~srow_mark;
     const I row_end = srow[logical + 1] & ~srow_mark;
@@ -596,7 +598,7 @@ template <typename I>
 __global__ __launch_bounds__(256) void csr_srow_mark_kernel(int64_t ntiles, I* __restrict__ srow)
 {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (t <= ntiles && srow[ntiles + 1] > split_rows_limit) srow[t] |= static_cast<I>(I{1} << (8 * sizeof(I) - 1));
+    if (t <= ntiles && srow[ntiles + 1] > split_rows_limit) srow[t] |= static_cast<I>(static_cast<typename std::make_unsigned<I>::type>(1) << (8 * sizeof(I) - 1));
 }
 
 // ---- several right-hand sides at once ---------------------------------------
