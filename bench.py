@@ -789,9 +789,10 @@ def main():
                         else:
                             ent["csrp_blocks"] = None
                             if Mf.colpart() is not None:
-                                info = (ctypes.c_int64 * 4)()
+                                info = (ctypes.c_int64 * 8)()
                                 gk.csr_colpart_info(Mf._colpart[0], ctypes.addressof(info))
                                 ent["csrp_blocks"] = int(info[0])
+                                ent["csrp_virtual_matrix_kernel"] = {0: "automatic (nonzero-split / load-balanced)", 1: "row-cut stream"}.get(int(info[4]), int(info[4]))
                             ent["csrp_max_rel_diff_vs_csr"] = float(((yi - ref_y).abs().max() / ref_y.abs().max()).item())
                         (_, evi), _ = timed_region(lambda i: Mf.apply(bi, yi), 40)
                         byts = 12 * Mi.nnz + 4 * (Mi.nrows + 1) + 16 * Mi.nrows

@@ -218,8 +218,8 @@ int gkomi_csr_analyse_gather_i32(gkomi_stream_t stream, int64_t ncols, int64_t n
  * k of nb, in their order), so that the workgroups resident at any moment gather from
  * ONE <= 2 MiB slice of b (it stays in every XCD's L2); the library's CSR kernels run on
  * the virtual matrix and a small kernel adds each row's nb partial sums in block order
- * (csrc/csr_colpart.hip; uniform random 16 per row on 1 M columns 172 -> 105 us,
- * power-law rows 126 -> 101 us).  Tolerance parity like load_balance (the groups of a
+ * (csrc/csr_colpart.hip; uniform random 16 per row on 1 M columns 172 -> 89 us,
+ * power-law rows 126 -> 100 us).  Tolerance parity like load_balance (the groups of a
  * row are added in another association), one right-hand side.
  *   blocks_for  nb for a matrix of this shape, 0 = cannot pay (b within one L2, fewer
  *               than 4 nonzeros per row, slices beyond 6 MiB); slices of ~2 MiB but no
@@ -236,7 +236,8 @@ int gkomi_csr_analyse_gather_i32(gkomi_stream_t stream, int64_t ncols, int64_t n
  *               copy knows nothing of writes through Csr::get_values()
  *   spmv        c = A b (alpha = beta = NULL) or c = alpha A b + beta c; the partial sums
  *               live in the plan: a handle applies on one stream at a time
- *   info        out[4] = { nb, virtual rows, longest virtual row, srow tile } */
+ *   info        out[5] = { nb, virtual rows, longest virtual row, srow tile, strategy word
+ *               of the kernel the analysis kept for the virtual matrix } */
 typedef struct gkomi_csr_colpart gkomi_csr_colpart;
 int64_t gkomi_csr_colpart_blocks_for(int64_t nrows, int64_t ncols, int64_t nnz);
 size_t gkomi_csr_colpart_plan_bytes(int64_t nrows, int64_t nnz, int64_t nb);

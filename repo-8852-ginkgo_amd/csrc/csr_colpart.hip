@@ -11,7 +11,7 @@
 // on the virtual matrix (nonzero-split / load-balanced, csr_spmv.hip; runs of empty virtual rows: its sparse-rows
 // mode), into nb * n partial sums; a second small kernel adds the nb partial sums of every row in block order and
 // applies alpha / beta.  Measured (tools/colpart_probe.py, profiles/r04_colpart_probe.md): uniform random 16 per row
-// on 1 M columns 172 -> 105 us, power-law rows 126 -> 101 us; bound by L2 requests then (one per gather).
+// on 1 M columns 172 -> 89 us, power-law rows 126 -> 100 us; bound by L2 requests then (one per gather).
 //
 // Results: every (row, block) group is added left to right, the groups of a row in block order -- a different
 // association than the reference's one left-to-right sum: tolerance parity like `load_balance`, not bit-exactness.
@@ -118,6 +118,7 @@ using namespace gkomi;
 struct gkomi_csr_colpart {
     uint32_t magic = colpart_magic;
     int64_t nrows = 0, ncols = 0, nnz = 0, nb = 0, tile = 0, max_row_nnz = -1;
+    int strategy = GKOMI_CSR_AUTO;  // kernel of the virtual matrix: automatic, or the row-cut stream kernel where the analysis found it faster
     char* plan = nullptr;
     colpart_layout l{};
 };
@@ -228,6 +229,26 @@ int time_apply(hipStream_t stream, const gkomi_csr_colpart* h, const double* b, 
     return err;
 }
 
+// which kernel for the virtual matrix: the automatic choice (nonzero-split for short rows, load-balanced with long ones)
+// or, for short virtual rows, the row-cut stream kernel -- virtual rows of ~4 (uniform random 16 per row in 4 blocks):
+// 82 vs 106 us; of ~8 (2 blocks): 105 vs 100 (tools/colpart_kernel_probe.py).  Timed; *us = the faster one's time.
+int choose_kernel(hipStream_t stream, gkomi_csr_colpart* h, const double* b, double* c, double* us)
+{
+    h->strategy = GKOMI_CSR_AUTO;
+    int err = time_apply(stream, h, b, c, us);
+    if (err || h->max_row_nnz > 256) return err;
+    double t_stream = 0.0;
+    h->strategy = GKOMI_CSR_STREAM;
+    err = time_apply(stream, h, b, c, &t_stream);
+    if (err) return err;
+    if (t_stream < *us) {
+        *us = t_stream;
+    } else {
+        h->strategy = GKOMI_CSR_AUTO;
+    }
+    return GKOMI_SUCCESS;
+}
+
 }  // namespace
 
 // Blocking (set-up): sorts the nonzeros by virtual row, builds the virtual CSR, its srow and row statistic in `plan`
@@ -255,15 +276,16 @@ extern "C" int gkomi_csr_colpart_create_f64_i32(gkomi_stream_t s, int64_t nrows,
     gkomi_csr_colpart built{};
     int err = build_into(s, nrows, ncols, nnz, row_ptrs, col_idxs, vals, candidates[0], base, &built);
     if (err) return err;
+    hipStream_t stream = to_stream(s);
+    device_buffer bvec, cvec, stat;
+    err = bvec.alloc(sizeof(double) * ncols);
+    if (!err) err = cvec.alloc(sizeof(double) * nrows);
+    if (!err) err = stat.alloc(sizeof(int32_t));
+    if (!err) err = static_cast<int>(hipMemsetAsync(bvec.p, 0, sizeof(double) * ncols, stream));
+    double t_first = 0.0, t_second = 1e30, t_plain = 0.0;
+    if (!err) err = choose_kernel(stream, &built, bvec.as<double>(), cvec.as<double>(), &t_first);
+    if (err) return err;
     if (nb == 0) {
-        hipStream_t stream = to_stream(s);
-        device_buffer bvec, cvec, stat;
-        err = bvec.alloc(sizeof(double) * ncols);
-        if (!err) err = cvec.alloc(sizeof(double) * nrows);
-        if (!err) err = stat.alloc(sizeof(int32_t));
-        if (!err) err = static_cast<int>(hipMemsetAsync(bvec.p, 0, sizeof(double) * ncols, stream));
-        double t_first = 0.0, t_second = 1e30, t_plain = 0.0;
-        if (!err) err = time_apply(stream, &built, bvec.as<double>(), cvec.as<double>(), &t_first);
         // ... and what the copy has to beat: the automatic kernel on the matrix itself (with its row statistic and the
         // column-window flag, as the strategy objects would pass them)
         int32_t longest = 0;
@@ -293,16 +315,18 @@ extern "C" int gkomi_csr_colpart_create_f64_i32(gkomi_stream_t s, int64_t nrows,
         gkomi_csr_colpart other{};
         if (!err && candidates[1] != 0) {
             err = build_into(s, nrows, ncols, nnz, row_ptrs, col_idxs, vals, candidates[1], base, &other);
-            if (!err) err = time_apply(stream, &other, bvec.as<double>(), cvec.as<double>(), &t_second);
+            if (!err) err = choose_kernel(stream, &other, bvec.as<double>(), cvec.as<double>(), &t_second);
         }
         if (err) return err;
         // a copy that does not beat the matrix's own kernel by 10 % is not worth its memory and its refresh contract
         if (std::min(t_first, t_second) > 0.9 * t_plain) return GKOMI_ENOTSUPPORTED;
         if (t_second < t_first) {
             built = other;
-        } else if (candidates[1] != 0) {  // the first one was faster: once more
+        } else if (candidates[1] != 0) {  // the first one was faster: once more (its kernel choice stands)
+            const int kept = built.strategy;
             err = build_into(s, nrows, ncols, nnz, row_ptrs, col_idxs, vals, candidates[0], base, &built);
             if (err) return err;
+            built.strategy = kept;
         }
     }
     *out = new gkomi_csr_colpart(built);
@@ -329,7 +353,7 @@ extern "C" int gkomi_csr_colpart_spmv_f64(gkomi_stream_t s, const gkomi_csr_colp
     double* partial = reinterpret_cast<double*>(h->plan + h->l.partial);
     int err = gkomi_csr_spmv_srow_f64_i32(s, h->nb * h->nrows, h->ncols, 1, h->nnz, reinterpret_cast<const int32_t*>(base + h->l.row_ptrs),
                                           reinterpret_cast<const int32_t*>(base + h->l.cols), reinterpret_cast<const double*>(base + h->l.vals), b,
-                                          b_stride, partial, 1, nullptr, nullptr, GKOMI_CSR_AUTO, h->max_row_nnz,
+                                          b_stride, partial, 1, nullptr, nullptr, h->strategy, h->max_row_nnz,
                                           reinterpret_cast<const int32_t*>(base + h->l.srow), h->tile);
     if (err) return err;
     const dim3 grid(grid_for(h->nrows, block));
@@ -366,6 +390,6 @@ extern "C" int gkomi_csr_colpart_matrix_apply_cb(void* ctx, gkomi_stream_t s, in
 extern "C" int gkomi_csr_colpart_info(const gkomi_csr_colpart* h, int64_t* out)
 {
     if (h == nullptr || h->magic != colpart_magic || out == nullptr) return GKOMI_EINVAL;
-    out[0] = h->nb; out[1] = h->nb * h->nrows; out[2] = h->max_row_nnz; out[3] = h->tile;
+    out[0] = h->nb; out[1] = h->nb * h->nrows; out[2] = h->max_row_nnz; out[3] = h->tile; out[4] = h->strategy;
     return GKOMI_SUCCESS;
 }

@@ -48,7 +48,7 @@ def test_partitioned_apply_matches_oracle(gk, oracle, kind, nb, advanced):
     c0 = rng.standard_normal((n, 1))
     M = formats.Csr.from_host(gk, n, ncols, rp, ci, v, strategy=formats.Csr.CSR_STRATEGIES["csrp"])
     assert M.colpart(nb) is not None
-    info = (ctypes.c_int64 * 4)()
+    info = (ctypes.c_int64 * 8)()
     gk.csr_colpart_info(M._colpart[0], ctypes.addressof(info))
     assert info[0] == nb and info[1] == nb * n
     if advanced:
@@ -91,7 +91,7 @@ def test_policy_and_refresh(gk, oracle):
     rp, ci, v = matgen.random_rows_csr(n, ncols, rng.integers(6, 12, size=n), 2)
     M = formats.Csr.from_host(gk, n, ncols, rp, ci, v, strategy=formats.Csr.CSR_STRATEGIES["csrp"])
     assert M.colpart() is not None and gk.csr_colpart_blocks_for(n, ncols, M.nnz) == 4
-    info = (ctypes.c_int64 * 4)()
+    info = (ctypes.c_int64 * 8)()
     gk.csr_colpart_info(M._colpart[0], ctypes.addressof(info))
     assert info[0] in (2, 4) and info[1] == info[0] * n     # the analysis timed both and kept one
     b2 = rng.standard_normal((ncols, 3))

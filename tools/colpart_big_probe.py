@@ -28,7 +28,7 @@ for rows, per in ((2000000, 16), (4000000, 16), (3000000, 8)):
         P = formats.Csr(gk, M.nrows, M.ncols, M.row_ptrs, M.col_idxs, M.vals, strategy=formats.Csr.CSR_STRATEGIES["csrp"])
         if P.colpart(nb) is None:
             print("   nb", nb, "not built"); continue
-        info = (ctypes.c_int64 * 4)()
+        info = (ctypes.c_int64 * 8)()
         gk.csr_colpart_info(P._colpart[0], ctypes.addressof(info))
         t1 = timed(lambda: P.apply(b, y))
         print(f"   {'analysis chose' if nb is None else 'forced'} nb {info[0]} (slice {8 * n / info[0] / 2**20:.1f} MiB): {t1:8.1f} us = {alg / t1 / 1e6:.2f} TB/s", flush=True)

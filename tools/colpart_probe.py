@@ -38,22 +38,27 @@ def partition(M, nb):
     return formats.Csr(gk, nb * n, nc, vrp, M.col_idxs[order].contiguous(), M.vals[order].contiguous())
 
 
-for kind in (sys.argv[1:] or ["uniform", "powerlaw", "local"]):
-    case = {"random": kind, "rows": 1000000, "nnz_per_row": 8 if kind == "powerlaw" else 16, "bandwidth": 2000}
-    M = bs.random_matrix(gk, case, 7)
-    n = M.nrows
-    b = torch.from_numpy(np.cos(0.001 * np.arange(n))).cuda().reshape(n, 1)
-    y = torch.zeros(n, 1, dtype=torch.float64, device="cuda")
-    t0 = timed(lambda: M.apply(b, y))
-    alg = 12 * M.nnz + 4 * (n + 1) + 16 * n
-    print(f"{kind}: n {n}, nnz {M.nnz}, library apply {t0:7.1f} us = {alg / t0 / 1e6:.2f} TB/s", flush=True)
-    for nb in (2, 4, 8, 16):
-        V = partition(M, nb)
-        part = torch.zeros(nb * n, 1, dtype=torch.float64, device="cuda")
-        t1 = timed(lambda: V.apply(b, part))
-        out = torch.empty(n, dtype=torch.float64, device="cuda")
-        t2 = timed(lambda: torch.sum(part.view(nb, n), 0, out=out))
-        err = float((out - y[:, 0]).abs().max() / y.abs().max())
-        print(f"   nb {nb:2d} (slice {8 * n / nb / 2**20:.1f} MiB): virtual SpMV {t1:7.1f} us + reduce {t2:5.1f} us = {t1 + t2:7.1f} us "
-              f"-> {alg / (t1 + t2) / 1e6:.2f} TB/s on the ORIGINAL matrix's bytes; max rel diff {err:.1e}", flush=True)
-        del V, part
+def main():
+  for kind in (sys.argv[1:] or ["uniform", "powerlaw", "local"]):
+      case = {"random": kind, "rows": 1000000, "nnz_per_row": 8 if kind == "powerlaw" else 16, "bandwidth": 2000}
+      M = bs.random_matrix(gk, case, 7)
+      n = M.nrows
+      b = torch.from_numpy(np.cos(0.001 * np.arange(n))).cuda().reshape(n, 1)
+      y = torch.zeros(n, 1, dtype=torch.float64, device="cuda")
+      t0 = timed(lambda: M.apply(b, y))
+      alg = 12 * M.nnz + 4 * (n + 1) + 16 * n
+      print(f"{kind}: n {n}, nnz {M.nnz}, library apply {t0:7.1f} us = {alg / t0 / 1e6:.2f} TB/s", flush=True)
+      for nb in (2, 4, 8, 16):
+          V = partition(M, nb)
+          part = torch.zeros(nb * n, 1, dtype=torch.float64, device="cuda")
+          t1 = timed(lambda: V.apply(b, part))
+          out = torch.empty(n, dtype=torch.float64, device="cuda")
+          t2 = timed(lambda: torch.sum(part.view(nb, n), 0, out=out))
+          err = float((out - y[:, 0]).abs().max() / y.abs().max())
+          print(f"   nb {nb:2d} (slice {8 * n / nb / 2**20:.1f} MiB): virtual SpMV {t1:7.1f} us + reduce {t2:5.1f} us = {t1 + t2:7.1f} us "
+                f"-> {alg / (t1 + t2) / 1e6:.2f} TB/s on the ORIGINAL matrix's bytes; max rel diff {err:.1e}", flush=True)
+          del V, part
+
+
+if __name__ == "__main__":
+    main()

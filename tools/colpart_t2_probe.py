@@ -24,6 +24,6 @@ for nb in (None, 2, 4):
     if P.colpart(nb) is None:
         print("   ", "analysis" if nb is None else f"nb {nb}", ": no copy (blocks_for", gk.csr_colpart_blocks_for(n, n, M.nnz), ")")
         continue
-    info = (ctypes.c_int64 * 4)()
+    info = (ctypes.c_int64 * 8)()
     gk.csr_colpart_info(P._colpart[0], ctypes.addressof(info))
     print(f"    {'analysis kept' if nb is None else 'forced'} nb {info[0]}: {timed(lambda: P.apply(b, y)):.1f} us")
