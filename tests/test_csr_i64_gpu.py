@@ -183,3 +183,28 @@ def test_more_than_2_31_nonzeros(gk):
     # interior in k: 6k - (k-1) - (k+1) - 4k = 0 wherever the four (i, j) neighbours exist
     assert bool(torch.all(y[1:-1, 1:-1, 1:-1] == 0.0))
     assert float(y[5, 5, 0]) == -1.0 and float(y[5, 5, g - 1]) == 6.0 * (g - 1) - (g - 2) - 4.0 * (g - 1)
+
+
+@pytest.mark.parametrize("advanced", [False, True], ids=["simple", "advanced"])
+def test_long_runs_of_empty_rows_int64(gk, oracle, advanced):
+    """the sparse-rows mode of the nonzero-split kernel (rows handed out by index when a tile owns more than 2048 of
+    them) in the int64 instantiation: the mark sits in bit 63 of the srow entries; same bits as the oracle"""
+    rng = np.random.default_rng(8)
+    nrows, ncols = 300007, 7001
+    counts = rng.integers(0, 6, size=nrows)
+    counts[4000:200000] = 0
+    counts[250000:251000] = 1
+    counts[290000:] = 0
+    rp, ci, v = matgen.random_rows_csr(nrows, ncols, counts, 9)
+    b = rng.standard_normal((ncols, 1))
+    c0 = rng.standard_normal((nrows, 1))
+    A = formats.Csr64.from_host(gk, nrows, ncols, rp, ci, v, split=True)
+    srow = host(A.srow())
+    assert srow[-1] > 2048 and np.all(srow[:-1] < 0)       # marked
+    if advanced:
+        expect = oracle_apply(oracle, nrows, rp.astype(np.int32), ci.astype(np.int32), v, b, c0, 1.5, -0.25)
+        got = host(A.apply(dev(b), dev(c0), alpha=1.5, beta=-0.25))
+    else:
+        expect = oracle_apply(oracle, nrows, rp.astype(np.int32), ci.astype(np.int32), v, b)
+        got = host(A.apply(dev(b), torch.full((nrows, 1), float("nan"), dtype=torch.float64, device="cuda:0")))
+    assert np.array_equal(got, expect)
