@@ -1485,7 +1485,9 @@ extern "C" int gkomi_csr_spmv_srow_f64_i32(
         // (GKOMI_CSR_COLBLOCK changes nothing here: matrices of short rows keep the kernels that give the
         // reference's bits; the flag adds column windows to the load-balanced kernel where that one is chosen
         // anyway, or with an explicit GKOMI_CSR_BALANCED)
-        if (split_ok && r == 1 && max_row_nnz_hint <= split_max_over + 1) {
+        // (a matrix with fewer nonzeros than rows -- the non-local block of a distributed matrix -- has too few tiles
+        // for its rows: 86 workgroups for 2 M rows; the row-cut kernel's grid follows the rows)
+        if (split_ok && r == 1 && max_row_nnz_hint <= split_max_over + 1 && nnz >= nrows) {
             kind = GKOMI_CSR_SPLIT;
         } else if (max_row_nnz_hint < 0 || max_row_nnz_hint <= 256) {
             kind = GKOMI_CSR_STREAM;
@@ -1777,7 +1779,7 @@ extern "C" int gkomi_csr_spmv_srow_f64_i64(gkomi_stream_t stream_, int64_t nrows
     const bool resident = 16 * nnz + 24 * nrows < (int64_t{288} << 20);
     const bool nt = !resident || (strategy & GKOMI_CSR_STREAMING) != 0;
     const int r = static_cast<int>(nrhs);
-    if (split_ok && (kind == GKOMI_CSR_SPLIT || (kind == GKOMI_CSR_AUTO && r == 1))) {
+    if (split_ok && (kind == GKOMI_CSR_SPLIT || (kind == GKOMI_CSR_AUTO && r == 1 && nnz >= nrows))) {  // (fewer nonzeros than rows: by rows)
         int over = split_max_over;
         if (max_row_nnz_hint >= 1 && max_row_nnz_hint <= split_max_over) {
             over = static_cast<int>(max_row_nnz_hint / 2 * 2);

@@ -139,6 +139,39 @@ def test_long_runs_of_empty_rows(gk, oracle, tile, advanced):
     assert e0.elapsed_time(e1) / 10 < 0.2, "ms per apply"
 
 
+def test_non_local_block_of_a_distributed_matrix(gk, oracle):
+    """x = 1 * A_nonlocal * halo + 1 * x as core/distributed/matrix.cpp:330-331 asks it of csr::advanced_spmv: 2 M rows,
+    nonzeros only in the first and last 65 536 of them.  Fewer nonzeros than rows: the automatic strategy takes the
+    row-cut kernel (its grid follows the rows); the explicit split strategy is correct too (sparse-rows mode)."""
+    n, halo = 2097152, 131072
+    counts = np.zeros(n, np.int64)
+    counts[:65536] = 1
+    counts[-65536:] = 1
+    rp = np.zeros(n + 1, np.int32)
+    np.cumsum(counts, out=rp[1:])
+    ci = np.arange(halo, dtype=np.int32)
+    rng = np.random.default_rng(2)
+    v = rng.standard_normal(halo)
+    b = rng.standard_normal((halo, 1))
+    c0 = rng.standard_normal((n, 1))
+    A = DevCsr(n, halo, rp, ci, v)
+    srow, tile = make_srow(gk, A)
+    expect = _oracle_apply(oracle, n, rp, ci, v, b, c0, 1.0, 1.0)
+    for strategy in (0, SPLIT):
+        got = host(csr_apply_srow(gk, A, dev(b), srow, tile, dev(c0), 1.0, 1.0, strategy))
+        assert np.array_equal(got, expect), strategy
+    out = dev(c0)
+    db = dev(b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    csr_apply_srow(gk, A, db, srow, tile, out, 1.0, 1.0, 0)
+    e0.record()
+    for _ in range(10):
+        csr_apply_srow(gk, A, db, srow, tile, out, 1.0, 1.0, 0)
+    e1.record()
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(e1) / 10 < 0.1, "ms per apply of the automatic strategy"
+
+
 @pytest.mark.parametrize("nnz_target", [2, 3, 1535, 1536, 1537, 3072, 2 * 1536 + 1])
 def test_tiny_odd_and_exact_multiple_nnz(gk, oracle, nnz_target):
     # one entry per row except a few longer ones, nnz hits the tile size exactly / +-1
