@@ -198,7 +198,8 @@ def test_long_runs_of_empty_rows_int64(gk, oracle, advanced):
     rp, ci, v = matgen.random_rows_csr(nrows, ncols, counts, 9)
     b = rng.standard_normal((ncols, 1))
     c0 = rng.standard_normal((nrows, 1))
-    A = formats.Csr64.from_host(gk, nrows, ncols, rp, ci, v, split=True)
+    # (explicit nonzero-split strategy: with fewer nonzeros than rows the automatic one goes by rows)
+    A = formats.Csr64.from_host(gk, nrows, ncols, rp, ci, v, strategy=4, split=True)
     srow = host(A.srow())
     assert srow[-1] > 2048 and np.all(srow[:-1] < 0)       # marked
     if advanced:
