@@ -210,6 +210,72 @@ int gkomi_csr_analyse_gather_i32(gkomi_stream_t stream, int64_t ncols, int64_t n
                                  const int32_t* col_idxs, double* scratch,
                                  int* host_flags, int64_t* host_footprint_bytes);
 
+/* ---- <float, int32>: the single-precision instantiation of the core of the path ------
+ * GKO_INSTANTIATE_FOR_EACH_VALUE_AND_INDEX_TYPE (include/ginkgo/core/base/types.hpp:544-560)
+ * instantiates every kernel for float too.  Here: csr::spmv / advanced_spmv
+ * (core/matrix/csr_kernels.hpp:58-75; reference/matrix/csr_kernels.cpp:75-128), the dense
+ * BLAS-1 kernels (reference/matrix/dense_kernels.cpp:127-364), the CG kernels
+ * (reference/solver/cg_kernels.cpp:53-123), stop::residual_norm
+ * (reference/stop/residual_norm_kernels.cpp:57-83) and a Cg driver on them
+ * (core/solver/cg.cpp:107-193: the reference's kernel sequence, Identity preconditioner,
+ * Combined(Iteration, ResidualNorm), one right-hand side).  Same contracts as the _f64
+ * entries of the same names; csrc/f32.hip.  csr::spmv and the elementwise kernels are
+ * bit-identical to the reference executor's float instantiation (every intermediate a
+ * float, no contraction), reductions are two-stage and reproducible (tolerance parity).
+ * Everything else of the path stays <double, *>. */
+int gkomi_csr_spmv_f32_i32(gkomi_stream_t s, int64_t nrows, int64_t ncols, int64_t nrhs,
+                           int64_t nnz, const int32_t* row_ptrs, const int32_t* col_idxs,
+                           const float* vals, const float* b, int64_t b_stride, float* c,
+                           int64_t c_stride, const float* alpha, const float* beta);
+int gkomi_dense_fill_f32(gkomi_stream_t s, int64_t nrows, int64_t ncols, float* x,
+                         int64_t stride, float value);
+int gkomi_dense_copy_f32(gkomi_stream_t s, int64_t nrows, int64_t ncols, const float* in,
+                         int64_t in_stride, float* out, int64_t out_stride);
+int gkomi_dense_scale_f32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                          const float* alpha, int64_t alpha_ncols, float* x,
+                          int64_t stride);
+int gkomi_dense_inv_scale_f32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                              const float* alpha, int64_t alpha_ncols, float* x,
+                              int64_t stride);
+int gkomi_dense_add_scaled_f32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                               const float* alpha, int64_t alpha_ncols, const float* x,
+                               int64_t x_stride, float* y, int64_t y_stride);
+int gkomi_dense_sub_scaled_f32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                               const float* alpha, int64_t alpha_ncols, const float* x,
+                               int64_t x_stride, float* y, int64_t y_stride);
+size_t gkomi_dense_reduction_workspace_bytes_f32(int64_t nrows, int64_t ncols);
+int gkomi_dense_compute_dot_f32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                                const float* x, int64_t x_stride, const float* y,
+                                int64_t y_stride, float* result, void* workspace,
+                                size_t workspace_bytes);
+int gkomi_dense_compute_norm2_f32(gkomi_stream_t s, int64_t nrows, int64_t ncols,
+                                  const float* x, int64_t x_stride, float* result,
+                                  void* workspace, size_t workspace_bytes);
+int gkomi_cg_initialize_f32(gkomi_stream_t s, int64_t nrows, int64_t nrhs, const float* b,
+                            int64_t b_stride, float* r, int64_t r_stride, float* z,
+                            int64_t z_stride, float* p, int64_t p_stride, float* q,
+                            int64_t q_stride, float* prev_rho, float* rho,
+                            uint8_t* stop_status);
+int gkomi_cg_step_1_f32(gkomi_stream_t s, int64_t nrows, int64_t nrhs, float* p,
+                        int64_t p_stride, const float* z, int64_t z_stride,
+                        const float* rho, const float* prev_rho,
+                        const uint8_t* stop_status);
+int gkomi_cg_step_2_f32(gkomi_stream_t s, int64_t nrows, int64_t nrhs, float* x,
+                        int64_t x_stride, float* r, int64_t r_stride, const float* p,
+                        int64_t p_stride, const float* q, int64_t q_stride,
+                        const float* beta, const float* rho, const uint8_t* stop_status);
+int gkomi_residual_norm_f32(gkomi_stream_t s, int64_t nrhs, const float* tau,
+                            const float* orig_tau, float rel_residual_goal,
+                            uint8_t stopping_id, int set_finalized, uint8_t* stop_status,
+                            uint8_t* device_flags, uint8_t* host_flags);
+size_t gkomi_cg_workspace_bytes_f32(int64_t n);
+/* host_info[4] = { iterations, converged, ||r||, baseline norm }; baseline 0 rhs_norm,
+ * 1 initial_resnorm, 2 absolute */
+int gkomi_cg_solve_f32(gkomi_stream_t s, int64_t n, int64_t nnz, const int32_t* row_ptrs,
+                       const int32_t* col_idxs, const float* vals, const float* b,
+                       float* x, int64_t max_iters, float reduction, int baseline,
+                       void* workspace, size_t workspace_bytes, double* host_info);
+
 /* ---- column-partitioned copy: an analysis-based CSR strategy for scattered columns --
  * Role: the reference's `sparselib` strategy (hipSPARSE csrmv behind an analysis,
  * hip/matrix/csr_kernels.hip.cpp:293-330) -- a second representation built once per

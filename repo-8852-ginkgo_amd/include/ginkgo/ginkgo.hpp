@@ -1026,7 +1026,23 @@ protected:
         : LinOp(exec, size), values_(exec, nnz), col_idxs_(exec, nnz), row_ptrs_(exec, size[0] + 1), strategy_(std::move(strategy)) {}
     void apply_impl(const LinOp* b, LinOp* x) const override { spmv(nullptr, b, nullptr, x); }
     void apply_impl(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const override { spmv(alpha, b, beta, x); }
-    void spmv(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const
+    void spmv(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const { spmv_as(V{}, alpha, b, beta, x); }
+    // <float, int32>: csr::spmv / advanced_spmv of the single-precision instantiation (gkomi_csr_spmv_f32_i32); no srow
+    void spmv_as(float, const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const
+    {
+        detail::require_device(exec_, "csr::spmv");
+        static_assert(!std::is_same<V, float>::value || std::is_same<I, int32>::value, "float: int32 indices");
+        auto db = dynamic_cast<const Dense<float>*>(b);
+        auto dx = dynamic_cast<Dense<float>*>(x);
+        auto da = alpha ? dynamic_cast<const Dense<float>*>(alpha) : nullptr;
+        auto dbeta = beta ? dynamic_cast<const Dense<float>*>(beta) : nullptr;
+        if (!db || !dx || (alpha && !da) || (beta && !dbeta)) GKO_NOT_SUPPORTED("Csr<float>::apply takes Dense<float> operands");
+        GKOMI_CALL(gkomi_csr_spmv_f32_i32(nullptr, size_[0], size_[1], db->get_size()[1], get_num_stored_elements(),
+                                          reinterpret_cast<const int32_t*>(get_const_row_ptrs()), reinterpret_cast<const int32_t*>(get_const_col_idxs()),
+                                          reinterpret_cast<const float*>(get_const_values()), db->get_const_values(), db->get_stride(), dx->get_values(),
+                                          dx->get_stride(), da ? da->get_const_values() : nullptr, dbeta ? dbeta->get_const_values() : nullptr));
+    }
+    void spmv_as(double, const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const
     {
         detail::require_device(exec_, "csr::spmv");
         auto db = detail_fmt::dense(b); auto dx = detail_fmt::dense(x);

@@ -140,6 +140,29 @@ namespace distributed_vector {
 void build_local(std::shared_ptr<const HipExecutor>, const device_matrix_data<double, int64>&, const experimental::distributed::Partition<int32, int64>*,
                  experimental::distributed::comm_index_type, Vec*);
 }
+namespace csr {
+void spmv(std::shared_ptr<const HipExecutor>, const matrix::Csr<float, int32>*, const matrix::Dense<float>*, matrix::Dense<float>*);
+void advanced_spmv(std::shared_ptr<const HipExecutor>, const matrix::Dense<float>*, const matrix::Csr<float, int32>*, const matrix::Dense<float>*,
+                   const matrix::Dense<float>*, matrix::Dense<float>*);
+}
+namespace dense {
+void fill(std::shared_ptr<const HipExecutor>, matrix::Dense<float>*, float);
+void add_scaled(std::shared_ptr<const HipExecutor>, const matrix::Dense<float>*, const matrix::Dense<float>*, matrix::Dense<float>*);
+void compute_dot(std::shared_ptr<const HipExecutor>, const matrix::Dense<float>*, const matrix::Dense<float>*, matrix::Dense<float>*, array<char>&);
+void compute_norm2(std::shared_ptr<const HipExecutor>, const matrix::Dense<float>*, matrix::Dense<float>*, array<char>&);
+}
+namespace cg {
+void initialize(std::shared_ptr<const HipExecutor>, const matrix::Dense<float>*, matrix::Dense<float>*, matrix::Dense<float>*, matrix::Dense<float>*,
+                matrix::Dense<float>*, matrix::Dense<float>*, matrix::Dense<float>*, array<stopping_status>*);
+void step_1(std::shared_ptr<const HipExecutor>, matrix::Dense<float>*, const matrix::Dense<float>*, const matrix::Dense<float>*,
+            const matrix::Dense<float>*, const array<stopping_status>*);
+void step_2(std::shared_ptr<const HipExecutor>, matrix::Dense<float>*, matrix::Dense<float>*, const matrix::Dense<float>*, const matrix::Dense<float>*,
+            const matrix::Dense<float>*, const matrix::Dense<float>*, const array<stopping_status>*);
+}
+namespace residual_norm {
+void residual_norm(std::shared_ptr<const HipExecutor>, const matrix::Dense<float>*, const matrix::Dense<float>*, float, uint8, bool,
+                   array<stopping_status>*, array<bool>*, bool*, bool*);
+}
 namespace distributed_matrix {
 void build_local_nonlocal(std::shared_ptr<const HipExecutor>, const device_matrix_data<double, int64>&, const experimental::distributed::Partition<int32, int64>*,
                           const experimental::distributed::Partition<int32, int64>*, experimental::distributed::comm_index_type, array<int32>&, array<int32>&,
@@ -826,6 +849,70 @@ int main()
         k::partition::has_ordered_parts(hip, part_t::build_from_mapping(hip, array<int>(hip, {1, 1, 0, 0, 2}), 3).get(), &unordered);
         k::partition::has_ordered_parts(hip, part_t::build_from_mapping(hip, array<int>(hip, {0, 1, 1, 2, 2}), 3).get(), &ordered);
         ran("partition::has_ordered_parts", !unordered && ordered);
+    }
+    // ---- the <float, int32> instantiations (shims/hip/float_kernels.hip.cpp): reference/test/matrix/csr_kernels.cpp:358-400 and
+    //      reference/test/solver/cg_kernels.cpp:181-252 in single precision ---------------------------------------------------------
+    {
+        using FVec = matrix::Dense<float>;
+        auto host = hip->get_master();
+        auto fvec = [&](std::initializer_list<float> v, size_type rows, size_type cols) {
+            auto d = FVec::create(hip, dim<2>(rows, cols));
+            std::vector<float> h(v);
+            hip->copy_from(host.get(), h.size(), h.data(), d->get_values());
+            return d;
+        };
+        auto values_of = [&](const FVec* d) {
+            std::vector<float> h(d->get_size()[0] * d->get_size()[1]);
+            host->copy_from(hip.get(), h.size(), d->get_const_values(), h.data());
+            return h;
+        };
+        // [1 3 2; 0 5 0] (2, 1, 4)^T = (13, 5)^T;  -1 A b + 2 (1, 2)^T = (-11, -1)^T
+        auto A = matrix::Csr<float, int32>::create(hip, dim<2>(2, 3), 4);
+        const int32 rp[3] = {0, 3, 4}, ci[4] = {0, 1, 2, 1};
+        const float av[4] = {1.0f, 3.0f, 2.0f, 5.0f};
+        hip->copy_from(host.get(), 3, rp, A->get_row_ptrs());
+        hip->copy_from(host.get(), 4, ci, A->get_col_idxs());
+        hip->copy_from(host.get(), 4, av, A->get_values());
+        auto b = fvec({2.0f, 1.0f, 4.0f}, 3, 1);
+        auto c = fvec({0.0f, 0.0f}, 2, 1);
+        k::csr::spmv(hip, A.get(), b.get(), c.get());
+        ran("csr::spmv<float>", values_of(c.get()) == std::vector<float>({13.0f, 5.0f}));
+        auto y = fvec({1.0f, 2.0f}, 2, 1);
+        auto al = fvec({-1.0f}, 1, 1), be = fvec({2.0f}, 1, 1);
+        k::csr::advanced_spmv(hip, al.get(), A.get(), b.get(), be.get(), y.get());
+        ran("csr::advanced_spmv<float>", values_of(y.get()) == std::vector<float>({-11.0f, -1.0f}));
+        auto u = fvec({0.0f, 0.0f, 0.0f}, 3, 1);
+        k::dense::fill(hip, u.get(), 1.5f);
+        k::dense::add_scaled(hip, be.get(), b.get(), u.get());   // 1.5 + 2 b
+        ran("dense::add_scaled<float>", values_of(u.get()) == std::vector<float>({5.5f, 3.5f, 9.5f}));
+        array<char> tmp(hip, 0);
+        auto res = fvec({0.0f}, 1, 1);
+        k::dense::compute_dot(hip, b.get(), u.get(), res.get(), tmp);       // 11 + 3.5 + 38 = 52.5
+        const bool dot_ok = values_of(res.get())[0] == 52.5f;
+        k::dense::compute_norm2(hip, b.get(), res.get(), tmp);              // sqrt(21)
+        ran("dense::compute_norm2<float>", dot_ok && std::abs(values_of(res.get())[0] - std::sqrt(21.0f)) < 1e-6f);
+        // cg::step_1 / step_2 (cg_kernels.cpp:181-197, 214-234): p = z + rho / prev_rho p
+        auto p = fvec({-2.0f, 3.0f, 5.0f, -4.0f}, 2, 2), z = fvec({4.0f, 3.0f, -2.0f, -1.0f}, 2, 2);
+        auto rho = fvec({-4.0f, 3.0f}, 1, 2), prev = fvec({2.0f, -3.0f}, 1, 2);
+        array<stopping_status> st(hip, 2);
+        auto q = fvec({0.0f, 0.0f, 0.0f, 0.0f}, 2, 2), r = fvec({0.0f, 0.0f, 0.0f, 0.0f}, 2, 2), zz = fvec({0.0f, 0.0f, 0.0f, 0.0f}, 2, 2),
+             pp = fvec({0.0f, 0.0f, 0.0f, 0.0f}, 2, 2), pr = fvec({0.0f, 0.0f}, 1, 2), rh = fvec({0.0f, 0.0f}, 1, 2);
+        k::cg::initialize(hip, p.get(), r.get(), zz.get(), pp.get(), q.get(), pr.get(), rh.get(), &st);   // also clears the stopping statuses
+        k::cg::step_1(hip, p.get(), z.get(), rho.get(), prev.get(), &st);
+        ran("cg::step_1<float>", values_of(p.get()) == std::vector<float>({8.0f, 0.0f, -12.0f, 3.0f}) &&
+                                     values_of(r.get()) == std::vector<float>({-2.0f, 3.0f, 5.0f, -4.0f}) && values_of(pr.get()) == std::vector<float>({1.0f, 1.0f}));
+        auto x = fvec({-1.0f, 2.0f, 3.0f, -4.0f}, 2, 2), rr = fvec({4.0f, -2.0f, 1.0f, 3.0f}, 2, 2), beta = fvec({2.0f, -3.0f}, 1, 2);
+        auto qq = fvec({1.0f, 2.0f, -3.0f, 4.0f}, 2, 2);
+        k::cg::step_2(hip, x.get(), rr.get(), p.get(), qq.get(), beta.get(), rho.get(), &st);   // tmp = rho / beta = (-2, -1)
+        ran("cg::step_2<float>", values_of(x.get()) == std::vector<float>({-17.0f, 2.0f, 27.0f, -7.0f}) &&
+                                     values_of(rr.get()) == std::vector<float>({6.0f, 0.0f, -5.0f, 7.0f}));
+        // residual_norm: tau (0.5, 3) against 0.1 * (10, 10): the first column converges
+        auto tau = fvec({0.5f, 3.0f}, 1, 2), orig = fvec({10.0f, 10.0f}, 1, 2);
+        array<bool> storage(hip, 2);
+        bool all = true, one = false;
+        k::residual_norm::residual_norm(hip, tau.get(), orig.get(), 0.1f, 1, true, &st, &storage, &all, &one);
+        const auto sth = st.to_host();
+        ran("residual_norm::residual_norm<float>", !all && one && (sth[0].data_ & GKOMI_STATUS_CONVERGED) != 0 && (sth[1].data_ & GKOMI_STATUS_ID_MASK) == 0);
     }
     std::printf("wrong: %d\n", wrong);
     return wrong;

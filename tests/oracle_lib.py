@@ -21,10 +21,10 @@ LIB = os.environ.get("GKO_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libgko_oracl
 _SCALARS = {
     "i64": ctypes.c_int64, "i32": ctypes.c_int32, "u8": ctypes.c_uint8,
     "int": ctypes.c_int, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
-    "u64": ctypes.c_uint64, "oracle_apply_fn": ctypes.c_void_p,
+    "u64": ctypes.c_uint64, "oracle_apply_fn": ctypes.c_void_p, "float": ctypes.c_float,
 }
 _NP = {"i64": np.int64, "i32": np.int32, "u8": np.uint8, "double": np.float64,
-       "int": np.int32, "u64": np.uint64}
+       "int": np.int32, "u64": np.uint64, "float": np.float32}
 
 
 def build(force=False):

@@ -196,7 +196,9 @@ SHIMS = ["matrix/csr_kernels", "matrix/dense_kernels", "solver/cg_kernels", "sto
          "matrix/ell_kernels", "matrix/sellp_kernels", "matrix/coo_kernels", "matrix/hybrid_kernels",
          "components/prefix_sum_kernels", "components/format_conversion_kernels", "components/fill_array_kernels",
          "solver/gmres_kernels", "solver/krylov_kernels", "factorization/par_ilu_kernels",
-         "base/device_matrix_data_kernels", "distributed/matrix_kernels"]
+         "base/device_matrix_data_kernels", "distributed/matrix_kernels",
+         # round 4: the <float, int32> instantiations of csr::spmv, the BLAS-1 kernels, the CG kernels, residual_norm
+         "float_kernels"]
 
 
 def _build_shims(tmp_path):
