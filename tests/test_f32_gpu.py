@@ -176,3 +176,28 @@ def test_cg_driver(gk, oracle):
     # the iteration limit stops an unconverged solve and says so
     x, iters, conv, _, _ = cg(gk, n, rp, ci, v, b, np.zeros(n), 5, 1e-7)
     assert iters == 5 and not conv
+
+
+@pytest.mark.parametrize("nnz_target", [1, 5, 8, 9, 10, 11, 2047, 2048, 2049, 2051, 4099])
+def test_csr_quads_and_tails(gk, oracle, nnz_target):
+    """the 16-B loads of the float kernel: matrices whose nonzero count is not a multiple of four, below eight (scalar
+    loads), on and around the 2048-nonzero tile; workgroups whose first nonzero is not on a quad boundary"""
+    rng = np.random.default_rng(nnz_target)
+    ncols = 97
+    nrows = max(1, nnz_target // 3 + 300)
+    counts = np.zeros(nrows, np.int64)
+    left = nnz_target
+    order = rng.permutation(nrows)
+    for r in order:
+        k = min(left, int(rng.integers(0, 8)))
+        counts[r] = k
+        left -= k
+        if left == 0:
+            break
+    counts[order[0]] += left
+    rp, ci, v = matgen.random_rows_csr(nrows, ncols, np.minimum(counts, ncols), 7)
+    rp, ci, v = rp.astype(np.int32), ci.astype(np.int32), v.astype(F)
+    b = rng.standard_normal((ncols, 1)).astype(F)
+    expect = np.full((nrows, 1), np.nan, F)
+    oracle.ref_csr_spmv_f32(nrows, 1, rp, ci, v, b, 1, expect, 1)
+    assert np.array_equal(spmv(gk, nrows, ncols, rp, ci, v, b), expect)
