@@ -180,8 +180,8 @@ def test_cg_driver(gk, oracle):
 
 @pytest.mark.parametrize("nnz_target", [1, 5, 8, 9, 10, 11, 2047, 2048, 2049, 2051, 4099])
 def test_csr_quads_and_tails(gk, oracle, nnz_target):
-    """the 16-B loads of the float kernel: matrices whose nonzero count is not a multiple of four, below eight (scalar
-    loads), on and around the 2048-nonzero tile; workgroups whose first nonzero is not on a quad boundary"""
+    """nonzero counts around the 2048-nonzero tile of the float kernel and tiny ones, rows scattered over the workgroups
+    (written for a variant with 16-B loads, which lost 12.2 -> 16.2 us and was dropped; the cases stay)"""
     rng = np.random.default_rng(nnz_target)
     ncols = 97
     nrows = max(1, nnz_target // 3 + 300)
