@@ -131,6 +131,30 @@ int main()
             std::cout << "csr_long_rows_diff " << worst << " nnz " << dl.nonzeros.size() << "\n";
         }
 
+        // Csr<float, int32>::apply: the single-precision instantiation of csr::spmv / advanced_spmv
+        // (reference/test/matrix/csr_kernels.cpp:358-400 in float: [1 3 2; 0 5 0] (2, 1, 4)^T = (13, 5)^T, then -1 A b + 2 c)
+        {
+            using fvec = gko::matrix::Dense<float>;
+            auto host = exec->get_master();
+            auto Af = gko::matrix::Csr<float, int>::create(exec, gko::dim<2>(2, 3), 4);
+            const int rp[3] = {0, 3, 4}, ci[4] = {0, 1, 2, 1};
+            const float av[4] = {1.0f, 3.0f, 2.0f, 5.0f}, bv[3] = {2.0f, 1.0f, 4.0f}, two_v[1] = {2.0f}, neg_v[1] = {-1.0f};
+            exec->copy_from(host.get(), 3, rp, Af->get_row_ptrs());
+            exec->copy_from(host.get(), 4, ci, Af->get_col_idxs());
+            exec->copy_from(host.get(), 4, av, Af->get_values());
+            auto bf = fvec::create(exec, gko::dim<2>(3, 1)), cf = fvec::create(exec, gko::dim<2>(2, 1));
+            auto two_f = fvec::create(exec, gko::dim<2>(1, 1)), neg_f = fvec::create(exec, gko::dim<2>(1, 1));
+            exec->copy_from(host.get(), 3, bv, bf->get_values());
+            exec->copy_from(host.get(), 1, two_v, two_f->get_values());
+            exec->copy_from(host.get(), 1, neg_v, neg_f->get_values());
+            Af->apply(bf.get(), cf.get());
+            float out[2] = {0.0f, 0.0f}, out2[2] = {0.0f, 0.0f};
+            host->copy_from(exec.get(), 2, cf->get_const_values(), out);
+            Af->apply(neg_f.get(), bf.get(), two_f.get(), cf.get());     // -1 (13, 5) + 2 (13, 5)
+            host->copy_from(exec.get(), 2, cf->get_const_values(), out2);
+            std::cout << "csr_float " << out[0] << " " << out[1] << " advanced " << out2[0] << " " << out2[1] << "\n";
+        }
+
         // the analysis-based strategy of this backend: a column-partitioned copy for scattered column patterns
         // (uniformly random columns over 4.8 MB of b); same product to rounding, also after the values changed
         {

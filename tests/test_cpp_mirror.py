@@ -101,6 +101,8 @@ def test_hot_path_tour(bins):
     # long rows + wide gathers: the strategy objects' column statistic -> windowed load-balanced kernel; sums of
     # 50 000 terms of size ~1, two summation orders
     assert float(kv["csr_long_rows_diff"][0]) < 1e-9 and int(kv["csr_long_rows_diff"][2]) > 700000
+    # Csr<float, int32>::apply (the single-precision instantiation): exact small integers
+    assert kv["csr_float"] == ["13", "5", "advanced", "13", "5"]
     # Csr::gkomi_partitioned: the column-partitioned copy exists for the scattered pattern, same product to rounding
     # (sums of 8 terms of size ~1 over 600 000 rows), also after new values went in through get_values()
     p = kv["csr_partitioned_diff"]
