@@ -169,7 +169,7 @@ def test_non_local_block_of_a_distributed_matrix(gk, oracle):
         csr_apply_srow(gk, A, db, srow, tile, out, 1.0, 1.0, 0)
     e1.record()
     torch.cuda.synchronize()
-    assert e0.elapsed_time(e1) / 10 < 0.1, "ms per apply of the automatic strategy"
+    assert e0.elapsed_time(e1) / 10 < 0.5, "ms per apply of the automatic strategy (0.05 measured, most of it the test's own scalar uploads; 5 ms when one workgroup walks the rows)"
 
 
 @pytest.mark.parametrize("nnz_target", [2, 3, 1535, 1536, 1537, 3072, 2 * 1536 + 1])
