@@ -136,7 +136,7 @@ def test_long_runs_of_empty_rows(gk, oracle, tile, advanced):
         csr_apply_srow(gk, A, db, srow, tile, out, strategy=SPLIT)
     e1.record()
     torch.cuda.synchronize()
-    assert e0.elapsed_time(e1) / 10 < 0.2, "ms per apply"
+    assert e0.elapsed_time(e1) / 10 < 0.6, "ms per apply (0.01-0.05 measured; > 1 ms when one workgroup walks the rows)"
 
 
 def test_non_local_block_of_a_distributed_matrix(gk, oracle):
