@@ -153,6 +153,26 @@ int main()
             Af->apply(neg_f.get(), bf.get(), two_f.get(), cf.get());     // -1 (13, 5) + 2 (13, 5)
             host->copy_from(exec.get(), 2, cf->get_const_values(), out2);
             std::cout << "csr_float " << out[0] << " " << out[1] << " advanced " << out2[0] << " " << out2[1] << "\n";
+            // Cg<float> on the reference's stencil system (reference/test/solver/cg_kernels.cpp:255-266): x = (1, 3, 2)
+            auto Sf = gko::share(gko::matrix::Csr<float, int>::create(exec, gko::dim<2>(3, 3), 7));
+            const int srp[4] = {0, 2, 5, 7}, sci[7] = {0, 1, 0, 1, 2, 1, 2};
+            const float sv[7] = {2.0f, -1.0f, -1.0f, 2.0f, -1.0f, -1.0f, 2.0f}, sb[3] = {-1.0f, 3.0f, 1.0f}, zero3[3] = {0.0f, 0.0f, 0.0f};
+            exec->copy_from(host.get(), 4, srp, Sf->get_row_ptrs());
+            exec->copy_from(host.get(), 7, sci, Sf->get_col_idxs());
+            exec->copy_from(host.get(), 7, sv, Sf->get_values());
+            auto rhs = fvec::create(exec, gko::dim<2>(3, 1)), sol3 = fvec::create(exec, gko::dim<2>(3, 1));
+            exec->copy_from(host.get(), 3, sb, rhs->get_values());
+            exec->copy_from(host.get(), 3, zero3, sol3->get_values());
+            auto cgf = gko::solver::Cg<float>::build()
+                           .with_criteria(gko::stop::Iteration::build().with_max_iters(400u).on(exec),
+                                          gko::stop::ResidualNorm<float>::build().with_reduction_factor(1.2e-6f).on(exec))
+                           .on(exec)
+                           ->generate(Sf);
+            cgf->apply(rhs.get(), sol3.get());
+            float xs[3] = {};
+            host->copy_from(exec.get(), 3, sol3->get_const_values(), xs);
+            std::cout << "cg_float_iters " << cgf->get_last_iteration_count() << " converged " << cgf->has_converged() << " err "
+                      << std::max(std::max(std::abs(xs[0] - 1.0f), std::abs(xs[1] - 3.0f)), std::abs(xs[2] - 2.0f)) << "\n";
         }
 
         // the analysis-based strategy of this backend: a column-partitioned copy for scattered column patterns

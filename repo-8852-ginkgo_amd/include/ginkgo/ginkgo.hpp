@@ -1998,7 +1998,29 @@ protected:
         if (size_[0] != size_[1]) throw DimensionMismatch(__FILE__, __LINE__, "Cg needs a square system matrix");
         precond_ = f->precond_ ? f->precond_ : (f->precond_factory_ ? std::shared_ptr<const LinOp>(f->precond_factory_->generate_impl(A_)) : nullptr);
     }
-    void apply_impl(const LinOp* b, LinOp* x) const override
+    void apply_impl(const LinOp* b, LinOp* x) const override { solve_as(V{}, b, x); }
+    // Cg<float>: the single-precision instantiation -- the reference's kernel sequence on the _f32 kernels (gkomi_cg_solve_f32):
+    // a Csr<float, int32> system matrix, Dense<float> vectors with one column, no preconditioner, Iteration + ResidualNorm
+    void solve_as(float, const LinOp* b, LinOp* x) const
+    {
+        ::gko::detail::require_device(exec_, "cg::apply");
+        auto A = dynamic_cast<const matrix::Csr<float, int32>*>(A_.get());
+        auto db = dynamic_cast<const matrix::Dense<float>*>(b);
+        auto dx = dynamic_cast<matrix::Dense<float>*>(x);
+        if (!A || !db || !dx || precond_ || settings_.implicit || db->get_size()[1] != 1 || db->get_stride() != 1 || dx->get_stride() != 1) {
+            GKO_NOT_SUPPORTED("Cg<float>: Csr<float, int32> system, Dense<float> vectors of one contiguous column, Iteration + ResidualNorm, no preconditioner");
+        }
+        const int64_t n = size_[0];
+        array<char> ws(exec_, gkomi_cg_workspace_bytes_f32(n));
+        double info[4] = {};
+        GKOMI_CALL(gkomi_cg_solve_f32(nullptr, n, static_cast<int64_t>(A->get_num_stored_elements()), A->get_const_row_ptrs(), A->get_const_col_idxs(),
+                                      A->get_const_values(), db->get_const_values(), dx->get_values(), settings_.max_iters,
+                                      static_cast<float>(settings_.reduction_factor), detail::baseline_code(settings_.baseline), ws.get_data(),
+                                      ws.get_num_elems(), info));
+        last_iters_ = static_cast<int64_t>(info[0]);
+        last_converged_ = info[1] != 0.0;
+    }
+    void solve_as(double, const LinOp* b, LinOp* x) const
     {
         ::gko::detail::require_device(exec_, "cg::apply");
         if (auto ds = dynamic_cast<const ::gko::detail::distributed_system*>(A_.get())) {
@@ -2026,7 +2048,9 @@ protected:
         last_iters_ = static_cast<int64_t>(info[0]);
         last_converged_ = info[1] != 0.0;
     }
-    void apply_impl(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const override
+    void apply_impl(const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const override { advanced_as(V{}, alpha, b, beta, x); }
+    void advanced_as(float, const LinOp*, const LinOp*, const LinOp*, LinOp*) const { GKO_NOT_SUPPORTED("Cg<float>: plain apply only"); }
+    void advanced_as(double, const LinOp* alpha, const LinOp* b, const LinOp* beta, LinOp* x) const
     {
         // x = alpha * solve(b) + beta * x  (core/solver/cg.cpp:196-210)
         auto dx = matrix::detail_fmt::dense(x);

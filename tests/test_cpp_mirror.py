@@ -103,6 +103,8 @@ def test_hot_path_tour(bins):
     assert float(kv["csr_long_rows_diff"][0]) < 1e-9 and int(kv["csr_long_rows_diff"][2]) > 700000
     # Csr<float, int32>::apply (the single-precision instantiation): exact small integers
     assert kv["csr_float"] == ["13", "5", "advanced", "13", "5"]
+    # Cg<float> on the reference's 3 x 3 stencil system (cg_kernels.cpp:255-266): r<float> = 1.2e-6
+    assert int(kv["cg_float_iters"][0]) <= 4 and kv["cg_float_iters"][2] == "1" and float(kv["cg_float_iters"][4]) < 1e-5
     # Csr::gkomi_partitioned: the column-partitioned copy exists for the scattered pattern, same product to rounding
     # (sums of 8 terms of size ~1 over 600 000 rows), also after new values went in through get_values()
     p = kv["csr_partitioned_diff"]
